@@ -1,0 +1,200 @@
+"""CPU oracle for the flow-matching mel decoder (TEST INFRASTRUCTURE — see oracle/__init__.py).
+
+Follows
+  * CausalMaskedDiffWithDiT.inference   server/model_utils/cosyvoice/flow/flow.py:367-430
+  * PreLookaheadLayer.forward           cosyvoice/transformer/upsample_encoder.py:82-103
+  * CausalConditionalCFM.forward        cosyvoice/flow/flow_matching.py:204-228
+  * ConditionalCFM.solve_euler          cosyvoice/flow/flow_matching.py:71-124
+  * DiT.forward                         cosyvoice/flow/DiT/dit.py:145-176
+  * TimestepEmbedding / SinusPositionEmbedding   cosyvoice/flow/DiT/modules.py:606-616, 71-83
+  * InputEmbedding / CausalConvPositionEmbedding cosyvoice/flow/DiT/dit.py:76-98, modules.py:115-144
+  * DiTBlock / AdaLayerNormZero / AttnProcessor / FeedForward  modules.py:516-530, 230-244, 349-407, 271-282
+  * AdaLayerNormZero_Final              modules.py:251-265
+Rotary embedding arithmetic is third-party x_transformers==2.12.2 (requirements.txt:51, absent from
+/root/reference): interleaved-pair rotation of the FIRST head_dim channels of the full q/k rows
+(applied before the head split, so only head 0 rotates), fp32 -> PARITY UNPINNED for this sub-step.
+Weights: flat dict with the reference's flow.pt keys.
+"""
+import math
+import torch
+import torch.nn.functional as F
+
+
+def pre_lookahead(x, sd, cfg, pre='pre_lookahead_layer.'):
+    """x: (1, N, 80) -> (1, N, 80); finalize=True path (zero right pad)."""
+    o = x.transpose(1, 2).contiguous()
+    o = F.pad(o, (0, cfg.pre_lookahead_len), value=0.0)
+    o = F.leaky_relu(F.conv1d(o, sd[pre + 'conv1.weight'], sd[pre + 'conv1.bias']))
+    k2 = sd[pre + 'conv2.weight'].shape[-1]
+    o = F.pad(o, (k2 - 1, 0), value=0.0)
+    o = F.conv1d(o, sd[pre + 'conv2.weight'], sd[pre + 'conv2.bias'])
+    return o.transpose(1, 2).contiguous() + x
+
+
+def sinus_pos_emb(t, dim, scale=1000.0):
+    half = dim // 2
+    e = math.log(10000) / (half - 1)
+    e = torch.exp(torch.arange(half).float() * -e)
+    e = scale * t.unsqueeze(1) * e.unsqueeze(0)
+    return torch.cat((e.sin(), e.cos()), dim=-1)
+
+
+def time_embed(t, sd, cfg, pre):
+    h = sinus_pos_emb(t, cfg.time_freq_dim).to(t.dtype)
+    h = F.linear(h, sd[pre + 'time_embed.time_mlp.0.weight'], sd[pre + 'time_embed.time_mlp.0.bias'])
+    return F.linear(F.silu(h), sd[pre + 'time_embed.time_mlp.2.weight'], sd[pre + 'time_embed.time_mlp.2.bias'])
+
+
+def rope_freqs(T, head_dim):
+    inv = 1.0 / (10000 ** (torch.arange(0, head_dim, 2).float() / head_dim))
+    fr = torch.einsum('i,j->ij', torch.arange(T).float(), inv)
+    return torch.stack((fr, fr), dim=-1).flatten(-2)          # (T, head_dim), interleaved duplicate
+
+
+def apply_rope_first(x, freqs):
+    """Rotate the first freqs.shape[-1] channels of x (B,T,D) in interleaved pairs, pass the rest."""
+    r = freqs.shape[-1]
+    xr, xp = x[..., :r].float(), x[..., r:]
+    x2 = xr.reshape(*xr.shape[:-1], -1, 2)
+    a, b = x2.unbind(-1)
+    rot = torch.stack((-b, a), dim=-1).flatten(-2)
+    xr = xr * freqs.cos() + rot * freqs.sin()
+    return torch.cat((xr.to(x.dtype), xp), dim=-1)
+
+
+def causal_conv_pos_embed(x, sd, cfg, pre):
+    k = cfg.conv_kernel
+    h = x.permute(0, 2, 1)
+    for name in ('conv1.0.', 'conv2.0.'):
+        h = F.pad(h, (k - 1, 0))
+        h = F.mish(F.conv1d(h, sd[pre + name + 'weight'], sd[pre + name + 'bias'], groups=cfg.conv_groups))
+    return h.permute(0, 2, 1)
+
+
+def dit_block(x, t_emb, sd, cfg, pre, freqs, key_mask):
+    B, T, D = x.shape
+    H, dh = cfg.heads, cfg.head_dim
+    emb = F.linear(F.silu(t_emb), sd[pre + 'attn_norm.linear.weight'], sd[pre + 'attn_norm.linear.bias'])
+    sh_a, sc_a, g_a, sh_m, sc_m, g_m = torch.chunk(emb, 6, dim=1)
+    n = F.layer_norm(x, (D,), eps=1e-6) * (1 + sc_a[:, None]) + sh_a[:, None]
+    q = F.linear(n, sd[pre + 'attn.to_q.weight'], sd[pre + 'attn.to_q.bias'])
+    k = F.linear(n, sd[pre + 'attn.to_k.weight'], sd[pre + 'attn.to_k.bias'])
+    v = F.linear(n, sd[pre + 'attn.to_v.weight'], sd[pre + 'attn.to_v.bias'])
+    q = apply_rope_first(q, freqs)
+    k = apply_rope_first(k, freqs)
+    q = q.view(B, T, H, dh).transpose(1, 2)
+    k = k.view(B, T, H, dh).transpose(1, 2)
+    v = v.view(B, T, H, dh).transpose(1, 2)
+    am = key_mask[:, None, None, :].expand(B, H, T, T)           # (B,1,T,T) repeated pad mask (dit.py:166)
+    a = F.scaled_dot_product_attention(q, k, v, attn_mask=am, dropout_p=0.0, is_causal=False)
+    a = a.transpose(1, 2).reshape(B, T, H * dh)
+    a = F.linear(a, sd[pre + 'attn.to_out.0.weight'], sd[pre + 'attn.to_out.0.bias'])
+    a = a.masked_fill(~key_mask[:, :, None], 0.0)                 # mask[:, 0, -1] row == pad mask (modules.py:400-405)
+    x = x + g_a.unsqueeze(1) * a
+    f = F.layer_norm(x, (D,), eps=1e-6) * (1 + sc_m[:, None]) + sh_m[:, None]
+    f = F.linear(f, sd[pre + 'ff.ff.0.0.weight'], sd[pre + 'ff.ff.0.0.bias'])
+    f = F.linear(F.gelu(f, approximate='tanh'), sd[pre + 'ff.ff.2.weight'], sd[pre + 'ff.ff.2.bias'])
+    return x + g_m.unsqueeze(1) * f
+
+
+def dit_forward(x, mask, mu, t, spks, cond, sd, cfg, pre='decoder.estimator.', n_blocks=None, taps=None):
+    """Estimator call, TRT argument order (flow_matching.py:126-153): x,mu,cond (B,80,T); mask (B,1,T);
+    t (B,); spks (B,80) -> (B,80,T).  Non-streaming mask."""
+    x = x.transpose(1, 2)
+    mu = mu.transpose(1, 2)
+    cond = cond.transpose(1, 2)
+    B, T, _ = x.shape
+    if t.ndim == 0:
+        t = t.repeat(B)
+    t_emb = time_embed(t, sd, cfg, pre)
+    h = torch.cat([x, cond, mu, spks[:, None, :].expand(B, T, spks.shape[-1])], dim=-1)
+    h = F.linear(h, sd[pre + 'input_embed.proj.weight'], sd[pre + 'input_embed.proj.bias'])
+    h = causal_conv_pos_embed(h, sd, cfg, pre + 'input_embed.conv_pos_embed.') + h
+    if taps is not None:
+        taps['input_embed'] = h.clone()
+    freqs = rope_freqs(T, cfg.head_dim)
+    key_mask = mask.bool()[:, 0, :]
+    nb = cfg.depth if n_blocks is None else n_blocks
+    for i in range(nb):
+        h = dit_block(h, t_emb, sd, cfg, pre + 'transformer_blocks.%d.' % i, freqs, key_mask)
+        if taps is not None:
+            taps['block%d' % i] = h.clone()
+    emb = F.linear(F.silu(t_emb), sd[pre + 'norm_out.linear.weight'], sd[pre + 'norm_out.linear.bias'])
+    scale, shift = torch.chunk(emb, 2, dim=1)
+    h = F.layer_norm(h, (h.shape[-1],), eps=1e-6) * (1 + scale)[:, None, :] + shift[:, None, :]
+    return F.linear(h, sd[pre + 'proj_out.weight'], sd[pre + 'proj_out.bias']).transpose(1, 2)
+
+
+def cosine_t_span(n_timesteps, dtype=torch.float32):
+    t = torch.linspace(0, 1, n_timesteps + 1, dtype=dtype)
+    return 1 - torch.cos(t * 0.5 * torch.pi)
+
+
+def cfm_noise(cfg):
+    """CausalConditionalCFM.__init__: set_all_random_seed(0); randn(1,80,50*300) (flow_matching.py:200-201)."""
+    g = torch.Generator()
+    g.manual_seed(0)
+    return torch.randn([1, cfg.mel, cfg.noise_frames], generator=g)
+
+
+def solve_euler(x, t_span, mu, mask, spks, cond, estimator, cfg_rate):
+    """flow_matching.py:71-124 with the batch-2 CFG trick (row 1 = unconditional zeros)."""
+    t, dt = t_span[0], t_span[1] - t_span[0]
+    t = t.unsqueeze(0)
+    T = x.size(2)
+    x_in = torch.zeros([2, x.size(1), T], dtype=spks.dtype)
+    mask_in = torch.zeros([2, 1, T], dtype=spks.dtype)
+    mu_in = torch.zeros([2, x.size(1), T], dtype=spks.dtype)
+    t_in = torch.zeros([2], dtype=spks.dtype)
+    spks_in = torch.zeros([2, spks.size(1)], dtype=spks.dtype)
+    cond_in = torch.zeros([2, x.size(1), T], dtype=spks.dtype)
+    traj = []
+    for step in range(1, len(t_span)):
+        x_in[:] = x
+        mask_in[:] = mask
+        mu_in[0] = mu
+        t_in[:] = t.unsqueeze(0)
+        spks_in[0] = spks
+        cond_in[0] = cond
+        d = estimator(x_in, mask_in, mu_in, t_in, spks_in, cond_in)
+        d, d_cfg = torch.split(d, [x.size(0), x.size(0)], dim=0)
+        d = (1.0 + cfg_rate) * d - cfg_rate * d_cfg
+        x = x + dt * d
+        t = t + dt
+        traj.append(x)
+        if step < len(t_span) - 1:
+            dt = t_span[step + 1] - t
+    return traj[-1].float(), traj
+
+
+def cfm_forward(mu, mask, spks, cond, sd, cfg, noise=None, estimator=None, n_timesteps=None):
+    """CausalConditionalCFM.forward (flow_matching.py:204-228)."""
+    noise = cfm_noise(cfg) if noise is None else noise
+    z = noise[:, :, :mu.size(2)].to(mu.dtype)
+    n = cfg.n_timesteps if n_timesteps is None else n_timesteps
+    t_span = cosine_t_span(n, mu.dtype)
+    if estimator is None:
+        def estimator(x, m, mu_, t, s, c):
+            return dit_forward(x, m, mu_, t, s, c, sd, cfg)
+    out, _ = solve_euler(z, t_span, mu, mask, spks, cond, estimator, cfg.cfg_rate)
+    return out
+
+
+def flow_inference(token, embedding, sd, cfg, prompt_token=None, prompt_feat=None, noise=None):
+    """flow.py:367-430, fp32, finalize=True, streaming=False.
+    token (1,N) int, embedding (1,192), prompt_token (1,Np) int, prompt_feat (1,Tp,80) -> mel (1,80,2N)."""
+    emb = F.normalize(embedding.float(), dim=1)
+    emb = F.linear(emb, sd['spk_embed_affine_layer.weight'], sd['spk_embed_affine_layer.bias'])
+    if prompt_token is not None:
+        token = torch.cat([prompt_token, token], dim=1)
+    h = sd['input_embedding.weight'][torch.clamp(token.long(), min=0)]          # mask is all ones for B=1
+    h = pre_lookahead(h, sd, cfg)
+    h = h.repeat_interleave(cfg.token_mel_ratio, dim=1)
+    T = h.shape[1]
+    mel_len1 = prompt_feat.shape[1] if prompt_feat is not None else 0
+    cond = torch.zeros(1, T, cfg.mel)
+    if prompt_feat is not None:
+        cond[:, :mel_len1] = prompt_feat
+    mask = torch.ones(1, 1, T)
+    feat = cfm_forward(h.transpose(1, 2).contiguous(), mask, emb, cond.transpose(1, 2), sd, cfg, noise=noise)
+    return feat[:, :, mel_len1:].float()

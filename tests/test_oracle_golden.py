@@ -1,0 +1,136 @@
+"""The CPU oracle against the golden vectors minted from the reference (tests/golden/make_golden.py)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, state_checksum
+from flowmirror_hydravox_amd import weights as W
+from oracle import sampler_ref, llm_ref, flow_ref, hift_ref
+
+
+@pytest.mark.parametrize('fname', ['sampler_small.npz', 'sampler_big.npz'])
+def test_sampler_ids_and_noise_consumption(fname):
+    g = load_golden(fname)
+    n = len(g['id'])
+    for i in range(n):
+        ns = sampler_ref.NoiseStream(seed=int(g['seed'][i]))
+        hist = g['hist'][i, :g['hist_len'][i]].tolist()
+        try:
+            got = sampler_ref.sampling_ids(g['logp'][i], hist, ns, int(g['Vs'][i]), bool(g['ignore_eos'][i]),
+                                           top_p=float(g['top_p'][i]), top_k=int(g['top_k'][i]),
+                                           win_size=int(g['win'][i]), tau_r=float(g['tau'][i]))
+        except RuntimeError:
+            got = -1
+        assert got == int(g['id'][i]), i
+        assert ns.cursor == int(g['consumed'][i]), i
+
+
+def test_noise_stream_is_chunk_invariant():
+    a = sampler_ref.NoiseStream(seed=3, chunk=7)
+    b = sampler_ref.NoiseStream(seed=3, chunk=4096)
+    xs = np.concatenate([a.take(n) for n in (3, 10, 6761, 1, 25)])
+    ys = b.take(len(xs))
+    assert np.array_equal(xs, ys)
+
+
+@pytest.fixture(scope='module')
+def llm_golden(tiny_cfg):
+    g = load_golden('llm_tiny.npz')
+    sd = W.make_llm_state(tiny_cfg.llm, seed=int(g['weight_seed']), init='fan_in', with_lm_head=True)
+    assert state_checksum(sd) == str(g['weight_sha']), 'synthetic weights differ from the ones the fixture was minted with'
+    return g, sd
+
+
+@pytest.mark.parametrize('use_cache', [False, True])
+def test_llm_token_streams(tiny_cfg, llm_golden, use_cache):
+    g, sd = llm_golden
+    cfg = tiny_cfg.llm
+    for r in range(int(g['n_runs'])):
+        p = 'r%d_' % r
+        top_p, top_k, win, tau = g[p + 'sampling']
+        ns = sampler_ref.NoiseStream(seed=int(g[p + 'seed']))
+        toks = list(llm_ref.llm_inference(
+            sd, cfg, torch.from_numpy(g[p + 'text']), ns, prompt_text=torch.from_numpy(g[p + 'ptext']),
+            prompt_speech_token=torch.from_numpy(g[p + 'pspeech']), inference_head_num=int(g[p + 'K']),
+            sampling=dict(top_p=float(top_p), top_k=int(top_k), win_size=int(win), tau_r=float(tau)),
+            max_token_text_ratio=float(g[p + 'ratios'][0]), min_token_text_ratio=float(g[p + 'ratios'][1]),
+            use_kv_cache=use_cache))
+        assert toks == g[p + 'tokens'].tolist(), r
+        assert all(t < cfg.speech_tokens for t in toks)
+
+
+def test_llm_first_step_numerics(tiny_cfg, llm_golden):
+    g, sd = llm_golden
+    cfg = tiny_cfg.llm
+    for r in range(int(g['n_runs'])):
+        p = 'r%d_' % r
+        x = llm_ref.build_prefix(sd, cfg, torch.from_numpy(g[p + 'text']), torch.from_numpy(g[p + 'ptext']), torch.from_numpy(g[p + 'pspeech']))
+        y = llm_ref.backbone(x, sd, cfg)
+        assert np.allclose(y[-1].numpy(), g[p + 'y_last'], atol=2e-5)
+        K = llm_ref.effective_heads(cfg, int(g[p + 'K']))
+        lps = torch.stack(llm_ref.head_logps(torch.from_numpy(g[p + 'y_last']), sd, cfg, K))
+        assert np.allclose(lps.numpy(), g[p + 'logps'], atol=5e-5)
+
+
+def test_flow_pieces_and_end_to_end(tiny_cfg):
+    g = load_golden('flow_tiny.npz')
+    c = tiny_cfg.flow
+    sd = W.make_flow_state(c, seed=int(g['weight_seed']), init='fan_in')
+    assert state_checksum(sd) == str(g['weight_sha'])
+    assert np.array_equal(flow_ref.cfm_noise(c)[0, :2, :8].numpy(), g['noise_head'])
+    for r in range(int(g['n_runs'])):
+        p = 'r%d_' % r
+        T = g[p + 'est_x'].shape[-1]
+        pla = flow_ref.pre_lookahead(torch.from_numpy(g[p + 'h0']), sd, c)
+        assert np.allclose(pla.numpy(), g[p + 'pla'], atol=1e-5)
+        est = flow_ref.dit_forward(torch.from_numpy(g[p + 'est_x']), torch.ones(2, 1, T), torch.from_numpy(g[p + 'est_mu']),
+                                   torch.from_numpy(g[p + 'est_t']), torch.from_numpy(g[p + 'est_spk']),
+                                   torch.from_numpy(g[p + 'est_cond']), sd, c)
+        assert np.allclose(est.numpy(), g[p + 'est_out'], atol=1e-4)
+        ptoken = torch.from_numpy(g[p + 'ptoken'])
+        has_p = ptoken.shape[1] > 0
+        mel = flow_ref.flow_inference(torch.from_numpy(g[p + 'token']), torch.from_numpy(g[p + 'emb']), sd, c,
+                                      prompt_token=ptoken if has_p else None,
+                                      prompt_feat=torch.from_numpy(g[p + 'pfeat']) if has_p else None)
+        assert mel.shape == g[p + 'mel'].shape
+        assert np.allclose(mel.numpy(), g[p + 'mel'], atol=2e-4)
+
+
+def test_cfm_schedule_and_cfg_combine():
+    # t-grid and CFG arithmetic with a stub linear estimator (flow_matching.py:71-124, 225-227)
+    ts = flow_ref.cosine_t_span(10)
+    assert ts[0] == 0 and abs(float(ts[-1]) - 1.0) < 1e-6 and torch.all(ts[1:] > ts[:-1])
+
+    def est(x, m, mu, t, s, c):
+        return 0.5 * x + mu + t[:, None, None]
+    x0 = torch.ones(1, 80, 4)
+    mu = 2 * torch.ones(1, 80, 4)
+    out, traj = flow_ref.solve_euler(x0, ts, mu, torch.ones(1, 1, 4), torch.zeros(1, 80), torch.zeros(1, 80, 4), est, 0.7)
+    x = x0.clone()
+    t = ts[0]
+    for k in range(10):
+        dt = ts[k + 1] - t
+        d = 1.7 * (0.5 * x + mu + t) - 0.7 * (0.5 * x + 0 + t)
+        x = x + dt * d
+        t = t + dt
+    assert torch.allclose(out, x, atol=1e-6)
+
+
+def test_hift_stages(tiny_cfg):
+    g = load_golden('hift_tiny.npz')
+    c = tiny_cfg.hift
+    sd = W.make_hift_state(c, seed=int(g['weight_seed']), init='fan_in')
+    assert state_checksum(sd) == str(g['weight_sha'])
+    tables = hift_ref.make_tables(c, seed=int(g['table_seed']))
+    for r in range(int(g['n_runs'])):
+        p = 'r%d_' % r
+        mel = torch.from_numpy(g[p + 'mel'])
+        f0 = hift_ref.f0_predictor(mel, sd)
+        assert np.allclose(f0.numpy(), g[p + 'f0'], atol=1e-3)
+        wav_s = hift_ref.decode(mel, torch.from_numpy(g[p + 'source']), sd, c)          # decode on the reference's source
+        assert np.allclose(wav_s.numpy(), g[p + 'wav'], atol=2e-4)
+        wav, s = hift_ref.hift_inference(mel, sd, c, tables)
+        assert wav.shape == (1, 480 * mel.shape[-1])
+        assert np.allclose(s.numpy(), g[p + 'source'], atol=1e-3)
+        # end to end the F0 -> phase accumulation amplifies fp32 rounding: looser bound
+        assert np.abs(wav.numpy() - g[p + 'wav']).max() < 5e-3
