@@ -1,0 +1,170 @@
+"""ctypes binding of libhvx.so (include/hvx.h).  The product path fails loudly when the library or a GPU
+is missing: there is no CPU fallback anywhere in this package."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libhvx.so')
+
+F32, BF16 = 0, 1
+
+# Act codes (csrc/hvx_device.h)
+ACT_NONE, ACT_GELU_TANH, ACT_SILU, ACT_MISH, ACT_ELU, ACT_LRELU, ACT_SNAKE, ACT_TANH, ACT_ABS = range(9)
+
+c_i32, c_i64, c_f32, c_vp, c_sz = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
+
+
+class HvxError(RuntimeError):
+    pass
+
+
+class SampleArgs(C.Structure):
+    _fields_ = [('n_seq', c_i32), ('head_k', c_i32), ('vocab', c_i32), ('speech_tokens', c_i32),
+                ('logp', c_vp), ('logp_seq_stride', c_i64), ('logp_head_stride', c_i64),
+                ('hist', c_vp), ('hist_seq_stride', c_i64), ('hist_len', c_vp),
+                ('min_len', c_vp), ('active', c_vp),
+                ('top_k', c_i32), ('top_p', c_f32), ('win_size', c_i32), ('rep_thresh', c_i32),
+                ('noise', c_vp), ('noise_seq_stride', c_i64), ('noise_len', c_i32),
+                ('cursor', c_vp), ('out_ids', c_vp), ('max_trials', c_i32)]
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [('dtype', c_i32), ('M', c_i32), ('N', c_i32), ('K', c_i32), ('batch', c_i32), ('groups', c_i32),
+                ('A', c_vp), ('a_bs', c_i64), ('lda', c_i32), ('a_gs', c_i32), ('rows_in', c_i32),
+                ('cin_pad', c_i32), ('conv_stride', c_i32), ('conv_dil', c_i32), ('pad_left', c_i32), ('up', c_i32),
+                ('W', c_vp), ('w_gs', c_i64),
+                ('bias', c_vp),
+                ('act', c_i32), ('act_param', c_f32), ('act_alpha', c_vp),
+                ('gate', c_vp), ('gate_bs', c_i64),
+                ('res', c_vp), ('res_bs', c_i64), ('ldres', c_i32), ('res_row_off', c_i32),
+                ('scale', c_f32),
+                ('out', c_vp), ('out_f32', c_i32), ('out_bs', c_i64), ('ldo', c_i32), ('out_row_off', c_i32), ('out_cols', c_i32),
+                ('out2', c_vp), ('act2', c_i32), ('act2_param', c_f32), ('act2_alpha', c_vp), ('out2_bs', c_i64),
+                ('ldo2', c_i32), ('out2_row_off', c_i32), ('out2_cols', c_i32)]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [('dtype', c_i32), ('batch', c_i32), ('heads', c_i32), ('t', c_i32), ('t_pad', c_i32),
+                ('q', c_vp), ('k', c_vp), ('vT', c_vp), ('out', c_vp), ('kv_len', c_vp),
+                ('causal', c_i32), ('scale', c_f32),
+                ('n_splits', c_i32), ('split_chunk', c_i32), ('part_o', c_vp), ('part_ml', c_vp)]
+
+
+class LLMConfig(C.Structure):
+    _fields_ = [('dtype', c_i32), ('hidden', c_i32), ('layers', c_i32), ('q_heads', c_i32), ('kv_heads', c_i32), ('inter', c_i32),
+                ('vocab', c_i32), ('vocab_pad', c_i32), ('speech_tokens', c_i32), ('text_vocab', c_i32),
+                ('head_num', c_i32), ('mtp_attn_dim', c_i32), ('mtp_inter', c_i32),
+                ('rms_eps', c_f32), ('mtp_rms_eps', c_f32), ('max_pos', c_i32)]
+
+
+class FlowConfig(C.Structure):
+    _fields_ = [('dtype', c_i32), ('vocab', c_i32), ('mel', c_i32), ('spk_dim', c_i32), ('pla_channels', c_i32), ('pla_len', c_i32),
+                ('dim', c_i32), ('depth', c_i32), ('heads', c_i32), ('ff', c_i32), ('conv_kernel', c_i32), ('conv_groups', c_i32),
+                ('time_freq_dim', c_i32), ('max_t', c_i32), ('cfg_rate', c_f32)]
+
+
+class HiftConfig(C.Structure):
+    _fields_ = [('mel', c_i32), ('base_channels', c_i32), ('nb_harmonics', c_i32), ('f0_channels', c_i32),
+                ('n_up', c_i32), ('up_rates', c_i32 * 4), ('up_kernels', c_i32 * 4),
+                ('n_rb', c_i32), ('rb_kernels', c_i32 * 4), ('rb_dils', (c_i32 * 3) * 4),
+                ('src_rb_kernels', c_i32 * 4), ('src_rb_dils', (c_i32 * 3) * 4),
+                ('n_fft', c_i32), ('hop', c_i32), ('conv_pre_kernel', c_i32), ('conv_post_kernel', c_i32),
+                ('sampling_rate', c_f32), ('nsf_alpha', c_f32), ('nsf_sigma', c_f32), ('voiced_threshold', c_f32),
+                ('lrelu_slope', c_f32), ('audio_limit', c_f32)]
+
+
+# every symbol include/hvx.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    'hvx_abi_version': (c_i32, []),
+    'hvx_last_error': (C.c_char_p, []),
+    'hvx_device_ok': (c_i32, []),
+    'hvx_ras_sample': (c_i32, [C.POINTER(SampleArgs), c_vp]),
+    'hvx_op_gemm': (c_i32, [C.POINTER(GemmArgs), c_vp]),
+    'hvx_op_attention': (c_i32, [C.POINTER(AttnArgs), c_vp]),
+    'hvx_op_skinny_gemm': (c_i32, [c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp]),
+    'hvx_llm_create': (c_i32, [C.POINTER(LLMConfig), C.POINTER(c_vp), c_i32, C.POINTER(c_vp)]),
+    'hvx_llm_destroy': (None, [c_vp]),
+    'hvx_llm_workspace_bytes': (c_sz, [c_vp, c_i32, c_i32, c_i32]),
+    'hvx_llm_kv_bytes': (c_sz, [c_vp, c_i32, c_i32]),
+    'hvx_llm_bind': (c_i32, [c_vp, c_vp, c_sz, c_i32, c_i32, c_vp, c_sz, c_i32, c_i32, c_vp]),
+    'hvx_llm_forward': (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp]),
+    'hvx_llm_last_hidden': (c_i32, [c_vp, c_vp, c_i32, c_vp]),
+    'hvx_flow_create': (c_i32, [C.POINTER(FlowConfig), C.POINTER(c_vp), c_i32, C.POINTER(c_vp)]),
+    'hvx_flow_destroy': (None, [c_vp]),
+    'hvx_flow_workspace_bytes': (c_sz, [c_vp, c_i32, c_i32]),
+    'hvx_flow_encode': (c_i32, [c_vp, c_vp, c_vp, c_sz, c_vp, c_i32, c_vp, c_vp, c_vp]),
+    'hvx_flow_prelookahead': (c_i32, [c_vp, c_vp, c_vp, c_sz, c_vp, c_i32, c_vp]),
+    'hvx_cfm_estimator': (c_i32, [c_vp, c_vp, c_vp, c_sz, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'hvx_cfm_solve': (c_i32, [c_vp, c_vp, c_vp, c_sz, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, C.POINTER(c_f32), C.POINTER(c_f32)]),
+    'hvx_hift_create': (c_i32, [C.POINTER(HiftConfig), C.POINTER(c_vp), c_i32, C.POINTER(c_vp)]),
+    'hvx_hift_destroy': (None, [c_vp]),
+    'hvx_hift_workspace_bytes': (c_sz, [c_vp, c_i32]),
+    'hvx_hift_f0': (c_i32, [c_vp, c_vp, c_vp, c_sz, c_vp, c_i32, c_vp]),
+    'hvx_hift_source': (c_i32, [c_vp, c_vp, c_vp, c_sz, c_vp, c_i32, c_vp, c_vp]),
+    'hvx_hift_decode': (c_i32, [c_vp, c_vp, c_vp, c_sz, c_vp, c_vp, c_i32, c_vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libhvx.so and bind every declared symbol.  Raises if the library was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HvxError('libhvx.so is missing at %s — run `python -m flowmirror_hydravox_amd.build` '
+                       '(hipcc --offload-arch=gfx950); there is no CPU fallback' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.hvx_abi_version() != 1:
+        raise HvxError('libhvx ABI version mismatch')
+    _lib = lib
+    return lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = load().hvx_last_error()
+        raise HvxError('%s failed: %s' % (what or 'hvx call', msg.decode() if msg else 'unknown error'))
+
+
+def require_gpu():
+    lib = load()
+    import torch
+    if not torch.cuda.is_available():
+        raise HvxError('no ROCm device visible: the HydraVox hot path runs on MI355X only (no CPU fallback)')
+    n = lib.hvx_device_ok()
+    if n <= 0:
+        msg = lib.hvx_last_error()
+        raise HvxError('libhvx cannot use the current device: %s' % (msg.decode() if msg else 'no gfx950 device'))
+    return n
+
+
+def ptr(t):
+    """Device/host pointer of a torch tensor (or None)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dtype_code(torch_dtype):
+    import torch
+    if torch_dtype == torch.float32:
+        return F32
+    if torch_dtype == torch.bfloat16:
+        return BF16
+    raise HvxError('unsupported dtype %s (hvx computes in bf16 or f32)' % torch_dtype)
+
+
+def ptr_array(tensors):
+    arr = (c_vp * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr

@@ -1,0 +1,248 @@
+// attention.hip — flash-style attention, head_dim 64, for gfx950 (see hvx_kernels.h: AttnArgs).
+//
+// One wave64 owns QT 16-row query tiles and walks its key range 32 keys at a time; there is no LDS
+// and no barrier (K / V^T fragments come straight from L2: both are produced fragment-friendly by
+// the fused QKV epilogues — K as [key][64], V already transposed as V^T [64][key]).
+//
+// Orientation (everything stays in registers):
+//   S^T[key, q] = K . Q^T          A = K rows (8 consecutive d per lane), B = Q^T (8 consecutive d per lane)
+//   C-layout of S^T: lane holds column q = lane & 15 and keys 4g..4g+3 (g = lane >> 4) of each 16-key tile
+//   -> a query's scores live in the 4 lanes {q, q+16, q+32, q+48}: row max / sum = 2 xor-shuffles.
+//   O^T[d, q] += V^T . P^T         the MFMA k-slot (g, j) is *defined* as key 4g+j (j<4) / 16+4g+(j-4) (j>=4)
+//   of the 32-key step, which is exactly what the lane already holds after the S^T MFMAs (no permute,
+//   no LDS round trip); V^T is read with the same slot->key map (two 4-key vectors per lane).
+// Used by: DiT self-attention (non-causal, key padding via kv_len), LLM prefill and decode (causal,
+// GQA-packed: the 7 query heads of a KV head are stacked as rows so each K/V byte is read once,
+// optional key splits with (m, l, o) partials combined by attn_combine_kernel).
+#include "hvx_device.h"
+#include "hvx_kernels.h"
+
+namespace hvx {
+
+template <class T> struct Vec4;
+template <> struct Vec4<bf16_t> { typedef bf16x4 type; };
+template <> struct Vec4<float> { typedef f32x4 type; };
+__device__ __forceinline__ bf16x4 load4(const bf16_t* p) { return *reinterpret_cast<const bf16x4*>(p); }
+__device__ __forceinline__ f32x4 load4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+template <class T, int QT>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+    typedef typename Vec8<T>::type V8;
+    typedef typename Vec4<T>::type V4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int n_qt = (a.n_rows + 16 * QT - 1) / (16 * QT);
+    const int w = blockIdx.x * 4 + wave;
+    if (w >= n_qt * a.n_splits) return;
+    const int qt = w / a.n_splits, sp = w - qt * a.n_splits;
+
+    const int kv_len = a.kv_len ? a.kv_len[b] : a.kv_len_const;
+    const int pos0 = (a.causal && a.pos0) ? a.pos0[b] : 0;
+    const int n_valid_lo = a.n_valid_lo ? a.n_valid_lo[b] : a.kn;
+    int key_begin = 0, key_end = kv_len;
+    if (a.n_splits > 1) {
+        key_begin = sp * a.split_chunk;
+        key_end = min(kv_len, key_begin + a.split_chunk);
+    }
+
+    // ---- this lane's query rows (one per q-tile) -----------------------------------------------------
+    int r_lo[QT];
+    bool r_ok[QT];
+    V8 qf[QT][2];
+    int max_pos = -1;
+#pragma unroll
+    for (int i = 0; i < QT; ++i) {
+        const int r = (qt * QT + i) * 16 + fr;
+        const int rh = r / a.kn;
+        r_lo[i] = r - rh * a.kn;
+        r_ok[i] = (r < a.n_rows) && (r_lo[i] < n_valid_lo);
+        if (r_ok[i]) {
+            const T* qp = reinterpret_cast<const T*>(a.q) + (long long)b * a.q_bs + (long long)h * a.q_hs + (long long)rh * a.q_hi +
+                          (long long)r_lo[i] * a.q_lo + fg * 8;
+            qf[i][0] = load8(qp);
+            qf[i][1] = load8(qp + 32);
+            max_pos = max(max_pos, pos0 + r_lo[i]);
+        } else {
+            qf[i][0] = zero8<T>();
+            qf[i][1] = zero8<T>();
+        }
+    }
+    if (a.causal) {
+        // no key beyond the largest visible position of this wave's rows needs to be touched
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) max_pos = max(max_pos, __shfl_xor(max_pos, o, 64));
+        key_end = min(key_end, max_pos + 1);
+    }
+
+    const int slot = a.kv_slot ? a.kv_slot[b] : b;
+    const T* __restrict__ kb = reinterpret_cast<const T*>(a.k) + (long long)slot * a.k_bs + (long long)h * a.k_hs;
+    const T* __restrict__ vb = reinterpret_cast<const T*>(a.vT) + (long long)slot * a.v_bs + (long long)h * a.v_hs;
+
+    float m_run[QT], l_run[QT];
+    f32x4 o_acc[QT][4];
+#pragma unroll
+    for (int i = 0; i < QT; ++i) {
+        m_run[i] = -INFINITY;
+        l_run[i] = 0.0f;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o_acc[i][dt] = f32x4{0, 0, 0, 0};
+    }
+
+    for (int key0 = key_begin; key0 < key_end; key0 += 32) {
+        // K fragments: 2 key tiles x 2 d-halves.  Rows past the end are clamped (their scores are masked by select).
+        V8 kf[2][2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            int key = key0 + kt * 16 + fr;
+            key = key < kv_len ? key : (kv_len - 1);
+            const T* kp = kb + (long long)key * 64 + fg * 8;
+            kf[kt][0] = load8(kp);
+            kf[kt][1] = load8(kp + 32);
+        }
+        // V^T fragments: 4 d-tiles, keys {4g..4g+3} and {16+4g..16+4g+3} of this 32-key step
+        V8 vf[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const T* vp = vb + (long long)(dt * 16 + fr) * a.v_ld + key0 + fg * 4;
+            const V4 lo = load4(vp), hi = load4(vp + 16);
+            V8 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j] = lo[j];
+                v[4 + j] = hi[j];
+            }
+            vf[dt] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < QT; ++i) {
+            f32x4 s[2];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                s[kt] = f32x4{0, 0, 0, 0};
+                mma32(s[kt], kf[kt][0], qf[i][0]);
+                mma32(s[kt], kf[kt][1], qf[i][1]);
+            }
+            // scale, mask, running max
+            const int lim = a.causal ? min(key_end, pos0 + r_lo[i] + 1) : key_end;
+            float sv[8];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = key0 + kt * 16 + fg * 4 + r;
+                    const float x = (key < lim) ? s[kt][r] * a.scale : -INFINITY;
+                    sv[kt * 4 + r] = x;
+                    mx = fmaxf(mx, x);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[i], mx);
+            const float m_safe = (m_new == -INFINITY) ? 0.0f : m_new;
+            const float alpha = (m_run[i] == -INFINITY) ? 0.0f : expf(m_run[i] - m_safe);
+            float psum = 0.0f;
+            V8 pf;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float p = (sv[e] == -INFINITY) ? 0.0f : expf(sv[e] - m_safe);
+                psum += p;
+                pf[e] = from_f32<T>(p);
+            }
+            l_run[i] = l_run[i] * alpha + psum;
+            m_run[i] = m_new;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                o_acc[i][dt] *= alpha;
+                mma32(o_acc[i][dt], vf[dt], pf);
+            }
+        }
+    }
+
+    // ---- finish -------------------------------------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < QT; ++i) {
+        float l = l_run[i];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const int r = (qt * QT + i) * 16 + fr;
+        if (!r_ok[i]) continue;
+        const int rh = r / a.kn;
+        if (a.n_splits == 1) {
+            const float inv = l > 0.0f ? 1.0f / l : 0.0f;
+            T* op = reinterpret_cast<T*>(a.out) + (long long)b * a.o_bs + (long long)h * a.o_hs + (long long)rh * a.o_hi +
+                    (long long)r_lo[i] * a.o_lo;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) op[dt * 16 + fg * 4 + e] = from_f32<T>(o_acc[i][dt][e] * inv);
+        } else {
+            const long long base = (((long long)b * a.heads + h) * a.n_splits + sp) * a.n_rows_pad + r;
+            float* po = a.part_o + base * 64;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) po[dt * 16 + fg * 4 + e] = o_acc[i][dt][e];
+            if (fg == 0) {
+                a.part_ml[base * 2 + 0] = m_run[i];
+                a.part_ml[base * 2 + 1] = l;
+            }
+        }
+    }
+}
+
+// out[row, :] = sum_s exp(m_s - m) o_s / sum_s exp(m_s - m) l_s      (fixed split order: deterministic)
+template <class T>
+__global__ void attn_combine_kernel(AttnArgs a) {
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int d = threadIdx.x & 63;
+    if (r >= a.n_rows) return;
+    const int rh = r / a.kn, rl = r - rh * a.kn;
+    const int n_valid_lo = a.n_valid_lo ? a.n_valid_lo[b] : a.kn;
+    if (rl >= n_valid_lo) return;
+    float m = -INFINITY;
+    for (int s = 0; s < a.n_splits; ++s) {
+        const long long base = (((long long)b * a.heads + h) * a.n_splits + s) * a.n_rows_pad + r;
+        m = fmaxf(m, a.part_ml[base * 2]);
+    }
+    float acc = 0.0f, l = 0.0f;
+    for (int s = 0; s < a.n_splits; ++s) {
+        const long long base = (((long long)b * a.heads + h) * a.n_splits + s) * a.n_rows_pad + r;
+        const float ms = a.part_ml[base * 2];
+        const float wgt = (ms == -INFINITY) ? 0.0f : expf(ms - m);
+        acc += wgt * a.part_o[base * 64 + d];
+        l += wgt * a.part_ml[base * 2 + 1];
+    }
+    T* op = reinterpret_cast<T*>(a.out) + (long long)b * a.o_bs + (long long)h * a.o_hs + (long long)rh * a.o_hi + (long long)rl * a.o_lo;
+    op[d] = from_f32<T>(l > 0.0f ? acc / l : 0.0f);
+}
+
+template <class T>
+static int launch_t(const AttnArgs& a, hipStream_t s) {
+    const bool big = a.n_rows >= 256;
+    const int rows_per_wave = big ? 32 : 16;
+    const int n_qt = (a.n_rows + rows_per_wave - 1) / rows_per_wave;
+    dim3 grid((n_qt * a.n_splits + 3) / 4, a.heads, a.batch);
+    if (big) hipLaunchKernelGGL((attn_fwd_kernel<T, 2>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<T, 1>), grid, dim3(256), 0, s, a);
+    if (a.n_splits > 1) {
+        dim3 g2((a.n_rows + 3) / 4, a.heads, a.batch);
+        hipLaunchKernelGGL((attn_combine_kernel<T>), g2, dim3(256), 0, s, a);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : (set_error("attention launch failed"), -1);
+}
+
+int launch_attention(const AttnArgs& a_in, hipStream_t s) {
+    AttnArgs a = a_in;
+    if (a.n_rows <= 0 || a.batch <= 0) return 0;
+    if (a.n_splits < 1) a.n_splits = 1;
+    if (a.kn < 1) a.kn = a.n_rows;
+    if ((a.v_ld & 31) || (a.n_splits > 1 && ((a.split_chunk & 31) || !a.part_o || !a.part_ml || a.n_rows_pad < a.n_rows))) {
+        set_error("launch_attention: bad geometry v_ld=%d split_chunk=%d", a.v_ld, a.split_chunk);
+        return -1;
+    }
+    return a.dtype == DT_BF16 ? launch_t<bf16_t>(a, s) : launch_t<float>(a, s);
+}
+
+}  // namespace hvx

@@ -1,0 +1,298 @@
+// elementwise.hip — small fused HBM-bound kernels of the hot path (norms, gathers, CFG/Euler update).
+// All of them are one pass over their data with coalesced row-contiguous accesses; statistics are
+// reduced with wave64 shuffles (+ one LDS hop across the 4 waves of a workgroup).
+#include "hvx_device.h"
+#include "hvx_kernels.h"
+
+namespace hvx {
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.0f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+    return t;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = -INFINITY;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t = fmaxf(t, red[w]);
+    return t;
+}
+
+// ---- split-K reduce + residual + RMSNorm (Qwen2 RMSNorm: fp32 statistics, eps inside rsqrt) ----------
+template <class T>
+__global__ __launch_bounds__(256) void reduce_rmsnorm_kernel(ReduceNormArgs a) {
+    __shared__ float red[4];
+    const int m = blockIdx.x, H = a.H;
+    const int z = m / a.rows_per_z, mz = m - z * a.rows_per_z;
+    float* xr = a.x + (long long)m * a.ldx;
+    const float* part = a.part ? a.part + (long long)z * a.part_zs + (long long)mz * H : nullptr;
+    const float* bias = a.bias ? a.bias + (long long)z * a.bias_zs : nullptr;
+    const float* gain = a.gain ? a.gain + (long long)z * a.gain_zs : nullptr;
+    float ss = 0.0f;
+    for (int c = threadIdx.x; c < H; c += 256) {
+        float v = xr[c];
+        if (part) {
+            float acc = 0.0f;
+            for (int s = 0; s < a.split_k; ++s) acc += part[(long long)s * a.part_stride + c];   // fixed order: deterministic
+            v += acc;
+            if (bias) v += bias[c];
+            xr[c] = v;
+        }
+        ss += v * v;
+    }
+    if (!a.y) return;
+    T* y = reinterpret_cast<T*>(a.y) + (long long)m * a.ldy;
+    if (!a.do_norm) {
+        for (int c = threadIdx.x; c < H; c += 256) y[c] = from_f32<T>(xr[c]);
+        return;
+    }
+    ss = block_sum(ss, red);
+    const float inv = rsqrtf(ss / (float)H + a.eps);
+    for (int c = threadIdx.x; c < H; c += 256) {
+        const float v = xr[c] * inv;
+        y[c] = from_f32<T>(gain ? gain[c] * to_f32(from_f32<T>(v)) : v);
+    }
+}
+
+int launch_reduce_rmsnorm(const ReduceNormArgs& a_in, hipStream_t s) {
+    ReduceNormArgs a = a_in;
+    if (a.M <= 0) return 0;
+    if (a.rows_per_z <= 0) a.rows_per_z = a.M;
+    if (a.dtype == DT_BF16) hipLaunchKernelGGL(reduce_rmsnorm_kernel<bf16_t>, dim3(a.M), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(reduce_rmsnorm_kernel<float>, dim3(a.M), dim3(256), 0, s, a);
+    return hipGetLastError() == hipSuccess ? 0 : (set_error("reduce_rmsnorm launch failed"), -1);
+}
+
+template <class T>
+__global__ void act_rows_kernel(const float* x, int ldx, T* y, int ldy, int act, float param, const float* alpha, long long rows, int cols) {
+    const long long total = rows * cols;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / cols;
+        const int c = (int)(i - r * cols);
+        y[r * ldy + c] = from_f32<T>(act_apply(act, x[r * ldx + c], param, alpha ? alpha[c] : 1.0f));
+    }
+}
+int launch_act_rows(const float* x, int ldx, void* y, int ldy, int dtype, int act, float param, const float* alpha, long long rows, int cols,
+                    hipStream_t s) {
+    if (rows <= 0 || cols <= 0) return 0;
+    const long long want = (rows * cols + 255) / 256;
+    const int blocks = (int)(want < 8192 ? want : 8192);
+    if (dtype == DT_BF16) hipLaunchKernelGGL(act_rows_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, x, ldx, (bf16_t*)y, ldy, act, param, alpha, rows, cols);
+    else hipLaunchKernelGGL(act_rows_kernel<float>, dim3(blocks), dim3(256), 0, s, x, ldx, (float*)y, ldy, act, param, alpha, rows, cols);
+    return hipGetLastError() == hipSuccess ? 0 : (set_error("act_rows launch failed"), -1);
+}
+
+// ---- row gathers ----------------------------------------------------------------------------------------
+__global__ void gather_rows_kernel(const float* x, int ldx, const int* idx, float* y, int ldy, int H) {
+    const int r = blockIdx.x;
+    const int src = idx[r];
+    for (int c = threadIdx.x; c < H; c += blockDim.x) y[(long long)r * ldy + c] = src >= 0 ? x[(long long)src * ldx + c] : 0.0f;
+}
+int launch_gather_rows_f32(const float* x, int ldx, const int* idx, float* y, int ldy, int rows, int H, hipStream_t s) {
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(rows), dim3(256), 0, s, x, ldx, idx, y, ldy, H);
+    return hipGetLastError() == hipSuccess ? 0 : (set_error("gather_rows launch failed"), -1);
+}
+
+template <class T>
+__global__ void embed_kernel(const T* table, const int* tok, float* x, int ldx, int H) {
+    const int r = blockIdx.x;
+    const int t = tok[r];
+    for (int c = threadIdx.x; c < H; c += blockDim.x) x[(long long)r * ldx + c] = t >= 0 ? to_f32(table[(long long)t * H + c]) : 0.0f;
+}
+int launch_embed(const void* table, int table_dtype, const int* tok, float* x, int ldx, int rows, int H, hipStream_t s) {
+    if (rows <= 0) return 0;
+    if (table_dtype == DT_BF16)
+        hipLaunchKernelGGL(embed_kernel<bf16_t>, dim3(rows), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(table), tok, x, ldx, H);
+    else
+        hipLaunchKernelGGL(embed_kernel<float>, dim3(rows), dim3(256), 0, s, reinterpret_cast<const float*>(table), tok, x, ldx, H);
+    return hipGetLastError() == hipSuccess ? 0 : (set_error("embed launch failed"), -1);
+}
+
+template <class T>
+__global__ void embed2_kernel(const T* speech, const T* text, const int* tok, float* x, int ldx, int H) {
+    const int r = blockIdx.x;
+    const int t = tok[r];
+    const T* src = t >= 0 ? speech + (long long)t * H : (t <= -2 ? text + (long long)(-t - 2) * H : nullptr);
+    for (int c = threadIdx.x; c < H; c += blockDim.x) x[(long long)r * ldx + c] = src ? to_f32(src[c]) : 0.0f;
+}
+int launch_embed2(const void* speech, const void* text, int dtype, const int* tok, float* x, int ldx, int rows, int H, hipStream_t s) {
+    if (rows <= 0) return 0;
+    if (dtype == DT_BF16)
+        hipLaunchKernelGGL(embed2_kernel<bf16_t>, dim3(rows), dim3(256), 0, s, (const bf16_t*)speech, (const bf16_t*)text, tok, x, ldx, H);
+    else
+        hipLaunchKernelGGL(embed2_kernel<float>, dim3(rows), dim3(256), 0, s, (const float*)speech, (const float*)text, tok, x, ldx, H);
+    return hipGetLastError() == hipSuccess ? 0 : (set_error("embed2 launch failed"), -1);
+}
+
+// ---- log_softmax over V (llm_multi_head_v3.py:888) ------------------------------------------------------
+__global__ __launch_bounds__(256) void log_softmax_kernel(float* x, int ld, int V) {
+    __shared__ float red[4];
+    float* xr = x + (long long)blockIdx.x * ld;
+    float mx = -INFINITY;
+    for (int c = threadIdx.x; c < V; c += 256) mx = fmaxf(mx, xr[c]);
+    mx = block_max(mx, red);
+    float sum = 0.0f;
+    for (int c = threadIdx.x; c < V; c += 256) sum += expf(xr[c] - mx);
+    sum = block_sum(sum, red);
+    const float lse = mx + logf(sum);
+    for (int c = threadIdx.x; c < V; c += 256) xr[c] = xr[c] - lse;
+}
+int launch_log_softmax(float* x, int ld, int rows, int V, hipStream_t s) {
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(log_softmax_kernel, dim3(rows), dim3(256), 0, s, x, ld, V);
+    return hipGetLastError() == hipSuccess ? 0 : (set_error("log_softmax launch failed"), -1);
+}
+
+// ---- DiT adaLN: LayerNorm (no affine, biased variance, eps) then (1 + scale) * . + shift -----------------
+template <class T>
+__global__ __launch_bounds__(256) void layernorm_mod_kernel(const float* x, const float* shift, const float* scale, long long mod_bs, float eps,
+                                                            T* y, int T_, int D) {
+    // one wave per row, 4 rows per workgroup
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.y;
+    if (row >= T_) return;
+    const int lane = threadIdx.x & 63;
+    const float* xr = x + ((long long)b * T_ + row) * D;
+    float s1 = 0.0f;
+    for (int c = lane; c < D; c += 64) s1 += xr[c];
+    const float mean = wave_sum(s1) / (float)D;
+    float s2 = 0.0f;
+    for (int c = lane; c < D; c += 64) {
+        const float d = xr[c] - mean;
+        s2 += d * d;
+    }
+    const float inv = rsqrtf(wave_sum(s2) / (float)D + eps);
+    const float* sh = shift + (long long)b * mod_bs;
+    const float* sc = scale + (long long)b * mod_bs;
+    T* yr = y + ((long long)b * T_ + row) * D;
+    for (int c = lane; c < D; c += 64) yr[c] = from_f32<T>((xr[c] - mean) * inv * (1.0f + sc[c]) + sh[c]);
+}
+int launch_layernorm_mod(const float* x, const float* shift, const float* scale, long long mod_bs, float eps, void* y, int dtype, int B, int T_,
+                         int D, hipStream_t s) {
+    if (B <= 0 || T_ <= 0) return 0;
+    dim3 grid((T_ + 3) / 4, B);
+    if (dtype == DT_BF16)
+        hipLaunchKernelGGL(layernorm_mod_kernel<bf16_t>, grid, dim3(256), 0, s, x, shift, scale, mod_bs, eps, reinterpret_cast<bf16_t*>(y), T_, D);
+    else
+        hipLaunchKernelGGL(layernorm_mod_kernel<float>, grid, dim3(256), 0, s, x, shift, scale, mod_bs, eps, reinterpret_cast<float*>(y), T_, D);
+    return hipGetLastError() == hipSuccess ? 0 : (set_error("layernorm_mod launch failed"), -1);
+}
+
+// ---- DiT input: cat[x, cond, mu, spks] as time-major rows (dit.py:91-97) ---------------------------------
+template <class T>
+__global__ void dit_concat_kernel(const float* x, const float* cond, const float* mu, const float* spk, T* y, int T_, int mel) {
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * blockDim.y + threadIdx.y;
+    if (t >= T_) return;
+    const int W = 4 * mel;
+    for (int c = threadIdx.x; c < W; c += blockDim.x) {
+        const int which = c / mel, ch = c - which * mel;
+        float v;
+        if (which == 0) v = x[((long long)b * mel + ch) * T_ + t];
+        else if (which == 1) v = cond[((long long)b * mel + ch) * T_ + t];
+        else if (which == 2) v = mu[((long long)b * mel + ch) * T_ + t];
+        else v = spk[(long long)b * mel + ch];
+        y[((long long)b * T_ + t) * W + c] = from_f32<T>(v);
+    }
+}
+int launch_dit_concat(const float* x, const float* cond, const float* mu, const float* spk, void* y, int dtype, int B, int T_, int mel,
+                      hipStream_t s) {
+    if (B <= 0 || T_ <= 0) return 0;
+    dim3 block(64, 4), grid((T_ + 3) / 4, B);
+    if (dtype == DT_BF16) hipLaunchKernelGGL(dit_concat_kernel<bf16_t>, grid, block, 0, s, x, cond, mu, spk, reinterpret_cast<bf16_t*>(y), T_, mel);
+    else hipLaunchKernelGGL(dit_concat_kernel<float>, grid, block, 0, s, x, cond, mu, spk, reinterpret_cast<float*>(y), T_, mel);
+    return hipGetLastError() == hipSuccess ? 0 : (set_error("dit_concat launch failed"), -1);
+}
+
+// ---- sinusoidal timestep embedding (modules.py:71-83, scale 1000) ----------------------------------------
+template <class T>
+__global__ void time_sinus_kernel(const float* t, T* y, int dim) {
+    const int b = blockIdx.x, half = dim / 2;
+    const float step = logf(10000.0f) / (float)(half - 1);
+    for (int i = threadIdx.x; i < half; i += blockDim.x) {
+        const float e = expf((float)i * -step);
+        const float v = 1000.0f * t[b] * e;
+        y[(long long)b * dim + i] = from_f32<T>(sinf(v));
+        y[(long long)b * dim + half + i] = from_f32<T>(cosf(v));
+    }
+}
+int launch_time_sinus(const float* t, void* y, int dtype, int B, int dim, hipStream_t s) {
+    if (B <= 0) return 0;
+    if (dtype == DT_BF16) hipLaunchKernelGGL(time_sinus_kernel<bf16_t>, dim3(B), dim3(128), 0, s, t, reinterpret_cast<bf16_t*>(y), dim);
+    else hipLaunchKernelGGL(time_sinus_kernel<float>, dim3(B), dim3(128), 0, s, t, reinterpret_cast<float*>(y), dim);
+    return hipGetLastError() == hipSuccess ? 0 : (set_error("time_sinus launch failed"), -1);
+}
+
+// ---- classifier-free guidance + Euler update (flow_matching.py:116-120) -----------------------------------
+__global__ void cfg_euler_kernel(float* x, const float* v, int ldv, long long v_bs, float dt, float rate, int T_, int mel) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ch = blockIdx.y;
+    if (t >= T_) return;
+    const float vc = v[(long long)t * ldv + ch], vu = v[v_bs + (long long)t * ldv + ch];
+    const float d = (1.0f + rate) * vc - rate * vu;
+    x[(long long)ch * T_ + t] = x[(long long)ch * T_ + t] + dt * d;
+}
+int launch_cfg_euler(float* x, const float* v, int ldv, long long v_bs, float dt, float rate, int T_, int mel, hipStream_t s) {
+    if (T_ <= 0) return 0;
+    hipLaunchKernelGGL(cfg_euler_kernel, dim3((T_ + 255) / 256, mel), dim3(256), 0, s, x, v, ldv, v_bs, dt, rate, T_, mel);
+    return hipGetLastError() == hipSuccess ? 0 : (set_error("cfg_euler launch failed"), -1);
+}
+
+// ---- casts / layout helpers --------------------------------------------------------------------------------
+template <class S, class D>
+__global__ void cast_kernel(const S* src, D* dst, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        dst[i] = from_f32<D>(to_f32(src[i]));
+}
+int launch_cast(const void* src, int sd, void* dst, int dd, long long n, hipStream_t s) {
+    if (n <= 0) return 0;
+    const long long want = (n + 255) / 256;
+    const int blocks = (int)(want < 4096 ? want : 4096);
+    if (sd == DT_F32 && dd == DT_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(blocks), dim3(256), 0, s, (const float*)src, (bf16_t*)dst, n);
+    else if (sd == DT_BF16 && dd == DT_F32) hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)src, (float*)dst, n);
+    else if (sd == DT_F32 && dd == DT_F32) hipLaunchKernelGGL((cast_kernel<float, float>), dim3(blocks), dim3(256), 0, s, (const float*)src, (float*)dst, n);
+    else hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, n);
+    return hipGetLastError() == hipSuccess ? 0 : (set_error("cast launch failed"), -1);
+}
+
+__global__ void transpose_kernel(const float* src, float* dst, int rows, int cols, int ld_src, int ld_dst) {
+    __shared__ float tile[32][33];
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+        const int r = r0 + i, c = c0 + threadIdx.x;
+        tile[i][threadIdx.x] = (r < rows && c < cols) ? src[(long long)r * ld_src + c] : 0.0f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+        const int c = c0 + i, r = r0 + threadIdx.x;
+        if (c < cols && r < rows) dst[(long long)c * ld_dst + r] = tile[threadIdx.x][i];
+    }
+}
+int launch_transpose_f32(const float* src, float* dst, int rows, int cols, int ld_src, int ld_dst, hipStream_t s) {
+    if (rows <= 0 || cols <= 0) return 0;
+    hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(32, 8), 0, s, src, dst, rows, cols, ld_src, ld_dst);
+    return hipGetLastError() == hipSuccess ? 0 : (set_error("transpose launch failed"), -1);
+}
+
+template <class D>
+__global__ void rows_to_dtype_kernel(const float* src, int ld_src, D* dst, int ld_dst, int cols, int cols_pad) {
+    const int r = blockIdx.x;
+    for (int c = threadIdx.x; c < cols_pad; c += blockDim.x)
+        dst[(long long)r * ld_dst + c] = from_f32<D>(c < cols ? src[(long long)r * ld_src + c] : 0.0f);
+}
+int launch_rows_to_dtype(const float* src, int ld_src, void* dst, int dd, int ld_dst, int rows, int cols, int cols_pad, hipStream_t s) {
+    if (rows <= 0) return 0;
+    if (dd == DT_BF16) hipLaunchKernelGGL(rows_to_dtype_kernel<bf16_t>, dim3(rows), dim3(128), 0, s, src, ld_src, (bf16_t*)dst, ld_dst, cols, cols_pad);
+    else hipLaunchKernelGGL(rows_to_dtype_kernel<float>, dim3(rows), dim3(128), 0, s, src, ld_src, (float*)dst, ld_dst, cols, cols_pad);
+    return hipGetLastError() == hipSuccess ? 0 : (set_error("rows_to_dtype launch failed"), -1);
+}
+
+}  // namespace hvx

@@ -1,0 +1,109 @@
+// hvx_api.hip — C-ABI glue: error text, device probe, operator-level entry points (include/hvx.h).
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "hvx.h"
+#include "hvx_kernels.h"
+
+namespace hvx {
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+}  // namespace hvx
+
+using namespace hvx;
+
+extern "C" {
+
+int hvx_abi_version(void) { return HVX_ABI_VERSION; }
+const char* hvx_last_error(void) { return g_err; }
+
+int hvx_device_ok(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 0;
+    if (strncmp(p.gcnArchName, "gfx950", 6) != 0) {
+        set_error("libhvx is built for gfx950 only, found %s", p.gcnArchName);
+        return 0;
+    }
+    return p.multiProcessorCount;
+}
+
+int hvx_ras_sample(const hvx_sample_args* a, hvx_stream s) {
+    if (!a) return set_error("hvx_ras_sample: null args"), -1;
+    SampleArgs k;
+    k.n_seq = a->n_seq; k.head_k = a->head_k; k.V = a->vocab; k.Vs = a->speech_tokens;
+    k.logp = a->logp; k.logp_ss = a->logp_seq_stride; k.logp_hs = a->logp_head_stride;
+    k.hist = a->hist; k.hist_ss = a->hist_seq_stride; k.hist_len = a->hist_len;
+    k.min_len = a->min_len; k.active = a->active;
+    k.top_k = a->top_k; k.top_p = a->top_p; k.win_size = a->win_size; k.rep_thresh = a->rep_thresh;
+    k.noise = a->noise; k.noise_ss = a->noise_seq_stride; k.noise_len = a->noise_len;
+    k.cursor = (long long*)a->cursor; k.out_ids = a->out_ids; k.max_trials = a->max_trials;
+    return launch_ras_sample(k, (hipStream_t)s);
+}
+
+int hvx_op_gemm(const hvx_gemm_args* a, hvx_stream s) {
+    if (!a) return set_error("hvx_op_gemm: null args"), -1;
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.dtype = a->dtype; g.M = a->M; g.N = a->N; g.K = a->K; g.batch = a->batch; g.groups = a->groups;
+    g.A = a->A; g.a_bs = a->a_bs; g.lda = a->lda; g.a_gs = a->a_gs; g.rows_in = a->rows_in;
+    g.cin_pad = a->cin_pad; g.conv_stride = a->conv_stride; g.conv_dil = a->conv_dil; g.pad_left = a->pad_left; g.up = a->up;
+    g.W = a->W; g.w_gs = a->w_gs; g.epi = EPI_GENERIC;
+    g.bias = a->bias; g.act = a->act; g.act_param = a->act_param; g.act_alpha = a->act_alpha;
+    g.gate = a->gate; g.gate_bs = a->gate_bs;
+    g.res = a->res; g.res_bs = a->res_bs; g.ldres = a->ldres; g.res_row_off = a->res_row_off;
+    g.scale = a->scale;
+    g.out = a->out; g.out_f32 = a->out_f32; g.out_bs = a->out_bs; g.ldo = a->ldo; g.out_row_off = a->out_row_off; g.out_cols = a->out_cols;
+    g.out2 = a->out2; g.act2 = a->act2; g.act2_param = a->act2_param; g.act2_alpha = a->act2_alpha; g.out2_bs = a->out2_bs;
+    g.ldo2 = a->ldo2; g.out2_row_off = a->out2_row_off; g.out2_cols = a->out2_cols;
+    return launch_gemm(g, (hipStream_t)s);
+}
+
+int hvx_op_attention(const hvx_attn_args* a, hvx_stream s) {
+    if (!a) return set_error("hvx_op_attention: null args"), -1;
+    AttnArgs k;
+    memset(&k, 0, sizeof(k));
+    const long long D = (long long)a->heads * 64;
+    k.dtype = a->dtype; k.batch = a->batch; k.heads = a->heads; k.n_rows = a->t; k.kn = a->t;
+    k.q = a->q; k.q_bs = (long long)a->heads * a->t_pad * 64; k.q_hs = (long long)a->t_pad * 64; k.q_hi = 0; k.q_lo = 64;
+    k.k = a->k; k.k_bs = k.q_bs; k.k_hs = k.q_hs;
+    k.vT = a->vT; k.v_bs = k.q_bs; k.v_hs = (long long)64 * a->t_pad; k.v_ld = a->t_pad;
+    k.kv_len = a->kv_len; k.kv_len_const = a->t; k.causal = a->causal; k.scale = a->scale;
+    k.out = a->out; k.o_bs = (long long)a->t * D; k.o_hs = 64; k.o_hi = 0; k.o_lo = D;
+    k.n_splits = a->n_splits > 1 ? a->n_splits : 1; k.split_chunk = a->split_chunk; k.part_o = a->part_o; k.part_ml = a->part_ml;
+    k.n_rows_pad = (a->t + 31) & ~31;
+    return launch_attention(k, (hipStream_t)s);
+}
+
+int hvx_op_skinny_gemm(int32_t dtype, int32_t M, int32_t N, int32_t K, const void* A, int32_t lda, const void* Wpacked, const float* bias,
+                       int32_t split_k, float* part_ws, float* out_f32, int32_t ldo, hvx_stream s) {
+    SkinnyArgs k;
+    memset(&k, 0, sizeof(k));
+    k.dtype = dtype; k.M = M; k.N = N; k.K = K; k.A = A; k.lda = lda; k.W = Wpacked; k.nz = 1;
+    if (split_k <= 1) {
+        k.split_k = 1; k.epi = SK_STORE; k.bias = bias; k.out = out_f32; k.out_f32 = 1; k.ldo = ldo;
+        return launch_skinny(k, (hipStream_t)s);
+    }
+    // split-K: partials + deterministic reduce into a zero-initialised output (uses the same kernels as the LLM step)
+    k.split_k = split_k; k.epi = SK_PARTIAL; k.part = part_ws;
+    if (launch_skinny(k, (hipStream_t)s)) return -1;
+    if (hipMemset2DAsync(out_f32, (size_t)ldo * 4, 0, (size_t)N * 4, M, (hipStream_t)s) != hipSuccess) return set_error("memset failed"), -1;
+    ReduceNormArgs r;
+    memset(&r, 0, sizeof(r));
+    r.x = out_f32; r.ldx = ldo; r.part = part_ws; r.split_k = split_k; r.part_stride = (long long)M * N; r.bias = bias;
+    r.M = M; r.H = N; r.rows_per_z = M; r.dtype = DT_F32;
+    return launch_reduce_rmsnorm(r, (hipStream_t)s);
+}
+
+}  // extern "C"

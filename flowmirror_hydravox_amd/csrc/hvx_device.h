@@ -1,0 +1,126 @@
+// hvx_device.h — device-side building blocks shared by every HIP kernel of libhvx (gfx950 only).
+//
+// One abstraction carries both arithmetic types of the hot path:
+//   T = bf16  -> v_mfma_f32_16x16x32_bf16        (production LLM / DiT)
+//   T = float -> 8 x v_mfma_f32_16x16x4_f32      (HiFT is fp32 in the reference; fp32 parity mode)
+// A "k-step" is 32 consecutive k values.  Within a k-step lane l of a wave64 owns row/col (l & 15)
+// of the 16-wide operand and the 8 consecutive k values starting at (l >> 4) * 8 ("slot (g, j)",
+// g = l >> 4, j = 0..7).  For bf16 that is exactly the hardware A/B fragment of 16x16x32; for f32
+// the j-th 16x16x4 instruction consumes slot (g, j) of both operands, so the same loads feed it.
+// C/D layout (both): col = l & 15, rows = (l >> 4) * 4 + r, r = 0..3   (MI355X guide §3).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hvx {
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return (float)v; }
+__device__ __forceinline__ bf16_t f32_to_bf16(float v) { return (bf16_t)v; }   // round-to-nearest-even
+
+template <class T> struct Vec8;
+template <> struct Vec8<bf16_t> { typedef bf16x8 type; };
+template <> struct Vec8<float> { typedef f32x8 type; };
+
+template <class T> __device__ __forceinline__ typename Vec8<T>::type zero8();
+template <> __device__ __forceinline__ bf16x8 zero8<bf16_t>() {
+    bf16x8 z;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) z[i] = (bf16_t)0.0f;
+    return z;
+}
+template <> __device__ __forceinline__ f32x8 zero8<float>() {
+    f32x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    return z;
+}
+
+// 8 consecutive elements from global / LDS (address must be 16-byte aligned)
+__device__ __forceinline__ bf16x8 load8(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
+__device__ __forceinline__ f32x8 load8(const float* p) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+    f32x8 r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return r;
+}
+__device__ __forceinline__ void store8(bf16_t* p, bf16x8 v) { *reinterpret_cast<bf16x8*>(p) = v; }
+__device__ __forceinline__ void store8(float* p, f32x8 v) {
+    f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+    *reinterpret_cast<f32x4*>(p) = a;
+    *reinterpret_cast<f32x4*>(p + 4) = b;
+}
+
+// acc(16x16) += A(16x32) * B(32x16) over one k-step, operands in the slot layout described above
+__device__ __forceinline__ void mma32(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma32(f32x4& acc, const f32x8& a, const f32x8& b) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc, 0, 0, 0);
+}
+
+template <class T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return f32_to_bf16(v); }
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16_t v) { return bf16_to_f32(v); }
+
+// ---- activations (fp32 math) ---------------------------------------------------------------------
+enum Act : int {
+    ACT_NONE = 0,
+    ACT_GELU_TANH = 1,   // nn.GELU(approximate="tanh")            (DiT/modules.py:277)
+    ACT_SILU = 2,
+    ACT_MISH = 3,        // x * tanh(softplus(x))                  (DiT/modules.py:122-127)
+    ACT_ELU = 4,         // alpha = 1                               (f0_predictor.py:64-83)
+    ACT_LRELU = 5,       // slope = param                           (generator.py:683,702)
+    ACT_SNAKE = 6,       // x + sin^2(a x) / (a + 1e-9), a per col  (activation.py:73-84)
+    ACT_TANH = 7,
+    ACT_ABS = 8,         // |x|                                     (f0_predictor.py:103)
+};
+
+__device__ __forceinline__ float act_apply(int act, float x, float param, float alpha) {
+    switch (act) {
+        case ACT_GELU_TANH: {
+            const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+            const float u = k0 * (x + k1 * x * x * x);
+            return 0.5f * x * (1.0f + tanhf(u));
+        }
+        case ACT_SILU: return x / (1.0f + expf(-x));
+        case ACT_MISH: {
+            const float sp = (x > 20.0f) ? x : log1pf(expf(x));      // torch softplus threshold 20
+            return x * tanhf(sp);
+        }
+        case ACT_ELU: return x > 0.0f ? x : expm1f(x);
+        case ACT_LRELU: return x > 0.0f ? x : x * param;
+        case ACT_SNAKE: {
+            const float s = sinf(x * alpha);
+            return x + (1.0f / (alpha + 1e-9f)) * (s * s);
+        }
+        case ACT_TANH: return tanhf(x);
+        case ACT_ABS: return fabsf(x);
+        default: return x;
+    }
+}
+
+// ---- wave / block reductions (wave = 64 lanes) ---------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+}  // namespace hvx

@@ -1,0 +1,345 @@
+// hvx_flow.hip — flow-matching mel decoder: token encoder, DiT estimator, CFG Euler solver (include/hvx.h: hvx_flow_*, hvx_cfm_*).
+//
+// Restates (file:line under server/model_utils/cosyvoice/):
+//   flow/flow.py:389-405            speaker affine, token embedding, pre-lookahead, x2 repeat
+//   transformer/upsample_encoder.py:82-103   PreLookaheadLayer
+//   flow/DiT/dit.py:145-176         DiT.forward             flow/DiT/modules.py:516-530  DiTBlock
+//   flow/DiT/modules.py:230-244     AdaLayerNormZero        :349-407 AttnProcessor   :271-282 FeedForward
+//   flow/DiT/modules.py:115-144     CausalConvPositionEmbedding      :606-616 TimestepEmbedding
+//   flow/flow_matching.py:71-124    solve_euler (batch-2 CFG)
+// Data layout in HBM: activations are time-major rows [B][T][C] (C contiguous) so that every Linear and every
+// Conv1d is one implicit-GEMM launch; the residual stream is fp32, GEMM operands are `dtype`; q/k are written
+// head-major and V already transposed by the QKV epilogue, which is what the attention kernel consumes.
+#include <string.h>
+
+#include <vector>
+
+#include "hvx.h"
+#include "hvx_device.h"
+#include "hvx_kernels.h"
+
+using namespace hvx;
+
+struct hvx_flow {
+    hvx_flow_config c;
+    std::vector<const void*> w;
+};
+
+namespace {
+
+size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+struct Carve {
+    char* base;
+    size_t off = 0;
+    explicit Carve(char* b) : base(b) {}
+    template <class T> T* take(size_t bytes) {
+        T* p = reinterpret_cast<T*>(base ? base + off : nullptr);
+        off += align_up(bytes);
+        return p;
+    }
+};
+
+struct EstBufs {
+    void *tsin, *th, *tsilu, *hin, *x0t, *c1, *n, *q, *k, *vT, *att, *ffh;
+    float *mods, *fmod, *x, *outrow;
+    // solver extras
+    float *x_in, *mu_in, *spk_in, *cond_in, *t_in;
+    // encoder extras
+    float *e_h0, *e_out;
+    void *e_h0t, *e_c1;
+    int t_pad;
+};
+
+size_t carve_est(const hvx_flow_config& c, char* base, int B, int T, EstBufs& b) {
+    const size_t es = dtype_size(c.dtype);
+    const int D = c.dim, H = c.heads;
+    const int Tp = (T + 31) & ~31;
+    b.t_pad = Tp;
+    Carve cv(base);
+    b.tsin = cv.take<void>((size_t)B * c.time_freq_dim * es);
+    b.th = cv.take<void>((size_t)B * D * es);
+    b.tsilu = cv.take<void>((size_t)B * D * es);
+    b.mods = cv.take<float>((size_t)c.depth * B * 6 * D * 4);
+    b.fmod = cv.take<float>((size_t)B * 2 * D * 4);
+    b.hin = cv.take<void>((size_t)B * T * 4 * c.mel * es);
+    b.x0t = cv.take<void>((size_t)B * T * D * es);
+    b.c1 = cv.take<void>((size_t)B * T * D * es);
+    b.x = cv.take<float>((size_t)B * T * D * 4);
+    b.n = cv.take<void>((size_t)B * T * D * es);
+    b.q = cv.take<void>((size_t)B * H * Tp * 64 * es);
+    b.k = cv.take<void>((size_t)B * H * Tp * 64 * es);
+    b.vT = cv.take<void>((size_t)B * H * Tp * 64 * es);
+    b.att = cv.take<void>((size_t)B * T * D * es);
+    b.ffh = cv.take<void>((size_t)B * T * c.ff * es);
+    b.outrow = cv.take<float>((size_t)B * T * c.mel * 4);
+    b.x_in = cv.take<float>((size_t)2 * c.mel * T * 4);
+    b.mu_in = cv.take<float>((size_t)2 * c.mel * T * 4);
+    b.spk_in = cv.take<float>((size_t)2 * c.mel * 4);
+    b.cond_in = cv.take<float>((size_t)2 * c.mel * T * 4);
+    b.t_in = cv.take<float>(64);
+    return cv.off;
+}
+
+size_t carve_enc(const hvx_flow_config& c, char* base, int n, EstBufs& b) {
+    const size_t es = dtype_size(c.dtype);
+    const int melp = (c.mel + 31) & ~31;
+    Carve cv(base);
+    b.e_h0 = cv.take<float>((size_t)n * c.mel * 4);
+    b.e_h0t = cv.take<void>((size_t)n * melp * es);
+    b.e_c1 = cv.take<void>((size_t)n * c.pla_channels * es);
+    b.e_out = cv.take<float>((size_t)n * c.mel * 4);
+    return cv.off;
+}
+
+GemmArgs linear(int dtype, int M, int N, int K, const void* A, int lda, const void* W, const float* bias) {
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.dtype = dtype; g.M = M; g.N = N; g.K = K; g.batch = 1; g.groups = 1;
+    g.A = A; g.lda = lda; g.rows_in = M; g.cin_pad = K; g.conv_stride = 1; g.conv_dil = 1; g.pad_left = 0; g.up = 1;
+    g.W = W; g.epi = EPI_GENERIC; g.bias = bias; g.scale = 1.0f;
+    return g;
+}
+
+// ---- tiny kernels local to the flow ------------------------------------------------------------------------
+__global__ void spk_affine_kernel(const float* emb, const float* W, const float* b, float* out, int in_dim, int out_dim) {
+    __shared__ float red[4];
+    __shared__ float xn[1024];
+    float ss = 0.0f;
+    for (int i = threadIdx.x; i < in_dim; i += 256) ss += emb[i] * emb[i];
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    const float nrm = fmaxf(sqrtf(red[0] + red[1] + red[2] + red[3]), 1e-12f);      // F.normalize eps
+    for (int i = threadIdx.x; i < in_dim; i += 256) xn[i] = emb[i] / nrm;
+    __syncthreads();
+    for (int o = threadIdx.x; o < out_dim; o += 256) {
+        float acc = 0.0f;
+        for (int i = 0; i < in_dim; ++i) acc += W[(long long)o * in_dim + i] * xn[i];
+        out[o] = acc + b[o];
+    }
+}
+
+__global__ void token_embed_kernel(const float* table, const int* tok, float* out, int n, int mel) {
+    const int i = blockIdx.x;
+    int t = tok[i];
+    t = t < 0 ? 0 : t;                                   // torch.clamp(token, min=0)  (flow.py:398)
+    for (int c = threadIdx.x; c < mel; c += blockDim.x) out[(long long)i * mel + c] = table[(long long)t * mel + c];
+}
+
+__global__ void mu_expand_kernel(const float* h, float* mu, int n, int mel, int ratio) {
+    // mu[c][ratio*i + r] = h[i][c]   (repeat_interleave along time, then transpose; flow.py:405, 421)
+    const int T = n * ratio;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.y;
+    if (t < T) mu[(long long)c * T + t] = h[(long long)(t / ratio) * mel + c];
+}
+
+__global__ void fill_kernel(float* p, int n, float v) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+#define HVX_CHECK(x) do { if (x) return -1; } while (0)
+#define HIP_OK(x) do { if ((x) != hipSuccess) return set_error("hip call failed: %s", #x), -1; } while (0)
+
+int prelookahead(const hvx_flow* h, hipStream_t s, EstBufs& b, const float* x, int n, float* y) {
+    const hvx_flow_config& c = h->c;
+    const int melp = (c.mel + 31) & ~31;
+    const void* const* w = h->w.data();
+    HVX_CHECK(launch_rows_to_dtype(x, c.mel, b.e_h0t, c.dtype, melp, n, c.mel, melp, s));
+    // conv1: Conv1d(mel -> C, k = len+1), input right-padded by `len` zeros, LeakyReLU(0.01)
+    GemmArgs g = linear(c.dtype, n, c.pla_channels, (c.pla_len + 1) * melp, b.e_h0t, melp, w[5], (const float*)w[6]);
+    g.cin_pad = melp; g.rows_in = n;
+    g.act = ACT_LRELU; g.act_param = 0.01f;
+    g.out = b.e_c1; g.out_f32 = 0; g.ldo = c.pla_channels; g.out_cols = c.pla_channels;
+    HVX_CHECK(launch_gemm(g, s));
+    // conv2: left pad 2, Conv1d(C -> mel, k = 3), + residual
+    g = linear(c.dtype, n, c.mel, 3 * c.pla_channels, b.e_c1, c.pla_channels, w[7], (const float*)w[8]);
+    g.cin_pad = c.pla_channels; g.rows_in = n; g.pad_left = 2;
+    g.res = x; g.ldres = c.mel;
+    g.out = y; g.out_f32 = 1; g.ldo = c.mel; g.out_cols = c.mel;
+    HVX_CHECK(launch_gemm(g, s));
+    return 0;
+}
+
+// estimator on time-major rows; leaves v in b.outrow [B][T][mel]
+int estimator_core(const hvx_flow* h, hipStream_t s, EstBufs& b, int B, int T, const float* x, const int* kv_len, const float* mu,
+                   const float* t, const float* spks, const float* cond) {
+    const hvx_flow_config& c = h->c;
+    const int dt = c.dtype, D = c.dim, H = c.heads, Tp = b.t_pad, mel = c.mel;
+    const size_t es = dtype_size(dt);
+    const void* const* w = h->w.data();
+    if (T > c.max_t) return set_error("estimator: T=%d exceeds max_t=%d", T, c.max_t), -1;
+
+    // ---- time embedding -> SiLU(t_emb) -> all adaLN modulation vectors --------------------------------------------
+    HVX_CHECK(launch_time_sinus(t, b.tsin, dt, B, c.time_freq_dim, s));
+    GemmArgs g = linear(dt, B, D, c.time_freq_dim, b.tsin, c.time_freq_dim, w[9], (const float*)w[10]);
+    g.act = ACT_SILU; g.out = b.th; g.ldo = D; g.out_cols = D;
+    HVX_CHECK(launch_gemm(g, s));
+    g = linear(dt, B, D, D, b.th, D, w[11], (const float*)w[12]);
+    g.out2 = b.tsilu; g.act2 = ACT_SILU; g.ldo2 = D; g.out2_cols = D;
+    HVX_CHECK(launch_gemm(g, s));
+    for (int i = 0; i < c.depth; ++i) {
+        const void* const* bw = w + 19 + 10 * i;
+        g = linear(dt, B, 6 * D, D, b.tsilu, D, bw[0], (const float*)bw[1]);
+        g.out = b.mods + (size_t)i * B * 6 * D; g.out_f32 = 1; g.ldo = 6 * D; g.out_cols = 6 * D;
+        HVX_CHECK(launch_gemm(g, s));
+    }
+    const void* const* tw = w + 19 + 10 * c.depth;
+    g = linear(dt, B, 2 * D, D, b.tsilu, D, tw[0], (const float*)tw[1]);
+    g.out = b.fmod; g.out_f32 = 1; g.ldo = 2 * D; g.out_cols = 2 * D;
+    HVX_CHECK(launch_gemm(g, s));
+
+    // ---- input embedding: Linear(cat[x, cond, mu, spks]) + causal grouped conv position embedding ------------------
+    HVX_CHECK(launch_dit_concat(x, cond, mu, spks, b.hin, dt, B, T, mel, s));
+    const int IN = 4 * mel;
+    g = linear(dt, T, D, IN, b.hin, IN, w[13], (const float*)w[14]);
+    g.batch = B; g.a_bs = (long long)T * IN;
+    g.out = b.x; g.out_f32 = 1; g.out_bs = (long long)T * D; g.ldo = D; g.out_cols = D;           // x0 (fp32, residual of the conv branch)
+    g.out2 = b.x0t; g.act2 = ACT_NONE; g.out2_bs = (long long)T * D; g.ldo2 = D; g.out2_cols = D;
+    HVX_CHECK(launch_gemm(g, s));
+    const int Cg = D / c.conv_groups, kc = c.conv_kernel;
+    for (int pass = 0; pass < 2; ++pass) {
+        g = linear(dt, T, Cg, kc * Cg, pass == 0 ? b.x0t : b.c1, D, w[15 + 2 * pass], (const float*)w[16 + 2 * pass]);
+        g.batch = B; g.groups = c.conv_groups; g.a_bs = (long long)T * D; g.a_gs = Cg; g.rows_in = T; g.cin_pad = Cg; g.pad_left = kc - 1;
+        g.w_gs = (long long)Cg * kc * Cg;
+        g.act = ACT_MISH;
+        if (pass == 0) {
+            g.out = b.c1; g.out_f32 = 0; g.out_bs = (long long)T * D; g.ldo = D; g.out_cols = D;
+        } else {
+            g.res = b.x; g.res_bs = (long long)T * D; g.ldres = D;                                // conv_pos_embed(x) + x  (dit.py:97)
+            g.out = b.x; g.out_f32 = 1; g.out_bs = (long long)T * D; g.ldo = D; g.out_cols = D;
+        }
+        HVX_CHECK(launch_gemm(g, s));
+    }
+
+    // ---- DiT blocks ---------------------------------------------------------------------------------------------------
+    HIP_OK(hipMemsetAsync(b.vT, 0, (size_t)B * H * Tp * 64 * es, s));       // padded key columns must be finite
+    for (int i = 0; i < c.depth; ++i) {
+        const void* const* bw = w + 19 + 10 * i;
+        const float* mod = b.mods + (size_t)i * B * 6 * D;
+        HVX_CHECK(launch_layernorm_mod(b.x, mod, mod + D, 6 * D, 1e-6f, b.n, dt, B, T, D, s));
+        g = linear(dt, T, 3 * D, D, b.n, D, bw[2], (const float*)bw[3]);
+        g.batch = B; g.a_bs = (long long)T * D; g.epi = EPI_QKV_DIT;
+        g.q = b.q; g.k = b.k; g.vT = b.vT; g.heads = H; g.t_pad = Tp; g.rope_cos = (const float*)w[0]; g.rope_sin = (const float*)w[1];
+        HVX_CHECK(launch_gemm(g, s));
+        AttnArgs at;
+        memset(&at, 0, sizeof(at));
+        at.dtype = dt; at.batch = B; at.heads = H; at.n_rows = T; at.kn = T;
+        at.q = b.q; at.q_bs = (long long)H * Tp * 64; at.q_hs = (long long)Tp * 64; at.q_lo = 64;
+        at.k = b.k; at.k_bs = at.q_bs; at.k_hs = at.q_hs;
+        at.vT = b.vT; at.v_bs = at.q_bs; at.v_hs = (long long)64 * Tp; at.v_ld = Tp;
+        at.kv_len = kv_len; at.kv_len_const = T; at.causal = 0; at.scale = 0.125f;
+        at.out = b.att; at.o_bs = (long long)T * D; at.o_hs = 64; at.o_lo = D; at.n_splits = 1;
+        HVX_CHECK(launch_attention(at, s));
+        g = linear(dt, T, D, D, b.att, D, bw[4], (const float*)bw[5]);
+        g.batch = B; g.a_bs = (long long)T * D;
+        g.gate = mod + 2 * D; g.gate_bs = 6 * D; g.res = b.x; g.res_bs = (long long)T * D; g.ldres = D;
+        g.out = b.x; g.out_f32 = 1; g.out_bs = (long long)T * D; g.ldo = D; g.out_cols = D;
+        HVX_CHECK(launch_gemm(g, s));
+        HVX_CHECK(launch_layernorm_mod(b.x, mod + 3 * D, mod + 4 * D, 6 * D, 1e-6f, b.n, dt, B, T, D, s));
+        g = linear(dt, T, c.ff, D, b.n, D, bw[6], (const float*)bw[7]);
+        g.batch = B; g.a_bs = (long long)T * D; g.act = ACT_GELU_TANH;
+        g.out = b.ffh; g.out_f32 = 0; g.out_bs = (long long)T * c.ff; g.ldo = c.ff; g.out_cols = c.ff;
+        HVX_CHECK(launch_gemm(g, s));
+        g = linear(dt, T, D, c.ff, b.ffh, c.ff, bw[8], (const float*)bw[9]);
+        g.batch = B; g.a_bs = (long long)T * c.ff;
+        g.gate = mod + 5 * D; g.gate_bs = 6 * D; g.res = b.x; g.res_bs = (long long)T * D; g.ldres = D;
+        g.out = b.x; g.out_f32 = 1; g.out_bs = (long long)T * D; g.ldo = D; g.out_cols = D;
+        HVX_CHECK(launch_gemm(g, s));
+    }
+    // ---- final adaLN (scale first, then shift: modules.py:262) + projection -------------------------------------------
+    HVX_CHECK(launch_layernorm_mod(b.x, b.fmod + D, b.fmod, 2 * D, 1e-6f, b.n, dt, B, T, D, s));
+    g = linear(dt, T, mel, D, b.n, D, tw[2], (const float*)tw[3]);
+    g.batch = B; g.a_bs = (long long)T * D;
+    g.out = b.outrow; g.out_f32 = 1; g.out_bs = (long long)T * mel; g.ldo = mel; g.out_cols = mel;
+    HVX_CHECK(launch_gemm(g, s));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hvx_flow_create(const hvx_flow_config* cfg, const void* const* weights, int32_t n_weights, hvx_flow** out) {
+    if (!cfg || !weights || !out) return set_error("hvx_flow_create: null argument"), -1;
+    const int expect = 19 + 10 * cfg->depth + 4;
+    if (n_weights != expect) return set_error("hvx_flow_create: expected %d weight pointers, got %d", expect, n_weights), -1;
+    if (cfg->dim != cfg->heads * 64 || cfg->dim % cfg->conv_groups || (cfg->dim / cfg->conv_groups) % 32 || cfg->pla_channels % 32 ||
+        cfg->ff % 32 || (4 * cfg->mel) % 32 || cfg->time_freq_dim % 32 || cfg->spk_dim > 1024)
+        return set_error("hvx_flow_create: unsupported dimensions"), -1;
+    for (int i = 0; i < n_weights; ++i)
+        if (!weights[i]) return set_error("hvx_flow_create: weight %d is null", i), -1;
+    hvx_flow* h = new hvx_flow();
+    h->c = *cfg;
+    h->w.assign(weights, weights + n_weights);
+    *out = h;
+    return 0;
+}
+void hvx_flow_destroy(hvx_flow* h) { delete h; }
+
+size_t hvx_flow_workspace_bytes(const hvx_flow* h, int32_t batch, int32_t t) {
+    EstBufs b;
+    const size_t a = carve_est(h->c, nullptr, batch, t, b);
+    const size_t e = carve_enc(h->c, nullptr, t, b);
+    return (a > e ? a : e) + 256;
+}
+
+int hvx_flow_prelookahead(hvx_flow* h, hvx_stream s, void* ws, size_t ws_bytes, const float* x, int32_t n, float* y) {
+    EstBufs b;
+    if (carve_enc(h->c, (char*)ws, n, b) > ws_bytes) return set_error("hvx_flow_prelookahead: workspace too small"), -1;
+    return prelookahead(h, (hipStream_t)s, b, x, n, y);
+}
+
+int hvx_flow_encode(hvx_flow* h, hvx_stream stream, void* ws, size_t ws_bytes, const int32_t* token, int32_t n, const float* embedding,
+                    float* mu, float* spk) {
+    hipStream_t s = (hipStream_t)stream;
+    const hvx_flow_config& c = h->c;
+    EstBufs b;
+    if (carve_enc(c, (char*)ws, n, b) > ws_bytes) return set_error("hvx_flow_encode: workspace too small"), -1;
+    hipLaunchKernelGGL(spk_affine_kernel, dim3(1), dim3(256), 0, s, embedding, (const float*)h->w[3], (const float*)h->w[4], spk, c.spk_dim, c.mel);
+    hipLaunchKernelGGL(token_embed_kernel, dim3(n), dim3(128), 0, s, (const float*)h->w[2], token, b.e_h0, n, c.mel);
+    HVX_CHECK(prelookahead(h, s, b, b.e_h0, n, b.e_out));
+    const int T = 2 * n;
+    hipLaunchKernelGGL(mu_expand_kernel, dim3((T + 255) / 256, c.mel), dim3(256), 0, s, b.e_out, mu, n, c.mel, 2);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int hvx_cfm_estimator(hvx_flow* h, hvx_stream stream, void* ws, size_t ws_bytes, int32_t batch, int32_t t_len, const float* x,
+                      const int32_t* kv_len, const float* mu, const float* t, const float* spks, const float* cond, float* out) {
+    hipStream_t s = (hipStream_t)stream;
+    EstBufs b;
+    if (carve_est(h->c, (char*)ws, batch, t_len, b) > ws_bytes) return set_error("hvx_cfm_estimator: workspace too small"), -1;
+    HVX_CHECK(estimator_core(h, s, b, batch, t_len, x, kv_len, mu, t, spks, cond));
+    for (int bi = 0; bi < batch; ++bi)
+        HVX_CHECK(launch_transpose_f32(b.outrow + (size_t)bi * t_len * h->c.mel, out + (size_t)bi * t_len * h->c.mel, t_len, h->c.mel, h->c.mel, t_len, s));
+    return 0;
+}
+
+int hvx_cfm_solve(hvx_flow* h, hvx_stream stream, void* ws, size_t ws_bytes, int32_t T, float* x, const float* mu, const float* spks,
+                  const float* cond, int32_t n_steps, const float* t_steps, const float* dt_steps) {
+    hipStream_t s = (hipStream_t)stream;
+    const hvx_flow_config& c = h->c;
+    EstBufs b;
+    if (carve_est(c, (char*)ws, 2, T, b) > ws_bytes) return set_error("hvx_cfm_solve: workspace too small"), -1;
+    const size_t plane = (size_t)c.mel * T * 4;
+    // row 0: conditional, row 1: unconditional (zeros)  (flow_matching.py:95-108)
+    HIP_OK(hipMemsetAsync(b.mu_in, 0, 2 * plane, s));
+    HIP_OK(hipMemsetAsync(b.cond_in, 0, 2 * plane, s));
+    HIP_OK(hipMemsetAsync(b.spk_in, 0, (size_t)2 * c.mel * 4, s));
+    HIP_OK(hipMemcpyAsync(b.mu_in, mu, plane, hipMemcpyDeviceToDevice, s));
+    HIP_OK(hipMemcpyAsync(b.cond_in, cond, plane, hipMemcpyDeviceToDevice, s));
+    HIP_OK(hipMemcpyAsync(b.spk_in, spks, (size_t)c.mel * 4, hipMemcpyDeviceToDevice, s));
+    for (int st = 0; st < n_steps; ++st) {
+        HIP_OK(hipMemcpyAsync(b.x_in, x, plane, hipMemcpyDeviceToDevice, s));
+        HIP_OK(hipMemcpyAsync((char*)b.x_in + plane, x, plane, hipMemcpyDeviceToDevice, s));
+        hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(64), 0, s, b.t_in, 2, t_steps[st]);
+        HVX_CHECK(estimator_core(h, s, b, 2, T, b.x_in, nullptr, b.mu_in, b.t_in, b.spk_in, b.cond_in));
+        HVX_CHECK(launch_cfg_euler(x, b.outrow, c.mel, (long long)T * c.mel, dt_steps[st], c.cfg_rate, T, c.mel, s));
+    }
+    return 0;
+}
+
+}  // extern "C"

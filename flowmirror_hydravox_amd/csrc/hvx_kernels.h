@@ -1,0 +1,179 @@
+// hvx_kernels.h — host-side launch interface of the HIP kernels (internal to libhvx).
+// Every launcher enqueues on the caller's stream, allocates nothing and never synchronises.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hvx {
+
+enum DType : int { DT_F32 = 0, DT_BF16 = 1 };
+inline size_t dtype_size(int dt) { return dt == DT_BF16 ? 2 : 4; }
+
+void set_error(const char* fmt, ...);
+
+// ------------------------------------------------------------------------------------------------
+// Tiled implicit-GEMM:  out[b, m, g*N + n] = epi( sum_{tap, ci} A[b, src(m, tap), g*a_gs + ci] * W[g, n, tap*cin_pad + ci] )
+//   src(m, tap) = floor((m*conv_stride + tap*conv_dil - pad_left) / up), zero outside [0, rows_in*up)
+// A, W are `dtype` (bf16 or f32), both K-contiguous ("NT" GEMM); accumulation is fp32 on MFMA.
+// A plain Linear is taps == 1 (cin_pad == K).  Covers every Conv1d flavour of the path:
+// CausalConv1d left/right (pad_left), dilation, CausalConv1dDownSample (conv_stride),
+// CausalConv1dUpsample (up = nearest-neighbour factor), grouped conv (groups, a_gs).
+// ------------------------------------------------------------------------------------------------
+enum Epi : int { EPI_GENERIC = 0, EPI_QKV_DIT = 1 };
+
+struct GemmArgs {
+    int dtype;                    // DType of A and W
+    int M, N, K;                  // per (batch, group); K % 32 == 0
+    int batch, groups;
+    const void* A; long long a_bs; int lda; int a_gs; int rows_in;
+    int cin_pad, conv_stride, conv_dil, pad_left, up;
+    const void* W; long long w_gs;            // [groups][N][K]
+    int epi;
+    // ---- EPI_GENERIC: v = act(acc + bias[gc]) * gate[b, gc] + res[b, m, gc] + res2[b, m, gc]; v *= scale
+    //      out[b, m + out_row_off, gc] = v (f32 or dtype); out2[b, m + out2_row_off, gc] = dtype(act2(v));  gc = g*N + n
+    //      (res is read at row m + res_row_off; rows whose shifted index is negative are skipped)
+    const float* bias;
+    int act; float act_param; const float* act_alpha;
+    const float* gate; long long gate_bs;
+    const float* res; long long res_bs; int ldres; int res_row_off;
+    const float* res2; long long res2_bs; int ldres2;
+    float scale; float div;       // v *= scale; if (div != 0) v /= div
+    void* out; int out_f32; long long out_bs; int ldo; int out_row_off; int out_cols;   // cols [groups*N, out_cols) zero-filled
+    void* out2; int act2; float act2_param; const float* act2_alpha; long long out2_bs; int ldo2; int out2_row_off; int out2_cols;
+    // ---- EPI_QKV_DIT: N = 3*heads*64; + bias; interleaved-pair RoPE on channels [0,64) of q and k (head 0);
+    //      q,k -> [b][head][t_pad][64], v -> vT [b][head][64][t_pad]   (all `dtype`)
+    void* q; void* k; void* vT; int heads; int t_pad; const float* rope_cos; const float* rope_sin;   // [t][32]
+};
+int launch_gemm(const GemmArgs& a, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
+// Skinny weight-streaming GEMM for the AR decode step:  out[m, n] = sum_k A[m, k] * W[n, k], M <= 128 per launch chunk.
+// W is pre-packed in MFMA fragment order [N/16][K/32][64 lanes][8] so that every wave-level load is one
+// contiguous 1 KiB (bf16) / 2 KiB (f32) burst.  A is row-major [M][lda].  Optional split-K writes fp32 partials.
+// ------------------------------------------------------------------------------------------------
+enum SkinnyEpi : int {
+    SK_PARTIAL = 0,     // part[ks][m][n] = acc                                   (split-K, reduced by llm_reduce_norm)
+    SK_STORE = 1,       // out[m][n] = acc + bias[n]           (f32 or dtype)
+    SK_QKV_ROPE = 2,    // + bias, rotate-half RoPE, q -> qbuf, k/v -> KV cache     (llm step)
+    SK_SWIGLU = 3,      // n-tiles alternate gate/up: out[m][n/2] = silu(gate) * up  (dtype)
+};
+struct SkinnyArgs {
+    int dtype;
+    int M, N, K;                  // N % 16 == 0, K % 32 == 0
+    const void* A; int lda;
+    const void* W;                // packed
+    int split_k;                  // >= 1
+    int epi;
+    const float* bias;
+    float* part;                  // [split_k][M][N]
+    void* out; int out_f32; int ldo;
+    // SK_QKV_ROPE (rows are a dense [n_seq][kn] grid: m = si*kn + lt)
+    int kn, q_heads, kv_heads;    // head_dim fixed at 64
+    const int* slot; const int* pos0; const int* n_new;          // device [n_seq]
+    const float* rope_cos; const float* rope_sin;                // [max_pos][32]
+    void* qbuf;                   // [n_seq][kn][q_heads*64]              (dtype)
+    void* kcache; void* vTcache;  // [slot][kv_heads][max_ctx][64] / [slot][kv_heads][64][max_ctx]   (dtype)
+    int max_ctx;
+    // layer-batched launches (MTP heads): blockIdx.z = head j, all pointers advance by these strides
+    int nz; long long w_zs; long long a_zs; long long bias_zs; long long out_zs; long long part_zs;
+};
+int launch_skinny(const SkinnyArgs& a, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
+// Attention (flash-style online softmax, head_dim 64, one wave per (q-tile, key-split)).
+// ------------------------------------------------------------------------------------------------
+struct AttnArgs {
+    int dtype;
+    int batch, heads;             // grid.z, grid.y  (heads = kv heads when GQA-packed)
+    int n_rows;                   // query rows per (batch, head) = rows_hi * kn
+    int kn;                       // r -> (r_hi, r_lo) = (r / kn, r % kn)
+    const void* q; long long q_bs, q_hs, q_hi, q_lo;
+    const void* k; long long k_bs, k_hs;        // [.][.][key][64]
+    const void* vT; long long v_bs, v_hs; int v_ld;   // [.][.][64][v_ld]
+    const int* kv_slot;           // optional: batch b reads cache slot kv_slot[b]
+    const int* kv_len;            // optional device [batch]; else kv_len_const
+    int kv_len_const;
+    int causal; const int* pos0;  // key j visible to row r iff j <= pos0[b] + r_lo  (pos0 may be null -> 0)
+    const int* n_valid_lo;        // optional: rows with r_lo >= n_valid_lo[b] are skipped (inactive)
+    float scale;
+    void* out; long long o_bs, o_hs, o_hi, o_lo;      // dtype
+    int n_splits; int split_chunk;                    // keys per split (multiple of 32) when n_splits > 1
+    float* part_o; float* part_ml;                    // [batch][heads][n_splits][n_rows_pad][64], [...][n_rows_pad][2]
+    int n_rows_pad;
+};
+int launch_attention(const AttnArgs& a, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
+// Small fused kernels
+// ------------------------------------------------------------------------------------------------
+// x[m,:] += sum_s part[s][m][:] (+ bias);  y[m,:] = dtype( rmsnorm(x[m,:]) * g )          (any of part/g may be null)
+//   rows are grouped in blocks of rows_per_z (MTP heads): block z uses part + z*part_zs, gain + z*gain_zs, bias + z*bias_zs.
+//   do_norm == 0 -> y = dtype(x) (plain cast).
+struct ReduceNormArgs {
+    float* x; int ldx;
+    const float* part; int split_k; long long part_stride; long long part_zs;
+    const float* bias; long long bias_zs;
+    const float* gain; long long gain_zs; float eps; int do_norm;
+    void* y; int ldy; int dtype;
+    int M, H, rows_per_z;
+};
+int launch_reduce_rmsnorm(const ReduceNormArgs& a, hipStream_t s);
+// y[r, c] = dtype(act(x[r, c])) for a [rows][cols] f32 matrix (per-column alpha for Snake)
+int launch_act_rows(const float* x, int ldx, void* y, int ldy, int dtype, int act, float param, const float* alpha, long long rows, int cols,
+                    hipStream_t s);
+// gather rows: y[r,:] = x[idx[r],:] (idx[r] < 0 -> zeros)
+int launch_gather_rows_f32(const float* x, int ldx, const int* idx, float* y, int ldy, int rows, int H, hipStream_t s);
+// embedding: x[r,:] = table[tok[r],:] as f32 (tok < 0 -> zeros); table dtype f32/bf16
+int launch_embed(const void* table, int table_dtype, const int* tok, float* x, int ldx, int rows, int H, hipStream_t s);
+// LLM input rows: tok >= 0 -> speech[tok]; tok <= -2 -> text[-tok-2]; tok == -1 -> zeros   (llm_multi_head_v3.py:941-952)
+int launch_embed2(const void* speech, const void* text, int dtype, const int* tok, float* x, int ldx, int rows, int H, hipStream_t s);
+// logits -> log_softmax (fp32, in place) over V columns, one block per row
+int launch_log_softmax(float* x, int ld, int rows, int V, hipStream_t s);
+// DiT: y = dtype( LN(x; eps, no affine) * (1 + scale[b]) + shift[b] ); x f32 [B][T][D]; shift/scale f32 [B][.] with stride mod_bs
+int launch_layernorm_mod(const float* x, const float* shift, const float* scale, long long mod_bs, float eps, void* y, int dtype,
+                         int B, int T, int D, hipStream_t s);
+// DiT input: y[b,t,:] = dtype( cat[x[b,:,t], cond[b,:,t], mu[b,:,t], spk[b,:]] ), inputs f32 channel-major (B,80,T)
+int launch_dit_concat(const float* x, const float* cond, const float* mu, const float* spk, void* y, int dtype, int B, int T, int mel,
+                      hipStream_t s);
+// sinusoidal time embedding (DiT/modules.py:71-83): y[b,:] = dtype([sin(1000 t e_i), cos(1000 t e_i)])
+int launch_time_sinus(const float* t, void* y, int dtype, int B, int dim, hipStream_t s);
+// CFG + Euler (flow_matching.py:116-120): x += dt * ((1+r) * v[0] - r * v[1]); v is [2][T][ldv] row-major f32, x is (80,T) f32
+int launch_cfg_euler(float* x, const float* v, int ldv, long long v_bs, float dt, float rate, int T, int mel, hipStream_t s);
+// generic strided f32 copy / cast helpers
+int launch_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long long n, hipStream_t s);
+int launch_transpose_f32(const float* src, float* dst, int rows, int cols, int ld_src, int ld_dst, hipStream_t s);   // dst[c][r] = src[r][c]
+int launch_rows_to_dtype(const float* src, int ld_src, void* dst, int dst_dtype, int ld_dst, int rows, int cols, int cols_pad, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
+// Sampler (common.py:138-166 + llm_multi_head_v3.py:151-166, 890-900)
+// ------------------------------------------------------------------------------------------------
+struct SampleArgs {
+    int n_seq, head_k, V, Vs;               // V = vocab (speech + stop ids), Vs = speech_token_size
+    const float* logp; long long logp_ss, logp_hs;     // [n_seq][head_k][V]
+    const int* hist; long long hist_ss; const int* hist_len;     // token history per seq (snapshot = first hist_len[s])
+    const int* min_len;                     // per seq: head j ignores EOS while hist_len + j < min_len
+    const int* active;                      // optional per seq (0 -> skip)
+    int top_k; float top_p; int win_size; int rep_thresh;   // rep_thresh = ceil(win_size * tau_r) computed on the host in double
+    const float* noise; long long noise_ss; int noise_len;  // Exp(1) stream per seq
+    long long* cursor;                      // in/out per seq: next unread noise value
+    int* out_ids;                           // [n_seq][head_k]; -1 = max_trials exhausted, -2 = noise exhausted (cursor unchanged)
+    int max_trials;
+};
+int launch_ras_sample(const SampleArgs& a, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
+// HiFT source / STFT / iSTFT
+// ------------------------------------------------------------------------------------------------
+// frame-level harmonic phases (generator.py:233-260): phase[t][h] = 2*pi*480*cumsum_t( (f0[t]*(h+1)/sr) % 1 )
+int launch_hift_phase(const float* f0, float* phase, int T, int H, float sr, int up, hipStream_t s);
+// per-sample source (generator.py:289-317, 358-375): s[n] = tanh( sum_h w[h]*(sin(phase[t][h])*amp*uv + namp*table[n][h]) + b )
+int launch_hift_source(const float* f0, const float* phase, const float* table, const float* w, const float* b, float* s_out,
+                       int T, int H, int up, float amp, float sigma, float vthr, hipStream_t s);
+// STFT n_fft=16 hop=4 hann, center/reflect (generator.py:491-497): spec[f][0..8]=re, [9..17]=im, row stride ld (>=18, rest zero)
+int launch_hift_stft(const float* s_in, float* spec, int L, int ld, hipStream_t s);
+// x[f][0..8] -> mag=exp clip 1e2, x[f][9..17] -> phase=sin; iSTFT; clamp (generator.py:702-710, 499-505)
+int launch_hift_istft(const float* x, int ld, float* wav, int frames, float limit, hipStream_t s);
+// reflection pad (1,0) on a time-major buffer: row0 = row2 (generator.py:686-687)
+int launch_copy_row(float* buf, int ld, int dst_row, int src_row, int cols, hipStream_t s);
+
+}  // namespace hvx

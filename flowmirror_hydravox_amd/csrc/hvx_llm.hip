@@ -1,0 +1,306 @@
+// hvx_llm.hip — KV-cached multi-head AR step of the speech-token LM (include/hvx.h: hvx_llm_*).
+//
+// Restates the per-step math of CosyVoice3LM.inference_wrapper
+// (server/model_utils/cosyvoice/llm/llm_multi_head_v3.py:871-888): Qwen2 backbone (HF Qwen2: RMSNorm,
+// q/k/v Linear+bias, rotate-half RoPE, GQA attention, o Linear, SwiGLU MLP), final RMSNorm, the K degenerate
+// MTP decoder layers (length-1 sequence => h1 = y + Wo(Wv n1 + bv)), llm_decoder, log_softmax.
+// The reference recomputes the full prefix every step (cache=None, :873-882); with a causal mask that equals
+// this KV-cached evaluation of the new rows only.
+//
+// Per layer: QKV GEMM (+bias +RoPE +KV append) | GQA-packed attention (+split combine) | o_proj split-K |
+// reduce+residual+RMSNorm | gate/up GEMM (+SwiGLU) | down split-K | reduce+residual+RMSNorm(next).
+// Residual stream x stays fp32; GEMM operands are `dtype` (bf16 production / f32 parity).
+#include <string.h>
+
+#include <vector>
+
+#include "hvx.h"
+#include "hvx_kernels.h"
+
+using namespace hvx;
+
+struct hvx_llm {
+    hvx_llm_config c;
+    std::vector<const void*> w;
+    // bound buffers
+    char* ws = nullptr;
+    size_t ws_bytes = 0;
+    int max_seq = 0, max_rows = 0, n_slots = 0, max_ctx = 0;
+    void* kcache = nullptr;
+    void* vTcache = nullptr;
+    // workspace carve
+    float* x = nullptr;          // [R][H]
+    void* a = nullptr;           // [R][H]      dtype
+    void* qbuf = nullptr;        // [R][q*64]   dtype
+    void* attn = nullptr;        // [R][q*64]   dtype
+    void* hmlp = nullptr;        // [R][inter]  dtype
+    float* part = nullptr;       // split-K partials (shared by backbone and heads)
+    float* att_o = nullptr;      // attention split partials
+    float* att_ml = nullptr;
+    float* ylast = nullptr;      // [S][H] f32 (post final norm)
+    float* hx = nullptr;         // [hn][S][H] f32
+    void* ha = nullptr;          // [hn][S][H]  dtype
+    void* hv = nullptr;          // [hn][S][A]  dtype
+    void* hm = nullptr;          // [hn][S][mtp_inter] dtype
+    float* logits = nullptr;     // [S][hn][vocab_pad] f32
+    int att_splits = 1, att_chunk = 0, att_rows_pad = 0;
+};
+
+namespace {
+
+constexpr int MAX_SPLIT = 16;
+constexpr int ATT_CHUNK = 256;
+
+size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+int pick_split(int N, int K, int nz) {
+    const int waves = (N / 16) * nz;
+    const int kt = K / 32;
+    int s = 512 / (waves > 0 ? waves : 1);
+    if (s > kt / 2) s = kt / 2;
+    if (s > MAX_SPLIT) s = MAX_SPLIT;
+    if (s < 1) s = 1;
+    return s;
+}
+
+struct Carve {
+    char* base;
+    size_t off = 0;
+    explicit Carve(char* b) : base(b) {}
+    template <class T> T* take(size_t bytes) {
+        T* p = reinterpret_cast<T*>(base ? base + off : nullptr);
+        off += align_up(bytes);
+        return p;
+    }
+};
+
+size_t carve(hvx_llm* h, char* base, int S, int R, int max_ctx) {
+    const hvx_llm_config& c = h->c;
+    const size_t es = dtype_size(c.dtype);
+    const int H = c.hidden, Q = c.q_heads * 64, A = c.mtp_attn_dim, hn = c.head_num;
+    Carve cv(base);
+    h->x = cv.take<float>((size_t)R * H * 4);
+    h->a = cv.take<void>((size_t)R * H * es);
+    h->qbuf = cv.take<void>((size_t)R * Q * es);
+    h->attn = cv.take<void>((size_t)R * Q * es);
+    h->hmlp = cv.take<void>((size_t)R * c.inter * es);
+    const size_t part_rows = (size_t)(R > hn * S ? R : hn * S);
+    h->part = cv.take<float>((size_t)MAX_SPLIT * part_rows * H * 4);
+    // attention split partials are only used for short query grids (decode): rows per (seq, kv head) = G * kn
+    const int G = c.q_heads / c.kv_heads;
+    h->att_chunk = ATT_CHUNK;
+    h->att_splits = (max_ctx + ATT_CHUNK - 1) / ATT_CHUNK;
+    h->att_rows_pad = ((G * 8 + 31) / 32) * 32;                       // kn <= 8 on the split path
+    h->att_o = cv.take<float>((size_t)S * c.kv_heads * h->att_splits * h->att_rows_pad * 64 * 4);
+    h->att_ml = cv.take<float>((size_t)S * c.kv_heads * h->att_splits * h->att_rows_pad * 2 * 4);
+    h->ylast = cv.take<float>((size_t)S * H * 4);
+    h->hx = cv.take<float>((size_t)hn * S * H * 4);
+    h->ha = cv.take<void>((size_t)hn * S * H * es);
+    h->hv = cv.take<void>((size_t)hn * S * A * es);
+    h->hm = cv.take<void>((size_t)hn * S * c.mtp_inter * es);
+    h->logits = cv.take<float>((size_t)S * hn * c.vocab_pad * 4);
+    return cv.off;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hvx_llm_create(const hvx_llm_config* cfg, const void* const* weights, int32_t n_weights, hvx_llm** out) {
+    if (!cfg || !weights || !out) return set_error("hvx_llm_create: null argument"), -1;
+    const int expect = 6 + 7 * cfg->layers + 7;
+    if (n_weights != expect) return set_error("hvx_llm_create: expected %d weight pointers, got %d", expect, n_weights), -1;
+    if (cfg->hidden % 32 || cfg->inter % 16 || cfg->mtp_inter % 16 || cfg->mtp_attn_dim % 32 || cfg->vocab_pad % 16 ||
+        cfg->q_heads % cfg->kv_heads || cfg->vocab_pad < cfg->vocab)
+        return set_error("hvx_llm_create: unsupported dimensions"), -1;
+    for (int i = 0; i < n_weights; ++i)
+        if (!weights[i]) return set_error("hvx_llm_create: weight %d is null", i), -1;
+    hvx_llm* h = new hvx_llm();
+    h->c = *cfg;
+    h->w.assign(weights, weights + n_weights);
+    *out = h;
+    return 0;
+}
+
+void hvx_llm_destroy(hvx_llm* h) { delete h; }
+
+size_t hvx_llm_workspace_bytes(const hvx_llm* h, int32_t max_seq, int32_t max_rows, int32_t max_ctx) {
+    hvx_llm tmp = *h;
+    return carve(&tmp, nullptr, max_seq, max_rows, max_ctx);
+}
+
+size_t hvx_llm_kv_bytes(const hvx_llm* h, int32_t n_slots, int32_t max_ctx) {
+    const hvx_llm_config& c = h->c;
+    return 2 * align_up((size_t)n_slots * c.layers * c.kv_heads * max_ctx * 64 * dtype_size(c.dtype));
+}
+
+int hvx_llm_bind(hvx_llm* h, void* workspace, size_t ws_bytes, int32_t max_seq, int32_t max_rows, void* kv, size_t kv_bytes,
+                 int32_t n_slots, int32_t max_ctx, hvx_stream s) {
+    if (!h || !workspace || !kv) return set_error("hvx_llm_bind: null argument"), -1;
+    if (max_ctx % 32 || max_ctx > h->c.max_pos) return set_error("hvx_llm_bind: max_ctx=%d must be a multiple of 32 and <= max_pos=%d", max_ctx, h->c.max_pos), -1;
+    const size_t need = carve(h, (char*)workspace, max_seq, max_rows, max_ctx);
+    if (need > ws_bytes) return set_error("hvx_llm_bind: workspace %zu < %zu bytes", ws_bytes, need), -1;
+    if (hvx_llm_kv_bytes(h, n_slots, max_ctx) > kv_bytes) return set_error("hvx_llm_bind: kv buffer too small"), -1;
+    h->ws = (char*)workspace; h->ws_bytes = ws_bytes;
+    h->max_seq = max_seq; h->max_rows = max_rows; h->n_slots = n_slots; h->max_ctx = max_ctx;
+    h->kcache = kv;
+    h->vTcache = (char*)kv + hvx_llm_kv_bytes(h, n_slots, max_ctx) / 2;
+    // padded key columns are multiplied by p == 0: they must be finite
+    if (hipMemsetAsync(kv, 0, kv_bytes, (hipStream_t)s) != hipSuccess) return set_error("hvx_llm_bind: memset failed"), -1;
+    if (hipMemsetAsync(workspace, 0, need, (hipStream_t)s) != hipSuccess) return set_error("hvx_llm_bind: memset failed"), -1;
+    return 0;
+}
+
+int hvx_llm_forward(hvx_llm* h, hvx_stream stream, int32_t n_seq, int32_t kn, const int32_t* tok, const int32_t* ctrl, int32_t head_k,
+                    float* logp) {
+    if (!h || !h->ws) return set_error("hvx_llm_forward: handle not bound"), -1;
+    hipStream_t s = (hipStream_t)stream;
+    const hvx_llm_config& c = h->c;
+    const int R = n_seq * kn;
+    if (n_seq < 1 || kn < 1 || n_seq > h->max_seq || R > h->max_rows) return set_error("hvx_llm_forward: grid %dx%d exceeds the bound workspace", n_seq, kn), -1;
+    if (head_k > c.head_num) return set_error("hvx_llm_forward: head_k=%d > head_num=%d", head_k, c.head_num), -1;
+    const int H = c.hidden, Q = c.q_heads * 64, G = c.q_heads / c.kv_heads;
+    const int dt = c.dtype;
+    const size_t es = dtype_size(dt);
+    const int32_t* d_slot = ctrl;
+    const int32_t* d_pos0 = ctrl + n_seq;
+    const int32_t* d_nnew = ctrl + 2 * n_seq;
+    const int32_t* d_kvlen = ctrl + 3 * n_seq;
+    const int32_t* d_last = ctrl + 4 * n_seq;
+    const void* const* w = h->w.data();
+    const float* rope_cos = (const float*)w[0];
+    const float* rope_sin = (const float*)w[1];
+
+    // ---- embeddings: speech ids (>= 0) and text ids (<= -2) come from different tables -----------------------
+    if (launch_embed2(w[4], w[5], dt, tok, h->x, H, R, H, s)) return -1;
+    ReduceNormArgs rn;
+    memset(&rn, 0, sizeof(rn));
+    rn.x = h->x; rn.ldx = H; rn.eps = c.rms_eps; rn.do_norm = 1; rn.y = h->a; rn.ldy = H; rn.dtype = dt; rn.M = R; rn.H = H; rn.rows_per_z = R;
+    rn.gain = (const float*)w[6];
+    if (launch_reduce_rmsnorm(rn, s)) return -1;
+
+    const bool use_split = (G * kn <= h->att_rows_pad) && (kn <= 8) && h->att_splits > 1;
+    for (int l = 0; l < c.layers; ++l) {
+        const void* const* lw = w + 6 + 7 * l;
+        // 1. QKV + bias + RoPE + KV append
+        SkinnyArgs g;
+        memset(&g, 0, sizeof(g));
+        g.dtype = dt; g.M = R; g.N = (c.q_heads + 2 * c.kv_heads) * 64; g.K = H; g.A = h->a; g.lda = H; g.W = lw[1]; g.split_k = 1; g.nz = 1;
+        g.epi = SK_QKV_ROPE; g.bias = (const float*)lw[2];
+        g.kn = kn; g.q_heads = c.q_heads; g.kv_heads = c.kv_heads; g.slot = d_slot; g.pos0 = d_pos0; g.n_new = d_nnew;
+        g.rope_cos = rope_cos; g.rope_sin = rope_sin; g.qbuf = h->qbuf;
+        const size_t layer_kv = (size_t)c.kv_heads * h->max_ctx * 64 * es;          // per (slot, layer)
+        // cache layout [layer][slot][kv_head][...]: the slot stride is what the kernels index with
+        g.kcache = (char*)h->kcache + (size_t)l * h->n_slots * layer_kv;
+        g.vTcache = (char*)h->vTcache + (size_t)l * h->n_slots * layer_kv;
+        g.max_ctx = h->max_ctx;
+        if (launch_skinny(g, s)) return -1;
+        // 2. attention, GQA-packed: rows = G query heads x kn new positions per KV head
+        AttnArgs at;
+        memset(&at, 0, sizeof(at));
+        at.dtype = dt; at.batch = n_seq; at.heads = c.kv_heads; at.n_rows = G * kn; at.kn = kn;
+        at.q = h->qbuf; at.q_bs = (long long)kn * Q; at.q_hs = (long long)G * 64; at.q_hi = 64; at.q_lo = Q;
+        at.k = g.kcache; at.k_bs = (long long)c.kv_heads * h->max_ctx * 64; at.k_hs = (long long)h->max_ctx * 64;
+        at.vT = g.vTcache; at.v_bs = at.k_bs; at.v_hs = (long long)64 * h->max_ctx; at.v_ld = h->max_ctx;
+        at.kv_slot = d_slot; at.kv_len = d_kvlen; at.causal = 1; at.pos0 = d_pos0; at.n_valid_lo = d_nnew;
+        at.scale = 0.125f;
+        at.out = h->attn; at.o_bs = at.q_bs; at.o_hs = at.q_hs; at.o_hi = 64; at.o_lo = Q;
+        if (use_split) {
+            at.n_splits = h->att_splits; at.split_chunk = h->att_chunk; at.part_o = h->att_o; at.part_ml = h->att_ml; at.n_rows_pad = h->att_rows_pad;
+        } else {
+            at.n_splits = 1;
+        }
+        if (launch_attention(at, s)) return -1;
+        // 3. o_proj (split-K partials) ; 4. x += sum ; a = RMSNorm(x) * ln2
+        memset(&g, 0, sizeof(g));
+        g.dtype = dt; g.M = R; g.N = H; g.K = Q; g.A = h->attn; g.lda = Q; g.W = lw[3]; g.nz = 1;
+        g.split_k = pick_split(H, Q, 1); g.epi = SK_PARTIAL; g.part = h->part;
+        if (launch_skinny(g, s)) return -1;
+        rn.part = h->part; rn.split_k = g.split_k; rn.part_stride = (long long)R * H; rn.gain = (const float*)lw[4]; rn.y = h->a; rn.do_norm = 1;
+        if (launch_reduce_rmsnorm(rn, s)) return -1;
+        // 5. gate/up + SwiGLU
+        memset(&g, 0, sizeof(g));
+        g.dtype = dt; g.M = R; g.N = 2 * c.inter; g.K = H; g.A = h->a; g.lda = H; g.W = lw[5]; g.split_k = 1; g.nz = 1;
+        g.epi = SK_SWIGLU; g.out = h->hmlp; g.ldo = c.inter;
+        if (launch_skinny(g, s)) return -1;
+        // 6. down (split-K) ; 7. x += sum ; a = RMSNorm(x) * ln1(next layer)   (last layer: residual only)
+        memset(&g, 0, sizeof(g));
+        g.dtype = dt; g.M = R; g.N = H; g.K = c.inter; g.A = h->hmlp; g.lda = c.inter; g.W = lw[6]; g.nz = 1;
+        g.split_k = pick_split(H, c.inter, 1); g.epi = SK_PARTIAL; g.part = h->part;
+        if (launch_skinny(g, s)) return -1;
+        rn.part = h->part; rn.split_k = g.split_k; rn.part_stride = (long long)R * H;
+        if (l + 1 < c.layers) {
+            rn.gain = (const float*)(w + 6 + 7 * (l + 1))[0]; rn.y = h->a; rn.do_norm = 1;
+        } else {
+            rn.gain = nullptr; rn.y = nullptr;
+        }
+        if (launch_reduce_rmsnorm(rn, s)) return -1;
+    }
+    if (head_k <= 0) return 0;
+
+    // ---- last rows -> final RMSNorm (hidden_states[-1], llm_multi_head_v3.py:248-260, 886) ---------------------
+    const int S = n_seq;
+    if (launch_gather_rows_f32(h->x, H, d_last, h->ylast, H, S, H, s)) return -1;
+    ReduceNormArgs fn;
+    memset(&fn, 0, sizeof(fn));
+    fn.x = h->ylast; fn.ldx = H; fn.gain = (const float*)w[2]; fn.eps = c.rms_eps; fn.do_norm = 1; fn.y = h->ylast; fn.ldy = H; fn.dtype = DT_F32;
+    fn.M = S; fn.H = H; fn.rows_per_z = S;
+    if (launch_reduce_rmsnorm(fn, s)) return -1;
+
+    // ---- K MTP heads, batched over blockIdx.z ----------------------------------------------------------------
+    const void* const* mw = w + 6 + 7 * c.layers;
+    const int A = c.mtp_attn_dim, I = c.mtp_inter, K = head_k;
+    for (int j = 0; j < K; ++j)
+        if (hipMemcpyAsync(h->hx + (size_t)j * S * H, h->ylast, (size_t)S * H * 4, hipMemcpyDeviceToDevice, s) != hipSuccess)
+            return set_error("hvx_llm_forward: memcpy failed"), -1;
+    ReduceNormArgs hn;
+    memset(&hn, 0, sizeof(hn));
+    hn.x = h->hx; hn.ldx = H; hn.gain = (const float*)mw[0]; hn.gain_zs = H; hn.eps = c.mtp_rms_eps; hn.do_norm = 1; hn.y = h->ha; hn.ldy = H;
+    hn.dtype = dt; hn.M = K * S; hn.H = H; hn.rows_per_z = S;
+    if (launch_reduce_rmsnorm(hn, s)) return -1;
+    SkinnyArgs g;
+    // v = Wv n1 + bv
+    memset(&g, 0, sizeof(g));
+    g.dtype = dt; g.M = S; g.N = A; g.K = H; g.A = h->ha; g.lda = H; g.a_zs = (long long)S * H; g.W = mw[1]; g.w_zs = (long long)A * H;
+    g.split_k = 1; g.nz = K; g.epi = SK_STORE; g.bias = (const float*)mw[2]; g.bias_zs = A; g.out = h->hv; g.out_f32 = 0; g.ldo = A; g.out_zs = (long long)S * A;
+    if (launch_skinny(g, s)) return -1;
+    // h1 = y + Wo v
+    memset(&g, 0, sizeof(g));
+    g.dtype = dt; g.M = S; g.N = H; g.K = A; g.A = h->hv; g.lda = A; g.a_zs = (long long)S * A; g.W = mw[3]; g.w_zs = (long long)H * A;
+    g.split_k = pick_split(H, A, K); g.nz = K; g.epi = SK_PARTIAL; g.part = h->part; g.part_zs = (long long)g.split_k * S * H;
+    if (launch_skinny(g, s)) return -1;
+    hn.part = h->part; hn.split_k = g.split_k; hn.part_stride = (long long)S * H; hn.part_zs = g.part_zs; hn.gain = (const float*)mw[4];
+    if (launch_reduce_rmsnorm(hn, s)) return -1;
+    // SwiGLU MLP
+    memset(&g, 0, sizeof(g));
+    g.dtype = dt; g.M = S; g.N = 2 * I; g.K = H; g.A = h->ha; g.lda = H; g.a_zs = (long long)S * H; g.W = mw[5]; g.w_zs = (long long)2 * I * H;
+    g.split_k = 1; g.nz = K; g.epi = SK_SWIGLU; g.out = h->hm; g.ldo = I; g.out_zs = (long long)S * I;
+    if (launch_skinny(g, s)) return -1;
+    memset(&g, 0, sizeof(g));
+    g.dtype = dt; g.M = S; g.N = H; g.K = I; g.A = h->hm; g.lda = I; g.a_zs = (long long)S * I; g.W = mw[6]; g.w_zs = (long long)H * I;
+    g.split_k = pick_split(H, I, K); g.nz = K; g.epi = SK_PARTIAL; g.part = h->part; g.part_zs = (long long)g.split_k * S * H;
+    if (launch_skinny(g, s)) return -1;
+    hn.part = h->part; hn.split_k = g.split_k; hn.part_stride = (long long)S * H; hn.part_zs = g.part_zs; hn.gain = nullptr; hn.do_norm = 0;   // plain cast
+    if (launch_reduce_rmsnorm(hn, s)) return -1;
+    // logits = llm_decoder(h) (shared weights) ; log_softmax
+    memset(&g, 0, sizeof(g));
+    g.dtype = dt; g.M = S; g.N = c.vocab_pad; g.K = H; g.A = h->ha; g.lda = H; g.a_zs = (long long)S * H; g.W = w[3]; g.w_zs = 0;
+    g.split_k = 1; g.nz = K; g.epi = SK_STORE; g.out = h->logits; g.out_f32 = 1; g.ldo = K * c.vocab_pad; g.out_zs = c.vocab_pad;
+    if (launch_skinny(g, s)) return -1;
+    if (launch_log_softmax(h->logits, c.vocab_pad, S * K, c.vocab, s)) return -1;
+    if (logp) {
+        if (hipMemcpy2DAsync(logp, (size_t)c.vocab * 4, h->logits, (size_t)c.vocab_pad * 4, (size_t)c.vocab * 4, (size_t)S * K,
+                             hipMemcpyDeviceToDevice, s) != hipSuccess)
+            return set_error("hvx_llm_forward: logp copy failed"), -1;
+    }
+    return 0;
+}
+
+int hvx_llm_last_hidden(hvx_llm* h, hvx_stream s, int32_t n_seq, float* out) {
+    if (!h || !h->ylast) return set_error("hvx_llm_last_hidden: handle not bound"), -1;
+    if (hipMemcpyAsync(out, h->ylast, (size_t)n_seq * h->c.hidden * 4, hipMemcpyDeviceToDevice, (hipStream_t)s) != hipSuccess)
+        return set_error("hvx_llm_last_hidden: memcpy failed"), -1;
+    return 0;
+}
+
+}  // extern "C"

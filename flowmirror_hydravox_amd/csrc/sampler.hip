@@ -1,0 +1,208 @@
+// sampler.hip — repetition-aware top-k/top-p sampler on gfx950 (see hvx_kernels.h: SampleArgs).
+//
+// Restates server/model_utils/cosyvoice/utils/common.py:138-166 (ras_sampling / nucleus_sampling /
+// random_sampling) and the EOS-rejection loop + shared history snapshot of
+// cosyvoice/llm/llm_multi_head_v3.py:151-166, 890-900.  One workgroup per sequence; the K heads are
+// sampled one after the other because each consumes a data-dependent amount of the sequence's
+// Exp(1) noise stream (torch CPU generator, produced by the host: `multinomial(1)` == argmax(p / q)).
+//   softmax      : fp32, block reduction (max, then sum in fp64), p kept in LDS
+//   top-k / top-p: tournament selection — every thread keeps its best (value desc, index asc) candidate,
+//                  a wave-shuffle + LDS reduction picks the winner, only the winner's owner rescans;
+//                  stops exactly like the reference loop `cum < top_p and n < top_k` (cum in fp32, sorted order)
+//   draw         : lane-parallel exponential race over the <= 64 candidates (first max)
+//   repetition   : count of the drawn id in the last win_size tokens; >= rep_thresh -> full-vocabulary race
+#include "hvx_device.h"
+#include "hvx_kernels.h"
+
+namespace hvx {
+
+struct Best {
+    float v;
+    int i;
+};
+__device__ __forceinline__ bool better(float v, int i, float v2, int i2) { return (v > v2) || (v == v2 && i < i2); }
+
+__device__ __forceinline__ Best wave_best(Best b) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float v2 = __shfl_xor(b.v, o, 64);
+        const int i2 = __shfl_xor(b.i, o, 64);
+        if (better(v2, i2, b.v, b.i)) {
+            b.v = v2;
+            b.i = i2;
+        }
+    }
+    return b;
+}
+
+// block-wide best; every thread returns the same winner.  red_v/red_i: LDS [4]
+__device__ __forceinline__ Best block_best(Best b, float* red_v, int* red_i) {
+    b = wave_best(b);
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+        red_v[wave] = b.v;
+        red_i[wave] = b.i;
+    }
+    __syncthreads();
+    Best r = {red_v[0], red_i[0]};
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+        if (better(red_v[w], red_i[w], r.v, r.i)) {
+            r.v = red_v[w];
+            r.i = red_i[w];
+        }
+    return r;
+}
+
+constexpr int MAX_CAND = 64;
+constexpr int BIG_IDX = 0x7fffffff;
+
+__global__ __launch_bounds__(256) void ras_sample_kernel(SampleArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int V = a.V;
+    float* p = reinterpret_cast<float*>(smem);                        // [V]
+    unsigned char* taken = smem + (size_t)((V + 3) & ~3) * 4;         // [V]
+    __shared__ float red_v[4];
+    __shared__ int red_i[4];
+    __shared__ double red_d[4];
+    __shared__ float cand_v[MAX_CAND];
+    __shared__ int cand_i[MAX_CAND];
+    __shared__ int sh_pick;
+
+    const int s = blockIdx.x, tid = threadIdx.x;
+    if (a.active && !a.active[s]) return;
+    const long long cursor0 = a.cursor[s];
+    long long cursor = cursor0;
+    const float* noise = a.noise + (long long)s * a.noise_ss;
+    const int hist_len = a.hist_len[s];
+    const int* hist = a.hist + (long long)s * a.hist_ss;
+    const int min_len = a.min_len[s];
+    const int win = (a.win_size == 0) ? hist_len : min(a.win_size, hist_len);
+    bool overflow = false;
+
+    for (int j = 0; j < a.head_k && !overflow; ++j) {
+        const float* lp = a.logp + (long long)s * a.logp_ss + (long long)j * a.logp_hs;
+        // ---- softmax(logp) (common.py:149 / :165) ---------------------------------------------------
+        float mx = -INFINITY;
+        for (int i = tid; i < V; i += 256) mx = fmaxf(mx, lp[i]);
+        {
+            Best b = block_best(Best{mx, tid}, red_v, red_i);
+            mx = b.v;
+        }
+        double sum = 0.0;
+        for (int i = tid; i < V; i += 256) {
+            const float e = expf(lp[i] - mx);
+            p[i] = e;
+            taken[i] = 0;
+            sum += (double)e;
+        }
+        sum = wave_sum_d(sum);
+        __syncthreads();
+        if ((tid & 63) == 0) red_d[tid >> 6] = sum;
+        __syncthreads();
+        const float denom = (float)(red_d[0] + red_d[1] + red_d[2] + red_d[3]);
+        for (int i = tid; i < V; i += 256) p[i] = p[i] / denom;
+        __syncthreads();
+
+        // ---- nucleus candidates: stable descending order, `cum < top_p and n < top_k` (common.py:146-157)
+        Best mine = {-1.0f, BIG_IDX};
+        for (int i = tid; i < V; i += 256)
+            if (better(p[i], i, mine.v, mine.i)) mine = Best{p[i], i};
+        int n = 0;
+        float cum = 0.0f;
+        const int kmax = min(min(a.top_k, MAX_CAND), V);
+        while (cum < a.top_p && n < kmax) {
+            const Best wv = block_best(mine, red_v, red_i);
+            if (tid == 0) {
+                cand_v[n] = wv.v;
+                cand_i[n] = wv.i;
+            }
+            cum = cum + wv.v;                                   // fp32, in sorted order, like the reference's 0-dim tensor
+            ++n;
+            if ((wv.i & 255) == tid) {                          // owner: retire the winner and rescan its stripe
+                taken[wv.i] = 1;
+                mine = Best{-1.0f, BIG_IDX};
+                for (int i = tid; i < V; i += 256)
+                    if (!taken[i] && better(p[i], i, mine.v, mine.i)) mine = Best{p[i], i};
+            }
+        }
+        __syncthreads();
+
+        const bool ignore_eos = (hist_len + j) < min_len;
+        int result = -1;
+        for (int trial = 0;; ++trial) {
+            // ---- multinomial(1) over the candidates == first argmax of p / Exp(1) ---------------------
+            if (cursor + n > a.noise_len) {
+                overflow = true;
+                break;
+            }
+            if (tid < 64) {
+                Best b = {-1.0f, BIG_IDX};
+                if (tid < n) b = Best{cand_v[tid] / noise[cursor + tid], tid};
+                b = wave_best(b);
+                if (tid == 0) sh_pick = cand_i[b.i];
+            }
+            __syncthreads();
+            int c = sh_pick;
+            cursor += n;
+            // ---- repetition check over the shared history snapshot (common.py:140-142) ----------------
+            int rep = 0;
+            for (int i = tid; i < win; i += 256) rep += (hist[hist_len - win + i] == c) ? 1 : 0;
+            rep = (int)wave_sum((float)rep);
+            __syncthreads();
+            if ((tid & 63) == 0) red_i[tid >> 6] = rep;
+            __syncthreads();
+            rep = red_i[0] + red_i[1] + red_i[2] + red_i[3];
+            if (rep >= a.rep_thresh) {
+                // random_sampling: race over the full vocabulary (common.py:164-166)
+                if (cursor + V > a.noise_len) {
+                    overflow = true;
+                    break;
+                }
+                Best b = {-1.0f, BIG_IDX};
+                for (int i = tid; i < V; i += 256) {
+                    const float r = p[i] / noise[cursor + i];
+                    if (better(r, i, b.v, b.i)) b = Best{r, i};
+                }
+                b = block_best(b, red_v, red_i);
+                c = b.i;
+                cursor += V;
+            }
+            __syncthreads();
+            if (!ignore_eos || c < a.Vs) {
+                result = c;
+                break;
+            }
+            if (trial + 1 > a.max_trials) {                     // num_trials > max_trials -> RuntimeError in the reference
+                result = -1;
+                break;
+            }
+        }
+        if (overflow) break;
+        if (tid == 0) a.out_ids[(long long)s * a.head_k + j] = result;
+        __syncthreads();
+    }
+    if (overflow) {
+        if (tid < a.head_k) a.out_ids[(long long)s * a.head_k + tid] = -2;
+    } else if (tid == 0) {
+        a.cursor[s] = cursor;
+    }
+}
+
+int launch_ras_sample(const SampleArgs& a, hipStream_t s) {
+    if (a.n_seq <= 0) return 0;
+    if (a.top_k < 1 || a.top_k > MAX_CAND) {
+        set_error("ras_sample: top_k=%d outside [1,%d]", a.top_k, MAX_CAND);
+        return -1;
+    }
+    if (a.head_k < 1 || a.head_k > 256) {
+        set_error("ras_sample: head_k=%d", a.head_k);
+        return -1;
+    }
+    const size_t lds = (size_t)((a.V + 3) & ~3) * 4 + (size_t)((a.V + 15) & ~15);
+    hipLaunchKernelGGL(ras_sample_kernel, dim3(a.n_seq), dim3(256), lds, s, a);
+    return hipGetLastError() == hipSuccess ? 0 : (set_error("ras_sample launch failed"), -1);
+}
+
+}  // namespace hvx

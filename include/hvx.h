@@ -1,0 +1,196 @@
+/* hvx.h — C ABI of libhvx, the MI355X-native (gfx950) HydraVox speech-synthesis hot path.
+ *
+ * The reference (jingzhunxue/FlowMirror_HydraVox) has no native boundary: the path sits behind Python
+ * objects (`llm.inference`, `flow.inference`, `hift.inference`, server/model_utils/infer_speech_model.py
+ * :549-595).  Its one native-style precedent is the TensorRT estimator call of
+ * server/model_utils/cosyvoice/flow/flow_matching.py:126-153 — raw device pointers in a fixed order
+ * (x, mask, mu, t, spks, cond -> x), executed on the caller's stream — and this ABI follows that
+ * template for every stage:
+ *   - plain pointers and sizes, no torch types; every buffer is owned by the caller;
+ *   - the callee never allocates device memory and never synchronises the stream;
+ *   - all entry points return 0 on success, non-zero on failure; hvx_last_error() gives the message;
+ *   - one handle per process (= per GPU), calls serialised by the single-threaded worker loop
+ *     (server/worker.py:54), hence no internal locking and no global mutable state besides the error text.
+ * Each entry point names the reference interface it replaces.
+ */
+#ifndef HVX_H
+#define HVX_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HVX_ABI_VERSION 1
+#define HVX_F32 0
+#define HVX_BF16 1
+
+typedef void* hvx_stream;                 /* hipStream_t */
+
+int hvx_abi_version(void);
+const char* hvx_last_error(void);
+/* number of compute units / whether a gfx950 device is current (0 = no usable device) */
+int hvx_device_ok(void);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Sampler — replaces cosyvoice/utils/common.py:138-166 (ras_sampling, nucleus_sampling, random_sampling)
+ * and the EOS-rejection loop of cosyvoice/llm/llm_multi_head_v3.py:151-166, for all K heads of a step
+ * against one history snapshot (:890-900).  `noise` is the per-sequence Exp(1) stream that
+ * torch.multinomial(1) would have drawn from the CPU generator; `cursor` (in/out) the next unread value.
+ * out_ids: >= 0 sampled id; -1 max_trials exhausted (the reference raises RuntimeError); -2 noise exhausted
+ * (cursor left untouched; refill and call again).
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t n_seq, head_k, vocab, speech_tokens;
+    const float* logp; int64_t logp_seq_stride, logp_head_stride;
+    const int32_t* hist; int64_t hist_seq_stride; const int32_t* hist_len;
+    const int32_t* min_len; const int32_t* active;
+    int32_t top_k; float top_p; int32_t win_size; int32_t rep_thresh;
+    const float* noise; int64_t noise_seq_stride; int32_t noise_len;
+    int64_t* cursor;
+    int32_t* out_ids;
+    int32_t max_trials;
+} hvx_sample_args;
+int hvx_ras_sample(const hvx_sample_args* a, hvx_stream s);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Building-block operators (exported for the parity tests; the model entry points below are chains of these)
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t dtype, M, N, K, batch, groups;
+    const void* A; int64_t a_bs; int32_t lda, a_gs, rows_in;
+    int32_t cin_pad, conv_stride, conv_dil, pad_left, up;
+    const void* W; int64_t w_gs;
+    const float* bias;
+    int32_t act; float act_param; const float* act_alpha;
+    const float* gate; int64_t gate_bs;
+    const float* res; int64_t res_bs; int32_t ldres, res_row_off;
+    float scale;
+    void* out; int32_t out_f32; int64_t out_bs; int32_t ldo, out_row_off, out_cols;
+    void* out2; int32_t act2; float act2_param; const float* act2_alpha; int64_t out2_bs; int32_t ldo2, out2_row_off, out2_cols;
+} hvx_gemm_args;
+/* implicit-GEMM Conv1d / Linear on MFMA (torch.nn.functional.conv1d / linear call sites of the path) */
+int hvx_op_gemm(const hvx_gemm_args* a, hvx_stream s);
+
+typedef struct {
+    int32_t dtype, batch, heads, t, t_pad;     /* q,k: [b][h][t_pad][64]; vT: [b][h][64][t_pad]; out: [b][t][h*64] */
+    const void* q; const void* k; const void* vT; void* out;
+    const int32_t* kv_len;                     /* optional [batch] */
+    int32_t causal; float scale;
+    int32_t n_splits, split_chunk; float* part_o; float* part_ml;   /* optional key splits (workspace) */
+} hvx_attn_args;
+/* F.scaled_dot_product_attention (cosyvoice/flow/DiT/modules.py:391) */
+int hvx_op_attention(const hvx_attn_args* a, hvx_stream s);
+
+/* packs a row-major [N][K] weight into the MFMA fragment order used by the decode GEMMs: [N/16][K/32][64][8] */
+int hvx_op_skinny_gemm(int32_t dtype, int32_t M, int32_t N, int32_t K, const void* A, int32_t lda, const void* Wpacked,
+                       const float* bias, int32_t split_k, float* part_ws, float* out_f32, int32_t ldo, hvx_stream s);
+
+/* ---------------------------------------------------------------------------------------------------
+ * LLM — replaces CosyVoice3LM.inference_wrapper's per-step math (cosyvoice/llm/llm_multi_head_v3.py
+ * :871-888): Qwen2 backbone over the NEW rows only (KV-cached; identical to the reference's full-prefix
+ * recompute because the mask is causal), K MTP heads, llm_decoder, log_softmax.
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t dtype;                               /* HVX_BF16 (production) or HVX_F32 (parity mode) */
+    int32_t hidden, layers, q_heads, kv_heads, inter;            /* head_dim == 64 */
+    int32_t vocab, vocab_pad, speech_tokens, text_vocab;
+    int32_t head_num, mtp_attn_dim, mtp_inter;
+    float rms_eps, mtp_rms_eps;
+    int32_t max_pos;
+} hvx_llm_config;
+
+/* weights[] order (device pointers; matrices in `dtype`, packed with hvx fragment order unless noted; vectors f32):
+ *   0 rope_cos f32 [max_pos][32]    1 rope_sin f32 [max_pos][32]     2 final norm gain [H]
+ *   3 llm_decoder packed [vocab_pad][H]   4 speech_embedding rows [vocab][H] (dtype)   5 text embedding rows [text_vocab][H] (dtype)
+ *   per layer l, 7 entries from 6+7l: ln1 gain, Wqkv packed [(q+2kv)*64][H], bqkv, Wo packed [H][q*64], ln2 gain,
+ *                                     Wgate/up packed as alternating 16-row tiles [2*inter][H], Wdown packed [H][inter]
+ *   then 7 entries stacked over the head_num MTP heads: ln1 [hn][H], Wv packed [hn][A][H], bv [hn][A], Wo packed [hn][H][A],
+ *                                     ln2 [hn][H], Wgate/up packed [hn][2*mtp_inter][H], Wdown packed [hn][H][mtp_inter]        */
+typedef struct hvx_llm hvx_llm;
+int hvx_llm_create(const hvx_llm_config* cfg, const void* const* weights, int32_t n_weights, hvx_llm** out);
+void hvx_llm_destroy(hvx_llm* h);
+size_t hvx_llm_workspace_bytes(const hvx_llm* h, int32_t max_seq, int32_t max_rows, int32_t max_ctx);
+size_t hvx_llm_kv_bytes(const hvx_llm* h, int32_t n_slots, int32_t max_ctx);
+int hvx_llm_bind(hvx_llm* h, void* workspace, size_t ws_bytes, int32_t max_seq, int32_t max_rows, void* kv, size_t kv_bytes,
+                 int32_t n_slots, int32_t max_ctx, hvx_stream s);
+/* One pass over a dense [n_seq][kn] grid of new rows.  Device int32 control arrays:
+ *   tok[n_seq*kn]  >= 0: speech_embedding row; <= -2: text-embedding row (-tok-2); -1: padding row
+ *   ctrl[5][n_seq] = slot, pos0 (KV length before this call), n_new (valid rows), kv_len (= pos0+n_new), last_row (grid row of the
+ *                    last valid row, -1 if none)
+ * head_k > 0: writes logp[n_seq][head_k][vocab] (fp32 log-probabilities of the K heads on each sequence's last new row). */
+int hvx_llm_forward(hvx_llm* h, hvx_stream s, int32_t n_seq, int32_t kn, const int32_t* tok, const int32_t* ctrl,
+                    int32_t head_k, float* logp);
+/* debugging / parity: copy the post-final-norm hidden of the last rows of the previous forward (fp32 [n_seq][H]) */
+int hvx_llm_last_hidden(hvx_llm* h, hvx_stream s, int32_t n_seq, float* out);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Flow — replaces CausalMaskedDiffWithDiT.inference (cosyvoice/flow/flow.py:367-430), PreLookaheadLayer
+ * (cosyvoice/transformer/upsample_encoder.py:82-103), CausalConditionalCFM.forward / solve_euler
+ * (cosyvoice/flow/flow_matching.py:204-228, 71-124) and DiT.forward (cosyvoice/flow/DiT/dit.py:145-176).
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t dtype;
+    int32_t vocab, mel, spk_dim, pla_channels, pla_len;
+    int32_t dim, depth, heads, ff, conv_kernel, conv_groups, time_freq_dim;
+    int32_t max_t;                                /* rows of the rope tables */
+    float cfg_rate;
+} hvx_flow_config;
+/* weights[] order (matrices `dtype` row-major [N][K] with conv kernels as [Cout][tap][Cin_pad]; vectors f32):
+ *   0 rope_cos f32 [max_t][32]  1 rope_sin   2 input_embedding f32 [vocab][mel]   3 spk affine W f32 [mel][spk_dim]  4 spk affine b
+ *   5 pla conv1 W [C][4][96]  6 b   7 pla conv2 W [mel][3][C]  8 b
+ *   9 time_mlp.0 W [D][256] 10 b  11 time_mlp.2 W [D][D] 12 b   13 input proj W [D][320] 14 b
+ *   15 conv_pos 1 W [groups][Cg][k*Cg] 16 b [D]  17 conv_pos 2 W  18 b
+ *   per block, 12 entries from 19+12i: adaLN W [6D][D], b; Wqkv [3D][D], bqkv; Wout [D][D], b; ff1 W [ff][D], b; ff2 W [D][ff], b ... (see flow.py)
+ *   tail: norm_out W [2D][D], b; proj_out W [mel][D], b                                                             */
+typedef struct hvx_flow hvx_flow;
+int hvx_flow_create(const hvx_flow_config* cfg, const void* const* weights, int32_t n_weights, hvx_flow** out);
+void hvx_flow_destroy(hvx_flow* h);
+size_t hvx_flow_workspace_bytes(const hvx_flow* h, int32_t batch, int32_t t);
+/* token (int32 [n], prompt already concatenated) + speaker embedding (f32 [spk_dim]) -> mu f32 (mel, 2n) channel-major, spk f32 [mel] */
+int hvx_flow_encode(hvx_flow* h, hvx_stream s, void* ws, size_t ws_bytes, const int32_t* token, int32_t n, const float* embedding,
+                    float* mu, float* spk);
+/* pre-lookahead only (parity): x f32 [n][mel] -> y f32 [n][mel] */
+int hvx_flow_prelookahead(hvx_flow* h, hvx_stream s, void* ws, size_t ws_bytes, const float* x, int32_t n, float* y);
+/* estimator, TensorRT argument order (flow_matching.py:130-153): x, mu, cond f32 (B, mel, T); mask -> kv_len int32 [B] (NULL: all T);
+ * t f32 [B]; spks f32 (B, mel); out f32 (B, mel, T) */
+int hvx_cfm_estimator(hvx_flow* h, hvx_stream s, void* ws, size_t ws_bytes, int32_t batch, int32_t t_len, const float* x,
+                      const int32_t* kv_len, const float* mu, const float* t, const float* spks, const float* cond, float* out);
+/* full Euler solve with batch-2 classifier-free guidance: x (mel,T) f32 in (noise) / out (mel); t_steps[n], dt_steps[n] from the host
+ * (computed exactly as the reference accumulates them) */
+int hvx_cfm_solve(hvx_flow* h, hvx_stream s, void* ws, size_t ws_bytes, int32_t t_len, float* x, const float* mu, const float* spks,
+                  const float* cond, int32_t n_steps, const float* t_steps, const float* dt_steps);
+
+/* ---------------------------------------------------------------------------------------------------
+ * HiFT — replaces CausalHiFTGenerator.inference / decode (cosyvoice/hifigan/generator.py:713-726, 672-711),
+ * CausalConvRNNF0Predictor.forward (cosyvoice/hifigan/f0_predictor.py:95-103), SourceModuleHnNSF / SineGen2
+ * (generator.py:358-375, 233-317).  fp32 throughout, like the reference (infer_speech_model.py:104).
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t mel, base_channels, nb_harmonics, f0_channels;
+    int32_t n_up; int32_t up_rates[4]; int32_t up_kernels[4];
+    int32_t n_rb; int32_t rb_kernels[4]; int32_t rb_dils[4][3];
+    int32_t src_rb_kernels[4]; int32_t src_rb_dils[4][3];
+    int32_t n_fft, hop, conv_pre_kernel, conv_post_kernel;
+    float sampling_rate, nsf_alpha, nsf_sigma, voiced_threshold, lrelu_slope, audio_limit;
+} hvx_hift_config;
+/* weights[]: f32, weight-norm folded, conv kernels as [Cout][tap][Cin_pad32]; consumed in the order documented in
+ * flowmirror_hydravox_amd/hift.py::pack_hift_weights (f0 predictor, source linear, conv_pre, per stage: up, source_down,
+ * source resblock, 3 resblocks; conv_post). */
+typedef struct hvx_hift hvx_hift;
+int hvx_hift_create(const hvx_hift_config* cfg, const void* const* weights, int32_t n_weights, hvx_hift** out);
+void hvx_hift_destroy(hvx_hift* h);
+size_t hvx_hift_workspace_bytes(const hvx_hift* h, int32_t t);
+/* mel f32 (mel, T) channel-major -> f0 f32 [T] */
+int hvx_hift_f0(hvx_hift* h, hvx_stream s, void* ws, size_t ws_bytes, const float* mel, int32_t t, float* f0);
+/* f0 f32 [T] + fixed noise table f32 [>= T*up][H] -> source f32 [T*up] */
+int hvx_hift_source(hvx_hift* h, hvx_stream s, void* ws, size_t ws_bytes, const float* f0, int32_t t, const float* sine_table,
+                    float* source);
+/* mel (mel, T) + source [T*up] -> wav f32 [T*up] */
+int hvx_hift_decode(hvx_hift* h, hvx_stream s, void* ws, size_t ws_bytes, const float* mel, const float* source, int32_t t, float* wav);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HVX_H */

@@ -1,0 +1,237 @@
+"""Parity of the HIP building-block kernels (through the C-ABI) against plain PyTorch fp32 math and the oracle."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda'
+
+
+def _mods():
+    from flowmirror_hydravox_amd import _lib, ops, packing
+    _lib.require_gpu()
+    return _lib, ops, packing
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale)
+
+
+def _tol(dtype):
+    # bf16 operands (8 mantissa bits) with fp32 accumulation vs fp32 reference on the SAME bf16-rounded operands
+    return dict(rtol=2e-2, atol=2e-2) if dtype == torch.bfloat16 else dict(rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('M,N,K', [(300, 200, 96), (1000, 1024, 1024), (5, 6144, 1024), (2000, 64, 704), (257, 80, 320), (4100, 64, 64)])
+def test_linear(dtype, M, N, K):
+    _lib, ops, packing = _mods()
+    x = _rand(1, M, K, seed=1).to(dtype)
+    w = (_rand(N, K, seed=2) / math.sqrt(K)).to(dtype)
+    b = _rand(N, seed=3)
+    ref = x.float() @ w.float().t() + b
+    out = ops.conv1d(x.to(DEV), w.to(DEV), b.to(DEV), n_out=N, taps=1, cin_pad=K)
+    torch.testing.assert_close(out.cpu(), ref, **_tol(dtype))
+
+
+def _pack_conv(w, dtype):
+    from flowmirror_hydravox_amd import packing
+    return packing.conv_weight(w).to(dtype)
+
+
+def _rows(x_bct, dtype, cpad=None):
+    """(B, C, T) -> time-major [B][T][Cpad]"""
+    B, Cc, T = x_bct.shape
+    cp = cpad or (Cc + 31) // 32 * 32
+    o = torch.zeros(B, T, cp)
+    o[:, :, :Cc] = x_bct.transpose(1, 2)
+    return o.to(dtype)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('cin,cout,k,dil,T', [(80, 64, 5, 1, 50), (64, 64, 11, 5, 333), (32, 48, 3, 3, 130), (18, 32, 1, 1, 77), (512, 256, 7, 1, 90)])
+def test_causal_conv_left_and_right(dtype, cin, cout, k, dil, T):
+    _lib, ops, packing = _mods()
+    x = _rand(2, cin, T, seed=4).to(dtype).float()
+    w = (_rand(cout, cin, k, seed=5) / math.sqrt(cin * k)).to(dtype).float()
+    b = _rand(cout, seed=6)
+    cp = (cin + 31) // 32 * 32
+    xr = _rows(x, dtype).to(DEV)
+    wp = _pack_conv(w, dtype).to(DEV)
+    pad = (k - 1) * dil
+    ref_left = F.conv1d(F.pad(x, (pad, 0)), w, b, dilation=dil)
+    out = ops.conv1d(xr, wp, b.to(DEV), n_out=cout, taps=k, cin_pad=cp, pad_left=pad, dil=dil)
+    torch.testing.assert_close(out.cpu().transpose(1, 2), ref_left, **_tol(dtype))
+    ref_right = F.conv1d(F.pad(x, (0, pad)), w, b, dilation=dil)
+    out = ops.conv1d(xr, wp, b.to(DEV), n_out=cout, taps=k, cin_pad=cp, pad_left=0, dil=dil)
+    torch.testing.assert_close(out.cpu().transpose(1, 2), ref_right, **_tol(dtype))
+
+
+@pytest.mark.parametrize('u,k', [(8, 16), (5, 11), (3, 7)])
+def test_upsample_conv(u, k):
+    _lib, ops, packing = _mods()
+    cin, cout, T = 64, 32, 41
+    x = _rand(1, cin, T, seed=7)
+    w = _rand(cout, cin, k, seed=8) / math.sqrt(cin * k)
+    b = _rand(cout, seed=9)
+    ref = F.conv1d(F.pad(F.interpolate(x, scale_factor=float(u), mode='nearest'), (k - 1, 0)), w, b)
+    out = ops.conv1d(_rows(x, torch.float32).to(DEV), _pack_conv(w, torch.float32).to(DEV), b.to(DEV), n_out=cout, taps=k, cin_pad=64,
+                     pad_left=k - 1, up=u, m_out=T * u)
+    torch.testing.assert_close(out.cpu().transpose(1, 2), ref, rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize('stride', [15, 3])
+def test_downsample_conv(stride):
+    _lib, ops, packing = _mods()
+    cin, cout, k = 18, 32, 2 * stride
+    T = 120 * 7 + 1
+    x = _rand(1, cin, T, seed=10)
+    w = _rand(cout, cin, k, seed=11) / math.sqrt(cin * k)
+    b = _rand(cout, seed=12)
+    ref = F.conv1d(F.pad(x, (stride - 1, 0)), w, b, stride=stride)
+    out = ops.conv1d(_rows(x, torch.float32).to(DEV), _pack_conv(w, torch.float32).to(DEV), b.to(DEV), n_out=cout, taps=k, cin_pad=32,
+                     pad_left=stride - 1, stride=stride, m_out=ref.shape[-1])
+    torch.testing.assert_close(out.cpu().transpose(1, 2), ref, rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_grouped_causal_conv_mish_residual(dtype):
+    _lib, ops, packing = _mods()
+    D, groups, k, T = 512, 16, 31, 97
+    x = _rand(2, D, T, seed=13).to(dtype).float()
+    w = (_rand(D, D // groups, k, seed=14) / math.sqrt(D // groups * k)).to(dtype).float()
+    b = _rand(D, seed=15)
+    res = _rand(2, T, D, seed=16)
+    ref = F.mish(F.conv1d(F.pad(x, (k - 1, 0)), w, b, groups=groups)).transpose(1, 2) + res
+    wp = packing.grouped_conv_weight(w, groups).to(dtype).to(DEV)
+    out = ops.conv1d(_rows(x, dtype, D).to(DEV), wp, b.to(DEV), n_out=D // groups, taps=k, cin_pad=D // groups, pad_left=k - 1, groups=groups,
+                     act=_lib.ACT_MISH, res=res.to(DEV))
+    torch.testing.assert_close(out.cpu(), ref, **_tol(dtype))
+
+
+def test_epilogue_activations_gate_and_second_output():
+    _lib, ops, packing = _mods()
+    M, N, K = 130, 96, 64
+    x = _rand(2, M, K, seed=17)
+    w = _rand(N, K, seed=18) / math.sqrt(K)
+    b = _rand(N, seed=19)
+    alpha = _rand(N, seed=20).abs() + 0.1
+    gate = _rand(2, N, seed=21)
+    res = _rand(2, M, N, seed=22)
+    lin = x @ w.t() + b
+    acts = {
+        _lib.ACT_GELU_TANH: lambda v: F.gelu(v, approximate='tanh'),
+        _lib.ACT_SILU: F.silu, _lib.ACT_MISH: F.mish, _lib.ACT_ELU: F.elu,
+        _lib.ACT_LRELU: lambda v: F.leaky_relu(v, 0.1),
+        _lib.ACT_SNAKE: lambda v: v + (1.0 / (alpha + 1e-9)) * torch.sin(v * alpha) ** 2,
+        _lib.ACT_TANH: torch.tanh, _lib.ACT_ABS: torch.abs,
+    }
+    for code, fn in acts.items():
+        out2 = torch.zeros(2, M, N, device=DEV)
+        out = ops.conv1d(x.to(DEV), w.to(DEV), b.to(DEV), n_out=N, taps=1, cin_pad=K, act=code, act_param=0.1, act_alpha=alpha.to(DEV),
+                         gate=gate.to(DEV), res=res.to(DEV), out=torch.zeros(2, M, N, device=DEV), out2=out2, act2=_lib.ACT_SNAKE,
+                         act2_alpha=alpha.to(DEV))
+        ref = fn(lin) * gate[:, None, :] + res
+        torch.testing.assert_close(out.cpu(), ref, rtol=2e-4, atol=2e-4)
+        ref2 = ref + (1.0 / (alpha + 1e-9)) * torch.sin(ref * alpha) ** 2
+        torch.testing.assert_close(out2.cpu(), ref2, rtol=5e-4, atol=5e-4)
+
+
+def _attn_ref(q, k, v, kv_len=None, causal=False):
+    B, H, T, d = q.shape
+    s = q @ k.transpose(-1, -2) / math.sqrt(d)
+    mask = torch.ones(B, 1, T, T, dtype=torch.bool)
+    if kv_len is not None:
+        mask = mask & (torch.arange(T)[None, None, None, :] < kv_len[:, None, None, None])
+    if causal:
+        mask = mask & torch.tril(torch.ones(T, T, dtype=torch.bool))[None, None]
+    s = s.masked_fill(~mask, float('-inf'))
+    return (torch.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(B, T, H * d)
+
+
+def _attn_inputs(B, H, T, dtype, seed):
+    Tp = (T + 31) // 32 * 32
+    q = _rand(B, H, T, 64, seed=seed).to(dtype)
+    k = _rand(B, H, T, 64, seed=seed + 1).to(dtype)
+    v = _rand(B, H, T, 64, seed=seed + 2).to(dtype)
+    qp = torch.zeros(B, H, Tp, 64, dtype=dtype)
+    kp = torch.zeros_like(qp)
+    vT = torch.zeros(B, H, 64, Tp, dtype=dtype)
+    qp[:, :, :T] = q
+    kp[:, :, :T] = k
+    vT[:, :, :, :T] = v.transpose(-1, -2)
+    return q, k, v, qp.to(DEV), kp.to(DEV), vT.to(DEV)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('T', [7, 100, 333])
+def test_attention_padding_mask(dtype, T):
+    _lib, ops, packing = _mods()
+    q, k, v, qd, kd, vd = _attn_inputs(2, 3, T, dtype, seed=30)
+    kv_len = torch.tensor([T, max(1, T - 5)], dtype=torch.int32)
+    ref = _attn_ref(q.float(), k.float(), v.float(), kv_len=kv_len)
+    out = ops.attention(qd, kd, vd, T, kv_len=kv_len.to(DEV))
+    tol = dict(rtol=3e-2, atol=3e-2) if dtype == torch.bfloat16 else dict(rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(out.float().cpu(), ref, **tol)
+
+
+@pytest.mark.parametrize('T,n_splits,chunk', [(50, 1, 0), (300, 1, 0), (200, 4, 64), (97, 5, 32)])
+def test_attention_causal_and_splits(T, n_splits, chunk):
+    _lib, ops, packing = _mods()
+    q, k, v, qd, kd, vd = _attn_inputs(1, 2, T, torch.float32, seed=40)
+    ref = _attn_ref(q, k, v, causal=True)
+    out = ops.attention(qd, kd, vd, T, causal=True, n_splits=n_splits, split_chunk=chunk)
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('M,N,K,split', [(16, 896, 896, 1), (16, 896, 4864, 8), (3, 304, 128, 2), (40, 6768, 896, 1), (130, 128, 256, 4)])
+def test_skinny_gemm(dtype, M, N, K, split):
+    _lib, ops, packing = _mods()
+    x = _rand(M, K, seed=50).to(dtype)
+    w = (_rand(N, K, seed=51) / math.sqrt(K)).to(dtype)
+    b = _rand(N, seed=52)
+    ref = x.float() @ w.float().t() + b
+    out = ops.skinny_gemm(x.to(DEV), packing.pack_frag(w).to(DEV), N, bias=b.to(DEV), split_k=split)
+    torch.testing.assert_close(out.cpu(), ref, **_tol(dtype))
+
+
+@pytest.mark.parametrize('fname', ['sampler_small.npz', 'sampler_big.npz'])
+def test_sampler_bit_exact_vs_golden(fname):
+    """ids and noise consumption of the HIP sampler == the reference's (golden minted from the reference)."""
+    _lib, ops, packing = _mods()
+    from oracle import sampler_ref
+    g = load_golden(fname)
+    n = len(g['id'])
+    V = g['logp'].shape[1]
+    ncap = 1 << 20
+    bad = []
+    # group cases by their scalar parameters (one launch per group)
+    keys = {}
+    for i in range(n):
+        keys.setdefault((int(g['top_k'][i]), float(g['top_p'][i]), int(g['win'][i]), float(g['tau'][i])), []).append(i)
+    for (top_k, top_p, win, tau), idxs in keys.items():
+        S = len(idxs)
+        logp = torch.from_numpy(g['logp'][idxs]).view(S, 1, V)
+        hist = torch.from_numpy(np.maximum(g['hist'][idxs], 0).astype(np.int32))
+        hist_len = torch.from_numpy(g['hist_len'][idxs].astype(np.int32))
+        min_len = torch.where(torch.from_numpy(g['ignore_eos'][idxs]) > 0, hist_len + 1, torch.zeros_like(hist_len)).to(torch.int32)
+        noise = torch.stack([torch.from_numpy(sampler_ref.NoiseStream(seed=int(g['seed'][i])).take(ncap).copy()) for i in idxs])
+        cursor = torch.zeros(S, dtype=torch.int64)
+        ids = ops.ras_sample(logp.to(DEV), hist.to(DEV), hist_len.to(DEV), min_len.to(DEV), noise.to(DEV), cur := cursor.to(DEV),
+                             speech_tokens=int(g['Vs'][idxs[0]]), top_k=top_k, top_p=top_p, win_size=win,
+                             rep_thresh=sampler_ref.rep_threshold(win, tau))
+        ids = ids.cpu().view(-1).tolist()
+        cur = cur.cpu().tolist()
+        for j, i in enumerate(idxs):
+            want_id, want_c = int(g['id'][i]), int(g['consumed'][i])
+            if ids[j] != want_id or (want_id >= 0 and cur[j] != want_c):
+                bad.append((i, ids[j], want_id, cur[j], want_c))
+    assert not bad, bad[:10]
