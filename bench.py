@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""bench.py — HydraVox-CV3 speech-synthesis hot path on MI355X (BASELINE.json metric / config).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1]): HydraVox-CV3, inference_head_num=2, batch = 8 x 512-char utterances
+per GPU (512 text tokens -> 2816 speech tokens, generation length pinned by min = max token/text ratio 5.5 because random
+weights never emit EOS sensibly -> 5632 mel frames -> 112.6 s of 24 kHz audio each), LLM and DiT in bf16, HiFT in fp32,
+sampler top_p 0.9 / top_k 10 / win_size 32 / tau_r 0.2, seeded N(0, 0.02) random weights of the [ASSUMED-CV3] architecture.
+One step = one batch through llm -> flow -> hift.  N > 1: weak scaling, every rank synthesises its own 8 utterances
+(global utterance index = seed) and the finished waveforms are gathered to rank 0 (grouped RCCL send/recv) inside the step.
+
+`value` = speech tokens per second of the whole job (all stages, all ranks); the reference's own per-stage figures
+(TPS = tokens / LLM wall, RTF = wall / audio seconds; infer_speech_model.py:563-565, 594-604) ride along as extra keys.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_BF16_PEAK_TF = 2500.0       # dense bf16
+MFMA_F32_PEAK_TF = 157.3         # f32-input MFMA == fp32 vector rate
+
+KINDS = {0: ('llm_decode_gemm', 'hbm'), 1: ('dit_gemm_bf16', 'mfma'), 2: ('dit_attention_bf16', 'mfma'), 3: ('ras_sampler', 'hbm'),
+         4: ('hift_conv_gemm_f32', 'mfma'), 5: ('llm_attention', 'hbm')}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=2)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--batch', type=int, default=8, help='utterances per GPU per step')
+    ap.add_argument('--chars', type=int, default=512, help='text tokens per utterance')
+    ap.add_argument('--heads', type=int, default=2, help='inference_head_num')
+    ap.add_argument('--tiny', action='store_true', help='toy dimensions (plumbing check only; INVALID as a benchmark)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--prof-period', type=int, default=16)
+    return ap.parse_args()
+
+
+def read_prof(lib):
+    out = {}
+    for k, (name, bound) in KINDS.items():
+        ms, work, ns, nl, lw = C.c_double(), C.c_double(), C.c_int64(), C.c_int64(), C.c_double()
+        lib.hvx_prof_read(k, C.byref(ms), C.byref(work), C.byref(ns), C.byref(nl), C.byref(lw))
+        if ns.value:
+            out[name] = dict(bound=bound, sampled=ns.value, launches=nl.value, avg_us=1e3 * ms.value / ns.value,
+                             est_total_ms=ms.value * nl.value / ns.value, work_per_launch=work.value / ns.value,
+                             rate=(work.value / (ms.value * 1e-3)) if ms.value > 0 else 0.0, launched_work=lw.value)
+    return out
+
+
+def roofline_of(name, p):
+    if p['bound'] == 'hbm':
+        ach = p['rate'] / 1e9
+        return dict(kernel=name, bound='hbm', achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(ach / HBM_PEAK_GBS, 4),
+                    traffic=None, avg_launch_us=round(p['avg_us'], 2), algorithmic_bytes_per_launch=round(p['work_per_launch']),
+                    launches_per_timed_region=p['launches'], sampled_launches=p['sampled'])
+    peak = MFMA_F32_PEAK_TF if name.endswith('f32') else MFMA_BF16_PEAK_TF
+    ach = p['rate'] / 1e12
+    return dict(kernel=name, bound='mfma', achieved=round(ach, 2), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4), traffic=None,
+                avg_launch_us=round(p['avg_us'], 2), algorithmic_flops_per_launch=round(p['work_per_launch']),
+                launches_per_timed_region=p['launches'], sampled_launches=p['sampled'])
+
+
+def cpu_baseline(cfg, pipe_seed, chars, heads):
+    """Reference algorithm on the host cores (oracle/ = the fp32 CPU restatement, including the reference's full-prefix
+    recompute per AR step), on a bounded sample of the same workload."""
+    from oracle import llm_ref, flow_ref, hift_ref, sampler_ref
+    from flowmirror_hydravox_amd import weights as W
+    from flowmirror_hydravox_amd.pipeline import synthetic_utterance
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    u = synthetic_utterance(cfg, 0, chars)
+    sampling = dict(top_p=0.9, top_k=10, win_size=32, tau_r=0.2)
+    # ---- LLM: first 4 AR steps (2*heads... tokens) of one utterance at the true context offset, no KV cache (reference behaviour)
+    sd = W.make_llm_state(cfg.llm, seed=pipe_seed, init='normal02')
+    n_steps = 3
+    t0 = time.time()
+    toks = list(llm_ref.llm_inference(sd, cfg.llm, u.text, sampler_ref.NoiseStream(seed=0), inference_head_num=heads, sampling=sampling,
+                                      max_token_text_ratio=5.5, min_token_text_ratio=5.5, use_kv_cache=False, max_steps=n_steps))
+    t_llm = (time.time() - t0) / max(len(toks), 1)
+    n_llm = len(toks)
+    del sd
+    # ---- flow + HiFT on a 64-token (128-frame) utterance; per-token cost (attention share grows with T: this favours the CPU)
+    n_tok = 64
+    g = torch.Generator().manual_seed(1)
+    token = torch.randint(0, cfg.flow.vocab, (1, n_tok), generator=g)
+    sdf = W.make_flow_state(cfg.flow, seed=pipe_seed + 1, init='normal02')
+    t0 = time.time()
+    mel = flow_ref.flow_inference(token, u.embedding[None], sdf, cfg.flow)
+    t_flow = (time.time() - t0) / n_tok
+    del sdf
+    sdh = W.make_hift_state(cfg.hift, seed=pipe_seed + 2, init='normal02')
+    tables = hift_ref.make_tables(cfg.hift, seed=0, n_samples=mel.shape[-1] * cfg.hift.upsample_total)
+    t0 = time.time()
+    hift_ref.hift_inference(mel, sdh, cfg.hift, tables)
+    t_hift = (time.time() - t0) / n_tok
+    per_tok = t_llm + t_flow + t_hift
+    return dict(value=round(1.0 / per_tok, 3), unit='speech-tokens/s', cores=cores, kind='port',
+                sample='oracle/ (fp32 CPU restatement of the reference algorithm, torch CPU, %d threads): LLM = first %d tokens of one %d-char '
+                       'utterance with the reference\'s no-KV-cache full-prefix recompute (%.2f s/token); flow (10 Euler steps, CFG) + HiFT on a '
+                       '%d-token / %d-frame utterance (%.3f + %.3f s/token); value = 1 / sum of per-token costs'
+                       % (cores, n_llm, chars, t_llm, n_tok, 2 * n_tok, t_flow, t_hift),
+                llm_tokens_per_s=round(1.0 / t_llm, 3))
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    else:
+        torch.cuda.set_device(0)
+    from flowmirror_hydravox_amd import _lib, cv3_config, tiny_config
+    from flowmirror_hydravox_amd.pipeline import HvxPipeline, synthetic_utterance
+    from flowmirror_hydravox_amd.dp import gather_waveforms
+    from flowmirror_hydravox_amd.sampling import ras_sampling
+    from functools import partial
+    _lib.require_gpu()
+    lib = _lib.load()
+
+    cfg = tiny_config() if args.tiny else cv3_config()
+    chars, B, K = args.chars, args.batch, args.heads
+    ratio = 5.5
+    n_spk = int(chars * ratio)
+    max_ctx = 2 + chars + n_spk + K + 32
+    sampling = partial(ras_sampling, top_p=0.9, top_k=10, win_size=32, tau_r=0.2)
+    t_build = time.time()
+    pipe = HvxPipeline(cfg, llm_dtype=torch.bfloat16, flow_dtype=torch.bfloat16, max_batch=B, max_ctx=max_ctx, max_t=2 * n_spk + 64,
+                       seed=1986, init='normal02', sampling=sampling, inference_head_num=K)
+    t_build = time.time() - t_build
+    utts = [synthetic_utterance(cfg, rank * B + i, chars) for i in range(B)]
+    gids = [rank * B + i for i in range(B)]
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        wavs, st = pipe.synthesize(utts, max_token_text_ratio=ratio, min_token_text_ratio=ratio)
+        got = gather_waveforms(wavs, gids, dst=0)
+        return st, got
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    lib.hvx_prof_enable(args.prof_period)
+    stats = []
+    t0 = time.time()
+    for _ in range(args.steps):
+        st, got = step()
+        stats.append(st)
+    barrier()
+    elapsed = time.time() - t0
+    prof = read_prof(lib)
+    lib.hvx_prof_enable(0)
+
+    tokens = sum(s.tokens for s in stats)
+    audio = sum(s.audio_seconds for s in stats)
+    llm_s = sum(s.llm_seconds for s in stats)
+    flow_s = sum(s.flow_seconds for s in stats)
+    hift_s = sum(s.hift_seconds for s in stats)
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed, float(tokens), audio, llm_s, flow_s, hift_s], dtype=torch.float64, device='cuda')
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax[0])
+        tokens, audio = float(tsum[1]), float(tsum[2])
+        llm_s, flow_s, hift_s = float(tmax[3]), float(tmax[4]), float(tmax[5])
+    if rank != 0:
+        return
+    assert world > 1 or len(got) == B
+
+    est = sorted(((p['est_total_ms'], n) for n, p in prof.items()), reverse=True)
+    dominant = est[0][1] if est else None
+    line = {
+        'metric': 'speech-tokens/sec + RTF, HydraVox-CV3 head_num=%d, %d-char batch' % (K, chars),
+        'value': round(tokens / elapsed, 2), 'unit': 'speech-tokens/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 2),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+        'config': {'workload': 'HydraVox-CV3%s inference_head_num=%d, batch=%dx%d-char utterances per GPU (%d text -> %d speech tokens -> %d mel frames '
+                               'each), llm+flow bf16 / hift fp32, llm->flow->hift end to end, seeded N(0,0.02) weights'
+                               % (' [TINY DIMS - NOT A BENCHMARK]' if args.tiny else '', K, B, chars, chars, n_spk, 2 * n_spk),
+                   'global_batch': B * world, 'parallelism': 'utterance-dp%d' % world,
+                   'sampling': {'top_p': 0.9, 'top_k': 10, 'win_size': 32, 'tau_r': 0.2}},
+        'rtf': round(elapsed / audio, 6) if audio else None,
+        'llm_tokens_per_s': round(tokens / llm_s, 2) if llm_s else None,
+        'stage_seconds_per_step': {'llm': round(llm_s / args.steps, 4), 'flow': round(flow_s / args.steps, 4), 'hift': round(hift_s / args.steps, 4)},
+        'audio_seconds_per_step': round(audio / args.steps, 2),
+        'setup_seconds': round(t_build, 1),
+    }
+    if dominant:
+        line['roofline'] = roofline_of(dominant, prof[dominant])
+        line['roofline_other'] = [roofline_of(n, prof[n]) for _, n in est[1:] if prof[n]['work_per_launch'] > 0]
+        line['kernel_time_share_ms'] = {n: round(t, 1) for t, n in est}
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            del pipe
+            torch.cuda.empty_cache()
+            line['cpu_baseline'] = cpu_baseline(cfg, 1986, chars, K)
+        except Exception as e:                    # the bench line must still be printed
+            line['cpu_baseline'] = {'value': None, 'unit': 'speech-tokens/s', 'cores': os.cpu_count(), 'kind': 'port', 'sample': 'failed: %r' % (e,)}
+    print(json.dumps(line))
+
+
+if __name__ == '__main__':
+    main()

@@ -78,6 +78,8 @@ SYMBOLS = {
     'hvx_abi_version': (c_i32, []),
     'hvx_last_error': (C.c_char_p, []),
     'hvx_device_ok': (c_i32, []),
+    'hvx_prof_enable': (c_i32, [c_i32]),
+    'hvx_prof_read': (c_i32, [c_i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(c_i64), C.POINTER(c_i64), C.POINTER(C.c_double)]),
     'hvx_ras_sample': (c_i32, [C.POINTER(SampleArgs), c_vp]),
     'hvx_op_gemm': (c_i32, [C.POINTER(GemmArgs), c_vp]),
     'hvx_op_attention': (c_i32, [C.POINTER(AttnArgs), c_vp]),

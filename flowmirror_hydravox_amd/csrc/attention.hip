@@ -224,12 +224,16 @@ static int launch_t(const AttnArgs& a, hipStream_t s) {
     const int rows_per_wave = big ? 32 : 16;
     const int n_qt = (a.n_rows + rows_per_wave - 1) / rows_per_wave;
     dim3 grid((n_qt * a.n_splits + 3) / 4, a.heads, a.batch);
+    // QK^T + PV flops when the key length is known on the host (DiT); 0 for the device-length LLM calls
+    const double flops = a.kv_len ? 0.0 : 4.0 * a.n_rows * (double)a.kv_len_const * 64.0 * a.heads * a.batch * (a.causal ? 0.5 : 1.0);
+    const int slot = prof_begin(a.kv_len ? PK_ATTN_LLM : PK_ATTN, flops, s);
     if (big) hipLaunchKernelGGL((attn_fwd_kernel<T, 2>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((attn_fwd_kernel<T, 1>), grid, dim3(256), 0, s, a);
     if (a.n_splits > 1) {
         dim3 g2((a.n_rows + 3) / 4, a.heads, a.batch);
         hipLaunchKernelGGL((attn_combine_kernel<T>), g2, dim3(256), 0, s, a);
     }
+    prof_end(slot, s);
     return hipGetLastError() == hipSuccess ? 0 : (set_error("attention launch failed"), -1);
 }
 

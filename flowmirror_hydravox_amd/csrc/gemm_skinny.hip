@@ -167,7 +167,12 @@ static int launch_one(const SkinnyArgs& a, hipStream_t s) {
     const int waves = (ntiles + NT - 1) / NT;
     const int mchunks = (a.M + MT * 16 - 1) / (MT * 16);
     dim3 grid((waves + 3) / 4, a.split_k, mchunks * a.nz);
+    // algorithmic HBM bytes of this launch: every weight once, the activation rows once, the result once
+    const double bytes = (double)a.nz * ((double)a.N * a.K * sizeof(T) + (double)a.M * a.K * sizeof(T) +
+                                         (double)a.M * a.N * (EPI == SK_PARTIAL ? 4.0 * a.split_k : (double)sizeof(T)));
+    const int slot = prof_begin(PK_SKINNY, bytes, s);
     hipLaunchKernelGGL((gemm_skinny_kernel<T, MT, NT, EPI>), grid, dim3(256), 0, s, a);
+    prof_end(slot, s);
     return hipGetLastError() == hipSuccess ? 0 : (set_error("skinny gemm launch failed"), -1);
 }
 

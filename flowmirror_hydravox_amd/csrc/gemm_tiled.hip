@@ -205,10 +205,12 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(GemmArgs a) {
 template <class T, int BM, int BN, int WM, int WN>
 static int launch_cfg(const GemmArgs& a, hipStream_t s) {
     dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, a.batch * a.groups);
+    const int slot = prof_begin(sizeof(T) == 2 ? PK_GEMM : PK_GEMM_F32, 2.0 * a.M * a.N * (double)a.K * a.batch * a.groups, s);
     if (a.epi == EPI_GENERIC)
         hipLaunchKernelGGL((gemm_tiled_kernel<T, BM, BN, WM, WN, EPI_GENERIC>), grid, dim3(256), 0, s, a);
     else
         hipLaunchKernelGGL((gemm_tiled_kernel<T, BM, BN, WM, WN, EPI_QKV_DIT>), grid, dim3(256), 0, s, a);
+    prof_end(slot, s);
     return hipGetLastError() == hipSuccess ? 0 : (set_error("gemm launch failed"), -1);
 }
 

@@ -3,6 +3,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <vector>
+
 #include "hvx.h"
 #include "hvx_kernels.h"
 
@@ -13,6 +15,33 @@ void set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+// ---- sampled kernel timing ------------------------------------------------------------------------------------------------
+struct ProfSlot { int kind; double work; hipEvent_t e0, e1; };
+static struct {
+    bool on = false;
+    int period = 1;
+    long long launched[PK_COUNT] = {};
+    double launched_work[PK_COUNT] = {};
+    std::vector<ProfSlot> slots;
+} g_prof;
+constexpr size_t PROF_MAX_SLOTS = 1 << 15;
+
+int prof_begin(int kind, double work, hipStream_t s) {
+    if (!g_prof.on) return -1;
+    const long long n = g_prof.launched[kind]++;
+    g_prof.launched_work[kind] += work;
+    if (n % g_prof.period != 0 || g_prof.slots.size() >= PROF_MAX_SLOTS) return -1;
+    ProfSlot p;
+    p.kind = kind; p.work = work;
+    if (hipEventCreate(&p.e0) != hipSuccess || hipEventCreate(&p.e1) != hipSuccess) return -1;
+    hipEventRecord(p.e0, s);
+    g_prof.slots.push_back(p);
+    return (int)g_prof.slots.size() - 1;
+}
+void prof_end(int slot, hipStream_t s) {
+    if (slot >= 0) hipEventRecord(g_prof.slots[slot].e1, s);
 }
 }  // namespace hvx
 
@@ -37,6 +66,33 @@ int hvx_device_ok(void) {
         return 0;
     }
     return p.multiProcessorCount;
+}
+
+int hvx_prof_enable(int32_t period) {
+    for (auto& p : g_prof.slots) { hipEventDestroy(p.e0); hipEventDestroy(p.e1); }
+    g_prof.slots.clear();
+    for (int k = 0; k < PK_COUNT; ++k) { g_prof.launched[k] = 0; g_prof.launched_work[k] = 0; }
+    g_prof.on = period > 0;
+    g_prof.period = period > 0 ? period : 1;
+    return 0;
+}
+
+int hvx_prof_read(int32_t kind, double* sampled_ms, double* sampled_work, int64_t* n_sampled, int64_t* n_launched, double* launched_work) {
+    if (kind < 0 || kind >= PK_COUNT) return set_error("hvx_prof_read: bad kind"), -1;
+    double ms = 0, work = 0;
+    long long n = 0;
+    for (auto& p : g_prof.slots) {
+        if (p.kind != kind) continue;
+        float t = 0;
+        if (hipEventSynchronize(p.e1) != hipSuccess || hipEventElapsedTime(&t, p.e0, p.e1) != hipSuccess) continue;
+        ms += t; work += p.work; ++n;
+    }
+    if (sampled_ms) *sampled_ms = ms;
+    if (sampled_work) *sampled_work = work;
+    if (n_sampled) *n_sampled = n;
+    if (n_launched) *n_launched = g_prof.launched[kind];
+    if (launched_work) *launched_work = g_prof.launched_work[kind];
+    return 0;
 }
 
 int hvx_ras_sample(const hvx_sample_args* a, hvx_stream s) {

@@ -201,7 +201,9 @@ int launch_ras_sample(const SampleArgs& a, hipStream_t s) {
         return -1;
     }
     const size_t lds = (size_t)((a.V + 3) & ~3) * 4 + (size_t)((a.V + 15) & ~15);
+    const int slot = prof_begin(PK_SAMPLER, (double)a.n_seq * a.head_k * a.V * 4.0, s);
     hipLaunchKernelGGL(ras_sample_kernel, dim3(a.n_seq), dim3(256), lds, s, a);
+    prof_end(slot, s);
     return hipGetLastError() == hipSuccess ? 0 : (set_error("ras_sample launch failed"), -1);
 }
 

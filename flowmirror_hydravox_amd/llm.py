@@ -1,0 +1,372 @@
+"""HvxLLM — drop-in for the reference's `CosyVoice3LM` inference surface on MI355X.
+
+Mirrors server/model_utils/cosyvoice/llm/llm_multi_head_v3.py:
+  * `inference(text, text_len, prompt_text, prompt_text_len, prompt_speech_token, prompt_speech_token_len, embedding,
+     sampling=25, max_token_text_ratio=20, min_token_text_ratio=2, uuid='')` -> generator of python ints   (:926-960)
+  * attributes the worker mutates per request: `sampling` (functools.partial of ras_sampling) and
+    `inference_head_num` (server/worker.py:58-64); `head_k = min(inference_head_num, head_num)`, <= 0 -> 1 (:867-869)
+  * `load_state_dict` takes the reference's flat llm.pt keys
+All arithmetic runs in libhvx (csrc/hvx_llm.hip, csrc/sampler.hip); this file only keeps the step bookkeeping of
+:890-922 (shared history snapshot, stop on any id >= speech_token_size, max_len) and feeds the noise stream.
+`generate_batch` runs several utterances in lockstep through the same kernels (the reference is batch-1).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from ._lib import check, ptr, stream_ptr
+from .config import LLMConfig
+from .packing import pack_frag, pack_gate_up
+from .sampling import NoiseStream, rep_threshold, sampling_params
+from .weights import llm_spec, check_state, DROP_KEYS
+
+
+def _rope_tables(max_pos, head_dim, theta):
+    """cos/sin exactly as HF Qwen2 rotary embedding computes them (fp32 on the host), first half only: [max_pos][head_dim/2]."""
+    inv = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim))
+    fr = torch.outer(torch.arange(max_pos, dtype=torch.float32), inv)
+    return fr.cos().contiguous(), fr.sin().contiguous()
+
+
+class _Request:
+    def __init__(self, prefix_tok, n_text, min_len, max_len, noise):
+        self.prefix = prefix_tok          # encoded int list (speech ids >= 0, text ids as -2-id)
+        self.min_len = min_len
+        self.max_len = max_len
+        self.noise = noise
+        self.out = []
+        self.done = False
+        self.cursor = 0                   # absolute noise position
+        self.pos = 0                      # KV length
+
+
+class HvxLLM:
+    def __init__(self, cfg: LLMConfig, state_dict=None, dtype=torch.bfloat16, device='cuda', sampling=None,
+                 inference_head_num=5, max_batch=8, max_ctx=4096, noise_cap=1 << 16):
+        _lib.require_gpu()
+        self.lib = _lib.load()
+        self.cfg = cfg
+        self.dtype = dtype
+        self.device = torch.device(device)
+        # reference attribute names
+        self.llm_input_size = cfg.hidden
+        self.llm_output_size = cfg.hidden
+        self.speech_token_size = cfg.speech_tokens
+        self.vocab_size = cfg.vocab
+        self.sos, self.eos_token, self.task_id, self.fill_token = cfg.sos, cfg.eos, cfg.task_id, cfg.speech_tokens + 3
+        self.head_num = cfg.head_num
+        self.inference_head_num = inference_head_num
+        self.stop_token_ids = [cfg.speech_tokens + i for i in range(cfg.extra_tokens)]
+        self.sampling = sampling
+        self.bf16 = dtype == torch.bfloat16
+        self.fp16 = False
+        self.max_batch = max_batch
+        self.max_ctx = (max_ctx + 31) // 32 * 32
+        self.noise_cap = noise_cap
+        self._h = None
+        self._bound = None
+        self.last_stats = {}
+        if state_dict is not None:
+            self.load_state_dict(state_dict)
+
+    # ------------------------------------------------------------------------------------------------------------
+    # weights
+    # ------------------------------------------------------------------------------------------------------------
+    def load_state_dict(self, sd, strict=True):
+        sd = {k: v for k, v in sd.items() if k not in DROP_KEYS}
+        check_state(sd, llm_spec(self.cfg, with_lm_head=True), 'CosyVoice3LM', optional=('llm.model.lm_head.weight',))
+        c, dt, dev = self.cfg, self.dtype, self.device
+
+        def W(k):
+            return sd[k].to(dev).float()
+
+        def mat(t):                       # GEMM operand in the compute dtype
+            return t.to(dt).contiguous()
+
+        def vec(t):
+            return t.float().contiguous()
+
+        cos, sin = _rope_tables(self.max_ctx, c.head_dim, c.rope_theta)
+        vpad = (c.vocab + 15) // 16 * 16
+        ws = [cos.to(dev), sin.to(dev), vec(W('llm.model.model.norm.weight')),
+              mat(pack_frag(W('llm_decoder.weight'))), mat(W('speech_embedding.weight')), mat(W('llm.model.model.embed_tokens.weight'))]
+        for i in range(c.layers):
+            p = 'llm.model.model.layers.%d.' % i
+            wqkv = torch.cat([W(p + 'self_attn.q_proj.weight'), W(p + 'self_attn.k_proj.weight'), W(p + 'self_attn.v_proj.weight')], 0)
+            bqkv = torch.cat([W(p + 'self_attn.q_proj.bias'), W(p + 'self_attn.k_proj.bias'), W(p + 'self_attn.v_proj.bias')], 0)
+            ws += [vec(W(p + 'input_layernorm.weight')), mat(pack_frag(wqkv)), vec(bqkv), mat(pack_frag(W(p + 'self_attn.o_proj.weight'))),
+                   vec(W(p + 'post_attention_layernorm.weight')),
+                   mat(pack_gate_up(W(p + 'mlp.gate_proj.weight'), W(p + 'mlp.up_proj.weight'))), mat(pack_frag(W(p + 'mlp.down_proj.weight')))]
+        hn = c.head_num
+
+        def stack(fn):
+            return torch.stack([fn('mtp_block.%d.' % j) for j in range(hn)], 0).contiguous()
+
+        ws += [vec(stack(lambda p: W(p + 'input_layernorm.weight'))),
+               mat(stack(lambda p: pack_frag(W(p + 'self_attn.v_proj.weight')))),
+               vec(stack(lambda p: W(p + 'self_attn.v_proj.bias'))),
+               mat(stack(lambda p: pack_frag(W(p + 'self_attn.o_proj.weight')))),
+               vec(stack(lambda p: W(p + 'post_attention_layernorm.weight'))),
+               mat(stack(lambda p: pack_gate_up(W(p + 'mlp.gate_proj.weight'), W(p + 'mlp.up_proj.weight')))),
+               mat(stack(lambda p: pack_frag(W(p + 'mlp.down_proj.weight'))))]
+        self._weights = ws                                   # keep device tensors alive
+        cc = _lib.LLMConfig(dtype=_lib.dtype_code(dt), hidden=c.hidden, layers=c.layers, q_heads=c.q_heads, kv_heads=c.kv_heads,
+                            inter=c.inter, vocab=c.vocab, vocab_pad=vpad, speech_tokens=c.speech_tokens, text_vocab=c.text_vocab,
+                            head_num=hn, mtp_attn_dim=c.mtp_attn_dim, mtp_inter=c.mtp_inter, rms_eps=c.rms_eps,
+                            mtp_rms_eps=c.mtp_rms_eps, max_pos=self.max_ctx)
+        if c.head_dim != 64:
+            raise _lib.HvxError('hvx kernels are specialised for head_dim 64')
+        if self._h is not None:
+            self.lib.hvx_llm_destroy(self._h)
+            self._h = None
+        h = C.c_void_p()
+        arr = _lib.ptr_array(ws)
+        check(self.lib.hvx_llm_create(C.byref(cc), arr, len(ws), C.byref(h)), 'hvx_llm_create')
+        self._h = h
+        self._bound = None
+        return self
+
+    def eval(self):
+        return self
+
+    def cuda(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def __del__(self):
+        try:
+            if getattr(self, '_h', None) is not None:
+                self.lib.hvx_llm_destroy(self._h)
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------------------------------------------------
+    # buffers
+    # ------------------------------------------------------------------------------------------------------------
+    def _bind(self, n_seq, max_rows):
+        key = (max(n_seq, 1), max_rows)
+        if self._bound is not None and self._bound[0] >= key[0] and self._bound[1] >= key[1]:
+            return
+        S = max(key[0], self.max_batch)
+        R = max(key[1], S * max(self.cfg.head_num, 1))
+        wsb = self.lib.hvx_llm_workspace_bytes(self._h, S, R, self.max_ctx)
+        kvb = self.lib.hvx_llm_kv_bytes(self._h, S, self.max_ctx)
+        self._ws = torch.empty(wsb, dtype=torch.uint8, device=self.device)
+        self._kv = torch.empty(kvb, dtype=torch.uint8, device=self.device)
+        check(self.lib.hvx_llm_bind(self._h, ptr(self._ws), wsb, S, R, ptr(self._kv), kvb, S, self.max_ctx, stream_ptr()), 'hvx_llm_bind')
+        self._bound = (S, R)
+
+    def _forward(self, n_seq, kn, tok, ctrl, head_k, logp):
+        check(self.lib.hvx_llm_forward(self._h, stream_ptr(), n_seq, kn, ptr(tok), ptr(ctrl), head_k, ptr(logp)), 'hvx_llm_forward')
+
+    # ------------------------------------------------------------------------------------------------------------
+    # reference surface
+    # ------------------------------------------------------------------------------------------------------------
+    def head_k(self):
+        k = int(min(getattr(self, 'inference_head_num', 1), getattr(self, 'head_num', 1)))     # :867-869
+        return 1 if k <= 0 else k
+
+    def _encode_prefix(self, text, prompt_text, prompt_speech_token):
+        """[sos | text | task_id | prompt_speech] as encoded ids (:941-952): speech-table rows >= 0, text-table rows as -2-id."""
+        t = []
+        if prompt_text is not None and prompt_text.numel():
+            t += prompt_text.reshape(-1).tolist()
+        t += text.reshape(-1).tolist()
+        enc = [self.cfg.sos] + [-2 - int(v) for v in t] + [self.cfg.task_id]
+        if prompt_speech_token is not None and prompt_speech_token.numel():
+            enc += [int(v) for v in prompt_speech_token.reshape(-1).tolist()]
+        return enc
+
+    @torch.inference_mode()
+    def inference(self, text, text_len, prompt_text, prompt_text_len, prompt_speech_token, prompt_speech_token_len, embedding,
+                  sampling=25, max_token_text_ratio=20, min_token_text_ratio=2, uuid='', seed=None):
+        text = torch.as_tensor(text)
+        n_text = int(text.numel())
+        # the reference mutates text_len in place (`text_len += prompt_text_len`, :942); keep that observable side effect
+        if isinstance(text_len, torch.Tensor) and isinstance(prompt_text_len, torch.Tensor):
+            text_len += prompt_text_len.to(text_len.device)
+        pst = prompt_speech_token
+        if prompt_speech_token_len is not None and int(torch.as_tensor(prompt_speech_token_len).reshape(-1)[0]) == 0:
+            pst = None
+        prefix = self._encode_prefix(text, prompt_text, pst)
+        min_len = int(n_text * min_token_text_ratio)            # (:955-956) text_len - prompt_text_len == len(text)
+        max_len = int(n_text * max_token_text_ratio)
+        req = _Request(prefix, n_text, min_len, max_len, NoiseStream(seed=seed))
+        for tok in self._run([req], stream_first=True):
+            yield tok
+
+    @torch.inference_mode()
+    def generate_batch(self, texts, prompt_texts=None, prompt_speech_tokens=None, seeds=None, max_token_text_ratio=20,
+                       min_token_text_ratio=2):
+        """Lock-step batched decoding of several utterances; returns one token list per utterance.  Utterance i uses its own
+        generator seeded with seeds[i], so results do not depend on the batch composition."""
+        reqs = []
+        for i, text in enumerate(texts):
+            text = torch.as_tensor(text)
+            pt = None if prompt_texts is None else prompt_texts[i]
+            ps = None if prompt_speech_tokens is None else prompt_speech_tokens[i]
+            n_text = int(text.numel())
+            reqs.append(_Request(self._encode_prefix(text, None if pt is None else torch.as_tensor(pt), None if ps is None else torch.as_tensor(ps)),
+                                 n_text, int(n_text * min_token_text_ratio), int(n_text * max_token_text_ratio),
+                                 NoiseStream(seed=None if seeds is None else seeds[i])))
+        for _ in self._run(reqs, stream_first=False):
+            pass
+        return [r.out for r in reqs]
+
+    # ------------------------------------------------------------------------------------------------------------
+    # engine
+    # ------------------------------------------------------------------------------------------------------------
+    def _run(self, reqs, stream_first):
+        import time
+        c = self.cfg
+        S = len(reqs)
+        K = self.head_k()
+        sp = sampling_params(self.sampling)
+        thr = rep_threshold(sp['win_size'], sp['tau_r'])
+        dev = self.device
+        longest = max(len(r.prefix) for r in reqs)
+        need_ctx = max(len(r.prefix) + r.max_len + K for r in reqs)
+        if need_ctx > self.max_ctx:
+            raise ValueError('context %d exceeds max_ctx=%d' % (need_ctx, self.max_ctx))
+        self._bind(S, max(longest, S * K))
+        t_start = time.time()
+
+        # ---- prefill: everything but the last prefix row, one utterance at a time (kn = its length) ------------------------
+        for i, r in enumerate(reqs):
+            n = len(r.prefix) - 1
+            if n > 0:
+                tok = torch.tensor(r.prefix[:n], dtype=torch.int32, device=dev)
+                ctrl = torch.tensor([i, 0, n, n, n - 1], dtype=torch.int32, device=dev)
+                self._forward(1, n, tok, ctrl, 0, None)
+            r.pos = n
+            r.next = [r.prefix[-1]]
+
+        # ---- decode: dense [S][K] grid per step -------------------------------------------------------------------------------
+        W = sp['win_size'] if sp['win_size'] > 0 else max(r.max_len for r in reqs)
+        W = max(W, 1)
+        n_ctl = S * K + 5 * S + S * W + 3 * S
+        ctl_host = torch.empty(n_ctl, dtype=torch.int32).pin_memory()
+        ctl_dev = torch.empty(n_ctl, dtype=torch.int32, device=dev)
+        o_tok, o_ctrl, o_hist, o_hlen, o_min, o_act = 0, S * K, S * K + 5 * S, S * K + 5 * S + S * W, S * K + 5 * S + S * W + S, S * K + 5 * S + S * W + 2 * S
+        logp = torch.empty(S, K, c.vocab, dtype=torch.float32, device=dev)
+        ncap = self.noise_cap
+        noise_host = torch.empty(S, ncap, dtype=torch.float32).pin_memory()
+        noise_dev = torch.empty(S, ncap, dtype=torch.float32, device=dev)
+        cur_dev = torch.zeros(S, dtype=torch.int64, device=dev)
+        nbase = [0] * S                        # absolute stream position of noise_dev[i, 0]
+        for i, r in enumerate(reqs):
+            noise_host[i].copy_(torch.from_numpy(r.noise.window(0, ncap)))
+        noise_dev.copy_(noise_host, non_blocking=True)
+        ids_host = torch.empty(S * K, dtype=torch.int32).pin_memory()
+        cur_host = torch.empty(S, dtype=torch.int64).pin_memory()
+        ch = ctl_host.numpy()
+        steps = 0
+        n_llm_tokens = 0
+        while not all(r.done for r in reqs):
+            ch[o_tok:o_tok + S * K] = -1
+            for i, r in enumerate(reqs):
+                nn = 0 if r.done else len(r.next)
+                if nn:
+                    ch[o_tok + i * K:o_tok + i * K + nn] = r.next
+                ch[o_ctrl + 0 * S + i] = i
+                ch[o_ctrl + 1 * S + i] = r.pos
+                ch[o_ctrl + 2 * S + i] = nn
+                ch[o_ctrl + 3 * S + i] = r.pos + nn
+                ch[o_ctrl + 4 * S + i] = (i * K + nn - 1) if nn else -1
+                hw = r.out[-W:]
+                ch[o_hist + i * W:o_hist + i * W + len(hw)] = hw
+                ch[o_hlen + i] = len(hw)
+                ch[o_min + i] = r.min_len - (len(r.out) - len(hw))       # (len(snapshot)+j < min_len) in window coordinates
+                ch[o_act + i] = 0 if r.done else 1
+            ctl_dev.copy_(ctl_host, non_blocking=True)
+            self._forward(S, K, ctl_dev[o_tok:], ctl_dev[o_ctrl:], K, logp)
+            act = ctl_dev[o_act:o_act + S]
+            idl = None
+            while True:
+                ids = ops.ras_sample(logp, ctl_dev[o_hist:o_hist + S * W].view(S, W), ctl_dev[o_hlen:o_hlen + S], ctl_dev[o_min:o_min + S],
+                                     noise_dev, cur_dev, speech_tokens=c.speech_tokens, top_k=sp['top_k'], top_p=sp['top_p'],
+                                     win_size=sp['win_size'], rep_thresh=thr, active=act)
+                ids_host.copy_(ids.view(-1), non_blocking=True)
+                cur_host.copy_(cur_dev, non_blocking=True)
+                torch.cuda.current_stream().synchronize()
+                new = ids_host.view(S, K).tolist()
+                if idl is None:
+                    idl = new
+                else:
+                    for i in short:
+                        idl[i] = new[i]
+                short = [i for i, r in enumerate(reqs) if not r.done and idl[i][0] == -2]
+                if not short:
+                    break
+                # these sequences ran out of pre-generated noise inside the step (their cursor was left untouched):
+                # enlarge the window and sample them again; everyone else keeps the ids already drawn
+                act = torch.zeros(S, dtype=torch.int32)
+                act[short] = 1
+                act = act.to(dev)
+                ncap *= 4
+                nh = torch.empty(S, ncap, dtype=torch.float32).pin_memory()
+                for i, r in enumerate(reqs):
+                    nbase[i] += int(cur_host[i])
+                    nh[i].copy_(torch.from_numpy(r.noise.window(nbase[i], ncap)))
+                noise_host = nh
+                noise_dev = torch.empty(S, ncap, dtype=torch.float32, device=dev)
+                noise_dev.copy_(noise_host)
+                cur_dev.zero_()
+            steps += 1
+            refill = False
+            for i, r in enumerate(reqs):
+                if r.done:
+                    continue
+                r.pos += len(r.next)
+                group = []
+                for t in idl[i]:
+                    if t == -1:
+                        raise RuntimeError('sampling reaches max_trials {} and still get eos when ignore_eos is True, check your input!'.format(100))
+                    if t >= c.speech_tokens:                # any stop id (:683, :904)
+                        r.done = True
+                        break
+                    r.out.append(t)
+                    group.append(t)
+                    n_llm_tokens += 1
+                    if stream_first and i == 0:
+                        yield t
+                    if len(r.out) >= r.max_len:
+                        r.done = True
+                        break
+                if not group:
+                    r.done = True
+                r.next = group
+                if int(cur_host[i]) > ncap // 2:
+                    refill = True
+            if refill and not all(r.done for r in reqs):
+                for i, r in enumerate(reqs):
+                    nbase[i] += int(cur_host[i])
+                    noise_host[i].copy_(torch.from_numpy(r.noise.window(nbase[i], ncap)))
+                noise_dev.copy_(noise_host, non_blocking=True)
+                cur_dev.zero_()
+                cur_host.zero_()
+        for i, r in enumerate(reqs):
+            r.cursor = nbase[i] + int(cur_host[i])
+            r.noise.finalize(r.cursor)
+        dt = time.time() - t_start
+        self.last_stats = dict(steps=steps, tokens=n_llm_tokens, seconds=dt, tps=n_llm_tokens / dt if dt > 0 else 0.0, head_k=K, batch=S)
+
+    @torch.inference_mode()
+    def prefill_logp(self, prefix_encoded, head_k=None):
+        """Parity helper: log-probs [K][vocab] of the K heads after a fresh prefill of one encoded prefix, plus the
+        post-final-norm hidden of its last row."""
+        K = self.head_k() if head_k is None else head_k
+        n = len(prefix_encoded)
+        self._bind(1, max(n, K))
+        dev = self.device
+        tok = torch.tensor(prefix_encoded, dtype=torch.int32, device=dev)
+        ctrl = torch.tensor([0, 0, n, n, n - 1], dtype=torch.int32, device=dev)
+        logp = torch.empty(1, K, self.cfg.vocab, dtype=torch.float32, device=dev)
+        self._forward(1, n, tok, ctrl, K, logp)
+        y = torch.empty(1, self.cfg.hidden, dtype=torch.float32, device=dev)
+        check(self.lib.hvx_llm_last_hidden(self._h, stream_ptr(), 1, ptr(y)), 'hvx_llm_last_hidden')
+        return logp[0], y[0]

@@ -33,6 +33,12 @@ const char* hvx_last_error(void);
 /* number of compute units / whether a gfx950 device is current (0 = no usable device) */
 int hvx_device_ok(void);
 
+/* Sampled per-kernel timing for bench.py (diagnostics, not on the product path): every `period`-th launch of a kernel class
+ * (0 decode GEMM, 1 tiled GEMM/conv, 2 attention, 3 sampler) is bracketed by hipEvents on its stream; period <= 0 disables.
+ * `work` is the algorithmic bytes (class 0) or flops (classes 1, 2) of the launches. */
+int hvx_prof_enable(int32_t period);
+int hvx_prof_read(int32_t kind, double* sampled_ms, double* sampled_work, int64_t* n_sampled, int64_t* n_launched, double* launched_work);
+
 /* ---------------------------------------------------------------------------------------------------
  * Sampler — replaces cosyvoice/utils/common.py:138-166 (ras_sampling, nucleus_sampling, random_sampling)
  * and the EOS-rejection loop of cosyvoice/llm/llm_multi_head_v3.py:151-166, for all K heads of a step
@@ -142,7 +148,7 @@ typedef struct {
  *   5 pla conv1 W [C][4][96]  6 b   7 pla conv2 W [mel][3][C]  8 b
  *   9 time_mlp.0 W [D][256] 10 b  11 time_mlp.2 W [D][D] 12 b   13 input proj W [D][320] 14 b
  *   15 conv_pos 1 W [groups][Cg][k*Cg] 16 b [D]  17 conv_pos 2 W  18 b
- *   per block, 12 entries from 19+12i: adaLN W [6D][D], b; Wqkv [3D][D], bqkv; Wout [D][D], b; ff1 W [ff][D], b; ff2 W [D][ff], b ... (see flow.py)
+ *   per block, 10 entries from 19+10i: adaLN W [6D][D], b; Wqkv [3D][D], bqkv; Wout [D][D], b; ff1 W [ff][D], b; ff2 W [D][ff], b
  *   tail: norm_out W [2D][D], b; proj_out W [mel][D], b                                                             */
 typedef struct hvx_flow hvx_flow;
 int hvx_flow_create(const hvx_flow_config* cfg, const void* const* weights, int32_t n_weights, hvx_flow** out);

@@ -1,0 +1,252 @@
+"""Parity of the three model stages (LLM, flow, HiFT) through the C-ABI against the golden vectors minted from the
+reference and against the CPU oracle on the same seeded inputs.
+
+Tolerances (stated per the north star): speech-token ids bit-exact in fp32 mode; fp32 mel/waveform within 1e-3 of the
+signal scale; bf16 mode (production dtype of LLM/DiT) within a few 1e-2 — 8-bit mantissa operands, fp32 accumulation."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, state_checksum
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-12)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# LLM
+# ------------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope='module')
+def llm_setup(tiny_cfg):
+    from flowmirror_hydravox_amd import weights as W
+    g = load_golden('llm_tiny.npz')
+    sd = W.make_llm_state(tiny_cfg.llm, seed=int(g['weight_seed']), init='fan_in', with_lm_head=True)
+    assert state_checksum(sd) == str(g['weight_sha'])
+    return g, sd
+
+
+def _run_case(llm, g, r, seed=None):
+    from functools import partial
+    from flowmirror_hydravox_amd.sampling import ras_sampling
+    p = 'r%d_' % r
+    top_p, top_k, win, tau = g[p + 'sampling']
+    llm.sampling = partial(ras_sampling, top_p=float(top_p), top_k=int(top_k), win_size=int(win), tau_r=float(tau))
+    llm.inference_head_num = int(g[p + 'K'])
+    text = torch.from_numpy(g[p + 'text'])[None]
+    ptext = torch.from_numpy(g[p + 'ptext'])[None]
+    ps = torch.from_numpy(g[p + 'pspeech'])[None]
+    return list(llm.inference(text=text, text_len=torch.tensor([text.shape[1]], dtype=torch.int32), prompt_text=ptext,
+                              prompt_text_len=torch.tensor([ptext.shape[1]], dtype=torch.int32),
+                              prompt_speech_token=ps if ps.shape[1] else None,
+                              prompt_speech_token_len=torch.tensor([ps.shape[1]], dtype=torch.int32), embedding=torch.zeros(0, 192),
+                              max_token_text_ratio=float(g[p + 'ratios'][0]), min_token_text_ratio=float(g[p + 'ratios'][1]),
+                              seed=int(g[p + 'seed']) if seed is None else seed))
+
+
+def test_llm_fp32_token_streams_bit_exact(tiny_cfg, llm_setup):
+    """K in {1,2,3,5,0}: the ids the HIP path emits == the ids the reference emitted (same text / prompt / seed)."""
+    from flowmirror_hydravox_amd.llm import HvxLLM
+    g, sd = llm_setup
+    llm = HvxLLM(tiny_cfg.llm, sd, dtype=torch.float32, max_batch=4, max_ctx=256)
+    for r in range(int(g['n_runs'])):
+        toks = _run_case(llm, g, r)
+        assert toks == g['r%d_tokens' % r].tolist(), r
+
+
+def test_llm_global_generator_is_left_where_the_reference_leaves_it(tiny_cfg, llm_setup):
+    from flowmirror_hydravox_amd.llm import HvxLLM
+    from oracle import sampler_ref
+    g, sd = llm_setup
+    llm = HvxLLM(tiny_cfg.llm, sd, dtype=torch.float32, max_batch=4, max_ctx=256)
+    torch.manual_seed(int(g['r1_seed']))
+    from functools import partial
+    from flowmirror_hydravox_amd.sampling import ras_sampling
+    top_p, top_k, win, tau = g['r1_sampling']
+    llm.sampling = partial(ras_sampling, top_p=float(top_p), top_k=int(top_k), win_size=int(win), tau_r=float(tau))
+    llm.inference_head_num = int(g['r1_K'])
+    text = torch.from_numpy(g['r1_text'])[None]
+    toks = list(llm.inference(text=text, text_len=torch.tensor([text.shape[1]], dtype=torch.int32),
+                              prompt_text=torch.zeros(1, 0, dtype=torch.int32), prompt_text_len=torch.tensor([0], dtype=torch.int32),
+                              prompt_speech_token=None, prompt_speech_token_len=torch.tensor([0], dtype=torch.int32),
+                              embedding=torch.zeros(0, 192), max_token_text_ratio=float(g['r1_ratios'][0]),
+                              min_token_text_ratio=float(g['r1_ratios'][1])))          # seed=None -> global generator
+    assert toks == g['r1_tokens'].tolist()
+    # the oracle tells how many noise values the reference consumed; the next global draw must be that stream position
+    from oracle import llm_ref
+    ns = sampler_ref.NoiseStream(seed=int(g['r1_seed']))
+    list(llm_ref.llm_inference(sd, tiny_cfg.llm, torch.from_numpy(g['r1_text']), ns, inference_head_num=int(g['r1_K']),
+                               sampling=dict(top_p=float(top_p), top_k=int(top_k), win_size=int(win), tau_r=float(tau)),
+                               max_token_text_ratio=float(g['r1_ratios'][0]), min_token_text_ratio=float(g['r1_ratios'][1]), use_kv_cache=True))
+    nxt = torch.empty(1).exponential_(1.0).item()
+    assert nxt == float(ns.peek(ns.cursor, 1)[0])
+
+
+@pytest.mark.parametrize('dtype,tol', [(torch.float32, 2e-4), (torch.bfloat16, 6e-2)])
+def test_llm_first_step_numerics(tiny_cfg, llm_setup, dtype, tol):
+    from flowmirror_hydravox_amd.llm import HvxLLM
+    g, sd = llm_setup
+    llm = HvxLLM(tiny_cfg.llm, sd, dtype=dtype, max_batch=2, max_ctx=128)
+    for r in range(int(g['n_runs'])):
+        p = 'r%d_' % r
+        llm.inference_head_num = int(g[p + 'K'])
+        enc = llm._encode_prefix(torch.from_numpy(g[p + 'text']), torch.from_numpy(g[p + 'ptext']), torch.from_numpy(g[p + 'pspeech']))
+        logp, y = llm.prefill_logp(enc)
+        assert _rel(y.cpu().numpy(), g[p + 'y_last']) < tol, (r, 'hidden')
+        assert np.abs(logp.cpu().numpy() - g[p + 'logps']).max() < (5e-4 if dtype == torch.float32 else 0.25), (r, 'logp')
+
+
+def test_llm_batched_equals_single(tiny_cfg, llm_setup):
+    """utterance-batched lock-step decoding returns, per utterance, exactly what batch-1 decoding returns."""
+    from flowmirror_hydravox_amd.llm import HvxLLM
+    g, sd = llm_setup
+    cfg = tiny_cfg.llm
+    llm = HvxLLM(cfg, sd, dtype=torch.float32, max_batch=4, max_ctx=256, inference_head_num=2)
+    gen = torch.Generator().manual_seed(77)
+    texts = [torch.randint(0, cfg.text_vocab, (n,), generator=gen, dtype=torch.int32) for n in (9, 14, 5, 11)]
+    prompts = [torch.randint(0, cfg.speech_tokens, (n,), generator=gen, dtype=torch.int32) for n in (0, 6, 3, 0)]
+    seeds = [11, 12, 13, 14]
+    batch = llm.generate_batch(texts, prompt_speech_tokens=prompts, seeds=seeds, max_token_text_ratio=4, min_token_text_ratio=2)
+    from oracle import llm_ref, sampler_ref
+    for i in range(4):
+        single = llm.generate_batch([texts[i]], prompt_speech_tokens=[prompts[i]], seeds=[seeds[i]], max_token_text_ratio=4, min_token_text_ratio=2)[0]
+        assert single == batch[i], i
+        ora = list(llm_ref.llm_inference(sd, cfg, texts[i], sampler_ref.NoiseStream(seed=seeds[i]), prompt_speech_token=prompts[i],
+                                         inference_head_num=2, max_token_text_ratio=4, min_token_text_ratio=2, use_kv_cache=True))
+        assert ora == batch[i], i
+        assert all(0 <= t < cfg.speech_tokens for t in batch[i]) and len(batch[i]) <= 4 * len(texts[i])
+
+
+def test_llm_bf16_tracks_the_fp32_oracle(tiny_cfg, llm_setup):
+    """bf16 production mode: the ids agree with the fp32 oracle until the first near-tie; report the common prefix."""
+    from flowmirror_hydravox_amd.llm import HvxLLM
+    g, sd = llm_setup
+    llm = HvxLLM(tiny_cfg.llm, sd, dtype=torch.bfloat16, max_batch=4, max_ctx=256)
+    agree = total = 0
+    for r in range(int(g['n_runs'])):
+        toks = _run_case(llm, g, r)
+        ref = g['r%d_tokens' % r].tolist()
+        assert all(0 <= t < tiny_cfg.llm.speech_tokens for t in toks)
+        n = 0
+        while n < min(len(toks), len(ref)) and toks[n] == ref[n]:
+            n += 1
+        agree += n
+        total += len(ref)
+    print('bf16 common-prefix agreement with the reference ids: %d / %d' % (agree, total))
+    # sampling decisions are discontinuous in the logits: one flipped draw ends the common prefix, so this is a report
+    # (DESIGN.md §3), not a bit-exactness claim; bit-exact ids are asserted in fp32 mode above
+    assert agree >= 1
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# flow
+# ------------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope='module')
+def flow_setup(tiny_cfg):
+    from flowmirror_hydravox_amd import weights as W
+    g = load_golden('flow_tiny.npz')
+    sd = W.make_flow_state(tiny_cfg.flow, seed=int(g['weight_seed']), init='fan_in')
+    assert state_checksum(sd) == str(g['weight_sha'])
+    return g, sd
+
+
+@pytest.mark.parametrize('dtype,tol', [(torch.float32, 1e-3), (torch.bfloat16, 5e-2)])
+def test_flow_stages_vs_reference(tiny_cfg, flow_setup, dtype, tol):
+    from flowmirror_hydravox_amd.flow import HvxFlow
+    g, sd = flow_setup
+    flow = HvxFlow(tiny_cfg.flow, sd, dtype=dtype, max_t=512)
+    assert np.array_equal(flow.rand_noise[0, :2, :8].cpu().numpy(), g['noise_head'])
+    for r in range(int(g['n_runs'])):
+        p = 'r%d_' % r
+        pla = flow.prelookahead(torch.from_numpy(g[p + 'h0'][0]))
+        assert _rel(pla.cpu().numpy(), g[p + 'pla'][0]) < tol, (r, 'pre-lookahead')
+        T = g[p + 'est_x'].shape[-1]
+        est = flow.estimator(torch.from_numpy(g[p + 'est_x']), torch.ones(2, 1, T), torch.from_numpy(g[p + 'est_mu']),
+                             torch.from_numpy(g[p + 'est_t']), torch.from_numpy(g[p + 'est_spk']), torch.from_numpy(g[p + 'est_cond']))
+        assert _rel(est.cpu().numpy(), g[p + 'est_out']) < tol, (r, 'estimator', _rel(est.cpu().numpy(), g[p + 'est_out']))
+        ptoken = torch.from_numpy(g[p + 'ptoken'])
+        has_p = ptoken.shape[1] > 0
+        token = torch.from_numpy(g[p + 'token'])
+        mel, _ = flow.inference(token=token.to(DEV), token_len=torch.tensor([token.shape[1]], dtype=torch.int32),
+                                embedding=torch.from_numpy(g[p + 'emb']).to(DEV), finalize=True,
+                                prompt_token=ptoken.to(DEV) if has_p else None,
+                                prompt_token_len=torch.tensor([ptoken.shape[1]], dtype=torch.int32) if has_p else None,
+                                prompt_feat=torch.from_numpy(g[p + 'pfeat']).to(DEV) if has_p else None,
+                                prompt_feat_len=torch.tensor([2 * ptoken.shape[1]], dtype=torch.int32) if has_p else None)
+        assert mel.dtype == torch.float32 and tuple(mel.shape) == g[p + 'mel'].shape
+        assert _rel(mel.cpu().numpy(), g[p + 'mel']) < (tol if dtype == torch.float32 else 0.15), (r, 'mel', _rel(mel.cpu().numpy(), g[p + 'mel']))
+
+
+def test_flow_estimator_key_padding_mask(tiny_cfg, flow_setup):
+    """padded batch rows: keys beyond the mask must not influence valid frames (mask path of dit.py:163-166)."""
+    from flowmirror_hydravox_amd.flow import HvxFlow
+    from oracle import flow_ref
+    g, sd = flow_setup
+    c = tiny_cfg.flow
+    flow = HvxFlow(c, sd, dtype=torch.float32, max_t=512)
+    gen = torch.Generator().manual_seed(3)
+    T, Tv = 70, 45
+    x, mu, cond = (torch.randn(2, 80, T, generator=gen) for _ in range(3))
+    spk = torch.randn(2, 80, generator=gen)
+    t = torch.tensor([0.55, 0.55])
+    mask = torch.ones(2, 1, T)
+    mask[1, :, Tv:] = 0
+    out = flow.estimator(x, mask, mu, t, spk, cond).cpu()
+    ref = flow_ref.dit_forward(x, mask, mu, t, spk, cond, sd, c)
+    assert _rel(out[0].numpy(), ref[0].numpy()) < 1e-3
+    assert _rel(out[1, :, :Tv].numpy(), ref[1, :, :Tv].numpy()) < 1e-3
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# HiFT
+# ------------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope='module')
+def hift_setup(tiny_cfg):
+    from flowmirror_hydravox_amd import weights as W
+    from oracle import hift_ref
+    g = load_golden('hift_tiny.npz')
+    sd = W.make_hift_state(tiny_cfg.hift, seed=int(g['weight_seed']), init='fan_in')
+    assert state_checksum(sd) == str(g['weight_sha'])
+    tables = hift_ref.make_tables(tiny_cfg.hift, seed=int(g['table_seed']))
+    return g, sd, tables
+
+
+def test_hift_stages_vs_reference(tiny_cfg, hift_setup):
+    from flowmirror_hydravox_amd.hift import HvxHift
+    g, sd, tables = hift_setup
+    hift = HvxHift(tiny_cfg.hift, sd, tables=tables)
+    for r in range(int(g['n_runs'])):
+        p = 'r%d_' % r
+        mel = torch.from_numpy(g[p + 'mel'])
+        f0 = hift.f0(mel[0]).cpu().numpy()
+        assert np.abs(f0 - g[p + 'f0'][0]).max() < 2e-3, (r, 'f0 [Hz]', np.abs(f0 - g[p + 'f0'][0]).max())
+        s = hift.source(torch.from_numpy(g[p + 'f0'][0])).cpu().numpy()            # source on the reference's own f0
+        assert np.abs(s - g[p + 'source'].reshape(-1)).max() < 2e-4, (r, 'source')
+        wav = hift.decode(mel[0], torch.from_numpy(g[p + 'source']).reshape(-1)).cpu().numpy()   # decode on the reference's source
+        assert _rel(wav, g[p + 'wav'][0]) < 1e-3, (r, 'decode', _rel(wav, g[p + 'wav'][0]))
+        wav2, s2 = hift.inference(speech_feat=mel.to(DEV))
+        assert tuple(wav2.shape) == (1, 480 * mel.shape[-1]) and tuple(s2.shape) == (1, 1, 480 * mel.shape[-1])
+        # end to end the F0 -> phase accumulation amplifies fp32 rounding differences: looser bound
+        assert np.abs(wav2.cpu().numpy() - g[p + 'wav']).max() < 2e-2, (r, 'end to end')
+        assert wav2.abs().max() <= tiny_cfg.hift.audio_limit + 1e-6
+
+
+def test_hift_matches_oracle_on_longer_input(tiny_cfg, hift_setup):
+    from flowmirror_hydravox_amd.hift import HvxHift
+    from oracle import hift_ref
+    g, sd, tables = hift_setup
+    c = tiny_cfg.hift
+    hift = HvxHift(c, sd, tables=tables)
+    mel = torch.randn(1, 80, 90, generator=torch.Generator().manual_seed(8))
+    taps = {}
+    o_wav, o_s = hift_ref.hift_inference(mel, sd, c, tables, taps)
+    f0 = hift.f0(mel[0]).cpu()
+    assert (f0 - taps['f0'][0]).abs().max() < 2e-3
+    s = hift.source(taps['f0'][0]).cpu()
+    assert (s - o_s.reshape(-1)).abs().max() < 2e-4
+    wav = hift.decode(mel[0], o_s.reshape(-1)).cpu()
+    assert _rel(wav.numpy(), o_wav[0].numpy()) < 1e-3
