@@ -162,7 +162,6 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    lib.hvx_prof_enable(args.prof_period)
     stats = []
     t0 = time.time()
     for _ in range(args.steps):
@@ -170,8 +169,19 @@ def main():
         stats.append(st)
     barrier()
     elapsed = time.time() - t0
-    prof = read_prof(lib)
-    lib.hvx_prof_enable(0)
+    # Per-kernel durations: hipEvent brackets on the launch stream, every `prof_period`-th launch of each kernel class.
+    # A hipGraph replay cannot be bracketed per kernel, so the brackets run over one more, identical step with the decode
+    # graph disabled (same kernels, same launch geometry; the rocprofv3 --kernel-trace summary under profiles/ covers the
+    # graph-replayed timed steps themselves and must agree).
+    prof = {}
+    if rank == 0:
+        lib.hvx_prof_enable(args.prof_period)
+        step_prof_t0 = time.time()
+        pipe.synthesize(utts, max_token_text_ratio=ratio, min_token_text_ratio=ratio)
+        torch.cuda.synchronize()
+        prof = read_prof(lib)
+        lib.hvx_prof_enable(0)
+    barrier()
 
     tokens = sum(s.tokens for s in stats)
     audio = sum(s.audio_seconds for s in stats)

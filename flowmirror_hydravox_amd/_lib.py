@@ -90,6 +90,7 @@ SYMBOLS = {
     'hvx_llm_kv_bytes': (c_sz, [c_vp, c_i32, c_i32]),
     'hvx_llm_bind': (c_i32, [c_vp, c_vp, c_sz, c_i32, c_i32, c_vp, c_sz, c_i32, c_i32, c_vp]),
     'hvx_llm_forward': (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp]),
+    'hvx_llm_use_graph': (c_i32, [c_vp, c_i32]),
     'hvx_llm_last_hidden': (c_i32, [c_vp, c_vp, c_i32, c_vp]),
     'hvx_flow_create': (c_i32, [C.POINTER(FlowConfig), C.POINTER(c_vp), c_i32, C.POINTER(c_vp)]),
     'hvx_flow_destroy': (None, [c_vp]),
@@ -97,6 +98,7 @@ SYMBOLS = {
     'hvx_flow_encode': (c_i32, [c_vp, c_vp, c_vp, c_sz, c_vp, c_i32, c_vp, c_vp, c_vp]),
     'hvx_flow_prelookahead': (c_i32, [c_vp, c_vp, c_vp, c_sz, c_vp, c_i32, c_vp]),
     'hvx_cfm_estimator': (c_i32, [c_vp, c_vp, c_vp, c_sz, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'hvx_flow_set_mod_cache': (c_i32, [c_vp, c_vp, c_sz]),
     'hvx_cfm_solve': (c_i32, [c_vp, c_vp, c_vp, c_sz, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, C.POINTER(c_f32), C.POINTER(c_f32)]),
     'hvx_hift_create': (c_i32, [C.POINTER(HiftConfig), C.POINTER(c_vp), c_i32, C.POINTER(c_vp)]),
     'hvx_hift_destroy': (None, [c_vp]),
@@ -117,6 +119,10 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise HvxError('libhvx.so is missing at %s — run `python -m flowmirror_hydravox_amd.build` '
                        '(hipcc --offload-arch=gfx950); there is no CPU fallback' % LIB_PATH)
+    # PyTorch-ROCm ships its own libamdhip64 (same SONAME as /opt/rocm's).  Import torch first so that libhvx binds to the
+    # HIP runtime instance torch already initialised: streams and device pointers are then shared, and there is exactly one
+    # runtime in the process (loaded the other way round, the system runtime comes up first and sees no device).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
@@ -139,6 +145,8 @@ def require_gpu():
     import torch
     if not torch.cuda.is_available():
         raise HvxError('no ROCm device visible: the HydraVox hot path runs on MI355X only (no CPU fallback)')
+    torch.cuda.init()
+    torch.zeros(1, device='cuda')          # make sure the HIP primary context exists before libhvx queries it
     n = lib.hvx_device_ok()
     if n <= 0:
         msg = lib.hvx_last_error()

@@ -141,5 +141,5 @@ def tiny_config() -> HvxConfig:
         # dim/conv_groups must give a multiple of 32 channels per group (MFMA k-step)
         flow=FlowConfig(vocab=96, pre_lookahead_channels=64, dim=512, depth=2, heads=8,
                         head_dim=64, ff_mult=2, conv_groups=16),
-        hift=HiftConfig(base_channels=64, f0_channels=64, noise_seconds=2),
+        hift=HiftConfig(base_channels=64, f0_channels=64, noise_seconds=8),
     )

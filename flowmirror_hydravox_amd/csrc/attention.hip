@@ -201,14 +201,20 @@ __global__ void attn_combine_kernel(AttnArgs a) {
     const int rh = r / a.kn, rl = r - rh * a.kn;
     const int n_valid_lo = a.n_valid_lo ? a.n_valid_lo[b] : a.kn;
     if (rl >= n_valid_lo) return;
+    // splits whose key range lies beyond this row's visible keys wrote nothing: only the first n_live splits are read
+    const int kv_len = a.kv_len ? a.kv_len[b] : a.kv_len_const;
+    int vis = kv_len;
+    if (a.causal) vis = min(vis, (a.pos0 ? a.pos0[b] : 0) + rl + 1);
+    const int n_live = min(a.n_splits, (vis + a.split_chunk - 1) / a.split_chunk);
+    const long long base0 = (((long long)b * a.heads + h) * a.n_splits) * a.n_rows_pad + r;
+    const long long sstride = a.n_rows_pad;
     float m = -INFINITY;
-    for (int s = 0; s < a.n_splits; ++s) {
-        const long long base = (((long long)b * a.heads + h) * a.n_splits + s) * a.n_rows_pad + r;
-        m = fmaxf(m, a.part_ml[base * 2]);
-    }
+#pragma unroll 8
+    for (int s = 0; s < n_live; ++s) m = fmaxf(m, a.part_ml[(base0 + s * sstride) * 2]);
     float acc = 0.0f, l = 0.0f;
-    for (int s = 0; s < a.n_splits; ++s) {
-        const long long base = (((long long)b * a.heads + h) * a.n_splits + s) * a.n_rows_pad + r;
+#pragma unroll 8
+    for (int s = 0; s < n_live; ++s) {
+        const long long base = base0 + s * sstride;
         const float ms = a.part_ml[base * 2];
         const float wgt = (ms == -INFINITY) ? 0.0f : expf(ms - m);
         acc += wgt * a.part_o[base * 64 + d];

@@ -36,17 +36,40 @@ __global__ __launch_bounds__(256) void reduce_rmsnorm_kernel(ReduceNormArgs a) {
     const float* bias = a.bias ? a.bias + (long long)z * a.bias_zs : nullptr;
     const float* gain = a.gain ? a.gain + (long long)z * a.gain_zs : nullptr;
     float ss = 0.0f;
-    for (int c = threadIdx.x; c < H; c += 256) {
-        float v = xr[c];
-        if (part) {
-            float acc = 0.0f;
-            for (int s = 0; s < a.split_k; ++s) acc += part[(long long)s * a.part_stride + c];   // fixed order: deterministic
+    if (part && (H & 3) == 0 && (a.part_stride & 3) == 0 && (a.ldx & 3) == 0) {
+        // 16-byte columns, all split partials of a column in flight at once (the loads are independent; only the adds are ordered)
+        for (int c = threadIdx.x * 4; c < H; c += 1024) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+            f32x4 acc = {0, 0, 0, 0};
+            int s = 0;
+            for (; s + 4 <= a.split_k; s += 4) {
+                const f32x4 p0 = *reinterpret_cast<const f32x4*>(part + (long long)(s + 0) * a.part_stride + c);
+                const f32x4 p1 = *reinterpret_cast<const f32x4*>(part + (long long)(s + 1) * a.part_stride + c);
+                const f32x4 p2 = *reinterpret_cast<const f32x4*>(part + (long long)(s + 2) * a.part_stride + c);
+                const f32x4 p3 = *reinterpret_cast<const f32x4*>(part + (long long)(s + 3) * a.part_stride + c);
+                acc = (((acc + p0) + p1) + p2) + p3;                                              // fixed order: deterministic
+            }
+            for (; s < a.split_k; ++s) acc += *reinterpret_cast<const f32x4*>(part + (long long)s * a.part_stride + c);
             v += acc;
-            if (bias) v += bias[c];
-            xr[c] = v;
+            if (bias) v += *reinterpret_cast<const f32x4*>(bias + c);
+            *reinterpret_cast<f32x4*>(xr + c) = v;
+            ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
         }
-        ss += v * v;
+    } else {
+        for (int c = threadIdx.x; c < H; c += 256) {
+            float v = xr[c];
+            if (part) {
+                float acc = 0.0f;
+                for (int s = 0; s < a.split_k; ++s) acc += part[(long long)s * a.part_stride + c];   // fixed order: deterministic
+                v += acc;
+                if (bias) v += bias[c];
+                xr[c] = v;
+            }
+            ss += v * v;
+        }
+        __syncthreads();
     }
+    __syncthreads();             // the normalisation pass below re-reads columns written by other threads
     if (!a.y) return;
     T* y = reinterpret_cast<T*>(a.y) + (long long)m * a.ldy;
     if (!a.do_norm) {

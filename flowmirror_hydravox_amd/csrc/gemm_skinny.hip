@@ -21,13 +21,15 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(SkinnyArgs a) {
     const int z = blockIdx.z % a.nz;
     const int mchunk = blockIdx.z / a.nz;
     const int m0 = mchunk * (MT * 16);
-    const int ntile0 = (blockIdx.x * 4 + wave) * NT;          // first 16-col tile of this wave
-    if (ntile0 * 16 >= a.N) return;
+    const int ntile0 = blockIdx.x * NT;                        // the 4 waves of a workgroup share these NT tiles ...
     const int KT = a.K >> 5;
     const int ks = blockIdx.y;
     const int kt_per = (KT + a.split_k - 1) / a.split_k;
-    const int kt0 = ks * kt_per;
-    const int kt1 = min(KT, kt0 + kt_per);
+    const int kb0 = ks * kt_per;
+    const int kb1 = min(KT, kb0 + kt_per);
+    const int kq = (kb1 - kb0 + 3) >> 2;                       // ... and split its K range in four (in-block split-K)
+    const int kt0 = kb0 + wave * kq;
+    const int kt1 = min(kb1, kt0 + kq);
 
     const T* __restrict__ A = reinterpret_cast<const T*>(a.A) + (long long)z * a.a_zs;
     const T* __restrict__ W = reinterpret_cast<const T*>(a.W) + (long long)z * a.w_zs;
@@ -54,18 +56,47 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(SkinnyArgs a) {
         wtile[j] = W + ((long long)nt * KT) * 512 + lane * 8;
     }
 
-#pragma unroll 4
-    for (int kt = kt0; kt < kt1; ++kt) {
-        V8 wf[NT], af[MT];
+    // U k-steps per trip: all of their weight / activation loads are issued before the first MFMA so that each wave keeps
+    // U * NT KiB of the weight stream in flight (a dependent load->MFMA chain per k-step is latency-bound: 0.6 TB/s measured).
+    constexpr int REGS = (NT + MT) * (sizeof(T) == 2 ? 4 : 8);
+    constexpr int U = REGS <= 16 ? 8 : (REGS <= 32 ? 4 : 2);
+    for (int kt = kt0; kt < kt1; kt += U) {
+        V8 wf[U][NT], af[U][MT];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) wf[j] = load8(wtile[j] + (long long)kt * 512);
+        for (int u = 0; u < U; ++u) {
+            const int k = min(kt + u, kt1 - 1);
 #pragma unroll
-        for (int i = 0; i < MT; ++i) af[i] = load8(arow[i] + kt * 32);
+            for (int j = 0; j < NT; ++j) wf[u][j] = load8(wtile[j] + (long long)k * 512);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) af[u][i] = load8(arow[i] + k * 32);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (kt + u < kt1) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) mma32(acc[i][j], af[u][i], wf[u][j]);
+            }
+        }
+    }
+
+    // in-block reduction in fixed wave order (deterministic): waves 1..3 park their tiles in LDS, wave 0 adds and finishes
+    __shared__ f32x4 red[3][MT][NT][64];
+    if (wave > 0) {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int j = 0; j < NT; ++j) mma32(acc[i][j], af[i], wf[j]);
+            for (int j = 0; j < NT; ++j) red[wave - 1][i][j][lane] = acc[i][j];
     }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] += red[w][i][j][lane];
 
     // ---- epilogues ---------------------------------------------------------------------------------
     if constexpr (EPI == SK_PARTIAL) {
@@ -164,9 +195,9 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(SkinnyArgs a) {
 template <class T, int MT, int NT, int EPI>
 static int launch_one(const SkinnyArgs& a, hipStream_t s) {
     const int ntiles = a.N / 16;
-    const int waves = (ntiles + NT - 1) / NT;
+    const int groups = (ntiles + NT - 1) / NT;
     const int mchunks = (a.M + MT * 16 - 1) / (MT * 16);
-    dim3 grid((waves + 3) / 4, a.split_k, mchunks * a.nz);
+    dim3 grid(groups, a.split_k, mchunks * a.nz);
     // algorithmic HBM bytes of this launch: every weight once, the activation rows once, the result once
     const double bytes = (double)a.nz * ((double)a.N * a.K * sizeof(T) + (double)a.M * a.K * sizeof(T) +
                                          (double)a.M * a.N * (EPI == SK_PARTIAL ? 4.0 * a.split_k : (double)sizeof(T)));

@@ -40,6 +40,7 @@ int prof_begin(int kind, double work, hipStream_t s) {
     g_prof.slots.push_back(p);
     return (int)g_prof.slots.size() - 1;
 }
+bool prof_enabled() { return g_prof.on; }
 void prof_end(int slot, hipStream_t s) {
     if (slot >= 0) hipEventRecord(g_prof.slots[slot].e1, s);
 }
@@ -54,13 +55,18 @@ const char* hvx_last_error(void) { return g_err; }
 
 int hvx_device_ok(void) {
     int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_error("hipGetDeviceCount: %s (count %d)", hipGetErrorString(e), n);
         (void)hipGetLastError();
         return 0;
     }
     int dev = 0;
     hipDeviceProp_t p;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 0;
+    if ((e = hipGetDevice(&dev)) != hipSuccess || (e = hipGetDeviceProperties(&p, dev)) != hipSuccess) {
+        set_error("hipGetDeviceProperties: %s", hipGetErrorString(e));
+        return 0;
+    }
     if (strncmp(p.gcnArchName, "gfx950", 6) != 0) {
         set_error("libhvx is built for gfx950 only, found %s", p.gcnArchName);
         return 0;

@@ -23,6 +23,12 @@ using namespace hvx;
 struct hvx_flow {
     hvx_flow_config c;
     std::vector<const void*> w;
+    // adaLN modulation cache for the CFG-2 solver: the Euler t-grid is a constant of the model (flow_matching.py:225-227),
+    // so the 22 x 6D + 2D modulation vectors of each step are computed once and reused by every later utterance.
+    float* mod_cache = nullptr;
+    int mod_slots = 0;
+    std::vector<float> mod_t;
+    size_t mod_slot_floats() const { return (size_t)c.depth * 2 * 6 * c.dim + (size_t)2 * 2 * c.dim; }
 };
 
 namespace {
@@ -165,7 +171,7 @@ int prelookahead(const hvx_flow* h, hipStream_t s, EstBufs& b, const float* x, i
 
 // estimator on time-major rows; leaves v in b.outrow [B][T][mel]
 int estimator_core(const hvx_flow* h, hipStream_t s, EstBufs& b, int B, int T, const float* x, const int* kv_len, const float* mu,
-                   const float* t, const float* spks, const float* cond) {
+                   const float* t, const float* spks, const float* cond, bool skip_mods = false) {
     const hvx_flow_config& c = h->c;
     const int dt = c.dtype, D = c.dim, H = c.heads, Tp = b.t_pad, mel = c.mel;
     const size_t es = dtype_size(dt);
@@ -173,8 +179,11 @@ int estimator_core(const hvx_flow* h, hipStream_t s, EstBufs& b, int B, int T, c
     if (T > c.max_t) return set_error("estimator: T=%d exceeds max_t=%d", T, c.max_t), -1;
 
     // ---- time embedding -> SiLU(t_emb) -> all adaLN modulation vectors --------------------------------------------
+    GemmArgs g;
+    const void* const* tw = w + 19 + 10 * c.depth;
+    if (!skip_mods) {
     HVX_CHECK(launch_time_sinus(t, b.tsin, dt, B, c.time_freq_dim, s));
-    GemmArgs g = linear(dt, B, D, c.time_freq_dim, b.tsin, c.time_freq_dim, w[9], (const float*)w[10]);
+    g = linear(dt, B, D, c.time_freq_dim, b.tsin, c.time_freq_dim, w[9], (const float*)w[10]);
     g.act = ACT_SILU; g.out = b.th; g.ldo = D; g.out_cols = D;
     HVX_CHECK(launch_gemm(g, s));
     g = linear(dt, B, D, D, b.th, D, w[11], (const float*)w[12]);
@@ -186,10 +195,10 @@ int estimator_core(const hvx_flow* h, hipStream_t s, EstBufs& b, int B, int T, c
         g.out = b.mods + (size_t)i * B * 6 * D; g.out_f32 = 1; g.ldo = 6 * D; g.out_cols = 6 * D;
         HVX_CHECK(launch_gemm(g, s));
     }
-    const void* const* tw = w + 19 + 10 * c.depth;
     g = linear(dt, B, 2 * D, D, b.tsilu, D, tw[0], (const float*)tw[1]);
     g.out = b.fmod; g.out_f32 = 1; g.ldo = 2 * D; g.out_cols = 2 * D;
     HVX_CHECK(launch_gemm(g, s));
+    }
 
     // ---- input embedding: Linear(cat[x, cond, mu, spks]) + causal grouped conv position embedding ------------------
     HVX_CHECK(launch_dit_concat(x, cond, mu, spks, b.hin, dt, B, T, mel, s));
@@ -318,6 +327,14 @@ int hvx_cfm_estimator(hvx_flow* h, hvx_stream stream, void* ws, size_t ws_bytes,
     return 0;
 }
 
+int hvx_flow_set_mod_cache(hvx_flow* h, void* buf, size_t bytes) {
+    if (!h) return set_error("hvx_flow_set_mod_cache: null handle"), -1;
+    h->mod_cache = (float*)buf;
+    h->mod_slots = buf ? (int)(bytes / (h->mod_slot_floats() * 4)) : 0;
+    h->mod_t.clear();
+    return 0;
+}
+
 int hvx_cfm_solve(hvx_flow* h, hvx_stream stream, void* ws, size_t ws_bytes, int32_t T, float* x, const float* mu, const float* spks,
                   const float* cond, int32_t n_steps, const float* t_steps, const float* dt_steps) {
     hipStream_t s = (hipStream_t)stream;
@@ -335,8 +352,28 @@ int hvx_cfm_solve(hvx_flow* h, hvx_stream stream, void* ws, size_t ws_bytes, int
     for (int st = 0; st < n_steps; ++st) {
         HIP_OK(hipMemcpyAsync(b.x_in, x, plane, hipMemcpyDeviceToDevice, s));
         HIP_OK(hipMemcpyAsync((char*)b.x_in + plane, x, plane, hipMemcpyDeviceToDevice, s));
-        hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(64), 0, s, b.t_in, 2, t_steps[st]);
-        HVX_CHECK(estimator_core(h, s, b, 2, T, b.x_in, nullptr, b.mu_in, b.t_in, b.spk_in, b.cond_in));
+        bool hit = false;
+        float* ws_mods = b.mods;
+        float* ws_fmod = b.fmod;
+        if (h->mod_cache) {
+            int slot = -1;
+            for (size_t e = 0; e < h->mod_t.size(); ++e)
+                if (memcmp(&h->mod_t[e], &t_steps[st], 4) == 0) slot = (int)e;
+            hit = slot >= 0;
+            if (!hit && (int)h->mod_t.size() < h->mod_slots) {
+                slot = (int)h->mod_t.size();
+                h->mod_t.push_back(t_steps[st]);
+            }
+            if (slot >= 0) {
+                b.mods = h->mod_cache + (size_t)slot * h->mod_slot_floats();
+                b.fmod = b.mods + (size_t)c.depth * 2 * 6 * c.dim;
+            }
+        }
+        if (!hit) hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(64), 0, s, b.t_in, 2, t_steps[st]);
+        const int rc = estimator_core(h, s, b, 2, T, b.x_in, nullptr, b.mu_in, b.t_in, b.spk_in, b.cond_in, hit);
+        b.mods = ws_mods;
+        b.fmod = ws_fmod;
+        if (rc) return -1;
         HVX_CHECK(launch_cfg_euler(x, b.outrow, c.mel, (long long)T * c.mel, dt_steps[st], c.cfg_rate, T, c.mel, s));
     }
     return 0;

@@ -16,6 +16,7 @@ void set_error(const char* fmt, ...);
 enum ProfKind : int { PK_SKINNY = 0, PK_GEMM = 1, PK_ATTN = 2, PK_SAMPLER = 3, PK_GEMM_F32 = 4, PK_ATTN_LLM = 5, PK_COUNT = 6 };
 int prof_begin(int kind, double work, hipStream_t s);     // returns a slot (>= 0) or -1 when this launch is not sampled
 void prof_end(int slot, hipStream_t s);
+bool prof_enabled();
 
 // ------------------------------------------------------------------------------------------------
 // Tiled implicit-GEMM:  out[b, m, g*N + n] = epi( sum_{tap, ci} A[b, src(m, tap), g*a_gs + ci] * W[g, n, tap*cin_pad + ci] )

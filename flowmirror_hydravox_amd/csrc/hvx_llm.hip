@@ -12,6 +12,8 @@
 // Residual stream x stays fp32; GEMM operands are `dtype` (bf16 production / f32 parity).
 #include <string.h>
 
+#include <map>
+#include <tuple>
 #include <vector>
 
 #include "hvx.h"
@@ -19,9 +21,24 @@
 
 using namespace hvx;
 
+struct GraphKey {
+    int n_seq, kn, head_k;
+    const void *tok, *ctrl, *logp;
+    hipStream_t s;
+    bool operator<(const GraphKey& o) const {
+        return std::tie(n_seq, kn, head_k, tok, ctrl, logp, s) < std::tie(o.n_seq, o.kn, o.head_k, o.tok, o.ctrl, o.logp, o.s);
+    }
+};
+
 struct hvx_llm {
     hvx_llm_config c;
     std::vector<const void*> w;
+    bool use_graph = false;
+    std::map<GraphKey, hipGraphExec_t> graphs;
+    void drop_graphs() {
+        for (auto& kv : graphs) hipGraphExecDestroy(kv.second);
+        graphs.clear();
+    }
     // bound buffers
     char* ws = nullptr;
     size_t ws_bytes = 0;
@@ -49,15 +66,17 @@ struct hvx_llm {
 namespace {
 
 constexpr int MAX_SPLIT = 16;
-constexpr int ATT_CHUNK = 256;
+constexpr int ATT_CHUNK = 64;      // keys per decode-attention split: 3.3k keys -> ~52 independent waves per (sequence, KV head)
 
 size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
 int pick_split(int N, int K, int nz) {
-    const int waves = (N / 16) * nz;
+    // workgroups = 16-column tiles x cross-block K splits; inside a workgroup the 4 waves split K again.  Aim at >= ~1.5
+    // workgroups per CU while leaving every wave at least 2 k-steps.
+    const int groups = (N / 16) * nz;
     const int kt = K / 32;
-    int s = 512 / (waves > 0 ? waves : 1);
-    if (s > kt / 2) s = kt / 2;
+    int s = 384 / (groups > 0 ? groups : 1);
+    if (s > kt / 8) s = kt / 8;
     if (s > MAX_SPLIT) s = MAX_SPLIT;
     if (s < 1) s = 1;
     return s;
@@ -122,10 +141,14 @@ int hvx_llm_create(const hvx_llm_config* cfg, const void* const* weights, int32_
     return 0;
 }
 
-void hvx_llm_destroy(hvx_llm* h) { delete h; }
+void hvx_llm_destroy(hvx_llm* h) {
+    if (h) h->drop_graphs();
+    delete h;
+}
 
 size_t hvx_llm_workspace_bytes(const hvx_llm* h, int32_t max_seq, int32_t max_rows, int32_t max_ctx) {
-    hvx_llm tmp = *h;
+    hvx_llm tmp;
+    tmp.c = h->c;
     return carve(&tmp, nullptr, max_seq, max_rows, max_ctx);
 }
 
@@ -141,6 +164,7 @@ int hvx_llm_bind(hvx_llm* h, void* workspace, size_t ws_bytes, int32_t max_seq, 
     const size_t need = carve(h, (char*)workspace, max_seq, max_rows, max_ctx);
     if (need > ws_bytes) return set_error("hvx_llm_bind: workspace %zu < %zu bytes", ws_bytes, need), -1;
     if (hvx_llm_kv_bytes(h, n_slots, max_ctx) > kv_bytes) return set_error("hvx_llm_bind: kv buffer too small"), -1;
+    h->drop_graphs();                       // captured launches hold the old buffer addresses
     h->ws = (char*)workspace; h->ws_bytes = ws_bytes;
     h->max_seq = max_seq; h->max_rows = max_rows; h->n_slots = n_slots; h->max_ctx = max_ctx;
     h->kcache = kv;
@@ -151,10 +175,50 @@ int hvx_llm_bind(hvx_llm* h, void* workspace, size_t ws_bytes, int32_t max_seq, 
     return 0;
 }
 
+static int forward_impl(hvx_llm* h, hipStream_t s, int32_t n_seq, int32_t kn, const int32_t* tok, const int32_t* ctrl, int32_t head_k,
+                        float* logp);
+
+// The decode step is ~200 short launches; replaying them as one hipGraph removes the per-launch host cost.  Every kernel
+// argument is a fixed device address (control arrays, KV cache, workspace) and every data-dependent quantity (context
+// length, active rows) is read from device memory, so one instantiated graph per (grid, pointers) serves the whole utterance.
 int hvx_llm_forward(hvx_llm* h, hvx_stream stream, int32_t n_seq, int32_t kn, const int32_t* tok, const int32_t* ctrl, int32_t head_k,
                     float* logp) {
     if (!h || !h->ws) return set_error("hvx_llm_forward: handle not bound"), -1;
     hipStream_t s = (hipStream_t)stream;
+    // (capture is illegal on the legacy default stream: such callers get the same launches eagerly)
+    if (!h->use_graph || head_k <= 0 || prof_enabled() || s == nullptr) return forward_impl(h, s, n_seq, kn, tok, ctrl, head_k, logp);
+    GraphKey key{n_seq, kn, head_k, tok, ctrl, logp, s};
+    auto it = h->graphs.find(key);
+    if (it == h->graphs.end()) {
+        hipGraph_t g = nullptr;
+        hipGraphExec_t ex = nullptr;
+        if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) return set_error("hvx_llm_forward: begin capture failed"), -1;
+        const int rc = forward_impl(h, s, n_seq, kn, tok, ctrl, head_k, logp);
+        const hipError_t e = hipStreamEndCapture(s, &g);
+        if (rc != 0 || e != hipSuccess || !g) {
+            if (g) hipGraphDestroy(g);
+            if (rc == 0) set_error("hvx_llm_forward: graph capture failed: %s", hipGetErrorString(e));
+            return -1;
+        }
+        if (hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) != hipSuccess) {
+            hipGraphDestroy(g);
+            return set_error("hvx_llm_forward: graph instantiate failed"), -1;
+        }
+        hipGraphDestroy(g);
+        it = h->graphs.emplace(key, ex).first;
+    }
+    if (hipGraphLaunch(it->second, s) != hipSuccess) return set_error("hvx_llm_forward: graph launch failed"), -1;
+    return 0;
+}
+
+int hvx_llm_use_graph(hvx_llm* h, int32_t enable) {
+    if (!h) return set_error("hvx_llm_use_graph: null handle"), -1;
+    h->use_graph = enable != 0;
+    return 0;
+}
+
+static int forward_impl(hvx_llm* h, hipStream_t s, int32_t n_seq, int32_t kn, const int32_t* tok, const int32_t* ctrl, int32_t head_k,
+                        float* logp) {
     const hvx_llm_config& c = h->c;
     const int R = n_seq * kn;
     if (n_seq < 1 || kn < 1 || n_seq > h->max_seq || R > h->max_rows) return set_error("hvx_llm_forward: grid %dx%d exceeds the bound workspace", n_seq, kn), -1;

@@ -44,7 +44,7 @@ class _Request:
 
 class HvxLLM:
     def __init__(self, cfg: LLMConfig, state_dict=None, dtype=torch.bfloat16, device='cuda', sampling=None,
-                 inference_head_num=5, max_batch=8, max_ctx=4096, noise_cap=1 << 16):
+                 inference_head_num=5, max_batch=8, max_ctx=4096, noise_cap=1 << 16, use_graph=True):
         _lib.require_gpu()
         self.lib = _lib.load()
         self.cfg = cfg
@@ -65,6 +65,7 @@ class HvxLLM:
         self.max_batch = max_batch
         self.max_ctx = (max_ctx + 31) // 32 * 32
         self.noise_cap = noise_cap
+        self.use_graph = use_graph
         self._h = None
         self._bound = None
         self.last_stats = {}
@@ -126,6 +127,7 @@ class HvxLLM:
         check(self.lib.hvx_llm_create(C.byref(cc), arr, len(ws), C.byref(h)), 'hvx_llm_create')
         self._h = h
         self._bound = None
+        check(self.lib.hvx_llm_use_graph(self._h, int(self.use_graph)), 'hvx_llm_use_graph')
         return self
 
     def eval(self):
@@ -221,6 +223,9 @@ class HvxLLM:
     # engine
     # ------------------------------------------------------------------------------------------------------------
     def _run(self, reqs, stream_first):
+        """Generator over the tokens of request 0 (stream_first) that drives all requests to completion.
+        Device work runs on a private stream (hipGraph capture is illegal on the legacy default stream); nothing
+        stays selected as torch's current stream across a yield."""
         import time
         c = self.cfg
         S = len(reqs)
@@ -232,38 +237,86 @@ class HvxLLM:
         need_ctx = max(len(r.prefix) + r.max_len + K for r in reqs)
         if need_ctx > self.max_ctx:
             raise ValueError('context %d exceeds max_ctx=%d' % (need_ctx, self.max_ctx))
-        self._bind(S, max(longest, S * K))
+        if getattr(self, '_stream', None) is None:
+            self._stream = torch.cuda.Stream(device=dev)
+        stream = self._stream
+        stream.wait_stream(torch.cuda.current_stream())
         t_start = time.time()
-
-        # ---- prefill: everything but the last prefix row, one utterance at a time (kn = its length) ------------------------
-        for i, r in enumerate(reqs):
-            n = len(r.prefix) - 1
-            if n > 0:
-                tok = torch.tensor(r.prefix[:n], dtype=torch.int32, device=dev)
-                ctrl = torch.tensor([i, 0, n, n, n - 1], dtype=torch.int32, device=dev)
-                self._forward(1, n, tok, ctrl, 0, None)
-            r.pos = n
-            r.next = [r.prefix[-1]]
-
-        # ---- decode: dense [S][K] grid per step -------------------------------------------------------------------------------
         W = sp['win_size'] if sp['win_size'] > 0 else max(r.max_len for r in reqs)
         W = max(W, 1)
         n_ctl = S * K + 5 * S + S * W + 3 * S
-        ctl_host = torch.empty(n_ctl, dtype=torch.int32).pin_memory()
-        ctl_dev = torch.empty(n_ctl, dtype=torch.int32, device=dev)
-        o_tok, o_ctrl, o_hist, o_hlen, o_min, o_act = 0, S * K, S * K + 5 * S, S * K + 5 * S + S * W, S * K + 5 * S + S * W + S, S * K + 5 * S + S * W + 2 * S
-        logp = torch.empty(S, K, c.vocab, dtype=torch.float32, device=dev)
-        ncap = self.noise_cap
-        noise_host = torch.empty(S, ncap, dtype=torch.float32).pin_memory()
-        noise_dev = torch.empty(S, ncap, dtype=torch.float32, device=dev)
-        cur_dev = torch.zeros(S, dtype=torch.int64, device=dev)
-        nbase = [0] * S                        # absolute stream position of noise_dev[i, 0]
-        for i, r in enumerate(reqs):
-            noise_host[i].copy_(torch.from_numpy(r.noise.window(0, ncap)))
-        noise_dev.copy_(noise_host, non_blocking=True)
-        ids_host = torch.empty(S * K, dtype=torch.int32).pin_memory()
-        cur_host = torch.empty(S, dtype=torch.int64).pin_memory()
+        o_tok, o_ctrl, o_hist = 0, S * K, S * K + 5 * S
+        o_hlen, o_min, o_act = o_hist + S * W, o_hist + S * W + S, o_hist + S * W + 2 * S
+        d = type('DecodeState', (), {})()
+        with torch.cuda.stream(stream):
+            self._bind(S, max(longest, S * K))
+            # ---- prefill: everything but the last prefix row, one utterance at a time (kn = its length) --------------------
+            for i, r in enumerate(reqs):
+                n = len(r.prefix) - 1
+                if n > 0:
+                    tok = torch.tensor(r.prefix[:n], dtype=torch.int32, device=dev)
+                    ctrl = torch.tensor([i, 0, n, n, n - 1], dtype=torch.int32, device=dev)
+                    self._forward(1, n, tok, ctrl, 0, None)
+                r.pos = n
+                r.next = [r.prefix[-1]]
+            # ---- decode buffers (fixed addresses: the step graph is captured once and replayed) -----------------------------
+            ctl_host = torch.empty(n_ctl, dtype=torch.int32).pin_memory()
+            ctl_dev = torch.empty(n_ctl, dtype=torch.int32, device=dev)
+            logp = torch.empty(S, K, c.vocab, dtype=torch.float32, device=dev)
+            d.ncap = self.noise_cap
+            d.noise_host = torch.empty(S, d.ncap, dtype=torch.float32).pin_memory()
+            d.noise_dev = torch.empty(S, d.ncap, dtype=torch.float32, device=dev)
+            d.cur_dev = torch.zeros(S, dtype=torch.int64, device=dev)
+            d.nbase = [0] * S                    # absolute stream position of noise_dev[i, 0]
+            for i, r in enumerate(reqs):
+                d.noise_host[i].copy_(torch.from_numpy(r.noise.window(0, d.ncap)))
+            d.noise_dev.copy_(d.noise_host, non_blocking=True)
+            ids_host = torch.empty(S * K, dtype=torch.int32).pin_memory()
+            d.cur_host = torch.zeros(S, dtype=torch.int64).pin_memory()
         ch = ctl_host.numpy()
+
+        def device_step():
+            """upload the control block, run the step, sample (re-sampling sequences that ran out of noise)"""
+            ctl_dev.copy_(ctl_host, non_blocking=True)
+            self._forward(S, K, ctl_dev[o_tok:], ctl_dev[o_ctrl:], K, logp)
+            act = ctl_dev[o_act:o_act + S]
+            idl, short = None, []
+            while True:
+                ids = ops.ras_sample(logp, ctl_dev[o_hist:o_hist + S * W].view(S, W), ctl_dev[o_hlen:o_hlen + S], ctl_dev[o_min:o_min + S],
+                                     d.noise_dev, d.cur_dev, speech_tokens=c.speech_tokens, top_k=sp['top_k'], top_p=sp['top_p'],
+                                     win_size=sp['win_size'], rep_thresh=thr, active=act)
+                ids_host.copy_(ids.view(-1), non_blocking=True)
+                d.cur_host.copy_(d.cur_dev, non_blocking=True)
+                stream.synchronize()
+                new = ids_host.view(S, K).tolist()
+                if idl is None:
+                    idl = new
+                else:
+                    for i in short:
+                        idl[i] = new[i]
+                short = [i for i, r in enumerate(reqs) if not r.done and idl[i][0] == -2]
+                if not short:
+                    return idl
+                # these sequences ran out of pre-generated noise inside the step (their cursor was left untouched):
+                # enlarge the window and sample them again; everyone else keeps the ids already drawn
+                act = torch.zeros(S, dtype=torch.int32)
+                act[short] = 1
+                act = act.to(dev)
+                d.ncap *= 4
+                refill_noise()
+
+        def refill_noise():
+            if d.noise_host.shape[1] != d.ncap:
+                d.noise_host = torch.empty(S, d.ncap, dtype=torch.float32).pin_memory()
+                d.noise_dev = torch.empty(S, d.ncap, dtype=torch.float32, device=dev)
+            for i, r in enumerate(reqs):
+                d.nbase[i] += int(d.cur_host[i])
+                d.noise_host[i].copy_(torch.from_numpy(r.noise.window(d.nbase[i], d.ncap)))
+            d.noise_dev.copy_(d.noise_host, non_blocking=True)
+            d.cur_dev.zero_()
+            d.cur_host.zero_()
+            stream.synchronize()
+
         steps = 0
         n_llm_tokens = 0
         while not all(r.done for r in reqs):
@@ -282,42 +335,10 @@ class HvxLLM:
                 ch[o_hlen + i] = len(hw)
                 ch[o_min + i] = r.min_len - (len(r.out) - len(hw))       # (len(snapshot)+j < min_len) in window coordinates
                 ch[o_act + i] = 0 if r.done else 1
-            ctl_dev.copy_(ctl_host, non_blocking=True)
-            self._forward(S, K, ctl_dev[o_tok:], ctl_dev[o_ctrl:], K, logp)
-            act = ctl_dev[o_act:o_act + S]
-            idl = None
-            while True:
-                ids = ops.ras_sample(logp, ctl_dev[o_hist:o_hist + S * W].view(S, W), ctl_dev[o_hlen:o_hlen + S], ctl_dev[o_min:o_min + S],
-                                     noise_dev, cur_dev, speech_tokens=c.speech_tokens, top_k=sp['top_k'], top_p=sp['top_p'],
-                                     win_size=sp['win_size'], rep_thresh=thr, active=act)
-                ids_host.copy_(ids.view(-1), non_blocking=True)
-                cur_host.copy_(cur_dev, non_blocking=True)
-                torch.cuda.current_stream().synchronize()
-                new = ids_host.view(S, K).tolist()
-                if idl is None:
-                    idl = new
-                else:
-                    for i in short:
-                        idl[i] = new[i]
-                short = [i for i, r in enumerate(reqs) if not r.done and idl[i][0] == -2]
-                if not short:
-                    break
-                # these sequences ran out of pre-generated noise inside the step (their cursor was left untouched):
-                # enlarge the window and sample them again; everyone else keeps the ids already drawn
-                act = torch.zeros(S, dtype=torch.int32)
-                act[short] = 1
-                act = act.to(dev)
-                ncap *= 4
-                nh = torch.empty(S, ncap, dtype=torch.float32).pin_memory()
-                for i, r in enumerate(reqs):
-                    nbase[i] += int(cur_host[i])
-                    nh[i].copy_(torch.from_numpy(r.noise.window(nbase[i], ncap)))
-                noise_host = nh
-                noise_dev = torch.empty(S, ncap, dtype=torch.float32, device=dev)
-                noise_dev.copy_(noise_host)
-                cur_dev.zero_()
+            with torch.cuda.stream(stream):
+                idl = device_step()
             steps += 1
-            refill = False
+            emitted = []
             for i, r in enumerate(reqs):
                 if r.done:
                     continue
@@ -332,26 +353,24 @@ class HvxLLM:
                     r.out.append(t)
                     group.append(t)
                     n_llm_tokens += 1
-                    if stream_first and i == 0:
-                        yield t
+                    if i == 0:
+                        emitted.append(t)
                     if len(r.out) >= r.max_len:
                         r.done = True
                         break
                 if not group:
                     r.done = True
                 r.next = group
-                if int(cur_host[i]) > ncap // 2:
-                    refill = True
-            if refill and not all(r.done for r in reqs):
-                for i, r in enumerate(reqs):
-                    nbase[i] += int(cur_host[i])
-                    noise_host[i].copy_(torch.from_numpy(r.noise.window(nbase[i], ncap)))
-                noise_dev.copy_(noise_host, non_blocking=True)
-                cur_dev.zero_()
-                cur_host.zero_()
+            if max(int(v) for v in d.cur_host.tolist()) > d.ncap // 2 and not all(r.done for r in reqs):
+                with torch.cuda.stream(stream):
+                    refill_noise()
+            if stream_first:
+                for t in emitted:
+                    yield t
         for i, r in enumerate(reqs):
-            r.cursor = nbase[i] + int(cur_host[i])
+            r.cursor = d.nbase[i] + int(d.cur_host[i])
             r.noise.finalize(r.cursor)
+        torch.cuda.current_stream().wait_stream(stream)
         dt = time.time() - t_start
         self.last_stats = dict(steps=steps, tokens=n_llm_tokens, seconds=dt, tps=n_llm_tokens / dt if dt > 0 else 0.0, head_k=K, batch=S)
 
@@ -369,4 +388,5 @@ class HvxLLM:
         self._forward(1, n, tok, ctrl, K, logp)
         y = torch.empty(1, self.cfg.hidden, dtype=torch.float32, device=dev)
         check(self.lib.hvx_llm_last_hidden(self._h, stream_ptr(), 1, ptr(y)), 'hvx_llm_last_hidden')
+        torch.cuda.synchronize()
         return logp[0], y[0]

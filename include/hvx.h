@@ -128,6 +128,8 @@ int hvx_llm_bind(hvx_llm* h, void* workspace, size_t ws_bytes, int32_t max_seq, 
  * head_k > 0: writes logp[n_seq][head_k][vocab] (fp32 log-probabilities of the K heads on each sequence's last new row). */
 int hvx_llm_forward(hvx_llm* h, hvx_stream s, int32_t n_seq, int32_t kn, const int32_t* tok, const int32_t* ctrl,
                     int32_t head_k, float* logp);
+/* replay the decode-step launches (head_k > 0) as one cached hipGraph per (grid, control/logp addresses, stream) */
+int hvx_llm_use_graph(hvx_llm* h, int32_t enable);
 /* debugging / parity: copy the post-final-norm hidden of the last rows of the previous forward (fp32 [n_seq][H]) */
 int hvx_llm_last_hidden(hvx_llm* h, hvx_stream s, int32_t n_seq, float* out);
 
@@ -163,6 +165,9 @@ int hvx_flow_prelookahead(hvx_flow* h, hvx_stream s, void* ws, size_t ws_bytes, 
  * t f32 [B]; spks f32 (B, mel); out f32 (B, mel, T) */
 int hvx_cfm_estimator(hvx_flow* h, hvx_stream s, void* ws, size_t ws_bytes, int32_t batch, int32_t t_len, const float* x,
                       const int32_t* kv_len, const float* mu, const float* t, const float* spks, const float* cond, float* out);
+/* optional persistent device buffer in which hvx_cfm_solve keeps the adaLN modulation vectors of each distinct step time t
+ * (they depend on t and the weights only); pass NULL to disable.  Must be re-set after the weights change. */
+int hvx_flow_set_mod_cache(hvx_flow* h, void* buf, size_t bytes);
 /* full Euler solve with batch-2 classifier-free guidance: x (mel,T) f32 in (noise) / out (mel); t_steps[n], dt_steps[n] from the host
  * (computed exactly as the reference accumulates them) */
 int hvx_cfm_solve(hvx_flow* h, hvx_stream s, void* ws, size_t ws_bytes, int32_t t_len, float* x, const float* mu, const float* spks,
