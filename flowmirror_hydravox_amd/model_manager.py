@@ -1,0 +1,172 @@
+"""HvxModelManager + the top-level synthesis functions — the drop-in surface consumed by the reference's worker.
+
+Mirrors server/model_utils/infer_speech_model.py:
+  * ModelManager.load_models(args)  (:50-143)  args.{config, model_dir, bf16, fp16, cpu}; loads `llm.pt`, `flow.pt`, `hift.pt`
+    (flat state dicts, keys epoch/step/_original_metadata/_conversion_info dropped :80-89, strict load :92-94);
+    sets .models = {'llm','flow','hift'}, .configs['sample_rate'], .frontend, .device, .is_loaded, .zero_shot_speakers
+  * ModelManager.load_pt(llm_pt, flow_pt) -> {"status": "success"|"error", "message": str}, never raises  (:169-184)
+  * inference_zero_shot / inference_tts / text_to_speech  (:523-606, :612-690, :743-820)
+Model hyper-parameters: the reference builds its modules from `<model_dir>/hydravox.yaml` through HyperPyYAML, which is not
+part of this build; dimensions come from `<model_dir>/hvx_config.json` when present, else the
+[ASSUMED-CV3] preset.  The text / audio frontend (ONNX tokenizers, text normalisation) is out of scope: `frontend` is any
+object with the reference's `text_normalize`, `frontend_sft`, `frontend_zero_shot` methods (e.g. the reference's own
+CosyVoiceFrontEnd), injected by the caller.
+"""
+import json
+import logging
+import os
+import time
+
+import torch
+import torch.nn.functional as F
+
+from .config import HvxConfig, LLMConfig, FlowConfig, HiftConfig, cv3_config
+from .flow import HvxFlow
+from .hift import HvxHift
+from .llm import HvxLLM
+from .weights import DROP_KEYS
+
+logger = logging.getLogger('hvx')
+
+
+def _load_config(model_dir):
+    p = os.path.join(model_dir or '', 'hvx_config.json')
+    if model_dir and os.path.exists(p):
+        with open(p) as f:
+            d = json.load(f)
+        return HvxConfig(llm=LLMConfig(**d.get('llm', {})), flow=FlowConfig(**d.get('flow', {})), hift=HiftConfig(**d.get('hift', {})),
+                         sample_rate=d.get('sample_rate', 24000))
+    return cv3_config()
+
+
+def _load_pt(path):
+    sd = torch.load(path, map_location='cpu')
+    for k in DROP_KEYS:
+        if k in sd:
+            sd.pop(k)
+    return sd
+
+
+class HvxModelManager:
+    def __init__(self, frontend_factory=None):
+        self.models = None
+        self.frontend = None
+        self.configs = None
+        self.device = None
+        self.is_loaded = False
+        self.zero_shot_speakers = None
+        self.hvx_config = None
+        self._frontend_factory = frontend_factory
+
+    def load_models(self, args):
+        if self.is_loaded:                                   # idempotent (:52-54)
+            logger.info('models already loaded, skipping')
+            return
+        if getattr(args, 'cpu', False) or not torch.cuda.is_available():
+            raise ValueError('HvxModelManager runs on MI355X only: there is no CPU path (TTS_CPU is not supported)')
+        cfg = _load_config(args.model_dir)
+        self.hvx_config = cfg
+        llm_sd = _load_pt(os.path.join(args.model_dir, 'llm.pt'))
+        flow_sd = _load_pt(os.path.join(args.model_dir, 'flow.pt'))
+        hift_sd = _load_pt(os.path.join(args.model_dir, 'hift.pt'))
+        self.device = 'cuda'
+        # precision policy of the reference (:101-118): llm bf16 / flow half / hift fp32.  fp16 requests run in bf16 as well:
+        # libhvx computes in bf16 (or fp32), with fp32 accumulation and an fp32 residual stream.
+        llm = HvxLLM(cfg.llm, llm_sd, dtype=torch.bfloat16)
+        flow = HvxFlow(cfg.flow, flow_sd, dtype=torch.bfloat16)
+        hift = HvxHift(cfg.hift, hift_sd)
+        llm.bf16, flow.bf16, llm.fp16, flow.fp16 = True, True, False, False
+        self.models = {'llm': llm, 'flow': flow, 'hift': hift}
+        self.configs = {'sample_rate': cfg.sample_rate}
+        if self._frontend_factory is not None:
+            self.frontend = self._frontend_factory(args, cfg)
+        spk = os.path.join(args.model_dir, 'zero_shot_speakers_16k.pt')
+        self.zero_shot_speakers = torch.load(spk) if os.path.exists(spk) else None
+        self.is_loaded = True
+        logger.info('models loaded')
+
+    def load_pt(self, llm_pt, flow_pt):
+        try:
+            self.models['llm'].load_state_dict(_load_pt(llm_pt))
+            self.models['llm'].bf16, self.models['llm'].fp16 = True, False
+            self.models['flow'].load_state_dict(_load_pt(flow_pt))
+            self.models['flow'].bf16, self.models['flow'].fp16 = True, False
+            return {'status': 'success', 'message': 'model weights loaded'}
+        except Exception as e:                               # never raises (:181-184)
+            logger.error('load_pt failed: %s', e)
+            return {'status': 'error', 'message': str(e)}
+
+    def get_available_speakers(self):
+        if not self.frontend or not hasattr(self.frontend, 'spk2info'):
+            return []
+        return list(self.frontend.spk2info.keys())
+
+
+def _synthesize(model_manager, model_input, speed, zero_shot):
+    """llm -> flow -> hift for one utterance (the body shared by :548-606 and :630-690)."""
+    dev = model_manager.device
+    start = time.time()
+    kw = dict(text=model_input['text'], text_len=model_input['text_len'], embedding=model_input['llm_embedding'])
+    if zero_shot:
+        kw.update(prompt_text=model_input['prompt_text'], prompt_text_len=model_input['prompt_text_len'],
+                  prompt_speech_token=model_input['llm_prompt_speech_token'],
+                  prompt_speech_token_len=model_input['llm_prompt_speech_token_len'])
+    else:
+        kw.update(prompt_text=torch.tensor([], dtype=torch.int32), prompt_text_len=torch.tensor([0], dtype=torch.int32),
+                  prompt_speech_token=None, prompt_speech_token_len=torch.tensor([0], dtype=torch.int32))
+    tokens = [t for t in model_manager.models['llm'].inference(**kw)]
+    llm_time = time.time() - start
+    tps = len(tokens) / llm_time if llm_time > 0 else 0
+    token_tensor = torch.tensor(tokens).unsqueeze(0).to(dev)
+    fkw = dict(token=token_tensor, token_len=torch.tensor([token_tensor.shape[1]], dtype=torch.int32), streaming=False, finalize=True)
+    if zero_shot:
+        fkw.update(prompt_token=model_input['flow_prompt_speech_token'], prompt_token_len=model_input['flow_prompt_speech_token_len'],
+                   prompt_feat=model_input['prompt_speech_feat'], prompt_feat_len=model_input['prompt_speech_feat_len'],
+                   embedding=model_input['flow_embedding'])
+    else:
+        fkw.update(embedding=model_input['flow_embedding'].unsqueeze(0))
+    tts_mel, _ = model_manager.models['flow'].inference(**fkw)
+    if speed <= 0:
+        raise ValueError('Invalid speed: %s' % speed)
+    if speed != 1.0:
+        tts_mel = F.interpolate(tts_mel, size=max(1, int(tts_mel.shape[2] / speed)), mode='linear')
+    tts_speech, _ = model_manager.models['hift'].inference(speech_feat=tts_mel)
+    total = time.time() - start
+    audio_len = tts_speech.shape[-1] / 24000
+    logger.info('inference done, total %.2fs, TPS %.2f, RTF %.4f', total, tps, total / audio_len if audio_len else 0.0)
+    return tts_speech.cpu()
+
+
+def inference_zero_shot(model_manager, tts_text, prompt_text, prompt_audio, prompt_sample_rate, speed=1.0):
+    if not model_manager.is_loaded:
+        raise ValueError('models are not loaded')
+    try:
+        fe = model_manager.frontend
+        p_text = fe.text_normalize(prompt_text, split=False, text_frontend=True)
+        t_text = fe.text_normalize(tts_text, split=True, text_frontend=True)
+        model_input = fe.frontend_zero_shot(t_text[0], p_text, (prompt_audio, prompt_sample_rate), model_manager.configs['sample_rate'],
+                                            zero_shot_spk_id='')
+        return _synthesize(model_manager, model_input, speed, zero_shot=True)
+    except Exception as e:
+        raise ValueError('zero-shot inference failed: %s' % e)
+
+
+def inference_tts(model_manager, text, spk_id, speed=1.0):
+    if not model_manager.is_loaded:
+        raise ValueError('models are not loaded')
+    try:
+        fe = model_manager.frontend
+        t_text = fe.text_normalize(text, split=True, text_frontend=True)
+        model_input = fe.frontend_sft(t_text[0], spk_id)
+        return _synthesize(model_manager, model_input, speed, zero_shot=False)
+    except Exception as e:
+        raise ValueError('TTS inference failed: %s' % e)
+
+
+def text_to_speech(model_manager, text, speaker_id, speed=1.0):
+    """-> {"output_audio": Tensor(1, L) cpu, "sample_rate", "format": "wav", "duration", "speaker_id", "segments_info"} (:743-820)"""
+    audio = inference_tts(model_manager, text, speaker_id, speed=speed)
+    sr = model_manager.configs['sample_rate']
+    dur = audio.shape[-1] / sr
+    return {'output_audio': audio, 'sample_rate': sr, 'format': 'wav', 'duration': dur, 'speaker_id': speaker_id,
+            'segments_info': [{'index': 0, 'text': text, 'duration': dur}]}

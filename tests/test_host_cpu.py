@@ -1,0 +1,231 @@
+"""CPU-only tests: the C-ABI library loads and exports every declared symbol, host-side logic, DP sharding and the
+world_size-2 gloo gather.  No compute call touches a GPU here."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+from functools import partial
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---- C ABI ---------------------------------------------------------------------------------------------------------------
+def _header_symbols():
+    src = open(os.path.join(ROOT, 'include', 'hvx.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(hvx_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    from flowmirror_hydravox_amd import build as hvx_build, _lib
+    path = hvx_build.build()
+    assert os.path.exists(path)
+    lib = ctypes.CDLL(path)
+    declared = _header_symbols()
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(lib, name), 'libhvx.so does not export %s' % name
+    # the ctypes binding covers exactly the header
+    assert sorted(_lib.SYMBOLS.keys()) == declared
+    assert _lib.load().hvx_abi_version() == 1
+
+
+def test_ctypes_struct_sizes_match_the_c_header(tmp_path):
+    """sizeof() of every argument struct as seen by a C compiler == the ctypes mirror (catches field drift)."""
+    from flowmirror_hydravox_amd import _lib
+    c = tmp_path / 's.c'
+    c.write_text('#include <stdio.h>\n#include "hvx.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(hvx_sample_args), '
+                 'sizeof(hvx_gemm_args), sizeof(hvx_attn_args), sizeof(hvx_llm_config), sizeof(hvx_flow_config), sizeof(hvx_hift_config));return 0;}\n')
+    exe = tmp_path / 's'
+    subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), str(c), '-o', str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    want = [ctypes.sizeof(t) for t in (_lib.SampleArgs, _lib.GemmArgs, _lib.AttnArgs, _lib.LLMConfig, _lib.FlowConfig, _lib.HiftConfig)]
+    assert got == want
+
+
+def test_product_path_fails_loudly_without_a_gpu():
+    from flowmirror_hydravox_amd import _lib
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    with pytest.raises(_lib.HvxError):
+        _lib.require_gpu()
+    from flowmirror_hydravox_amd.llm import HvxLLM
+    from flowmirror_hydravox_amd.config import tiny_config
+    with pytest.raises(_lib.HvxError):
+        HvxLLM(tiny_config().llm)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, 'flowmirror_hydravox_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h', '.cpp')):
+                txt = open(os.path.join(dirpath, f), errors='ignore').read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', txt, flags=re.M), f
+
+
+# ---- host logic ----------------------------------------------------------------------------------------------------------
+def test_sampling_params_from_partial_like_the_worker_builds_it():
+    from flowmirror_hydravox_amd.sampling import ras_sampling, sampling_params, rep_threshold, DEFAULTS
+    p = sampling_params(partial(ras_sampling, top_p=0.9, top_k=10, win_size=24, tau_r=0.2))
+    assert p == dict(top_p=0.9, top_k=10, win_size=24, tau_r=0.2)
+    assert sampling_params(None) == DEFAULTS
+
+    def foreign_ras(weighted_scores, decoded_tokens, sampling, top_p=0.8, top_k=25, win_size=10, tau_r=0.1):   # the reference's own function
+        raise AssertionError
+    assert sampling_params(partial(foreign_ras, top_k=5))['top_k'] == 5
+    with pytest.raises(ValueError):
+        sampling_params(partial(ras_sampling, top_k=500))
+    # integer form of `rep_num >= win_size * tau_r` with Python's double product
+    for win in (4, 10, 24, 32):
+        for tau in (0.05, 0.1, 0.2, 0.5):
+            thr = rep_threshold(win, tau)
+            for rep in range(0, win + 1):
+                assert (rep >= win * tau) == (rep >= thr)
+
+
+def test_noise_stream_equals_reference_draws_and_rewinds_the_generator():
+    from flowmirror_hydravox_amd.sampling import NoiseStream
+    from oracle import sampler_ref
+    a = NoiseStream(seed=5, chunk=100)
+    b = sampler_ref.NoiseStream(seed=5)
+    w = a.window(0, 1000).copy()
+    assert np.array_equal(w, b.peek(0, 1000))
+    assert np.array_equal(a.window(700, 50), b.peek(700, 50))
+    # multinomial(1) == argmax(p / q) on the same stream
+    g = torch.Generator().manual_seed(9)
+    p = torch.rand(40, generator=torch.Generator().manual_seed(1))
+    ns = NoiseStream(seed=9)
+    for k in range(20):
+        idx = int(p.multinomial(1, replacement=True, generator=g))
+        q = torch.from_numpy(ns.window(40 * k, 40).copy())
+        assert idx == int((p / q).argmax())
+    # global generator: after finalize(n) the next global draw is stream position n
+    torch.manual_seed(3)
+    s = NoiseStream()
+    ref = s.window(0, 500).copy()
+    s.finalize(123)
+    assert torch.empty(1).exponential_(1.0).item() == float(ref[123])
+
+
+def test_euler_schedule_matches_oracle_accumulation():
+    from flowmirror_hydravox_amd.flow import euler_schedule
+    from oracle import flow_ref
+    ts, dts = euler_schedule(10)
+    seen = []
+
+    def est(x, m, mu, t, s, c):
+        seen.append(float(t[0]))
+        return torch.zeros_like(x)
+    flow_ref.solve_euler(torch.zeros(1, 80, 4), flow_ref.cosine_t_span(10), torch.zeros(1, 80, 4), torch.ones(1, 1, 4), torch.zeros(1, 80),
+                         torch.zeros(1, 80, 4), est, 0.7)
+    assert seen == ts and len(dts) == 10 and abs(sum(dts) - 1.0) < 1e-6
+
+
+def test_packing_layouts():
+    from flowmirror_hydravox_amd import packing
+    w = torch.arange(32 * 64, dtype=torch.float32).view(32, 64)
+    p = packing.pack_frag(w).view(2, 2, 4, 16, 8)            # [N/16][K/32][g][r][j]
+    for nt in range(2):
+        for kt in range(2):
+            for g in range(4):
+                for r in (0, 7, 15):
+                    assert torch.equal(p[nt, kt, g, r], w[nt * 16 + r, kt * 32 + g * 8: kt * 32 + g * 8 + 8])
+    wg, wu = torch.randn(32, 32), torch.randn(32, 32)
+    gu = packing.pack_gate_up(wg, wu).view(4, 1, 4, 16, 8)   # tiles: gate0, up0, gate1, up1
+    assert torch.equal(gu[0, 0, 0, 3], wg[3, 0:8]) and torch.equal(gu[1, 0, 0, 3], wu[3, 0:8]) and torch.equal(gu[2, 0, 1, 0], wg[16, 8:16])
+    cw = packing.conv_weight(torch.randn(5, 18, 3))
+    assert cw.shape == (5, 3 * 32) and torch.all(cw.view(5, 3, 32)[:, :, 18:] == 0)
+
+
+def test_checkpoint_validation_is_strict():
+    from flowmirror_hydravox_amd import weights as W
+    from flowmirror_hydravox_amd.config import tiny_config
+    c = tiny_config().hift
+    sd = W.make_hift_state(c, seed=1)
+    W.check_state(sd, W.hift_spec(c), 'hift')
+    sd2 = dict(sd)
+    sd2.pop('conv_pre.bias')
+    with pytest.raises(RuntimeError, match='missing keys'):
+        W.check_state(sd2, W.hift_spec(c), 'hift')
+    sd3 = dict(sd)
+    sd3['conv_pre.bias'] = torch.zeros(3)
+    with pytest.raises(RuntimeError, match='size mismatch'):
+        W.check_state(sd3, W.hift_spec(c), 'hift')
+    sd4 = dict(sd, epoch=3, step=7)                           # dropped like infer_speech_model.py:80-89
+    W.check_state(sd4, W.hift_spec(c), 'hift')
+
+
+def test_full_size_budget_matches_the_survey():
+    from flowmirror_hydravox_amd import weights as W
+    from flowmirror_hydravox_amd.config import cv3_config
+    c = cv3_config()
+    n = lambda spec: sum(int(np.prod(s)) for _, s, _ in spec)
+    per_head = n([e for e in W.llm_spec(c.llm) if e[0].startswith('mtp_block.0.')])
+    assert abs(per_head - 62.39e6) < 0.05e6
+    assert abs(n(W.hift_spec(c.hift)) - 20.78e6) < 0.3e6      # + weight-norm g vectors
+    dit = n([e for e in W.flow_spec(c.flow) if e[0].startswith('decoder.estimator.')])
+    assert abs(dit - 331.14e6) < 0.1e6
+
+
+# ---- data parallel ---------------------------------------------------------------------------------------------------------
+def test_shard_by_cost_balances_and_covers():
+    from flowmirror_hydravox_amd.dp import shard_by_cost
+    costs = [512, 64, 300, 300, 128, 500, 64, 64, 256]
+    shards = shard_by_cost(costs, 4)
+    assert sorted(i for s in shards for i in s) == list(range(len(costs)))
+    loads = [sum(costs[i] for i in s) for s in shards]
+    assert max(loads) - min(loads) <= max(costs)
+    assert shard_by_cost(costs, 4) == shards                 # deterministic
+
+
+_GLOO_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from flowmirror_hydravox_amd.dp import gather_waveforms, shard_by_cost
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+dist.init_process_group('gloo')
+lens = [1000, 1, 777, 0, 4242]
+shards = shard_by_cost([float(l) for l in lens], world)
+mine = shards[rank]
+wavs = [torch.full((lens[i],), float(i)) + torch.arange(lens[i]) * 1e-3 for i in mine]
+got = gather_waveforms(wavs, mine, dst=0)
+if rank == 0:
+    assert sorted(got) == list(range(len(lens))), sorted(got)
+    for i, l in enumerate(lens):
+        assert got[i].numel() == l
+        if l:
+            assert torch.allclose(got[i], torch.full((l,), float(i)) + torch.arange(l) * 1e-3)
+    print('GATHER_OK')
+else:
+    assert got == {}
+dist.destroy_process_group()
+'''
+
+
+def test_waveform_gather_world_size_2_gloo(tmp_path):
+    script = tmp_path / 'w.py'
+    script.write_text(_GLOO_WORKER % ROOT)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29631', WORLD_SIZE='2')
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert 'GATHER_OK' in outs[0]
+
+
+def test_model_manager_surface_and_load_pt_never_raises():
+    from flowmirror_hydravox_amd.model_manager import HvxModelManager
+    mm = HvxModelManager()
+    assert mm.models is None and mm.is_loaded is False and mm.frontend is None
+    r = mm.load_pt('/nonexistent/llm.pt', '/nonexistent/flow.pt')
+    assert r['status'] == 'error' and isinstance(r['message'], str)
+    import argparse
+    if not torch.cuda.is_available():
+        with pytest.raises(ValueError):
+            mm.load_models(argparse.Namespace(config=None, model_dir='/tmp', bf16=True, fp16=False, cpu=True))
