@@ -224,8 +224,174 @@ __global__ void attn_combine_kernel(AttnArgs a) {
     op[d] = from_f32<T>(l > 0.0f ? acc / l : 0.0f);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Long-sequence bf16 form (DiT: non-causal, thousands of keys): a workgroup of 4 waves owns 128 query rows (32 per wave) and
+// walks the keys 64 at a time; the K tile [64 keys][64] and the V^T tile [64 d][64 keys] are staged once per workgroup in LDS
+// (double-buffered, global -> registers -> LDS with the next tile's loads in flight during the MFMAs) instead of once per
+// wave from L2.  Same register-resident S^T / P^T orientation as above.  Softmax runs on exp2 with the scale folded into one
+// fma per score, and the key-padding mask is only evaluated on the last tile.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_dit_kernel(AttnArgs a) {
+    typedef bf16_t T;
+    constexpr int KT = 64;                 // keys per tile
+    constexpr int LD = 72;                 // LDS row stride (elements): 144 B keeps the 16 rows of a lane group on distinct 16-B slots
+    __shared__ __attribute__((aligned(16))) T Ks[2][KT * LD];
+    __shared__ __attribute__((aligned(16))) T Vs[2][64 * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int row0 = blockIdx.x * 128 + wave * 32;
+    const int kv_len = a.kv_len ? a.kv_len[b] : a.kv_len_const;
+    const T* __restrict__ kb = reinterpret_cast<const T*>(a.k) + (long long)b * a.k_bs + (long long)h * a.k_hs;
+    const T* __restrict__ vb = reinterpret_cast<const T*>(a.vT) + (long long)b * a.v_bs + (long long)h * a.v_hs;
+
+    bf16x8 qf[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = row0 + i * 16 + fr;
+        if (r < a.n_rows) {
+            const T* qp = reinterpret_cast<const T*>(a.q) + (long long)b * a.q_bs + (long long)h * a.q_hs + (long long)r * a.q_lo + fg * 8;
+            qf[i][0] = load8(qp);
+            qf[i][1] = load8(qp + 32);
+        } else {
+            qf[i][0] = zero8<T>();
+            qf[i][1] = zero8<T>();
+        }
+    }
+    // tile loader: thread t moves 2 x 16 B of K (rows t/8 and t/8+32, chunk t%8) and 2 x 16 B of V^T
+    const int lrow = tid >> 3, lchunk = (tid & 7) * 8;
+    bf16x8 rk[2], rv[2];
+    auto gload = [&](int key0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int key = key0 + lrow + i * 32;
+            key = key < kv_len ? key : kv_len - 1;                       // clamped rows are masked below
+            rk[i] = load8(kb + (long long)key * 64 + lchunk);
+            rv[i] = load8(vb + (long long)(lrow + i * 32) * a.v_ld + key0 + lchunk);
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            store8(&Ks[buf][(lrow + i * 32) * LD + lchunk], rk[i]);
+            store8(&Vs[buf][(lrow + i * 32) * LD + lchunk], rv[i]);
+        }
+    };
+
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.0f, 0.0f};
+    f32x4 o_acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o_acc[i][dt] = f32x4{0, 0, 0, 0};
+    const float c = a.scale * 1.4426950408889634f;                      // softmax(s * scale) == exp2(s * c - m * c)
+
+    const int n_tiles = (kv_len + KT - 1) / KT;
+    if (n_tiles > 0) {
+        gload(0);
+        stash(0);
+    }
+    __syncthreads();
+    for (int it = 0; it < n_tiles; ++it) {
+        const int buf = it & 1, key0 = it * KT;
+        const bool more = (it + 1) < n_tiles;
+        if (more) gload(key0 + KT);
+        const bool tail = (key0 + KT) > kv_len;
+        // V^T fragments of this tile: [d-tile][32-key step]
+        bf16x8 vf[4][2];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const T* vp = &Vs[buf][(dt * 16 + fr) * LD + m * 32 + fg * 4];
+                const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vp), hi = *reinterpret_cast<const bf16x4*>(vp + 16);
+                bf16x8 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[j] = lo[j];
+                    v[4 + j] = hi[j];
+                }
+                vf[dt][m] = v;
+            }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            f32x4 s[4];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const bf16x8 k0 = load8(&Ks[buf][(kt * 16 + fr) * LD + fg * 8]);
+                const bf16x8 k1 = load8(&Ks[buf][(kt * 16 + fr) * LD + 32 + fg * 8]);
+                s[kt] = f32x4{0, 0, 0, 0};
+                mma32(s[kt], k0, qf[i][0]);
+                mma32(s[kt], k1, qf[i][1]);
+            }
+            float mx = -INFINITY;
+            if (tail) {
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (key0 + kt * 16 + fg * 4 + r >= kv_len) s[kt][r] = -INFINITY;
+                        mx = fmaxf(mx, s[kt][r]);
+                    }
+            } else {
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) mx = fmaxf(mx, fmaxf(fmaxf(s[kt][0], s[kt][1]), fmaxf(s[kt][2], s[kt][3])));
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[i], mx * c);               // running max in scaled (log2) units; c > 0
+            const float alpha = exp2f(m_run[i] - m_new);                 // exp2(-inf) == 0 on the first tile
+            float psum = 0.0f;
+            bf16x8 pf[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float p = exp2f(fmaf(s[2 * m + (e >> 2)][e & 3], c, -m_new));      // s == -inf -> 0
+                    psum += p;
+                    pf[m][e] = f32_to_bf16(p);
+                }
+            l_run[i] = l_run[i] * alpha + psum;
+            m_run[i] = m_new;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                o_acc[i][dt] *= alpha;
+                mma32(o_acc[i][dt], vf[dt][0], pf[0]);
+                mma32(o_acc[i][dt], vf[dt][1], pf[1]);
+            }
+        }
+        if (more) stash(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        float l = l_run[i];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const int r = row0 + i * 16 + fr;
+        if (r >= a.n_rows) continue;
+        const float inv = l > 0.0f ? 1.0f / l : 0.0f;
+        T* op = reinterpret_cast<T*>(a.out) + (long long)b * a.o_bs + (long long)h * a.o_hs + (long long)r * a.o_lo;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            bf16x4 o4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o4[e] = f32_to_bf16(o_acc[i][dt][e] * inv);
+            *reinterpret_cast<bf16x4*>(op + dt * 16 + fg * 4) = o4;
+        }
+    }
+}
+
 template <class T>
 static int launch_t(const AttnArgs& a, hipStream_t s) {
+    if (sizeof(T) == 2 && !a.causal && a.n_splits == 1 && a.kn >= a.n_rows && !a.kv_slot && !a.n_valid_lo && a.n_rows >= 256 &&
+        (a.v_ld & 63) == 0) {
+        const double fl = 4.0 * a.n_rows * (double)a.kv_len_const * 64.0 * a.heads * a.batch;
+        const int slot = prof_begin(PK_ATTN, a.kv_len ? 0.0 : fl, s);
+        hipLaunchKernelGGL(attn_dit_kernel, dim3((a.n_rows + 127) / 128, a.heads, a.batch), dim3(256), 0, s, a);
+        prof_end(slot, s);
+        return hipGetLastError() == hipSuccess ? 0 : (set_error("attention launch failed"), -1);
+    }
     const bool big = a.n_rows >= 256;
     const int rows_per_wave = big ? 32 : 16;
     const int n_qt = (a.n_rows + rows_per_wave - 1) / rows_per_wave;

@@ -60,7 +60,7 @@ struct EstBufs {
 size_t carve_est(const hvx_flow_config& c, char* base, int B, int T, EstBufs& b) {
     const size_t es = dtype_size(c.dtype);
     const int D = c.dim, H = c.heads;
-    const int Tp = (T + 31) & ~31;
+    const int Tp = (T + 63) & ~63;                 // the LDS-staged attention walks 64-key tiles
     b.t_pad = Tp;
     Carve cv(base);
     b.tsin = cv.take<void>((size_t)B * c.time_freq_dim * es);

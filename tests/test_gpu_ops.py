@@ -157,7 +157,7 @@ def _attn_ref(q, k, v, kv_len=None, causal=False):
 
 
 def _attn_inputs(B, H, T, dtype, seed):
-    Tp = (T + 31) // 32 * 32
+    Tp = (T + 63) // 64 * 64
     q = _rand(B, H, T, 64, seed=seed).to(dtype)
     k = _rand(B, H, T, 64, seed=seed + 1).to(dtype)
     v = _rand(B, H, T, 64, seed=seed + 2).to(dtype)
@@ -171,7 +171,7 @@ def _attn_inputs(B, H, T, dtype, seed):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize('T', [7, 100, 333])
+@pytest.mark.parametrize('T', [7, 100, 333, 700])
 def test_attention_padding_mask(dtype, T):
     _lib, ops, packing = _mods()
     q, k, v, qd, kd, vd = _attn_inputs(2, 3, T, dtype, seed=30)
