@@ -157,20 +157,34 @@ int launch_embed2(const void* speech, const void* text, int dtype, const int* to
 
 // ---- log_softmax over V (llm_multi_head_v3.py:888) ------------------------------------------------------
 __global__ __launch_bounds__(256) void log_softmax_kernel(float* x, int ld, int V) {
+    extern __shared__ __attribute__((aligned(16))) float row[];      // the row is read from global memory once
     __shared__ float red[4];
     float* xr = x + (long long)blockIdx.x * ld;
     float mx = -INFINITY;
-    for (int c = threadIdx.x; c < V; c += 256) mx = fmaxf(mx, xr[c]);
+    for (int base = 0; base < V; base += 256 * 8) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = base + u * 256 + threadIdx.x;
+            t[u] = c < V ? xr[c] : -INFINITY;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = base + u * 256 + threadIdx.x;
+            if (c < V) row[c] = t[u];
+            mx = fmaxf(mx, t[u]);
+        }
+    }
     mx = block_max(mx, red);
     float sum = 0.0f;
-    for (int c = threadIdx.x; c < V; c += 256) sum += expf(xr[c] - mx);
+    for (int c = threadIdx.x; c < V; c += 256) sum += expf(row[c] - mx);
     sum = block_sum(sum, red);
     const float lse = mx + logf(sum);
-    for (int c = threadIdx.x; c < V; c += 256) xr[c] = xr[c] - lse;
+    for (int c = threadIdx.x; c < V; c += 256) xr[c] = row[c] - lse;
 }
 int launch_log_softmax(float* x, int ld, int rows, int V, hipStream_t s) {
     if (rows <= 0) return 0;
-    hipLaunchKernelGGL(log_softmax_kernel, dim3(rows), dim3(256), 0, s, x, ld, V);
+    hipLaunchKernelGGL(log_softmax_kernel, dim3(rows), dim3(256), (size_t)V * 4, s, x, ld, V);
     return hipGetLastError() == hipSuccess ? 0 : (set_error("log_softmax launch failed"), -1);
 }
 

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(SkinnyArgs a) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int col = (ntile0 + j) * 16 + fr;
-            if (col >= a.N) continue;
+            if (col >= (a.n_valid ? a.n_valid : a.N)) continue;
             const float bv = bias ? bias[col] : 0.0f;
 #pragma unroll
             for (int i = 0; i < MT; ++i)
@@ -150,42 +150,38 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(SkinnyArgs a) {
                     reinterpret_cast<T*>(a.out)[(long long)z * a.out_zs + (long long)row * a.ldo + col] = from_f32<T>(v);
                 }
         }
-    } else {   // SK_QKV_ROPE: one wave = one 64-wide head (NT == 4)
-        static_assert(EPI != SK_QKV_ROPE || NT == 4, "QKV epilogue needs one head per wave");
-        const int head = ntile0 >> 2;                       // global head index over [q heads | k heads | v heads]
+    } else {   // SK_QKV_ROPE
+        // The checkpoint rows of every 64-wide head are permuted at pack time (packing.pack_qkv_rows) so that tile t of a
+        // head holds d = 8t..8t+7 (lanes fr < 8) and their rotate-half partners d + 32 (lanes fr >= 8): the RoPE pair is one
+        // xor-8 shuffle inside a single 16-column tile, and the GEMM can use one tile per workgroup (4x the workgroups).
+        static_assert(EPI != SK_QKV_ROPE || NT == 1, "QKV epilogue works on single permuted tiles");
+        const int head = ntile0 >> 2, t = ntile0 & 3;       // global head index over [q heads | k heads | v heads]
         const int which = head < a.q_heads ? 0 : (head < a.q_heads + a.kv_heads ? 1 : 2);
         const int hh = which == 0 ? head : (which == 1 ? head - a.q_heads : head - a.q_heads - a.kv_heads);
+        const int d = (fr < 8) ? (8 * t + fr) : (32 + 8 * t + (fr - 8));
+        const int f = 8 * t + (fr & 7);                     // rotary frequency index (d mod 32)
+        const float bias = a.bias ? a.bias[ntile0 * 16 + fr] : 0.0f;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = m0 + i * 16 + fg * 4 + r;
+                float x = acc[i][0][r] + bias;
+                const float partner = __shfl_xor(x, 8, 64);         // same row (same fg), the other half of the head
                 if (row >= a.M) continue;
                 const int si = row / a.kn, lt = row - si * a.kn;
                 if (lt >= a.n_new[si]) continue;                    // inactive row
                 const int pos = a.pos0[si] + lt;
-                float x[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) x[j] = acc[i][j][r] + (a.bias ? a.bias[(ntile0 + j) * 16 + fr] : 0.0f);
-                if (which < 2) {                                    // rotate-half RoPE: d pairs with d +- 32 (HF Qwen2)
-                    const float c0 = a.rope_cos[(long long)pos * 32 + fr], s0 = a.rope_sin[(long long)pos * 32 + fr];
-                    const float c1 = a.rope_cos[(long long)pos * 32 + 16 + fr], s1 = a.rope_sin[(long long)pos * 32 + 16 + fr];
-                    const float y0 = x[0] * c0 - x[2] * s0, y2 = x[2] * c0 + x[0] * s0;
-                    const float y1 = x[1] * c1 - x[3] * s1, y3 = x[3] * c1 + x[1] * s1;
-                    x[0] = y0; x[1] = y1; x[2] = y2; x[3] = y3;
+                if (which < 2) {                                    // rotate-half RoPE (HF Qwen2): d pairs with d +- 32
+                    const float cs = a.rope_cos[(long long)pos * 32 + f], sn = a.rope_sin[(long long)pos * 32 + f];
+                    x = (fr < 8) ? (x * cs - partner * sn) : (x * cs + partner * sn);
                 }
                 if (which == 0) {
-                    T* q = reinterpret_cast<T*>(a.qbuf) + ((long long)row * a.q_heads + hh) * 64;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) q[j * 16 + fr] = from_f32<T>(x[j]);
+                    reinterpret_cast<T*>(a.qbuf)[((long long)row * a.q_heads + hh) * 64 + d] = from_f32<T>(x);
                 } else if (which == 1) {
-                    T* kc = reinterpret_cast<T*>(a.kcache) + (((long long)a.slot[si] * a.kv_heads + hh) * a.max_ctx + pos) * 64;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) kc[j * 16 + fr] = from_f32<T>(x[j]);
+                    reinterpret_cast<T*>(a.kcache)[(((long long)a.slot[si] * a.kv_heads + hh) * a.max_ctx + pos) * 64 + d] = from_f32<T>(x);
                 } else {
-                    T* vc = reinterpret_cast<T*>(a.vTcache) + (((long long)a.slot[si] * a.kv_heads + hh) * 64) * a.max_ctx + pos;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) vc[(long long)(j * 16 + fr) * a.max_ctx] = from_f32<T>(x[j]);
+                    reinterpret_cast<T*>(a.vTcache)[(((long long)a.slot[si] * a.kv_heads + hh) * 64 + d) * a.max_ctx + pos] = from_f32<T>(x);
                 }
             }
         }
@@ -213,7 +209,7 @@ static int launch_mt(const SkinnyArgs& a, hipStream_t s) {
         case SK_PARTIAL: return launch_one<T, MT, 1, SK_PARTIAL>(a, s);
         case SK_STORE: return launch_one<T, MT, 1, SK_STORE>(a, s);
         case SK_SWIGLU: return launch_one<T, MT, 2, SK_SWIGLU>(a, s);
-        case SK_QKV_ROPE: return launch_one<T, MT, 4, SK_QKV_ROPE>(a, s);
+        case SK_QKV_ROPE: return launch_one<T, MT, 1, SK_QKV_ROPE>(a, s);
     }
     set_error("launch_skinny: bad epilogue %d", a.epi);
     return -1;

@@ -7,6 +7,10 @@
 // (bf16: 80 B, f32: 144 B) so that the 16 rows read by one ds_read_b128 lane group fall on
 // 16 distinct 16-byte slots.  The conv index map (tap, dilation, stride, nearest-upsample,
 // zero padding) lives in the A-tile loader; every epilogue variant is fused.
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "hvx_device.h"
 #include "hvx_kernels.h"
 
@@ -14,18 +18,27 @@ namespace hvx {
 
 template <class T> struct LdsPad { static constexpr int value = (sizeof(T) == 2) ? 8 : 4; };
 
-template <class T, int BM, int BN, int WM, int WN, int EPI>
+template <class T, int BM, int BN, int WM, int WN, int EPI, int BK, int NBUF = 1>
 __global__ __launch_bounds__(256) void gemm_tiled_kernel(GemmArgs a) {
-    constexpr int BK = 32;
+    // BK = 64 (bf16, 144-byte LDS rows) halves the barriers and global-load round trips per flop; BK = 32 serves fp32 and the
+    // convs whose padded channel count is not a multiple of 64 (a K-step must not straddle two taps)
     constexpr int LDK = BK + LdsPad<T>::value;
     constexpr int MT = WM / 16, NT = WN / 16;
     constexpr int WAVES_N = BN / WN;
     static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
-    constexpr int A_VECS = BM * 4 / 256, B_VECS = BN * 4 / 256;
+    constexpr int CPR = BK / 8;                      // 8-element chunks per tile row
+    constexpr int RPP = 256 / CPR;                   // tile rows covered by one pass of the 256 threads
+    constexpr int A_VECS = BM / RPP, B_VECS = BN / RPP;
     typedef typename Vec8<T>::type V8;
 
-    __shared__ __attribute__((aligned(16))) T As[BM * LDK];
-    __shared__ __attribute__((aligned(16))) T Bs[BN * LDK];
+    // one LDS allocation: K-step tiles during the main loop, per-wave fp32 staging tiles in the epilogue
+    constexpr int SLD = WN + 4;                      // staging row stride (floats)
+    constexpr int ROWS_PASS = (64 / WN) * 16;        // rows a wave stages per pass: 64 lanes x 16 columns each
+    constexpr int TILE_BYTES = NBUF * (BM + BN) * LDK * (int)sizeof(T);
+    constexpr int SCR_BYTES = 4 * ROWS_PASS * SLD * 4;
+    __shared__ __attribute__((aligned(16))) char smem[TILE_BYTES > SCR_BYTES ? TILE_BYTES : SCR_BYTES];
+    T (*As)[BM * LDK] = reinterpret_cast<T (*)[BM * LDK]>(smem);
+    T (*Bs)[BN * LDK] = reinterpret_cast<T (*)[BN * LDK]>(smem + NBUF * BM * LDK * sizeof(T));
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
@@ -38,14 +51,14 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(GemmArgs a) {
     // ---- per-thread tile-load coordinates ------------------------------------------------------
     int a_row[A_VECS], a_m[A_VECS];
     int b_row[B_VECS];
-    const int chunk = tid & 3;                      // which 8-element chunk of the 32-wide K-step
+    const int chunk = tid % CPR;                    // which 8-element chunk of the K-step
 #pragma unroll
     for (int i = 0; i < A_VECS; ++i) {
-        a_row[i] = (tid >> 2) + i * 64;
+        a_row[i] = (tid / CPR) + i * RPP;
         a_m[i] = m0 + a_row[i];
     }
 #pragma unroll
-    for (int i = 0; i < B_VECS; ++i) b_row[i] = (tid >> 2) + i * 64;
+    for (int i = 0; i < B_VECS; ++i) b_row[i] = (tid / CPR) + i * RPP;
 
     const int nk = a.K / BK;
     const long long in_span = (long long)a.rows_in * a.up;
@@ -74,11 +87,11 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(GemmArgs a) {
             else rb[i] = zero8<T>();
         }
     };
-    auto stash = [&](const V8 (&ra)[A_VECS], const V8 (&rb)[B_VECS]) {
+    auto stash = [&](int buf, const V8 (&ra)[A_VECS], const V8 (&rb)[B_VECS]) {
 #pragma unroll
-        for (int i = 0; i < A_VECS; ++i) store8(&As[a_row[i] * LDK + chunk * 8], ra[i]);
+        for (int i = 0; i < A_VECS; ++i) store8(&As[buf][a_row[i] * LDK + chunk * 8], ra[i]);
 #pragma unroll
-        for (int i = 0; i < B_VECS; ++i) store8(&Bs[b_row[i] * LDK + chunk * 8], rb[i]);
+        for (int i = 0; i < B_VECS; ++i) store8(&Bs[buf][b_row[i] * LDK + chunk * 8], rb[i]);
     };
 
     f32x4 acc[MT][NT];
@@ -90,57 +103,167 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(GemmArgs a) {
     V8 ra[A_VECS], rb[B_VECS];
     load_a(0, ra);
     load_b(0, rb);
-    stash(ra, rb);
+    stash(0, ra, rb);
     __syncthreads();
 
     const int fr = lane & 15, fg = lane >> 4;
     for (int kc = 0; kc < nk; ++kc) {
         const bool more = (kc + 1) < nk;
+        const int cur = (NBUF == 2) ? (kc & 1) : 0;
         if (more) {
             load_a(kc + 1, ra);
             load_b(kc + 1, rb);
         }
-        V8 af[MT], bf[NT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) af[i] = load8(&As[(wm0 + i * 16 + fr) * LDK + fg * 8]);
+        for (int kk = 0; kk < BK; kk += 32) {
+            V8 af[MT], bf[NT];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) bf[j] = load8(&Bs[(wn0 + j * 16 + fr) * LDK + fg * 8]);
+            for (int i = 0; i < MT; ++i) af[i] = load8(&As[cur][(wm0 + i * 16 + fr) * LDK + kk + fg * 8]);
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+            for (int j = 0; j < NT; ++j) bf[j] = load8(&Bs[cur][(wn0 + j * 16 + fr) * LDK + kk + fg * 8]);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) mma32(acc[i][j], af[i], bf[j]);
-        __syncthreads();
-        if (more) {
-            stash(ra, rb);
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) mma32(acc[i][j], af[i], bf[j]);
+        }
+        if constexpr (NBUF == 2) {
+            // the other buffer was last read one iteration ago and every wave has passed the barrier since: one barrier per K-step
+            if (more) stash(cur ^ 1, ra, rb);
             __syncthreads();
+        } else {
+            __syncthreads();
+            if (more) {
+                stash(0, ra, rb);
+                __syncthreads();
+            }
         }
     }
 
     // ---- epilogue ----------------------------------------------------------------------------------
+    // The MFMA C layout gives a lane 4 rows x 1 column per tile: stored directly that is 2-4 byte scatters.  Each wave
+    // therefore transposes its accumulators through a private fp32 LDS tile and every lane finishes 16 CONSECUTIVE columns
+    // of one row: bias / gate / residual come in as 16-byte loads and the result leaves as 32-64 contiguous bytes per lane
+    // (a full 128-256 B row segment per 4 lanes).
+    float* scr = reinterpret_cast<float*>(smem) + wave * ROWS_PASS * SLD;
+    constexpr int MT_PASS = ROWS_PASS / 16;
+    static_assert(MT % MT_PASS == 0, "wave tile must be a whole number of staging passes");
+    auto stage = [&](auto IP) {
+        constexpr int ip = decltype(IP)::value;                // compile-time: a runtime index would push acc[][] to scratch
+#pragma unroll
+        for (int ii = 0; ii < MT_PASS; ++ii)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) scr[(ii * 16 + fg * 4 + r) * SLD + j * 16 + fr] = acc[ip + ii][j][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto unstage = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+
     if constexpr (EPI == EPI_GENERIC) {
+        constexpr int LPR = WN / 16;                     // lanes per staged row
+        const int prow = lane / LPR, pcs = (lane % LPR) * 16;
         const long long ob = (long long)bz * a.out_bs;
-        const int total_cols = a.groups * a.N;
+        const int col0 = n0 + wn0 + pcs;
+        const int gc0 = g * a.N + col0;
+        const bool full = (col0 + 16) <= a.N;
+        // 16-byte vector access is legal when every leading dimension / base keeps 4-float (8-bf16) alignment
+        auto al = [](const void* p, long long ld, int esz) { return p == nullptr || ((((unsigned long long)p) & 15) == 0 && ((ld * esz) & 15) == 0); };
+        const bool vec = al(a.bias, 0, 4) && al(a.act_alpha, 0, 4) && al(a.act2_alpha, 0, 4) && al(a.gate, a.gate_bs, 4) &&
+                         al(a.res, a.ldres, 4) && ((a.res_bs * 4) & 15) == 0 && al(a.res2, a.ldres2, 4) && ((a.res2_bs * 4) & 15) == 0 &&
+                         al(a.out, a.ldo, a.out_f32 ? 4 : (int)sizeof(T)) && ((a.out_bs * (a.out_f32 ? 4 : (int)sizeof(T))) & 15) == 0 &&
+                         al(a.out2, a.ldo2, (int)sizeof(T)) && ((a.out2_bs * (int)sizeof(T)) & 15) == 0 && ((g * a.N) & 7) == 0;
+        auto do_pass = [&](auto IP) {
+            constexpr int ip = decltype(IP)::value;
+            stage(IP);
+            float x[16];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int col = n0 + wn0 + j * 16 + fr;
-            const int gc = g * a.N + col;
-            const bool col_ok = col < a.N;
-            const bool col_pad = (!col_ok) && (g == a.groups - 1) && (gc < a.out_cols);     // zero-fill padded channels
-            const bool col_pad2 = (!col_ok) && (g == a.groups - 1) && (gc < a.out2_cols);
-            if (!col_ok && !col_pad && !col_pad2) continue;
-            const float bias = (col_ok && a.bias) ? a.bias[gc] : 0.0f;
-            const float alpha = (col_ok && a.act_alpha) ? a.act_alpha[gc] : 1.0f;
-            const float alpha2 = (col_ok && a.act2_alpha) ? a.act2_alpha[gc] : 1.0f;
-            const float gate = (col_ok && a.gate) ? a.gate[(long long)bz * a.gate_bs + gc] : 1.0f;
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(&scr[prow * SLD + pcs + q * 4]);
+                x[q * 4 + 0] = t[0]; x[q * 4 + 1] = t[1]; x[q * 4 + 2] = t[2]; x[q * 4 + 3] = t[3];
+            }
+            unstage();
+            const int row = m0 + wm0 + ip * 16 + prow;
+            if (row >= a.M || (row + a.out_row_off) < 0) return;
+            if (full) {
+                // four self-contained 4-column chunks (keeps the live register set small: the accumulators own most of the file)
+                const float* resp = a.res ? a.res + (long long)bz * a.res_bs + (long long)(row + a.res_row_off) * a.ldres + gc0 : nullptr;
+                const float* res2p = a.res2 ? a.res2 + (long long)bz * a.res2_bs + (long long)row * a.ldres2 + gc0 : nullptr;
+                const long long o1 = ob + (long long)(row + a.out_row_off) * a.ldo + gc0;
+                const long long o2 = (long long)bz * a.out2_bs + (long long)(row + a.out2_row_off) * a.ldo2 + gc0;
 #pragma unroll
-            for (int i = 0; i < MT; ++i) {
+                for (int q = 0; q < 4; ++q) {
+                    const int c4 = q * 4;
+                    auto ld4 = [&](const float* p) -> f32x4 {
+                        if (vec) return *reinterpret_cast<const f32x4*>(p);
+                        return f32x4{p[0], p[1], p[2], p[3]};
+                    };
+                    f32x4 v = {x[c4], x[c4 + 1], x[c4 + 2], x[c4 + 3]};
+                    if (a.bias) v += ld4(a.bias + gc0 + c4);
+                    if (a.act != ACT_NONE) {
+                        f32x4 al = {1.0f, 1.0f, 1.0f, 1.0f};
+                        if (a.act_alpha) al = ld4(a.act_alpha + gc0 + c4);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = m0 + wm0 + i * 16 + fg * 4 + r;
-                    if (row >= a.M || (row + a.out_row_off) < 0) continue;
+                        for (int e = 0; e < 4; ++e) v[e] = act_apply(a.act, v[e], a.act_param, al[e]);
+                    }
+                    if (a.gate) v *= ld4(a.gate + (long long)bz * a.gate_bs + gc0 + c4);
+                    if (resp) v += ld4(resp + c4);
+                    if (res2p) v += ld4(res2p + c4);
+                    v *= a.scale;
+                    if (a.div != 0.0f) v = v / a.div;
+                    if (a.out) {
+                        if (a.out_f32) {
+                            float* op = reinterpret_cast<float*>(a.out) + o1 + c4;
+                            if (vec) *reinterpret_cast<f32x4*>(op) = v;
+                            else { op[0] = v[0]; op[1] = v[1]; op[2] = v[2]; op[3] = v[3]; }
+                        } else {
+                            T* op = reinterpret_cast<T*>(a.out) + o1 + c4;
+                            if constexpr (sizeof(T) == 2) {
+                                bf16x4 w4 = {f32_to_bf16(v[0]), f32_to_bf16(v[1]), f32_to_bf16(v[2]), f32_to_bf16(v[3])};
+                                if (vec) *reinterpret_cast<bf16x4*>(op) = w4;
+                                else { op[0] = w4[0]; op[1] = w4[1]; op[2] = w4[2]; op[3] = w4[3]; }
+                            } else {
+                                if (vec) *reinterpret_cast<f32x4*>(op) = v;
+                                else { op[0] = v[0]; op[1] = v[1]; op[2] = v[2]; op[3] = v[3]; }
+                            }
+                        }
+                    }
+                    if (a.out2) {
+                        f32x4 al2 = {1.0f, 1.0f, 1.0f, 1.0f};
+                        if (a.act2_alpha) al2 = ld4(a.act2_alpha + gc0 + c4);
+                        f32x4 u;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) u[e] = act_apply(a.act2, v[e], a.act2_param, al2[e]);
+                        T* op = reinterpret_cast<T*>(a.out2) + o2 + c4;
+                        if constexpr (sizeof(T) == 2) {
+                            bf16x4 w4 = {f32_to_bf16(u[0]), f32_to_bf16(u[1]), f32_to_bf16(u[2]), f32_to_bf16(u[3])};
+                            if (vec) *reinterpret_cast<bf16x4*>(op) = w4;
+                            else { op[0] = w4[0]; op[1] = w4[1]; op[2] = w4[2]; op[3] = w4[3]; }
+                        } else {
+                            if (vec) *reinterpret_cast<f32x4*>(op) = u;
+                            else { op[0] = u[0]; op[1] = u[1]; op[2] = u[2]; op[3] = u[3]; }
+                        }
+                    }
+                }
+            } else {
+                // partial column tile: element-wise with the padding rules (cols [groups*N, out_cols) are zero-filled)
+                for (int c = 0; c < 16; ++c) {
+                    const int col = col0 + c, gc = gc0 + c;
+                    const bool col_ok = col < a.N;
+                    const bool col_pad = (!col_ok) && (g == a.groups - 1) && (gc < a.out_cols);
+                    const bool col_pad2 = (!col_ok) && (g == a.groups - 1) && (gc < a.out2_cols);
+                    if (!col_ok && !col_pad && !col_pad2) continue;
                     float v = 0.0f;
+                    float al2 = 1.0f;
                     if (col_ok) {
-                        v = act_apply(a.act, acc[i][j][r] + bias, a.act_param, alpha) * gate;
+                        const float bi = a.bias ? a.bias[gc] : 0.0f;
+                        const float al1 = a.act_alpha ? a.act_alpha[gc] : 1.0f;
+                        al2 = a.act2_alpha ? a.act2_alpha[gc] : 1.0f;
+                        const float gt = a.gate ? a.gate[(long long)bz * a.gate_bs + gc] : 1.0f;
+                        v = act_apply(a.act, x[c] + bi, a.act_param, al1) * gt;
                         if (a.res) v += a.res[(long long)bz * a.res_bs + (long long)(row + a.res_row_off) * a.ldres + gc];
                         if (a.res2) v += a.res2[(long long)bz * a.res2_bs + (long long)row * a.ldres2 + gc];
                         v *= a.scale;
@@ -153,65 +276,113 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(GemmArgs a) {
                     }
                     if (a.out2 && (col_ok || col_pad2)) {
                         const long long o2 = (long long)bz * a.out2_bs + (long long)(row + a.out2_row_off) * a.ldo2 + gc;
-                        reinterpret_cast<T*>(a.out2)[o2] = from_f32<T>(col_ok ? act_apply(a.act2, v, a.act2_param, alpha2) : 0.0f);
+                        reinterpret_cast<T*>(a.out2)[o2] = from_f32<T>(col_ok ? act_apply(a.act2, v, a.act2_param, al2) : 0.0f);
                     }
                 }
             }
-        }
-        (void)total_cols;
-    } else {   // EPI_QKV_DIT
+        };
+        do_pass(std::integral_constant<int, 0>{});
+        if constexpr (MT > 1 * MT_PASS) do_pass(std::integral_constant<int, 1 * MT_PASS>{});
+        if constexpr (MT > 2 * MT_PASS) do_pass(std::integral_constant<int, 2 * MT_PASS>{});
+        if constexpr (MT > 3 * MT_PASS) do_pass(std::integral_constant<int, 3 * MT_PASS>{});
+    } else {   // EPI_QKV_DIT: a wave's WN columns lie inside one of q / k / v and one head
         const int D = a.heads * 64;
+        const int cw = n0 + wn0;                          // first column of this wave
+        const bool wave_ok = cw < a.N;
+        const int which = wave_ok ? cw / D : 0;
+        const int cb = cw - which * D;                    // channel inside q / k / v
+        const int h = cb >> 6;
+        constexpr int LPR = WN / 16;
+        auto do_pass = [&](auto IP) {
+            constexpr int ip = decltype(IP)::value;
+            stage(IP);
+            if (which < 2) {
+                // q, k: row-major, 16 consecutive channels per lane; interleaved-pair RoPE on channels [0, 64) of the row
+                const int prow = lane / LPR, pcs = (lane % LPR) * 16;
+                float x[16];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int col = n0 + wn0 + j * 16 + fr;
-            const bool col_ok = col < a.N;
-            const int which = col_ok ? col / D : 0;
-            const int c = col_ok ? col - which * D : 0;
-            const int h = c >> 6, d = c & 63;
-            const float bias = (col_ok && a.bias) ? a.bias[col] : 0.0f;
-            const bool rot = col_ok && which < 2 && c < 64;      // x_transformers partial rotary: first 64 channels of the row
-#pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const int row0 = m0 + wm0 + i * 16 + fg * 4;
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float x = acc[i][j][r] + bias;
-                    const float partner = __shfl_xor(x, 1, 64);          // neighbouring channel, same rows
-                    if (rot && (row0 + r) < a.M) {
-                        const float cs = a.rope_cos[(long long)(row0 + r) * 32 + (d >> 1)];
-                        const float sn = a.rope_sin[(long long)(row0 + r) * 32 + (d >> 1)];
-                        x = (d & 1) ? (x * cs + partner * sn) : (x * cs - partner * sn);
-                    }
-                    v[r] = x;
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(&scr[prow * SLD + pcs + q * 4]);
+                    x[q * 4 + 0] = t[0]; x[q * 4 + 1] = t[1]; x[q * 4 + 2] = t[2]; x[q * 4 + 3] = t[3];
                 }
-                if (!col_ok) continue;
-                if (which < 2) {
-                    T* dst = reinterpret_cast<T*>(which == 0 ? a.q : a.k) + (((long long)bz * a.heads + h) * a.t_pad) * 64 + d;
+                unstage();
+                const int row = m0 + wm0 + ip * 16 + prow;
+                const int c0 = cb + pcs, d0 = c0 & 63;
+                if (!wave_ok || row >= a.M) return;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (row0 + r < a.M) dst[(long long)(row0 + r) * 64] = from_f32<T>(v[r]);
+                for (int c = 0; c < 16; ++c) x[c] += a.bias ? a.bias[cw + pcs + c] : 0.0f;
+                if (c0 < 64) {
+#pragma unroll
+                    for (int c = 0; c < 16; c += 2) {
+                        const float cs = a.rope_cos[(long long)row * 32 + ((d0 + c) >> 1)], sn = a.rope_sin[(long long)row * 32 + ((d0 + c) >> 1)];
+                        const float e = x[c], o = x[c + 1];
+                        x[c] = e * cs - o * sn;
+                        x[c + 1] = o * cs + e * sn;
+                    }
+                }
+                T* dst = reinterpret_cast<T*>(which == 0 ? a.q : a.k) + ((((long long)bz * a.heads + h) * a.t_pad) + row) * 64 + d0;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    typename Vec8<T>::type w8;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) w8[e] = from_f32<T>(x[q * 8 + e]);
+                    store8(dst + q * 8, w8);
+                }
+            } else {
+                // v: written transposed (V^T [d][t]): a lane takes one channel and 16 consecutive time steps
+                const int pc = lane % WN, rblk = lane / WN;
+                float x[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) x[r] = scr[(rblk * 16 + r) * SLD + pc];
+                unstage();
+                const int row0 = m0 + wm0 + ip * 16 + rblk * 16;
+                if (!wave_ok || row0 >= a.M) return;
+                const float bi = a.bias ? a.bias[cw + pc] : 0.0f;
+                const int d = (cb + pc) & 63;
+                T* dst = reinterpret_cast<T*>(a.vT) + (((long long)bz * a.heads + h) * 64 + d) * a.t_pad + row0;
+                if (row0 + 16 <= a.M) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        typename Vec8<T>::type w8;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) w8[e] = from_f32<T>(x[q * 8 + e] + bi);
+                        store8(dst + q * 8, w8);
+                    }
                 } else {
-                    T* dst = reinterpret_cast<T*>(a.vT) + (((long long)bz * a.heads + h) * 64 + d) * a.t_pad + row0;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (row0 + r < a.M) dst[r] = from_f32<T>(v[r]);
+                    for (int r = 0; r < 16 && row0 + r < a.M; ++r) dst[r] = from_f32<T>(x[r] + bi);
                 }
             }
-        }
+        };
+        do_pass(std::integral_constant<int, 0>{});
+        if constexpr (MT > 1 * MT_PASS) do_pass(std::integral_constant<int, 1 * MT_PASS>{});
+        if constexpr (MT > 2 * MT_PASS) do_pass(std::integral_constant<int, 2 * MT_PASS>{});
+        if constexpr (MT > 3 * MT_PASS) do_pass(std::integral_constant<int, 3 * MT_PASS>{});
     }
+}
+
+template <class T, int BM, int BN, int WM, int WN, int BK, int NBUF = 1>
+static int launch_cfg_bk(const GemmArgs& a, hipStream_t s) {
+    dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, a.batch * a.groups);
+    const int slot = prof_begin(sizeof(T) == 2 ? PK_GEMM : PK_GEMM_F32, 2.0 * a.M * a.N * (double)a.K * a.batch * a.groups, s);
+    if (a.epi == EPI_GENERIC)
+        hipLaunchKernelGGL((gemm_tiled_kernel<T, BM, BN, WM, WN, EPI_GENERIC, BK, NBUF>), grid, dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((gemm_tiled_kernel<T, BM, BN, WM, WN, EPI_QKV_DIT, BK, NBUF>), grid, dim3(256), 0, s, a);
+    prof_end(slot, s);
+    return hipGetLastError() == hipSuccess ? 0 : (set_error("gemm launch failed"), -1);
 }
 
 template <class T, int BM, int BN, int WM, int WN>
 static int launch_cfg(const GemmArgs& a, hipStream_t s) {
-    dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, a.batch * a.groups);
-    const int slot = prof_begin(sizeof(T) == 2 ? PK_GEMM : PK_GEMM_F32, 2.0 * a.M * a.N * (double)a.K * a.batch * a.groups, s);
-    if (a.epi == EPI_GENERIC)
-        hipLaunchKernelGGL((gemm_tiled_kernel<T, BM, BN, WM, WN, EPI_GENERIC>), grid, dim3(256), 0, s, a);
-    else
-        hipLaunchKernelGGL((gemm_tiled_kernel<T, BM, BN, WM, WN, EPI_QKV_DIT>), grid, dim3(256), 0, s, a);
-    prof_end(slot, s);
-    return hipGetLastError() == hipSuccess ? 0 : (set_error("gemm launch failed"), -1);
+    if constexpr (sizeof(T) == 2) {
+        // measured on MI355X (tools/bench_ops.py): the BK = 64 variant of this two-barrier structure is slower (179 vs 304 TF/s on the
+        // DiT shapes), so it stays opt-in for experiments
+        static const bool bk64 = getenv("HVX_GEMM_BK64") != nullptr;
+        if (bk64 && (a.K & 63) == 0 && (a.cin_pad & 63) == 0) return launch_cfg_bk<T, BM, BN, WM, WN, 64>(a, s);
+        static const bool dbuf = getenv("HVX_GEMM_DBUF") != nullptr;
+        if (dbuf) return launch_cfg_bk<T, BM, BN, WM, WN, 32, 2>(a, s);
+    }
+    return launch_cfg_bk<T, BM, BN, WM, WN, 32>(a, s);
 }
 
 template <class T>

@@ -83,6 +83,7 @@ struct SkinnyArgs {
     int max_ctx;
     // layer-batched launches (MTP heads): blockIdx.z = head j, all pointers advance by these strides
     int nz; long long w_zs; long long a_zs; long long bias_zs; long long out_zs; long long part_zs;
+    int n_valid;                  // SK_STORE: columns >= n_valid are not stored (0 = N)
 };
 int launch_skinny(const SkinnyArgs& a, hipStream_t s);
 

@@ -349,14 +349,12 @@ static int forward_impl(hvx_llm* h, hipStream_t s, int32_t n_seq, int32_t kn, co
     // logits = llm_decoder(h) (shared weights) ; log_softmax
     memset(&g, 0, sizeof(g));
     g.dtype = dt; g.M = S; g.N = c.vocab_pad; g.K = H; g.A = h->ha; g.lda = H; g.a_zs = (long long)S * H; g.W = w[3]; g.w_zs = 0;
-    g.split_k = 1; g.nz = K; g.epi = SK_STORE; g.out = h->logits; g.out_f32 = 1; g.ldo = K * c.vocab_pad; g.out_zs = c.vocab_pad;
+    // straight into the caller's [S][K][vocab] buffer when there is one (the 16-row padding of the decoder is not stored)
+    float* dst = logp ? logp : h->logits;
+    const int ld = logp ? c.vocab : c.vocab_pad;
+    g.split_k = 1; g.nz = K; g.epi = SK_STORE; g.out = dst; g.out_f32 = 1; g.ldo = K * ld; g.out_zs = ld; g.n_valid = c.vocab;
     if (launch_skinny(g, s)) return -1;
-    if (launch_log_softmax(h->logits, c.vocab_pad, S * K, c.vocab, s)) return -1;
-    if (logp) {
-        if (hipMemcpy2DAsync(logp, (size_t)c.vocab * 4, h->logits, (size_t)c.vocab_pad * 4, (size_t)c.vocab * 4, (size_t)S * K,
-                             hipMemcpyDeviceToDevice, s) != hipSuccess)
-            return set_error("hvx_llm_forward: logp copy failed"), -1;
-    }
+    if (launch_log_softmax(dst, ld, S * K, c.vocab, s)) return -1;
     return 0;
 }
 

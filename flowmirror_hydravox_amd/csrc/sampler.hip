@@ -84,15 +84,30 @@ __global__ __launch_bounds__(256) void ras_sample_kernel(SampleArgs a) {
     for (int j = 0; j < a.head_k && !overflow; ++j) {
         const float* lp = a.logp + (long long)s * a.logp_ss + (long long)j * a.logp_hs;
         // ---- softmax(logp) (common.py:149 / :165) ---------------------------------------------------
+        // one pass over global memory with 8 independent loads in flight per thread (a dependent strided loop is pure latency),
+        // staged in LDS; every later pass reads LDS
         float mx = -INFINITY;
-        for (int i = tid; i < V; i += 256) mx = fmaxf(mx, lp[i]);
+        for (int base = 0; base < V; base += 256 * 8) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = base + u * 256 + tid;
+                t[u] = i < V ? lp[i] : -INFINITY;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = base + u * 256 + tid;
+                if (i < V) p[i] = t[u];
+                mx = fmaxf(mx, t[u]);
+            }
+        }
         {
             Best b = block_best(Best{mx, tid}, red_v, red_i);
             mx = b.v;
         }
         double sum = 0.0;
         for (int i = tid; i < V; i += 256) {
-            const float e = expf(lp[i] - mx);
+            const float e = expf(p[i] - mx);
             p[i] = e;
             taken[i] = 0;
             sum += (double)e;
@@ -161,9 +176,21 @@ __global__ __launch_bounds__(256) void ras_sample_kernel(SampleArgs a) {
                     break;
                 }
                 Best b = {-1.0f, BIG_IDX};
-                for (int i = tid; i < V; i += 256) {
-                    const float r = p[i] / noise[cursor + i];
-                    if (better(r, i, b.v, b.i)) b = Best{r, i};
+                for (int base = 0; base < V; base += 256 * 8) {
+                    float q[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int i = base + u * 256 + tid;
+                        q[u] = i < V ? noise[cursor + i] : 1.0f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int i = base + u * 256 + tid;
+                        if (i < V) {
+                            const float r = p[i] / q[u];
+                            if (better(r, i, b.v, b.i)) b = Best{r, i};
+                        }
+                    }
                 }
                 b = block_best(b, red_v, red_i);
                 c = b.i;

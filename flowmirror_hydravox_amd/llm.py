@@ -18,7 +18,7 @@ import torch
 from . import _lib, ops
 from ._lib import check, ptr, stream_ptr
 from .config import LLMConfig
-from .packing import pack_frag, pack_gate_up
+from .packing import pack_frag, pack_gate_up, qkv_row_perm
 from .sampling import NoiseStream, rep_threshold, sampling_params
 from .weights import llm_spec, check_state, DROP_KEYS
 
@@ -97,6 +97,8 @@ class HvxLLM:
             p = 'llm.model.model.layers.%d.' % i
             wqkv = torch.cat([W(p + 'self_attn.q_proj.weight'), W(p + 'self_attn.k_proj.weight'), W(p + 'self_attn.v_proj.weight')], 0)
             bqkv = torch.cat([W(p + 'self_attn.q_proj.bias'), W(p + 'self_attn.k_proj.bias'), W(p + 'self_attn.v_proj.bias')], 0)
+            perm = qkv_row_perm(c.q_heads + 2 * c.kv_heads).to(dev)        # RoPE pairs into one MFMA tile (csrc/gemm_skinny.hip)
+            wqkv, bqkv = wqkv[perm], bqkv[perm]
             ws += [vec(W(p + 'input_layernorm.weight')), mat(pack_frag(wqkv)), vec(bqkv), mat(pack_frag(W(p + 'self_attn.o_proj.weight'))),
                    vec(W(p + 'post_attention_layernorm.weight')),
                    mat(pack_gate_up(W(p + 'mlp.gate_proj.weight'), W(p + 'mlp.up_proj.weight'))), mat(pack_frag(W(p + 'mlp.down_proj.weight')))]

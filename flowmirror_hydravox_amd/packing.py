@@ -27,6 +27,17 @@ def pack_frag(w):
     return w.view(N // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous().view(N, K)
 
 
+def qkv_row_perm(n_heads, head_dim=64):
+    """Row order of the fused [q | k | v] projection consumed by the SK_QKV_ROPE epilogue: inside every 64-row head, 16-row tile t
+    holds d = 8t..8t+7 followed by their rotate-half partners d + 32, so a RoPE pair sits in one MFMA tile (lanes fr and fr ^ 8)."""
+    assert head_dim == 64
+    idx = []
+    for h in range(n_heads):
+        for t in range(4):
+            idx += [h * 64 + 8 * t + i for i in range(8)] + [h * 64 + 32 + 8 * t + i for i in range(8)]
+    return torch.tensor(idx, dtype=torch.long)
+
+
 def pack_gate_up(wg, wu):
     """Interleave gate / up projections as alternating 16-row tiles, then pack (SwiGLU epilogue pairs tile 2p with 2p+1)."""
     I, H = wg.shape
