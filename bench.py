@@ -45,6 +45,7 @@ def parse():
     ap.add_argument('--tiny', action='store_true', help='toy dimensions (plumbing check only; INVALID as a benchmark)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--prof-period', type=int, default=16)
+    ap.add_argument('--cpu-baseline-worker', action='store_true', help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -79,7 +80,8 @@ def cpu_baseline(cfg, pipe_seed, chars, heads):
     from oracle import llm_ref, flow_ref, hift_ref, sampler_ref
     from flowmirror_hydravox_amd import weights as W
     from flowmirror_hydravox_amd.pipeline import synthetic_utterance
-    cores = os.cpu_count() or 1
+    # 256 OpenMP threads on a 2-socket host make these small fp32 GEMMs slower, not faster: use at most 32 and say so
+    cores = min(os.cpu_count() or 1, int(os.environ.get('HVX_CPU_BASELINE_THREADS', '32')))
     torch.set_num_threads(cores)
     u = synthetic_utterance(cfg, 0, chars)
     sampling = dict(top_p=0.9, top_k=10, win_size=32, tau_r=0.2)
@@ -117,6 +119,10 @@ def cpu_baseline(cfg, pipe_seed, chars, heads):
 
 def main():
     args = parse()
+    if args.cpu_baseline_worker:
+        from flowmirror_hydravox_amd.config import cv3_config, tiny_config
+        print(json.dumps(cpu_baseline(tiny_config() if args.tiny else cv3_config(), 1986, args.chars, args.heads)))
+        return
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -228,7 +234,12 @@ def main():
         try:
             del pipe
             torch.cuda.empty_cache()
-            line['cpu_baseline'] = cpu_baseline(cfg, 1986, chars, K)
+            # separate process with a hard wall-clock limit: the GPU line must be printed whatever the host cores do
+            import subprocess
+            cmd = [sys.executable, os.path.abspath(__file__), '--cpu-baseline-worker', '--chars', str(chars), '--heads', str(K)] + (['--tiny'] if args.tiny else [])
+            out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=int(os.environ.get('HVX_CPU_BASELINE_TIMEOUT', '240')),
+                                 env=dict(os.environ, HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES=''))
+            line['cpu_baseline'] = json.loads(out.stdout.strip().splitlines()[-1])
         except Exception as e:                    # the bench line must still be printed
             line['cpu_baseline'] = {'value': None, 'unit': 'speech-tokens/s', 'cores': os.cpu_count(), 'kind': 'port', 'sample': 'failed: %r' % (e,)}
     print(json.dumps(line))

@@ -297,8 +297,57 @@ __global__ __launch_bounds__(256) void attn_dit_kernel(AttnArgs a) {
         const bool more = (it + 1) < n_tiles;
         if (more) gload(key0 + KT);
         const bool tail = (key0 + KT) > kv_len;
-        // V^T fragments of this tile: [d-tile][32-key step]
-        bf16x8 vf[4][2];
+        // S^T = K Q^T for both query tiles; each K fragment is read from LDS once and used twice
+        f32x4 s[2][4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            const bf16x8 k0 = load8(&Ks[buf][(kt * 16 + fr) * LD + fg * 8]);
+            const bf16x8 k1 = load8(&Ks[buf][(kt * 16 + fr) * LD + 32 + fg * 8]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                s[i][kt] = f32x4{0, 0, 0, 0};
+                mma32(s[i][kt], k0, qf[i][0]);
+                mma32(s[i][kt], k1, qf[i][1]);
+            }
+        }
+        bf16x8 pf[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float mx = -INFINITY;
+            if (tail) {
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (key0 + kt * 16 + fg * 4 + r >= kv_len) s[i][kt][r] = -INFINITY;
+                        mx = fmaxf(mx, s[i][kt][r]);
+                    }
+            } else {
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) mx = fmaxf(mx, fmaxf(fmaxf(s[i][kt][0], s[i][kt][1]), fmaxf(s[i][kt][2], s[i][kt][3])));
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[i], mx * c);               // running max in scaled (log2) units; c > 0
+            float psum = 0.0f;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float p = __builtin_amdgcn_exp2f(fmaf(s[i][2 * m + (e >> 2)][e & 3], c, -m_new));      // s == -inf -> 0
+                    psum += p;
+                    pf[i][m][e] = f32_to_bf16(p);
+                }
+            if (__any(m_new != m_run[i])) {                              // wave-uniform: most tiles do not raise any row's maximum
+                const float alpha = __builtin_amdgcn_exp2f(m_run[i] - m_new);     // exp2(-inf) == 0 on the first tile
+                l_run[i] *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) o_acc[i][dt] *= alpha;
+                m_run[i] = m_new;
+            }
+            l_run[i] += psum;
+        }
+        // O^T += V^T P^T; each V^T fragment is read from LDS once and used for both query tiles
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
@@ -311,55 +360,9 @@ __global__ __launch_bounds__(256) void attn_dit_kernel(AttnArgs a) {
                     v[j] = lo[j];
                     v[4 + j] = hi[j];
                 }
-                vf[dt][m] = v;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) mma32(o_acc[i][dt], v, pf[i][m]);
             }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            f32x4 s[4];
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
-                const bf16x8 k0 = load8(&Ks[buf][(kt * 16 + fr) * LD + fg * 8]);
-                const bf16x8 k1 = load8(&Ks[buf][(kt * 16 + fr) * LD + 32 + fg * 8]);
-                s[kt] = f32x4{0, 0, 0, 0};
-                mma32(s[kt], k0, qf[i][0]);
-                mma32(s[kt], k1, qf[i][1]);
-            }
-            float mx = -INFINITY;
-            if (tail) {
-#pragma unroll
-                for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if (key0 + kt * 16 + fg * 4 + r >= kv_len) s[kt][r] = -INFINITY;
-                        mx = fmaxf(mx, s[kt][r]);
-                    }
-            } else {
-#pragma unroll
-                for (int kt = 0; kt < 4; ++kt) mx = fmaxf(mx, fmaxf(fmaxf(s[kt][0], s[kt][1]), fmaxf(s[kt][2], s[kt][3])));
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run[i], mx * c);               // running max in scaled (log2) units; c > 0
-            const float alpha = exp2f(m_run[i] - m_new);                 // exp2(-inf) == 0 on the first tile
-            float psum = 0.0f;
-            bf16x8 pf[2];
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float p = exp2f(fmaf(s[2 * m + (e >> 2)][e & 3], c, -m_new));      // s == -inf -> 0
-                    psum += p;
-                    pf[m][e] = f32_to_bf16(p);
-                }
-            l_run[i] = l_run[i] * alpha + psum;
-            m_run[i] = m_new;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                o_acc[i][dt] *= alpha;
-                mma32(o_acc[i][dt], vf[dt][0], pf[0]);
-                mma32(o_acc[i][dt], vf[dt][1], pf[1]);
-            }
-        }
         if (more) stash(buf ^ 1);
         __syncthreads();
     }

@@ -198,6 +198,48 @@ __global__ __launch_bounds__(256) void layernorm_mod_kernel(const float* x, cons
     if (row >= T_) return;
     const int lane = threadIdx.x & 63;
     const float* xr = x + ((long long)b * T_ + row) * D;
+    const float* sh = shift + (long long)b * mod_bs;
+    const float* sc = scale + (long long)b * mod_bs;
+    T* yr = y + ((long long)b * T_ + row) * D;
+    if ((D & 255) == 0 && D <= 2048) {
+        // the row is read from memory once: 4 consecutive channels per lane and step (16-byte loads), kept in registers
+        f32x4 v[8];
+        const int nq = D >> 8;
+        float s1 = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (q < nq) {
+                v[q] = *reinterpret_cast<const f32x4*>(xr + q * 256 + lane * 4);
+                s1 += (v[q][0] + v[q][1]) + (v[q][2] + v[q][3]);
+            }
+        const float mean = wave_sum(s1) / (float)D;
+        float s2 = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (q < nq) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = v[q][e] - mean;
+                    s2 += d * d;
+                }
+            }
+        const float inv = rsqrtf(wave_sum(s2) / (float)D + eps);
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (q < nq) {
+                const int c = q * 256 + lane * 4;
+                const f32x4 s4 = *reinterpret_cast<const f32x4*>(sc + c), h4 = *reinterpret_cast<const f32x4*>(sh + c);
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (v[q][e] - mean) * inv * (1.0f + s4[e]) + h4[e];
+                if constexpr (sizeof(T) == 2) {
+                    *reinterpret_cast<bf16x4*>(yr + c) = bf16x4{f32_to_bf16(o[0]), f32_to_bf16(o[1]), f32_to_bf16(o[2]), f32_to_bf16(o[3])};
+                } else {
+                    *reinterpret_cast<f32x4*>(yr + c) = o;
+                }
+            }
+        return;
+    }
     float s1 = 0.0f;
     for (int c = lane; c < D; c += 64) s1 += xr[c];
     const float mean = wave_sum(s1) / (float)D;
@@ -207,9 +249,6 @@ __global__ __launch_bounds__(256) void layernorm_mod_kernel(const float* x, cons
         s2 += d * d;
     }
     const float inv = rsqrtf(wave_sum(s2) / (float)D + eps);
-    const float* sh = shift + (long long)b * mod_bs;
-    const float* sc = scale + (long long)b * mod_bs;
-    T* yr = y + ((long long)b * T_ + row) * D;
     for (int c = lane; c < D; c += 64) yr[c] = from_f32<T>((xr[c] - mean) * inv * (1.0f + sc[c]) + sh[c]);
 }
 int launch_layernorm_mod(const float* x, const float* shift, const float* scale, long long mod_bs, float eps, void* y, int dtype, int B, int T_,

@@ -58,11 +58,12 @@ __device__ __forceinline__ Best block_best(Best b, float* red_v, int* red_i) {
 constexpr int MAX_CAND = 64;
 constexpr int BIG_IDX = 0x7fffffff;
 
+constexpr int VPT = 32;                    // vocabulary entries per thread: V <= 256 * 32 = 8192
+
 __global__ __launch_bounds__(256) void ras_sample_kernel(SampleArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // Each thread keeps its strided slice of the distribution (index i = u * 256 + tid) in REGISTERS for the whole head:
+    // softmax, the tournament rescans and the full-vocabulary race never go back to memory.
     const int V = a.V;
-    float* p = reinterpret_cast<float*>(smem);                        // [V]
-    unsigned char* taken = smem + (size_t)((V + 3) & ~3) * 4;         // [V]
     __shared__ float red_v[4];
     __shared__ int red_i[4];
     __shared__ double red_d[4];
@@ -83,33 +84,25 @@ __global__ __launch_bounds__(256) void ras_sample_kernel(SampleArgs a) {
 
     for (int j = 0; j < a.head_k && !overflow; ++j) {
         const float* lp = a.logp + (long long)s * a.logp_ss + (long long)j * a.logp_hs;
-        // ---- softmax(logp) (common.py:149 / :165) ---------------------------------------------------
-        // one pass over global memory with 8 independent loads in flight per thread (a dependent strided loop is pure latency),
-        // staged in LDS; every later pass reads LDS
+        // ---- softmax(logp) (common.py:149 / :165): 32 independent loads per thread, then registers only ------------
+        float pv[VPT];
         float mx = -INFINITY;
-        for (int base = 0; base < V; base += 256 * 8) {
-            float t[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = base + u * 256 + tid;
-                t[u] = i < V ? lp[i] : -INFINITY;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = base + u * 256 + tid;
-                if (i < V) p[i] = t[u];
-                mx = fmaxf(mx, t[u]);
-            }
+        for (int u = 0; u < VPT; ++u) {
+            const int i = u * 256 + tid;
+            pv[u] = i < V ? lp[i] : -INFINITY;
         }
+#pragma unroll
+        for (int u = 0; u < VPT; ++u) mx = fmaxf(mx, pv[u]);
         {
             Best b = block_best(Best{mx, tid}, red_v, red_i);
             mx = b.v;
         }
         double sum = 0.0;
-        for (int i = tid; i < V; i += 256) {
-            const float e = expf(p[i] - mx);
-            p[i] = e;
-            taken[i] = 0;
+#pragma unroll
+        for (int u = 0; u < VPT; ++u) {
+            const float e = (u * 256 + tid) < V ? expf(pv[u] - mx) : 0.0f;
+            pv[u] = e;
             sum += (double)e;
         }
         sum = wave_sum_d(sum);
@@ -117,13 +110,21 @@ __global__ __launch_bounds__(256) void ras_sample_kernel(SampleArgs a) {
         if ((tid & 63) == 0) red_d[tid >> 6] = sum;
         __syncthreads();
         const float denom = (float)(red_d[0] + red_d[1] + red_d[2] + red_d[3]);
-        for (int i = tid; i < V; i += 256) p[i] = p[i] / denom;
-        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < VPT; ++u) pv[u] = (u * 256 + tid) < V ? pv[u] / denom : -1.0f;       // padding can never win
 
         // ---- nucleus candidates: stable descending order, `cum < top_p and n < top_k` (common.py:146-157)
-        Best mine = {-1.0f, BIG_IDX};
-        for (int i = tid; i < V; i += 256)
-            if (better(p[i], i, mine.v, mine.i)) mine = Best{p[i], i};
+        unsigned taken = 0;                                      // bit u: entry u of this thread already selected
+        auto local_best = [&]() {
+            Best m = {-1.0f, BIG_IDX};
+#pragma unroll
+            for (int u = 0; u < VPT; ++u) {
+                const float v = ((taken >> u) & 1u) ? -1.0f : pv[u];
+                if (v > m.v) m = Best{v, u * 256 + tid};         // ascending u == ascending index: ties keep the lower index
+            }
+            return m;
+        };
+        Best mine = local_best();
         int n = 0;
         float cum = 0.0f;
         const int kmax = min(min(a.top_k, MAX_CAND), V);
@@ -135,11 +136,9 @@ __global__ __launch_bounds__(256) void ras_sample_kernel(SampleArgs a) {
             }
             cum = cum + wv.v;                                   // fp32, in sorted order, like the reference's 0-dim tensor
             ++n;
-            if ((wv.i & 255) == tid) {                          // owner: retire the winner and rescan its stripe
-                taken[wv.i] = 1;
-                mine = Best{-1.0f, BIG_IDX};
-                for (int i = tid; i < V; i += 256)
-                    if (!taken[i] && better(p[i], i, mine.v, mine.i)) mine = Best{p[i], i};
+            if ((wv.i & 255) == tid) {                          // owner: retire the winner and rescan its registers
+                taken |= 1u << (wv.i >> 8);
+                mine = local_best();
             }
         }
         __syncthreads();
@@ -175,22 +174,18 @@ __global__ __launch_bounds__(256) void ras_sample_kernel(SampleArgs a) {
                     overflow = true;
                     break;
                 }
+                float q[VPT];
+#pragma unroll
+                for (int u = 0; u < VPT; ++u) {
+                    const int i = u * 256 + tid;
+                    q[u] = i < V ? noise[cursor + i] : 1.0f;
+                }
                 Best b = {-1.0f, BIG_IDX};
-                for (int base = 0; base < V; base += 256 * 8) {
-                    float q[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int i = base + u * 256 + tid;
-                        q[u] = i < V ? noise[cursor + i] : 1.0f;
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int i = base + u * 256 + tid;
-                        if (i < V) {
-                            const float r = p[i] / q[u];
-                            if (better(r, i, b.v, b.i)) b = Best{r, i};
-                        }
-                    }
+                for (int u = 0; u < VPT; ++u) {
+                    const int i = u * 256 + tid;
+                    const float r = pv[u] / q[u];
+                    if (i < V && better(r, i, b.v, b.i)) b = Best{r, i};
                 }
                 b = block_best(b, red_v, red_i);
                 c = b.i;
@@ -227,7 +222,11 @@ int launch_ras_sample(const SampleArgs& a, hipStream_t s) {
         set_error("ras_sample: head_k=%d", a.head_k);
         return -1;
     }
-    const size_t lds = (size_t)((a.V + 3) & ~3) * 4 + (size_t)((a.V + 15) & ~15);
+    if (a.V > 256 * VPT) {
+        set_error("ras_sample: vocab %d exceeds %d", a.V, 256 * VPT);
+        return -1;
+    }
+    const size_t lds = 0;
     const int slot = prof_begin(PK_SAMPLER, (double)a.n_seq * a.head_k * a.V * 4.0, s);
     hipLaunchKernelGGL(ras_sample_kernel, dim3(a.n_seq), dim3(256), lds, s, a);
     prof_end(slot, s);
