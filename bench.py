@@ -61,11 +61,26 @@ def read_prof(lib):
     return out
 
 
+def pmc_traffic(name):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r*_pmc_traffic.json; FETCH_SIZE / WRITE_SIZE in
+    separate passes with the gfx950 x2 FETCH correction).  PMC collection cannot run inside the timed bench."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')), reverse=True):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            if name in d:
+                return int(d[name]['hbm_bytes_per_launch'])
+        except Exception:
+            pass
+    return None
+
+
 def roofline_of(name, p):
     if p['bound'] == 'hbm':
         ach = p['rate'] / 1e9
         return dict(kernel=name, bound='hbm', achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(ach / HBM_PEAK_GBS, 4),
-                    traffic=None, avg_launch_us=round(p['avg_us'], 2), algorithmic_bytes_per_launch=round(p['work_per_launch']),
+                    traffic=pmc_traffic(name), avg_launch_us=round(p['avg_us'], 2), algorithmic_bytes_per_launch=round(p['work_per_launch']),
                     launches_per_timed_region=p['launches'], sampled_launches=p['sampled'])
     peak = MFMA_F32_PEAK_TF if name.endswith('f32') else MFMA_BF16_PEAK_TF
     ach = p['rate'] / 1e12

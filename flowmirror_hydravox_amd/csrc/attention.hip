@@ -33,9 +33,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     const int fr = lane & 15, fg = lane >> 4;
     const int b = blockIdx.z, h = blockIdx.y;
     const int n_qt = (a.n_rows + 16 * QT - 1) / (16 * QT);
-    const int w = blockIdx.x * 4 + wave;
-    if (w >= n_qt * a.n_splits) return;
-    const int qt = w / a.n_splits, sp = w - qt * a.n_splits;
+    const bool merge = (QT == 1) && a.sub_chunk > 0;          // decode form: workgroup = one split, waves = its four quarters
+    const int w = merge ? blockIdx.x : blockIdx.x * 4 + wave;
+    if (!merge && w >= n_qt * a.n_splits) return;
+    const int qt = merge ? 0 : w / a.n_splits, sp = merge ? blockIdx.x : w - qt * a.n_splits;
 
     const int kv_len = a.kv_len ? a.kv_len[b] : a.kv_len_const;
     const int pos0 = (a.causal && a.pos0) ? a.pos0[b] : 0;
@@ -44,6 +45,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     if (a.n_splits > 1) {
         key_begin = sp * a.split_chunk;
         key_end = min(kv_len, key_begin + a.split_chunk);
+        if (merge) {
+            key_begin += wave * a.sub_chunk;
+            key_end = min(key_end, key_begin + a.sub_chunk);
+        }
     }
 
     // ---- this lane's query rows (one per q-tile) -----------------------------------------------------
@@ -160,6 +165,48 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     }
 
     // ---- finish -------------------------------------------------------------------------------------
+    if constexpr (QT == 1) {
+        if (merge) {
+            // merge the four waves' partial softmax states in LDS (fixed wave order) and write ONE partial per workgroup
+            __shared__ float mo[4][16][64];
+            __shared__ float mml[4][16][2];
+            float l = l_run[0];
+            l += __shfl_xor(l, 16, 64);
+            l += __shfl_xor(l, 32, 64);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) mo[wave][fr][dt * 16 + fg * 4 + e] = o_acc[0][dt][e];
+            if (fg == 0) {
+                mml[wave][fr][0] = m_run[0];
+                mml[wave][fr][1] = l;
+            }
+            __syncthreads();
+            const int row = threadIdx.x >> 4, d0 = (threadIdx.x & 15) * 4;
+            const int rh = row / a.kn, rl = row - rh * a.kn;
+            if (row < a.n_rows && rl < n_valid_lo) {
+                float m = -INFINITY;
+#pragma unroll
+                for (int ww = 0; ww < 4; ++ww) m = fmaxf(m, mml[ww][row][0]);
+                f32x4 acc = {0, 0, 0, 0};
+                float ls = 0.0f;
+#pragma unroll
+                for (int ww = 0; ww < 4; ++ww) {
+                    const float mw = mml[ww][row][0];
+                    const float wgt = (mw == -INFINITY) ? 0.0f : expf(mw - m);
+                    acc += wgt * *reinterpret_cast<const f32x4*>(&mo[ww][row][d0]);
+                    ls += wgt * mml[ww][row][1];
+                }
+                const long long base = (((long long)b * a.heads + h) * a.n_splits + sp) * a.n_rows_pad + row;
+                *reinterpret_cast<f32x4*>(a.part_o + base * 64 + d0) = acc;
+                if (d0 == 0) {
+                    a.part_ml[base * 2 + 0] = m;
+                    a.part_ml[base * 2 + 1] = ls;
+                }
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < QT; ++i) {
         float l = l_run[i];
@@ -399,6 +446,7 @@ static int launch_t(const AttnArgs& a, hipStream_t s) {
     const int rows_per_wave = big ? 32 : 16;
     const int n_qt = (a.n_rows + rows_per_wave - 1) / rows_per_wave;
     dim3 grid((n_qt * a.n_splits + 3) / 4, a.heads, a.batch);
+    if (!big && a.sub_chunk > 0) grid.x = a.n_splits;              // one workgroup per split, 4 waves merge in LDS
     // QK^T + PV flops when the key length is known on the host (DiT); 0 for the device-length LLM calls
     const double flops = a.kv_len ? 0.0 : 4.0 * a.n_rows * (double)a.kv_len_const * 64.0 * a.heads * a.batch * (a.causal ? 0.5 : 1.0);
     const int slot = prof_begin(a.kv_len ? PK_ATTN_LLM : PK_ATTN, flops, s);
@@ -417,6 +465,7 @@ int launch_attention(const AttnArgs& a_in, hipStream_t s) {
     if (a.n_rows <= 0 || a.batch <= 0) return 0;
     if (a.n_splits < 1) a.n_splits = 1;
     if (a.kn < 1) a.kn = a.n_rows;
+    if (a.n_splits == 1 || a.n_rows > 16 || a.sub_chunk * 4 != a.split_chunk || (a.sub_chunk & 31)) a.sub_chunk = 0;
     if ((a.v_ld & 31) || (a.n_splits > 1 && ((a.split_chunk & 31) || !a.part_o || !a.part_ml || a.n_rows_pad < a.n_rows))) {
         set_error("launch_attention: bad geometry v_ld=%d split_chunk=%d", a.v_ld, a.split_chunk);
         return -1;

@@ -66,7 +66,7 @@ struct hvx_llm {
 namespace {
 
 constexpr int MAX_SPLIT = 16;
-constexpr int ATT_CHUNK = 64;      // keys per decode-attention split: 3.3k keys -> ~52 independent waves per (sequence, KV head)
+constexpr int ATT_CHUNK = 256;     // keys per decode-attention split (one workgroup); its 4 waves take 64 keys each and merge in LDS
 
 size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
@@ -270,7 +270,7 @@ static int forward_impl(hvx_llm* h, hipStream_t s, int32_t n_seq, int32_t kn, co
         at.scale = 0.125f;
         at.out = h->attn; at.o_bs = at.q_bs; at.o_hs = at.q_hs; at.o_hi = 64; at.o_lo = Q;
         if (use_split) {
-            at.n_splits = h->att_splits; at.split_chunk = h->att_chunk; at.part_o = h->att_o; at.part_ml = h->att_ml; at.n_rows_pad = h->att_rows_pad;
+            at.n_splits = h->att_splits; at.split_chunk = h->att_chunk; at.sub_chunk = h->att_chunk / 4; at.part_o = h->att_o; at.part_ml = h->att_ml; at.n_rows_pad = h->att_rows_pad;
         } else {
             at.n_splits = 1;
         }

@@ -105,7 +105,8 @@ def test_llm_batched_equals_single(tiny_cfg, llm_setup):
     from flowmirror_hydravox_amd.llm import HvxLLM
     g, sd = llm_setup
     cfg = tiny_cfg.llm
-    llm = HvxLLM(cfg, sd, dtype=torch.float32, max_batch=4, max_ctx=256, inference_head_num=2)
+    # max_ctx 1024 -> 4 key splits: exercises the split decode attention (in-workgroup merge + combine kernel)
+    llm = HvxLLM(cfg, sd, dtype=torch.float32, max_batch=4, max_ctx=1024, inference_head_num=2)
     gen = torch.Generator().manual_seed(77)
     texts = [torch.randint(0, cfg.text_vocab, (n,), generator=gen, dtype=torch.int32) for n in (9, 14, 5, 11)]
     prompts = [torch.randint(0, cfg.speech_tokens, (n,), generator=gen, dtype=torch.int32) for n in (0, 6, 3, 0)]
