@@ -5,33 +5,72 @@
 // K-slice; it streams its weight fragments straight from HBM into VGPRs — the checkpoint is
 // re-packed at load time into MFMA fragment order [N/16][K/32][64 lanes][8], so every wave-level
 // load instruction is one fully coalesced 1 KiB (bf16) burst — and re-reads the small, L2-resident
-// activation rows as A fragments.  No LDS, no barriers: a wave never waits on another wave.
-// Split-K (blockIdx.y) gives the narrow projections (N = 896) enough waves to cover 256 CUs; the fp32
-// partials are reduced in fixed order by reduce_rmsnorm (deterministic, no atomics).
+// activation rows as A fragments.  The KW waves of a workgroup split K among themselves and meet once, in
+// LDS, where wave 0 adds the partial tiles in fixed order (deterministic, no atomics) and runs the fused
+// epilogue: bias + RoPE + KV-cache scatter, SwiGLU, or the in-place residual update.  Split-K across
+// workgroups (blockIdx.y, fp32 partials reduced by reduce_rmsnorm) remains for the MTP-head GEMMs.
+#include <type_traits>
+
 #include "hvx_device.h"
 #include "hvx_kernels.h"
 
 namespace hvx {
 
-template <class T, int MT, int NT, int EPI>
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(SkinnyArgs a) {
+// fp32 -> operand type, 8 elements
+template <class T> __device__ __forceinline__ typename Vec8<T>::type cvt8(const f32x8& x);
+template <> __device__ __forceinline__ f32x8 cvt8<float>(const f32x8& x) { return x; }
+template <> __device__ __forceinline__ bf16x8 cvt8<bf16_t>(const f32x8& x) {
+    bf16x8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = f32_to_bf16(x[e]);
+    return r;
+}
+
+// per-row operands of the QKV epilogue (position, cache slot, rotary factors); loaded before the weight stream when MT == 1
+struct RowCtl {
+    int ok, pos, slot;
+    float cs, sn;
+};
+__device__ __forceinline__ RowCtl load_rowctl(const SkinnyArgs& a, int row, int f, int which) {
+    RowCtl c = {0, 0, 0, 1.0f, 0.0f};
+    if (row >= a.M) return c;
+    const int si = row / a.kn, lt = row - si * a.kn;
+    if (lt >= a.n_new[si]) return c;                            // inactive row
+    c.ok = 1;
+    c.pos = a.pos0[si] + lt;
+    c.slot = a.slot[si];
+    if (which < 2) {
+        c.cs = a.rope_cos[(long long)c.pos * 32 + f];
+        c.sn = a.rope_sin[(long long)c.pos * 32 + f];
+    }
+    return c;
+}
+
+// ANORM == 1: A is the fp32 residual stream x and the GEMM computes RMSNorm(x) @ W^T without a norm kernel in front of it.
+// RMSNorm is a per-row scale: norm(x)[k] = gain[k] * x[k] * rsqrt(mean(x^2) + eps).  The gain is folded into the weight columns when
+// the checkpoint is packed (llm.py), the A fragment is T(x), the sum of squares is accumulated from the very fragments the MFMA
+// consumes (every wave sees its K slice of the 16 rows), and the epilogue multiplies the accumulator by rsqrt(ss / K + eps):
+// no extra loads, no extra pass, nothing in front of the weight stream.
+template <class T, int MT, int NT, int EPI, int KW, int ANORM, int U>
+__global__ __launch_bounds__(64 * KW) void gemm_skinny_kernel(SkinnyArgs a) {
     typedef typename Vec8<T>::type V8;
+    typedef typename std::conditional<ANORM != 0, f32x8, V8>::type AV;      // A fragment as loaded
+    constexpr bool HOIST = MT == 1;      // decode geometry: epilogue operands are fetched ahead of the weight stream
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     const int z = blockIdx.z % a.nz;
     const int mchunk = blockIdx.z / a.nz;
     const int m0 = mchunk * (MT * 16);
-    const int ntile0 = blockIdx.x * NT;                        // the 4 waves of a workgroup share these NT tiles ...
+    const int ntile0 = blockIdx.x * NT;                        // the KW waves of a workgroup share these NT tiles ...
     const int KT = a.K >> 5;
     const int ks = blockIdx.y;
     const int kt_per = (KT + a.split_k - 1) / a.split_k;
     const int kb0 = ks * kt_per;
     const int kb1 = min(KT, kb0 + kt_per);
-    const int kq = (kb1 - kb0 + 3) >> 2;                       // ... and split its K range in four (in-block split-K)
+    const int kq = (kb1 - kb0 + KW - 1) / KW;                  // ... and split its K range among them (in-block split-K)
     const int kt0 = kb0 + wave * kq;
     const int kt1 = min(kb1, kt0 + kq);
 
-    const T* __restrict__ A = reinterpret_cast<const T*>(a.A) + (long long)z * a.a_zs;
     const T* __restrict__ W = reinterpret_cast<const T*>(a.W) + (long long)z * a.w_zs;
 
     f32x4 acc[MT][NT];
@@ -41,12 +80,15 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(SkinnyArgs a) {
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
 
     // A fragment rows (clamped; masked at the store)
-    const T* arow[MT];
+    typedef typename std::conditional<ANORM != 0, float, T>::type AT;
+    const AT* arow[MT];
+    float ssq[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         int r = m0 + i * 16 + fr;
         r = r < a.M ? r : a.M - 1;
-        arow[i] = A + (long long)r * a.lda + fg * 8;
+        arow[i] = reinterpret_cast<const AT*>(a.A) + (long long)z * a.a_zs + (long long)r * a.lda + fg * 8;
+        ssq[i] = 0.0f;
     }
     const T* wtile[NT];
 #pragma unroll
@@ -56,17 +98,64 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(SkinnyArgs a) {
         wtile[j] = W + ((long long)nt * KT) * 512 + lane * 8;
     }
 
+    // ---- epilogue operands of the finishing wave, requested before the weight stream so their latency hides under it ------------
+    float e_bias[NT];
+    float e_res[MT][NT][4];
+    RowCtl e_rc[MT][4];
+    int q_which = 0, q_hh = 0, q_d = 0, q_f = 0;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) e_bias[j] = 0.0f;
+    if constexpr (EPI == SK_QKV_ROPE) {
+        // The checkpoint rows of every 64-wide head are permuted at pack time (packing.qkv_row_perm) so that tile t of a
+        // head holds d = 8t..8t+7 (lanes fr < 8) and their rotate-half partners d + 32 (lanes fr >= 8): the RoPE pair is one
+        // xor-8 shuffle inside a single 16-column tile, and the GEMM can use one tile per workgroup (4x the workgroups).
+        static_assert(EPI != SK_QKV_ROPE || NT == 1, "QKV epilogue works on single permuted tiles");
+        const int head = ntile0 >> 2, t = ntile0 & 3;       // global head index over [q heads | k heads | v heads]
+        q_which = head < a.q_heads ? 0 : (head < a.q_heads + a.kv_heads ? 1 : 2);
+        q_hh = q_which == 0 ? head : (q_which == 1 ? head - a.q_heads : head - a.q_heads - a.kv_heads);
+        q_d = (fr < 8) ? (8 * t + fr) : (32 + 8 * t + (fr - 8));
+        q_f = 8 * t + (fr & 7);                             // rotary frequency index (d mod 32)
+    }
+    if (wave == 0) {
+        if constexpr (EPI == SK_RESID || EPI == SK_STORE || EPI == SK_QKV_ROPE) {
+            const float* bias = a.bias ? a.bias + (long long)z * a.bias_zs : nullptr;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int col = (ntile0 + j) * 16 + fr;
+                e_bias[j] = (bias && col < a.N) ? bias[col] : 0.0f;
+            }
+        }
+        if constexpr (EPI == SK_RESID && HOIST) {
+            const float* xo = reinterpret_cast<const float*>(a.out) + (long long)z * a.out_zs;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = m0 + i * 16 + fg * 4 + r, col = (ntile0 + j) * 16 + fr;
+                        e_res[i][j][r] = (row < a.M && col < a.N) ? xo[(long long)row * a.ldo + col] : 0.0f;
+                    }
+        }
+        if constexpr (EPI == SK_QKV_ROPE && HOIST) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) e_rc[i][r] = load_rowctl(a, m0 + i * 16 + fg * 4 + r, q_f, q_which);
+        }
+    }
+
     // U k-steps per trip: all of their weight / activation loads are issued before the first MFMA so that each wave keeps
     // U * NT KiB of the weight stream in flight (a dependent load->MFMA chain per k-step is latency-bound: 0.6 TB/s measured).
-    constexpr int REGS = (NT + MT) * (sizeof(T) == 2 ? 4 : 8);
-    constexpr int U = REGS <= 16 ? 8 : (REGS <= 32 ? 4 : 2);
+    // The decode shapes are dispatched so that a wave's whole K slice is one trip.
     for (int kt = kt0; kt < kt1; kt += U) {
-        V8 wf[U][NT], af[U][MT];
+        V8 wf[U][NT];
+        AV af[U][MT];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int k = min(kt + u, kt1 - 1);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) wf[u][j] = load8(wtile[j] + (long long)k * 512);
+            for (int j = 0; j < NT; ++j) wf[u][j] = load8_nt(wtile[j] + (long long)k * 512);
 #pragma unroll
             for (int i = 0; i < MT; ++i) af[u][i] = load8(arow[i] + k * 32);
         }
@@ -74,15 +163,35 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(SkinnyArgs a) {
         for (int u = 0; u < U; ++u) {
             if (kt + u < kt1) {
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
+                for (int i = 0; i < MT; ++i) {
+                    V8 av;
+                    if constexpr (ANORM) {
+                        const f32x8 x = af[u][i];
+                        ssq[i] += ((x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3])) + ((x[4] * x[4] + x[5] * x[5]) + (x[6] * x[6] + x[7] * x[7]));
+                        av = cvt8<T>(x);
+                    } else {
+                        av = af[u][i];
+                    }
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) mma32(acc[i][j], af[u][i], wf[u][j]);
+                    for (int j = 0; j < NT; ++j) mma32(acc[i][j], av, wf[u][j]);
+                }
             }
         }
     }
 
-    // in-block reduction in fixed wave order (deterministic): waves 1..3 park their tiles in LDS, wave 0 adds and finishes
-    __shared__ f32x4 red[3][MT][NT][64];
+    // in-block reduction in fixed wave order (deterministic): waves 1.. park their tiles (and row sums of squares) in LDS,
+    // wave 0 adds them and finishes
+    __shared__ f32x4 red[KW > 1 ? KW - 1 : 1][MT][NT][64];
+    __shared__ float s_ss[ANORM ? KW : 1][MT * 16];
+    if constexpr (ANORM) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            float v = ssq[i];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (fg == 0) s_ss[wave][i * 16 + fr] = v;
+        }
+    }
     if (wave > 0) {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -92,11 +201,24 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(SkinnyArgs a) {
     __syncthreads();
     if (wave > 0) return;
 #pragma unroll
-    for (int w = 0; w < 3; ++w)
+    for (int w = 0; w < KW - 1; ++w)
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < NT; ++j) acc[i][j] += red[w][i][j][lane];
+    if constexpr (ANORM) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float ss = 0.0f;
+#pragma unroll
+                for (int w = 0; w < KW; ++w) ss += s_ss[w][i * 16 + fg * 4 + r];
+                const float inv = rsqrtf(ss / (float)a.K + a.norm_eps);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j][r] *= inv;
+            }
+    }
 
     // ---- epilogues ---------------------------------------------------------------------------------
     if constexpr (EPI == SK_PARTIAL) {
@@ -113,20 +235,36 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(SkinnyArgs a) {
                     if (row < a.M) part[(long long)row * a.N + col] = acc[i][j][r];
                 }
         }
-    } else if constexpr (EPI == SK_STORE) {
-        const float* bias = a.bias ? a.bias + (long long)z * a.bias_zs : nullptr;
+    } else if constexpr (EPI == SK_RESID) {
+        // residual stream update in place: x[row][col] += acc (+ bias).  split_k == 1, so every element has exactly one writer.
+        float* xo = reinterpret_cast<float*>(a.out) + (long long)z * a.out_zs;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int col = (ntile0 + j) * 16 + fr;
-            if (col >= (a.n_valid ? a.n_valid : a.N)) continue;
-            const float bv = bias ? bias[col] : 0.0f;
+            if (col >= a.N) continue;
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = m0 + i * 16 + fg * 4 + r;
                     if (row >= a.M) continue;
-                    const float v = acc[i][j][r] + bv;
+                    float* px = xo + (long long)row * a.ldo + col;
+                    const float x0 = HOIST ? e_res[i][j][r] : *px;
+                    *px = x0 + (acc[i][j][r] + e_bias[j]);
+                }
+        }
+    } else if constexpr (EPI == SK_STORE) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int col = (ntile0 + j) * 16 + fr;
+            if (col >= (a.n_valid ? a.n_valid : a.N)) continue;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = m0 + i * 16 + fg * 4 + r;
+                    if (row >= a.M) continue;
+                    const float v = acc[i][j][r] + e_bias[j];
                     const long long o = (long long)z * a.out_zs + (long long)row * a.ldo + col;
                     if (a.out_f32) reinterpret_cast<float*>(a.out)[o] = v;
                     else reinterpret_cast<T*>(a.out)[o] = from_f32<T>(v);
@@ -134,9 +272,9 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(SkinnyArgs a) {
         }
     } else if constexpr (EPI == SK_SWIGLU) {
         // tiles come in (gate, up) pairs: tile 2p holds gate columns 16p..16p+15, tile 2p+1 the matching up columns
-        static_assert(NT % 2 == 0, "SwiGLU needs tile pairs");
+        static_assert(EPI != SK_SWIGLU || NT % 2 == 0, "SwiGLU needs tile pairs");
 #pragma unroll
-        for (int j = 0; j < NT; j += 2) {
+        for (int j = 0; j + 1 < NT; j += 2) {
             const int col = ((ntile0 + j) >> 1) * 16 + fr;
             if (col * 2 >= a.N) continue;
 #pragma unroll
@@ -151,45 +289,34 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(SkinnyArgs a) {
                 }
         }
     } else {   // SK_QKV_ROPE
-        // The checkpoint rows of every 64-wide head are permuted at pack time (packing.pack_qkv_rows) so that tile t of a
-        // head holds d = 8t..8t+7 (lanes fr < 8) and their rotate-half partners d + 32 (lanes fr >= 8): the RoPE pair is one
-        // xor-8 shuffle inside a single 16-column tile, and the GEMM can use one tile per workgroup (4x the workgroups).
-        static_assert(EPI != SK_QKV_ROPE || NT == 1, "QKV epilogue works on single permuted tiles");
-        const int head = ntile0 >> 2, t = ntile0 & 3;       // global head index over [q heads | k heads | v heads]
-        const int which = head < a.q_heads ? 0 : (head < a.q_heads + a.kv_heads ? 1 : 2);
-        const int hh = which == 0 ? head : (which == 1 ? head - a.q_heads : head - a.q_heads - a.kv_heads);
-        const int d = (fr < 8) ? (8 * t + fr) : (32 + 8 * t + (fr - 8));
-        const int f = 8 * t + (fr & 7);                     // rotary frequency index (d mod 32)
-        const float bias = a.bias ? a.bias[ntile0 * 16 + fr] : 0.0f;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = m0 + i * 16 + fg * 4 + r;
-                float x = acc[i][0][r] + bias;
+                float x = acc[i][0][r] + e_bias[0];
                 const float partner = __shfl_xor(x, 8, 64);         // same row (same fg), the other half of the head
-                if (row >= a.M) continue;
-                const int si = row / a.kn, lt = row - si * a.kn;
-                if (lt >= a.n_new[si]) continue;                    // inactive row
-                const int pos = a.pos0[si] + lt;
-                if (which < 2) {                                    // rotate-half RoPE (HF Qwen2): d pairs with d +- 32
-                    const float cs = a.rope_cos[(long long)pos * 32 + f], sn = a.rope_sin[(long long)pos * 32 + f];
-                    x = (fr < 8) ? (x * cs - partner * sn) : (x * cs + partner * sn);
-                }
-                if (which == 0) {
-                    reinterpret_cast<T*>(a.qbuf)[((long long)row * a.q_heads + hh) * 64 + d] = from_f32<T>(x);
-                } else if (which == 1) {
-                    reinterpret_cast<T*>(a.kcache)[(((long long)a.slot[si] * a.kv_heads + hh) * a.max_ctx + pos) * 64 + d] = from_f32<T>(x);
+                const RowCtl c = HOIST ? e_rc[i][r] : load_rowctl(a, row, q_f, q_which);
+                if (!c.ok) continue;
+                if (q_which < 2)                                    // rotate-half RoPE (HF Qwen2): d pairs with d +- 32
+                    x = (fr < 8) ? (x * c.cs - partner * c.sn) : (x * c.cs + partner * c.sn);
+                if (q_which == 0) {
+                    reinterpret_cast<T*>(a.qbuf)[((long long)row * a.q_heads + q_hh) * 64 + q_d] = from_f32<T>(x);
+                } else if (q_which == 1) {
+                    reinterpret_cast<T*>(a.kcache)[(((long long)c.slot * a.kv_heads + q_hh) * a.max_ctx + c.pos) * 64 + q_d] = from_f32<T>(x);
                 } else {
-                    reinterpret_cast<T*>(a.vTcache)[(((long long)a.slot[si] * a.kv_heads + hh) * 64 + d) * a.max_ctx + pos] = from_f32<T>(x);
+                    reinterpret_cast<T*>(a.vTcache)[(((long long)c.slot * a.kv_heads + q_hh) * 64 + q_d) * a.max_ctx + c.pos] = from_f32<T>(x);
                 }
             }
         }
     }
 }
 
-template <class T, int MT, int NT, int EPI>
+template <class T, int MT, int NT, int EPI, int KW = 4, int ANORM = 0, int U_ = 0>
 static int launch_one(const SkinnyArgs& a, hipStream_t s) {
+    // k-steps in flight per wave: sized so that the fragment registers stay within ~96 VGPRs unless the caller knows better
+    constexpr int REGS = NT * (sizeof(T) == 2 ? 4 : 8) + MT * (ANORM ? 8 : (sizeof(T) == 2 ? 4 : 8));
+    constexpr int U = U_ ? U_ : (REGS <= 16 ? 8 : (REGS <= 32 ? 4 : 2));
     const int ntiles = a.N / 16;
     const int groups = (ntiles + NT - 1) / NT;
     const int mchunks = (a.M + MT * 16 - 1) / (MT * 16);
@@ -198,7 +325,7 @@ static int launch_one(const SkinnyArgs& a, hipStream_t s) {
     const double bytes = (double)a.nz * ((double)a.N * a.K * sizeof(T) + (double)a.M * a.K * sizeof(T) +
                                          (double)a.M * a.N * (EPI == SK_PARTIAL ? 4.0 * a.split_k : (double)sizeof(T)));
     const int slot = prof_begin(PK_SKINNY, bytes, s);
-    hipLaunchKernelGGL((gemm_skinny_kernel<T, MT, NT, EPI>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((gemm_skinny_kernel<T, MT, NT, EPI, KW, ANORM, U>), grid, dim3(64 * KW), 0, s, a);
     prof_end(slot, s);
     return hipGetLastError() == hipSuccess ? 0 : (set_error("skinny gemm launch failed"), -1);
 }
@@ -208,8 +335,15 @@ static int launch_mt(const SkinnyArgs& a, hipStream_t s) {
     switch (a.epi) {
         case SK_PARTIAL: return launch_one<T, MT, 1, SK_PARTIAL>(a, s);
         case SK_STORE: return launch_one<T, MT, 1, SK_STORE>(a, s);
-        case SK_SWIGLU: return launch_one<T, MT, 2, SK_SWIGLU>(a, s);
-        case SK_QKV_ROPE: return launch_one<T, MT, 1, SK_QKV_ROPE>(a, s);
+        case SK_SWIGLU: return a.a_norm ? launch_one<T, MT, 2, SK_SWIGLU, 4, 1>(a, s) : launch_one<T, MT, 2, SK_SWIGLU>(a, s);
+        case SK_QKV_ROPE: return a.a_norm ? launch_one<T, MT, 1, SK_QKV_ROPE, 4, 1>(a, s) : launch_one<T, MT, 1, SK_QKV_ROPE>(a, s);
+        case SK_RESID:
+            // long-K residual projections (down_proj): only N/16 workgroups exist, so K is split over 16 waves and each wave's
+            // whole slice (<= 10 k-steps for K = 4864) is requested in one go
+            if constexpr (MT == 1) {
+                if (a.K >= 2048 && a.K <= 16 * 10 * 32) return launch_one<T, 1, 1, SK_RESID, 16, 0, (sizeof(T) == 2 ? 10 : 5)>(a, s);
+            }
+            return launch_one<T, MT, 1, SK_RESID>(a, s);
     }
     set_error("launch_skinny: bad epilogue %d", a.epi);
     return -1;
@@ -234,6 +368,10 @@ int launch_skinny(const SkinnyArgs& a_in, hipStream_t s) {
     }
     if (a.epi != SK_PARTIAL && a.split_k != 1) {
         set_error("launch_skinny: fused epilogues need split_k == 1");
+        return -1;
+    }
+    if (a.a_norm && ((a.epi != SK_SWIGLU && a.epi != SK_QKV_ROPE) || (a.K & 3) || a.nz != 1)) {
+        set_error("launch_skinny: fused RMSNorm prologue is available for the QKV and gate/up GEMMs only");
         return -1;
     }
     if (a.epi == SK_QKV_ROPE && (a.N != (a.q_heads + 2 * a.kv_heads) * 64)) {

@@ -374,14 +374,9 @@ static int launch_cfg_bk(const GemmArgs& a, hipStream_t s) {
 
 template <class T, int BM, int BN, int WM, int WN>
 static int launch_cfg(const GemmArgs& a, hipStream_t s) {
-    if constexpr (sizeof(T) == 2) {
-        // measured on MI355X (tools/bench_ops.py): the BK = 64 variant of this two-barrier structure is slower (179 vs 304 TF/s on the
-        // DiT shapes), so it stays opt-in for experiments
-        static const bool bk64 = getenv("HVX_GEMM_BK64") != nullptr;
-        if (bk64 && (a.K & 63) == 0 && (a.cin_pad & 63) == 0) return launch_cfg_bk<T, BM, BN, WM, WN, 64>(a, s);
-        static const bool dbuf = getenv("HVX_GEMM_DBUF") != nullptr;
-        if (dbuf) return launch_cfg_bk<T, BM, BN, WM, WN, 32, 2>(a, s);
-    }
+    // Measured on MI355X (tools/bench_ops.py, DiT shapes): with this two-barrier structure BK = 64 is slower (180 vs 300 TF/s) and a
+    // double-buffered LDS (NBUF = 2, one barrier per K-step) changes nothing — the template keeps both knobs, only BK = 32 / NBUF = 1
+    // is instantiated.
     return launch_cfg_bk<T, BM, BN, WM, WN, 32>(a, s);
 }
 

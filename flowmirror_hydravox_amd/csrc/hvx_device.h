@@ -47,6 +47,14 @@ __device__ __forceinline__ f32x8 load8(const float* p) {
     f32x8 r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
     return r;
 }
+// the same for data read exactly once by one CU (streamed weights): non-temporal, does not displace the L2-resident activations
+__device__ __forceinline__ bf16x8 load8_nt(const bf16_t* p) { return __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p)); }
+__device__ __forceinline__ f32x8 load8_nt(const float* p) {
+    const f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+    const f32x4 b = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + 4));
+    f32x8 r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return r;
+}
 __device__ __forceinline__ void store8(bf16_t* p, bf16x8 v) { *reinterpret_cast<bf16x8*>(p) = v; }
 __device__ __forceinline__ void store8(float* p, f32x8 v) {
     f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};

@@ -63,6 +63,7 @@ enum SkinnyEpi : int {
     SK_STORE = 1,       // out[m][n] = acc + bias[n]           (f32 or dtype)
     SK_QKV_ROPE = 2,    // + bias, rotate-half RoPE, q -> qbuf, k/v -> KV cache     (llm step)
     SK_SWIGLU = 3,      // n-tiles alternate gate/up: out[m][n/2] = silu(gate) * up  (dtype)
+    SK_RESID = 4,       // out[m][n] += acc + bias  (fp32 residual stream, in place; split_k == 1)
 };
 struct SkinnyArgs {
     int dtype;
@@ -84,6 +85,9 @@ struct SkinnyArgs {
     // layer-batched launches (MTP heads): blockIdx.z = head j, all pointers advance by these strides
     int nz; long long w_zs; long long a_zs; long long bias_zs; long long out_zs; long long part_zs;
     int n_valid;                  // SK_STORE: columns >= n_valid are not stored (0 = N)
+    // fused RMSNorm (QKV / gate-up): A is the fp32 residual stream [M][lda], W has the norm gain folded into its columns and the
+    // accumulator is scaled by rsqrt(mean(x^2) + eps) per row before the epilogue
+    int a_norm; float norm_eps;
 };
 int launch_skinny(const SkinnyArgs& a, hipStream_t s);
 

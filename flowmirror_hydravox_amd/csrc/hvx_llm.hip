@@ -237,19 +237,17 @@ static int forward_impl(hvx_llm* h, hipStream_t s, int32_t n_seq, int32_t kn, co
 
     // ---- embeddings: speech ids (>= 0) and text ids (<= -2) come from different tables -----------------------
     if (launch_embed2(w[4], w[5], dt, tok, h->x, H, R, H, s)) return -1;
-    ReduceNormArgs rn;
-    memset(&rn, 0, sizeof(rn));
-    rn.x = h->x; rn.ldx = H; rn.eps = c.rms_eps; rn.do_norm = 1; rn.y = h->a; rn.ldy = H; rn.dtype = dt; rn.M = R; rn.H = H; rn.rows_per_z = R;
-    rn.gain = (const float*)w[6];
-    if (launch_reduce_rmsnorm(rn, s)) return -1;
-
+    // Five launches per layer: both RMSNorms ride inside the GEMM that consumes them (gain folded into the weights, 1/rms applied to
+    // the accumulator; gemm_skinny.hip) and both residual adds in the epilogue of the GEMM that produces them (x += ..., one writer
+    // per element).
     const bool use_split = (G * kn <= h->att_rows_pad) && (kn <= 8) && h->att_splits > 1;
     for (int l = 0; l < c.layers; ++l) {
         const void* const* lw = w + 6 + 7 * l;
         // 1. QKV + bias + RoPE + KV append
         SkinnyArgs g;
         memset(&g, 0, sizeof(g));
-        g.dtype = dt; g.M = R; g.N = (c.q_heads + 2 * c.kv_heads) * 64; g.K = H; g.A = h->a; g.lda = H; g.W = lw[1]; g.split_k = 1; g.nz = 1;
+        g.dtype = dt; g.M = R; g.N = (c.q_heads + 2 * c.kv_heads) * 64; g.K = H; g.A = h->x; g.lda = H; g.W = lw[1]; g.split_k = 1; g.nz = 1;
+        g.a_norm = 1; g.norm_eps = c.rms_eps;               // input_layernorm gain is folded into lw[1] (llm.py)
         g.epi = SK_QKV_ROPE; g.bias = (const float*)lw[2];
         g.kn = kn; g.q_heads = c.q_heads; g.kv_heads = c.kv_heads; g.slot = d_slot; g.pos0 = d_pos0; g.n_new = d_nnew;
         g.rope_cos = rope_cos; g.rope_sin = rope_sin; g.qbuf = h->qbuf;
@@ -275,30 +273,22 @@ static int forward_impl(hvx_llm* h, hipStream_t s, int32_t n_seq, int32_t kn, co
             at.n_splits = 1;
         }
         if (launch_attention(at, s)) return -1;
-        // 3. o_proj (split-K partials) ; 4. x += sum ; a = RMSNorm(x) * ln2
+        // 3. x += o_proj(attn)
         memset(&g, 0, sizeof(g));
-        g.dtype = dt; g.M = R; g.N = H; g.K = Q; g.A = h->attn; g.lda = Q; g.W = lw[3]; g.nz = 1;
-        g.split_k = pick_split(H, Q, 1); g.epi = SK_PARTIAL; g.part = h->part;
+        g.dtype = dt; g.M = R; g.N = H; g.K = Q; g.A = h->attn; g.lda = Q; g.W = lw[3]; g.nz = 1; g.split_k = 1;
+        g.epi = SK_RESID; g.out = h->x; g.out_f32 = 1; g.ldo = H;
         if (launch_skinny(g, s)) return -1;
-        rn.part = h->part; rn.split_k = g.split_k; rn.part_stride = (long long)R * H; rn.gain = (const float*)lw[4]; rn.y = h->a; rn.do_norm = 1;
-        if (launch_reduce_rmsnorm(rn, s)) return -1;
-        // 5. gate/up + SwiGLU
+        // 4. hmlp = SwiGLU(RMSNorm(x) * ln2)
         memset(&g, 0, sizeof(g));
-        g.dtype = dt; g.M = R; g.N = 2 * c.inter; g.K = H; g.A = h->a; g.lda = H; g.W = lw[5]; g.split_k = 1; g.nz = 1;
+        g.dtype = dt; g.M = R; g.N = 2 * c.inter; g.K = H; g.A = h->x; g.lda = H; g.W = lw[5]; g.split_k = 1; g.nz = 1;
+        g.a_norm = 1; g.norm_eps = c.rms_eps;               // post_attention_layernorm gain is folded into lw[5]
         g.epi = SK_SWIGLU; g.out = h->hmlp; g.ldo = c.inter;
         if (launch_skinny(g, s)) return -1;
-        // 6. down (split-K) ; 7. x += sum ; a = RMSNorm(x) * ln1(next layer)   (last layer: residual only)
+        // 5. x += down(hmlp)
         memset(&g, 0, sizeof(g));
-        g.dtype = dt; g.M = R; g.N = H; g.K = c.inter; g.A = h->hmlp; g.lda = c.inter; g.W = lw[6]; g.nz = 1;
-        g.split_k = pick_split(H, c.inter, 1); g.epi = SK_PARTIAL; g.part = h->part;
+        g.dtype = dt; g.M = R; g.N = H; g.K = c.inter; g.A = h->hmlp; g.lda = c.inter; g.W = lw[6]; g.nz = 1; g.split_k = 1;
+        g.epi = SK_RESID; g.out = h->x; g.out_f32 = 1; g.ldo = H;
         if (launch_skinny(g, s)) return -1;
-        rn.part = h->part; rn.split_k = g.split_k; rn.part_stride = (long long)R * H;
-        if (l + 1 < c.layers) {
-            rn.gain = (const float*)(w + 6 + 7 * (l + 1))[0]; rn.y = h->a; rn.do_norm = 1;
-        } else {
-            rn.gain = nullptr; rn.y = nullptr;
-        }
-        if (launch_reduce_rmsnorm(rn, s)) return -1;
     }
     if (head_k <= 0) return 0;
 

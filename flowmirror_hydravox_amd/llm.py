@@ -99,9 +99,13 @@ class HvxLLM:
             bqkv = torch.cat([W(p + 'self_attn.q_proj.bias'), W(p + 'self_attn.k_proj.bias'), W(p + 'self_attn.v_proj.bias')], 0)
             perm = qkv_row_perm(c.q_heads + 2 * c.kv_heads).to(dev)        # RoPE pairs into one MFMA tile (csrc/gemm_skinny.hip)
             wqkv, bqkv = wqkv[perm], bqkv[perm]
-            ws += [vec(W(p + 'input_layernorm.weight')), mat(pack_frag(wqkv)), vec(bqkv), mat(pack_frag(W(p + 'self_attn.o_proj.weight'))),
-                   vec(W(p + 'post_attention_layernorm.weight')),
-                   mat(pack_gate_up(W(p + 'mlp.gate_proj.weight'), W(p + 'mlp.up_proj.weight'))), mat(pack_frag(W(p + 'mlp.down_proj.weight')))]
+            # RMSNorm gains are folded into the columns of the GEMM that consumes the normalised rows (the kernel applies 1/rms to its
+            # accumulator, csrc/gemm_skinny.hip): norm(x) @ W^T == (x / rms) @ (W * gain)^T
+            ln1, ln2 = W(p + 'input_layernorm.weight'), W(p + 'post_attention_layernorm.weight')
+            ws += [vec(ln1), mat(pack_frag(wqkv * ln1[None, :])), vec(bqkv), mat(pack_frag(W(p + 'self_attn.o_proj.weight'))),
+                   vec(ln2),
+                   mat(pack_gate_up(W(p + 'mlp.gate_proj.weight') * ln2[None, :], W(p + 'mlp.up_proj.weight') * ln2[None, :])),
+                   mat(pack_frag(W(p + 'mlp.down_proj.weight')))]
         hn = c.head_num
 
         def stack(fn):

@@ -111,7 +111,9 @@ typedef struct {
  *   0 rope_cos f32 [max_pos][32]    1 rope_sin f32 [max_pos][32]     2 final norm gain [H]
  *   3 llm_decoder packed [vocab_pad][H]   4 speech_embedding rows [vocab][H] (dtype)   5 text embedding rows [text_vocab][H] (dtype)
  *   per layer l, 7 entries from 6+7l: ln1 gain, Wqkv packed [(q+2kv)*64][H], bqkv, Wo packed [H][q*64], ln2 gain,
- *                                     Wgate/up packed as alternating 16-row tiles [2*inter][H], Wdown packed [H][inter]
+ *                                     Wgate/up packed as alternating 16-row tiles [2*inter][H], Wdown packed [H][inter];
+ *                                     the backbone's Wqkv / Wgate/up carry their RMSNorm gain folded in (W[n][k] * ln[k]): the
+ *                                     kernels scale by 1/rms only, the ln1 / ln2 entries are kept for layout stability and not read
  *   then 7 entries stacked over the head_num MTP heads: ln1 [hn][H], Wv packed [hn][A][H], bv [hn][A], Wo packed [hn][H][A],
  *                                     ln2 [hn][H], Wgate/up packed [hn][2*mtp_inter][H], Wdown packed [hn][H][mtp_inter]        */
 typedef struct hvx_llm hvx_llm;
