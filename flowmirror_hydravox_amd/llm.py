@@ -244,7 +244,7 @@ class HvxLLM:
         if need_ctx > self.max_ctx:
             raise ValueError('context %d exceeds max_ctx=%d' % (need_ctx, self.max_ctx))
         if getattr(self, '_stream', None) is None:
-            self._stream = torch.cuda.Stream(device=dev)
+            self._stream = torch.cuda.Stream(device=dev, priority=-1)       # decode launches go ahead of a concurrent acoustic stage
         stream = self._stream
         stream.wait_stream(torch.cuda.current_stream())
         t_start = time.time()

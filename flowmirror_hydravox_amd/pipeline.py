@@ -78,23 +78,16 @@ class HvxPipeline:
         self.hift = HvxHift(cfg.hift, hift_sd, device=device, tables=hift_tables)
         self.device = torch.device(device)
 
-    @torch.inference_mode()
-    def synthesize(self, utts: List[Utterance], max_token_text_ratio=20, min_token_text_ratio=2):
-        """-> (list of waveforms f32 [samples] on the device, SynthStats)"""
-        st = SynthStats()
-        dev = self.device
-        torch.cuda.synchronize()
-        t0 = time.time()
-        toks = self.llm.generate_batch([u.text for u in utts],
+    # ---- stages -----------------------------------------------------------------------------------------------------------------
+    def _speech_tokens(self, utts, max_token_text_ratio, min_token_text_ratio):
+        return self.llm.generate_batch([u.text for u in utts],
                                        prompt_texts=[u.prompt_text for u in utts] if any(u.prompt_text is not None for u in utts) else None,
                                        prompt_speech_tokens=[u.prompt_speech_token for u in utts] if any(u.prompt_speech_token is not None for u in utts) else None,
                                        seeds=[u.seed for u in utts], max_token_text_ratio=max_token_text_ratio,
                                        min_token_text_ratio=min_token_text_ratio)
-        torch.cuda.synchronize()
-        t1 = time.time()
-        st.llm_seconds = t1 - t0
-        st.per_utt_tokens = [len(t) for t in toks]
-        st.tokens = sum(st.per_utt_tokens)
+
+    def _mels(self, utts, toks):
+        dev = self.device
         mels = []
         for u, t in zip(utts, toks):
             if not t:
@@ -108,19 +101,84 @@ class HvxPipeline:
             mel, _ = self.flow.inference(token=token, token_len=torch.tensor([token.shape[1]], dtype=torch.int32), embedding=u.embedding[None].to(dev),
                                          finalize=True, **kw)
             mels.append(mel)
-        torch.cuda.synchronize()
-        t2 = time.time()
-        st.flow_seconds = t2 - t1
+        return mels
+
+    def _waves(self, mels):
         wavs = []
         for mel in mels:
             if mel is None:
-                wavs.append(torch.zeros(0, device=dev))
+                wavs.append(torch.zeros(0, device=self.device))
                 continue
             wav, _ = self.hift.inference(speech_feat=mel)
             wavs.append(wav[0])
+        return wavs
+
+    @torch.inference_mode()
+    def synthesize(self, utts: List[Utterance], max_token_text_ratio=20, min_token_text_ratio=2):
+        """-> (list of waveforms f32 [samples] on the device, SynthStats); the three stages run back to back"""
+        st = SynthStats()
+        torch.cuda.synchronize()
+        t0 = time.time()
+        toks = self._speech_tokens(utts, max_token_text_ratio, min_token_text_ratio)
+        torch.cuda.synchronize()
+        t1 = time.time()
+        st.llm_seconds = t1 - t0
+        st.per_utt_tokens = [len(t) for t in toks]
+        st.tokens = sum(st.per_utt_tokens)
+        mels = self._mels(utts, toks)
+        torch.cuda.synchronize()
+        t2 = time.time()
+        st.flow_seconds = t2 - t1
+        wavs = self._waves(mels)
         torch.cuda.synchronize()
         t3 = time.time()
         st.hift_seconds = t3 - t2
         st.total_seconds = t3 - t0
         st.audio_seconds = sum(w.numel() for w in wavs) / float(self.cfg.sample_rate)
         return wavs, st
+
+    # ---- software pipeline over batches ------------------------------------------------------------------------------------------
+    def _acoustic_worker(self, utts, toks, st):
+        """flow + vocoder of one batch on the background stream (runs in the worker thread; returns when the waveforms are complete)"""
+        torch.cuda.set_device(self._bg_stream.device)              # the current device is per thread
+        with torch.inference_mode(), torch.cuda.stream(self._bg_stream):
+            t0 = time.time()
+            mels = self._mels(utts, toks)
+            t1 = time.time()                       # enqueue time only: the stream is not drained between the stages
+            wavs = self._waves(mels)
+            self._bg_stream.synchronize()
+            t2 = time.time()
+        st.flow_seconds, st.hift_seconds = t1 - t0, t2 - t1
+        st.audio_seconds = sum(w.numel() for w in wavs) / float(self.cfg.sample_rate)
+        return wavs
+
+    @torch.inference_mode()
+    def synthesize_pipelined(self, batches, max_token_text_ratio=20, min_token_text_ratio=2):
+        """Generator over (waveforms, SynthStats) of successive batches, in order, with the stages of neighbouring batches overlapped:
+        while the multi-head LM decodes batch i (a chain of short, latency-bound launches that leaves most CUs idle) the flow decoder and
+        the vocoder of batch i-1 (MFMA-bound) run on a second, lower-priority stream driven by a worker thread.  Results are identical to
+        synthesize(): every utterance carries its own sampler seed and no stage depends on another batch.  In the stats llm_seconds is the
+        decode wall time and flow_seconds + hift_seconds the wall time of the acoustic stages, both measured while overlapped."""
+        from concurrent.futures import ThreadPoolExecutor
+        if getattr(self, '_bg_stream', None) is None:
+            self._bg_stream = torch.cuda.Stream(device=self.device, priority=0)
+            self._bg_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix='hvx-acoustic')
+        pending = None
+        for utts in batches:
+            st = SynthStats()
+            t0 = time.time()
+            toks = self._speech_tokens(utts, max_token_text_ratio, min_token_text_ratio)
+            st.llm_seconds = time.time() - t0
+            st.per_utt_tokens = [len(t) for t in toks]
+            st.tokens = sum(st.per_utt_tokens)
+            if pending is not None:
+                fut, pst, pt0 = pending
+                wavs = fut.result()
+                pst.total_seconds = time.time() - pt0
+                yield wavs, pst
+            pending = (self._bg_pool.submit(self._acoustic_worker, utts, toks, st), st, t0)
+        if pending is not None:
+            fut, pst, pt0 = pending
+            wavs = fut.result()
+            pst.total_seconds = time.time() - pt0
+            yield wavs, pst
