@@ -94,72 +94,85 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         for (int dt = 0; dt < 4; ++dt) o_acc[i][dt] = f32x4{0, 0, 0, 0};
     }
 
-    for (int key0 = key_begin; key0 < key_end; key0 += 32) {
+    // KS 32-key steps per trip.  The decode form (one q-tile) requests both steps of a wave's 64 keys before the first MFMA: the walk
+    // is a chain of dependent round trips to L2 / HBM otherwise, and latency is all a decode step has to lose.
+    constexpr int KS = (QT == 1) ? 2 : 1;
+    for (int key0 = key_begin; key0 < key_end; key0 += 32 * KS) {
         // K fragments: 2 key tiles x 2 d-halves.  Rows past the end are clamped (their scores are masked by select).
-        V8 kf[2][2];
+        V8 kf[KS][2][2];
+        // V^T fragments: 4 d-tiles, keys {4g..4g+3} and {16+4g..16+4g+3} of each 32-key step
+        V8 vf[KS][4];
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-            int key = key0 + kt * 16 + fr;
-            key = key < kv_len ? key : (kv_len - 1);
-            const T* kp = kb + (long long)key * 64 + fg * 8;
-            kf[kt][0] = load8(kp);
-            kf[kt][1] = load8(kp + 32);
-        }
-        // V^T fragments: 4 d-tiles, keys {4g..4g+3} and {16+4g..16+4g+3} of this 32-key step
-        V8 vf[4];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            const T* vp = vb + (long long)(dt * 16 + fr) * a.v_ld + key0 + fg * 4;
-            const V4 lo = load4(vp), hi = load4(vp + 16);
-            V8 v;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                v[j] = lo[j];
-                v[4 + j] = hi[j];
-            }
-            vf[dt] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < QT; ++i) {
-            f32x4 s[2];
+        for (int ks = 0; ks < KS; ++ks) {
+            // a step that starts past the end (only the second of a trip can) re-reads the first one and is skipped below
+            const int kbase = (key0 + 32 * ks < key_end) ? key0 + 32 * ks : key0;
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) {
-                s[kt] = f32x4{0, 0, 0, 0};
-                mma32(s[kt], kf[kt][0], qf[i][0]);
-                mma32(s[kt], kf[kt][1], qf[i][1]);
+                int key = kbase + kt * 16 + fr;
+                key = key < kv_len ? key : (kv_len - 1);
+                const T* kp = kb + (long long)key * 64 + fg * 8;
+                kf[ks][kt][0] = load8(kp);
+                kf[ks][kt][1] = load8(kp + 32);
             }
-            // scale, mask, running max
-            const int lim = a.causal ? min(key_end, pos0 + r_lo[i] + 1) : key_end;
-            float sv[8];
-            float mx = -INFINITY;
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = key0 + kt * 16 + fg * 4 + r;
-                    const float x = (key < lim) ? s[kt][r] * a.scale : -INFINITY;
-                    sv[kt * 4 + r] = x;
-                    mx = fmaxf(mx, x);
-                }
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run[i], mx);
-            const float m_safe = (m_new == -INFINITY) ? 0.0f : m_new;
-            const float alpha = (m_run[i] == -INFINITY) ? 0.0f : expf(m_run[i] - m_safe);
-            float psum = 0.0f;
-            V8 pf;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float p = (sv[e] == -INFINITY) ? 0.0f : expf(sv[e] - m_safe);
-                psum += p;
-                pf[e] = from_f32<T>(p);
-            }
-            l_run[i] = l_run[i] * alpha + psum;
-            m_run[i] = m_new;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                o_acc[i][dt] *= alpha;
-                mma32(o_acc[i][dt], vf[dt], pf);
+                const T* vp = vb + (long long)(dt * 16 + fr) * a.v_ld + kbase + fg * 4;
+                const V4 lo = load4(vp), hi = load4(vp + 16);
+                V8 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[j] = lo[j];
+                    v[4 + j] = hi[j];
+                }
+                vf[ks][dt] = v;
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int kstep = key0 + 32 * ks;
+            if (kstep >= key_end) break;
+#pragma unroll
+            for (int i = 0; i < QT; ++i) {
+                f32x4 s[2];
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) {
+                    s[kt] = f32x4{0, 0, 0, 0};
+                    mma32(s[kt], kf[ks][kt][0], qf[i][0]);
+                    mma32(s[kt], kf[ks][kt][1], qf[i][1]);
+                }
+                // scale, mask, running max
+                const int lim = a.causal ? min(key_end, pos0 + r_lo[i] + 1) : key_end;
+                float sv[8];
+                float mx = -INFINITY;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = kstep + kt * 16 + fg * 4 + r;
+                        const float x = (key < lim) ? s[kt][r] * a.scale : -INFINITY;
+                        sv[kt * 4 + r] = x;
+                        mx = fmaxf(mx, x);
+                    }
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float m_new = fmaxf(m_run[i], mx);
+                const float m_safe = (m_new == -INFINITY) ? 0.0f : m_new;
+                const float alpha = (m_run[i] == -INFINITY) ? 0.0f : expf(m_run[i] - m_safe);
+                float psum = 0.0f;
+                V8 pf;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float p = (sv[e] == -INFINITY) ? 0.0f : expf(sv[e] - m_safe);
+                    psum += p;
+                    pf[e] = from_f32<T>(p);
+                }
+                l_run[i] = l_run[i] * alpha + psum;
+                m_run[i] = m_new;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    o_acc[i][dt] *= alpha;
+                    mma32(o_acc[i][dt], vf[ks][dt], pf);
+                }
             }
         }
     }
@@ -255,17 +268,32 @@ __global__ void attn_combine_kernel(AttnArgs a) {
     const int n_live = min(a.n_splits, (vis + a.split_chunk - 1) / a.split_chunk);
     const long long base0 = (((long long)b * a.heads + h) * a.n_splits) * a.n_rows_pad + r;
     const long long sstride = a.n_rows_pad;
-    float m = -INFINITY;
-#pragma unroll 8
-    for (int s = 0; s < n_live; ++s) m = fmaxf(m, a.part_ml[(base0 + s * sstride) * 2]);
-    float acc = 0.0f, l = 0.0f;
-#pragma unroll 8
-    for (int s = 0; s < n_live; ++s) {
-        const long long base = base0 + s * sstride;
-        const float ms = a.part_ml[base * 2];
-        const float wgt = (ms == -INFINITY) ? 0.0f : expf(ms - m);
-        acc += wgt * a.part_o[base * 64 + d];
-        l += wgt * a.part_ml[base * 2 + 1];
+    // one round trip per 8 splits: their (m, l, o) are all requested before the first is used; batches are merged online
+    constexpr int SB = 8;
+    float m = -INFINITY, acc = 0.0f, l = 0.0f;
+    for (int s0 = 0; s0 < n_live; s0 += SB) {
+        float ms[SB], ls[SB], os[SB];
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+            const long long base = base0 + (long long)min(s0 + u, n_live - 1) * sstride;
+            const float2 ml = *reinterpret_cast<const float2*>(a.part_ml + base * 2);
+            ms[u] = (s0 + u < n_live) ? ml.x : -INFINITY;
+            ls[u] = ml.y;
+            os[u] = a.part_o[base * 64 + d];
+        }
+        float mb = m;
+#pragma unroll
+        for (int u = 0; u < SB; ++u) mb = fmaxf(mb, ms[u]);
+        const float resc = (m == -INFINITY) ? 0.0f : expf(m - mb);
+        acc *= resc;
+        l *= resc;
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+            const float wgt = (ms[u] == -INFINITY) ? 0.0f : expf(ms[u] - mb);
+            acc += wgt * os[u];
+            l += wgt * ls[u];
+        }
+        m = mb;
     }
     T* op = reinterpret_cast<T*>(a.out) + (long long)b * a.o_bs + (long long)h * a.o_hs + (long long)rh * a.o_hi + (long long)rl * a.o_lo;
     op[d] = from_f32<T>(l > 0.0f ? acc / l : 0.0f);

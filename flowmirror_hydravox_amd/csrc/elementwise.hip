@@ -140,18 +140,21 @@ int launch_embed(const void* table, int table_dtype, const int* tok, float* x, i
 }
 
 template <class T>
-__global__ void embed2_kernel(const T* speech, const T* text, const int* tok, float* x, int ldx, int H) {
+__global__ void embed2_kernel(const T* speech, const T* text, const int* tok, float* x, int ldx, T* x_copy, int H) {
     const int r = blockIdx.x;
     const int t = tok[r];
     const T* src = t >= 0 ? speech + (long long)t * H : (t <= -2 ? text + (long long)(-t - 2) * H : nullptr);
-    for (int c = threadIdx.x; c < H; c += blockDim.x) x[(long long)r * ldx + c] = src ? to_f32(src[c]) : 0.0f;
+    for (int c = threadIdx.x; c < H; c += blockDim.x) {
+        x[(long long)r * ldx + c] = src ? to_f32(src[c]) : 0.0f;
+        if (x_copy) x_copy[(long long)r * ldx + c] = src ? src[c] : from_f32<T>(0.0f);      // the table row itself
+    }
 }
-int launch_embed2(const void* speech, const void* text, int dtype, const int* tok, float* x, int ldx, int rows, int H, hipStream_t s) {
+int launch_embed2(const void* speech, const void* text, int dtype, const int* tok, float* x, int ldx, void* x_copy, int rows, int H, hipStream_t s) {
     if (rows <= 0) return 0;
     if (dtype == DT_BF16)
-        hipLaunchKernelGGL(embed2_kernel<bf16_t>, dim3(rows), dim3(256), 0, s, (const bf16_t*)speech, (const bf16_t*)text, tok, x, ldx, H);
+        hipLaunchKernelGGL(embed2_kernel<bf16_t>, dim3(rows), dim3(256), 0, s, (const bf16_t*)speech, (const bf16_t*)text, tok, x, ldx, (bf16_t*)x_copy, H);
     else
-        hipLaunchKernelGGL(embed2_kernel<float>, dim3(rows), dim3(256), 0, s, (const float*)speech, (const float*)text, tok, x, ldx, H);
+        hipLaunchKernelGGL(embed2_kernel<float>, dim3(rows), dim3(256), 0, s, (const float*)speech, (const float*)text, tok, x, ldx, (float*)x_copy, H);
     return hipGetLastError() == hipSuccess ? 0 : (set_error("embed2 launch failed"), -1);
 }
 

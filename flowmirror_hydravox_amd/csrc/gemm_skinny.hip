@@ -16,16 +16,6 @@
 
 namespace hvx {
 
-// fp32 -> operand type, 8 elements
-template <class T> __device__ __forceinline__ typename Vec8<T>::type cvt8(const f32x8& x);
-template <> __device__ __forceinline__ f32x8 cvt8<float>(const f32x8& x) { return x; }
-template <> __device__ __forceinline__ bf16x8 cvt8<bf16_t>(const f32x8& x) {
-    bf16x8 r;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) r[e] = f32_to_bf16(x[e]);
-    return r;
-}
-
 // per-row operands of the QKV epilogue (position, cache slot, rotary factors); loaded before the weight stream when MT == 1
 struct RowCtl {
     int ok, pos, slot;
@@ -46,15 +36,15 @@ __device__ __forceinline__ RowCtl load_rowctl(const SkinnyArgs& a, int row, int 
     return c;
 }
 
-// ANORM == 1: A is the fp32 residual stream x and the GEMM computes RMSNorm(x) @ W^T without a norm kernel in front of it.
-// RMSNorm is a per-row scale: norm(x)[k] = gain[k] * x[k] * rsqrt(mean(x^2) + eps).  The gain is folded into the weight columns when
-// the checkpoint is packed (llm.py), the A fragment is T(x), the sum of squares is accumulated from the very fragments the MFMA
-// consumes (every wave sees its K slice of the 16 rows), and the epilogue multiplies the accumulator by rsqrt(ss / K + eps):
-// no extra loads, no extra pass, nothing in front of the weight stream.
+// ANORM == 1: A is the residual stream x (in the operand type: the producing epilogue keeps a T copy beside the fp32 stream) and the
+// GEMM computes RMSNorm(x) @ W^T without a norm kernel in front of it.  RMSNorm is a per-row scale:
+// norm(x)[k] = gain[k] * x[k] * rsqrt(mean(x^2) + eps).  The gain is folded into the weight columns when the checkpoint is packed
+// (llm.py), the sum of squares is accumulated from the very fragments the MFMA consumes (every wave sees its K slice of the 16
+// rows), and the epilogue multiplies the accumulator by rsqrt(ss / K + eps): no extra loads, no extra pass, nothing in front of
+// the weight stream.
 template <class T, int MT, int NT, int EPI, int KW, int ANORM, int U>
 __global__ __launch_bounds__(64 * KW) void gemm_skinny_kernel(SkinnyArgs a) {
     typedef typename Vec8<T>::type V8;
-    typedef typename std::conditional<ANORM != 0, f32x8, V8>::type AV;      // A fragment as loaded
     constexpr bool HOIST = MT == 1;      // decode geometry: epilogue operands are fetched ahead of the weight stream
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fr = lane & 15, fg = lane >> 4;
@@ -80,14 +70,13 @@ __global__ __launch_bounds__(64 * KW) void gemm_skinny_kernel(SkinnyArgs a) {
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
 
     // A fragment rows (clamped; masked at the store)
-    typedef typename std::conditional<ANORM != 0, float, T>::type AT;
-    const AT* arow[MT];
+    const T* arow[MT];
     float ssq[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         int r = m0 + i * 16 + fr;
         r = r < a.M ? r : a.M - 1;
-        arow[i] = reinterpret_cast<const AT*>(a.A) + (long long)z * a.a_zs + (long long)r * a.lda + fg * 8;
+        arow[i] = reinterpret_cast<const T*>(a.A) + (long long)z * a.a_zs + (long long)r * a.lda + fg * 8;
         ssq[i] = 0.0f;
     }
     const T* wtile[NT];
@@ -149,8 +138,7 @@ __global__ __launch_bounds__(64 * KW) void gemm_skinny_kernel(SkinnyArgs a) {
     // U * NT KiB of the weight stream in flight (a dependent load->MFMA chain per k-step is latency-bound: 0.6 TB/s measured).
     // The decode shapes are dispatched so that a wave's whole K slice is one trip.
     for (int kt = kt0; kt < kt1; kt += U) {
-        V8 wf[U][NT];
-        AV af[U][MT];
+        V8 wf[U][NT], af[U][MT];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int k = min(kt + u, kt1 - 1);
@@ -164,16 +152,14 @@ __global__ __launch_bounds__(64 * KW) void gemm_skinny_kernel(SkinnyArgs a) {
             if (kt + u < kt1) {
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
-                    V8 av;
                     if constexpr (ANORM) {
-                        const f32x8 x = af[u][i];
+                        float x[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) x[e] = to_f32(af[u][i][e]);
                         ssq[i] += ((x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3])) + ((x[4] * x[4] + x[5] * x[5]) + (x[6] * x[6] + x[7] * x[7]));
-                        av = cvt8<T>(x);
-                    } else {
-                        av = af[u][i];
                     }
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) mma32(acc[i][j], av, wf[u][j]);
+                    for (int j = 0; j < NT; ++j) mma32(acc[i][j], af[u][i], wf[u][j]);
                 }
             }
         }
@@ -250,7 +236,9 @@ __global__ __launch_bounds__(64 * KW) void gemm_skinny_kernel(SkinnyArgs a) {
                     if (row >= a.M) continue;
                     float* px = xo + (long long)row * a.ldo + col;
                     const float x0 = HOIST ? e_res[i][j][r] : *px;
-                    *px = x0 + (acc[i][j][r] + e_bias[j]);
+                    const float x1 = x0 + (acc[i][j][r] + e_bias[j]);
+                    *px = x1;
+                    if (a.out2) reinterpret_cast<T*>(a.out2)[(long long)z * a.out_zs + (long long)row * a.ldo2 + col] = from_f32<T>(x1);
                 }
         }
     } else if constexpr (EPI == SK_STORE) {
@@ -315,7 +303,7 @@ __global__ __launch_bounds__(64 * KW) void gemm_skinny_kernel(SkinnyArgs a) {
 template <class T, int MT, int NT, int EPI, int KW = 4, int ANORM = 0, int U_ = 0>
 static int launch_one(const SkinnyArgs& a, hipStream_t s) {
     // k-steps in flight per wave: sized so that the fragment registers stay within ~96 VGPRs unless the caller knows better
-    constexpr int REGS = NT * (sizeof(T) == 2 ? 4 : 8) + MT * (ANORM ? 8 : (sizeof(T) == 2 ? 4 : 8));
+    constexpr int REGS = (NT + MT) * (sizeof(T) == 2 ? 4 : 8);
     constexpr int U = U_ ? U_ : (REGS <= 16 ? 8 : (REGS <= 32 ? 4 : 2));
     const int ntiles = a.N / 16;
     const int groups = (ntiles + NT - 1) / NT;
@@ -330,12 +318,121 @@ static int launch_one(const SkinnyArgs& a, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? 0 : (set_error("skinny gemm launch failed"), -1);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Narrow form for the two residual projections of the decode step (o_proj, down_proj: N = hidden, one 16-row activation tile).
+// A CU pulls ~45 GB/s out of HBM however many waves ask (tools/stream_probe.hip), so a weight matrix has to be spread over ALL CUs:
+// with 16-column tiles N = 896 gives only 56 workgroups, and each of them also re-reads the whole [16][K] activation tile.  Here a
+// workgroup owns FOUR output columns over the full K (N/4 = 224 workgroups) and still feeds the 16x16x32 MFMA: the 16 tile columns
+// are (4 output columns) x (4 consecutive 32-wide K sub-blocks), i.e. lane (c16, g) holds W[4*nt + (c16 & 3)][128*kb + 32*(c16 >> 2)
+// + 8g ..+8] — one fully coalesced 1 KiB load per 128-wide K block (checkpoint packed as [N/4][K/128][64][8], packing.pack_narrow4).
+// MFMA number s of a block multiplies the activation sub-block s with the weight fragment masked to the lanes whose sub-block is s,
+// so tile column (c, s) accumulates exactly its own K quarter; two xor-shuffles add the four quarters at the end.  The matrix cores
+// do 4x redundant work (free: the kernel is bound by bytes per CU), the K split stays inside the workgroup (LDS, fixed order), and
+// the residual update x += ... has one writer per element.
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <class T, int KW, int UB>
+__global__ __launch_bounds__(64 * KW) void gemm_narrow_resid_kernel(SkinnyArgs a) {
+    typedef typename Vec8<T>::type V8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c16 = lane & 15, fg = lane >> 4;
+    const int c4 = c16 & 3, ksub = c16 >> 2;
+    const int nt = blockIdx.x, m0 = blockIdx.z * 16;
+    const int KB = a.K >> 7;                                   // 128-wide K blocks
+    const int bq = (KB + KW - 1) / KW;
+    const int kb0 = wave * bq, kb1 = min(KB, kb0 + bq);
+    int r = m0 + c16;
+    r = r < a.M ? r : a.M - 1;
+    const T* __restrict__ arow = reinterpret_cast<const T*>(a.A) + (long long)r * a.lda + fg * 8;
+    const T* __restrict__ wp = reinterpret_cast<const T*>(a.W) + ((long long)nt * KB) * 512 + lane * 8;
+
+    // epilogue operands of the finishing wave, requested ahead of the weight stream
+    float e_res[4] = {0, 0, 0, 0}, e_bias = 0.0f;
+    float* xo = reinterpret_cast<float*>(a.out);
+    const int col = nt * 4 + c4;
+    if (wave == 0 && ksub == 0) {
+        if (a.bias) e_bias = a.bias[col];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = m0 + fg * 4 + q;
+            if (row < a.M) e_res[q] = xo[(long long)row * a.ldo + col];
+        }
+    }
+
+    f32x4 acc = {0, 0, 0, 0};
+    for (int kb = kb0; kb < kb1; kb += UB) {
+        V8 wf[UB], af[UB][4];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int k = min(kb + u, kb1 - 1);
+            wf[u] = load8_nt(wp + (long long)k * 512);
+#pragma unroll
+            for (int sblk = 0; sblk < 4; ++sblk) af[u][sblk] = load8(arow + k * 128 + sblk * 32);
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            if (kb + u < kb1) {
+#pragma unroll
+                for (int sblk = 0; sblk < 4; ++sblk) {
+                    V8 wm;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) wm[e] = (ksub == sblk) ? wf[u][e] : from_f32<T>(0.0f);
+                    mma32(acc, af[u][sblk], wm);
+                }
+            }
+        }
+    }
+    // the four K quarters of an output column sit in tile columns c4, c4 + 4, c4 + 8, c4 + 12
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        acc[q] += __shfl_xor(acc[q], 4, 64);
+        acc[q] += __shfl_xor(acc[q], 8, 64);
+    }
+    __shared__ f32x4 red[KW > 1 ? KW - 1 : 1][64];
+    if (wave > 0) red[wave - 1][lane] = acc;
+    __syncthreads();
+    if (wave > 0 || ksub != 0) return;
+#pragma unroll
+    for (int w = 0; w < KW - 1; ++w) acc += red[w][lane];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = m0 + fg * 4 + q;
+        if (row >= a.M) continue;
+        const float x1 = e_res[q] + (acc[q] + e_bias);
+        xo[(long long)row * a.ldo + col] = x1;
+        if (a.out2) reinterpret_cast<T*>(a.out2)[(long long)row * a.ldo2 + col] = from_f32<T>(x1);
+    }
+}
+
+template <class T, int KW, int UB>
+static int launch_narrow(const SkinnyArgs& a, hipStream_t s) {
+    dim3 grid(a.N / 4, 1, (a.M + 15) / 16);
+    const double bytes = (double)a.N * a.K * sizeof(T) + (double)a.M * a.K * sizeof(T) + (double)a.M * a.N * 8.0;
+    const int slot = prof_begin(PK_SKINNY, bytes, s);
+    hipLaunchKernelGGL((gemm_narrow_resid_kernel<T, KW, UB>), grid, dim3(64 * KW), 0, s, a);
+    prof_end(slot, s);
+    return hipGetLastError() == hipSuccess ? 0 : (set_error("narrow gemm launch failed"), -1);
+}
+
+template <class T>
+static int launch_narrow_t(const SkinnyArgs& a, hipStream_t s) {
+    const int KB = a.K >> 7;
+    if (KB <= 8) return launch_narrow<T, 8, 1>(a, s);                                  // o_proj: one block per wave
+    if (KB <= 40) return launch_narrow<T, 8, (sizeof(T) == 2 ? 5 : 3)>(a, s);          // down_proj (K = 4864: 38 blocks, 5 per wave)
+    return launch_narrow<T, 8, 4>(a, s);
+}
+
 template <class T, int MT>
 static int launch_mt(const SkinnyArgs& a, hipStream_t s) {
     switch (a.epi) {
         case SK_PARTIAL: return launch_one<T, MT, 1, SK_PARTIAL>(a, s);
         case SK_STORE: return launch_one<T, MT, 1, SK_STORE>(a, s);
-        case SK_SWIGLU: return a.a_norm ? launch_one<T, MT, 2, SK_SWIGLU, 4, 1>(a, s) : launch_one<T, MT, 2, SK_SWIGLU>(a, s);
+        case SK_SWIGLU:
+            // decode: two (gate, up) pairs per workgroup halve the number of workgroups that re-read the activation rows, and a wave's
+            // whole K slice (K <= 1024: 8 k-steps) is requested in one go
+            if constexpr (MT == 1 && sizeof(T) == 2) {
+                if (a.a_norm && (a.N & 63) == 0 && a.K <= 4 * 8 * 32) return launch_one<T, 1, 4, SK_SWIGLU, 4, 1, 8>(a, s);
+            }
+            return a.a_norm ? launch_one<T, MT, 2, SK_SWIGLU, 4, 1>(a, s) : launch_one<T, MT, 2, SK_SWIGLU>(a, s);
         case SK_QKV_ROPE: return a.a_norm ? launch_one<T, MT, 1, SK_QKV_ROPE, 4, 1>(a, s) : launch_one<T, MT, 1, SK_QKV_ROPE>(a, s);
         case SK_RESID:
             // long-K residual projections (down_proj): only N/16 workgroups exist, so K is split over 16 waves and each wave's
@@ -369,6 +466,13 @@ int launch_skinny(const SkinnyArgs& a_in, hipStream_t s) {
     if (a.epi != SK_PARTIAL && a.split_k != 1) {
         set_error("launch_skinny: fused epilogues need split_k == 1");
         return -1;
+    }
+    if (a.w_narrow) {
+        if (a.epi != SK_RESID || (a.K & 127) || (a.N & 3) || a.nz != 1 || a.split_k != 1 || (a.lda & 7)) {
+            set_error("launch_skinny: the narrow weight layout serves the residual projections only (K %% 128 == 0, N %% 4 == 0)");
+            return -1;
+        }
+        return a.dtype == DT_BF16 ? launch_narrow_t<bf16_t>(a, s) : launch_narrow_t<float>(a, s);
     }
     if (a.a_norm && ((a.epi != SK_SWIGLU && a.epi != SK_QKV_ROPE) || (a.K & 3) || a.nz != 1)) {
         set_error("launch_skinny: fused RMSNorm prologue is available for the QKV and gate/up GEMMs only");

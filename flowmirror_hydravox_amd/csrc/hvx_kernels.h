@@ -85,9 +85,12 @@ struct SkinnyArgs {
     // layer-batched launches (MTP heads): blockIdx.z = head j, all pointers advance by these strides
     int nz; long long w_zs; long long a_zs; long long bias_zs; long long out_zs; long long part_zs;
     int n_valid;                  // SK_STORE: columns >= n_valid are not stored (0 = N)
-    // fused RMSNorm (QKV / gate-up): A is the fp32 residual stream [M][lda], W has the norm gain folded into its columns and the
+    // fused RMSNorm (QKV / gate-up): A is the residual stream [M][lda] (dtype), W has the norm gain folded into its columns and the
     // accumulator is scaled by rsqrt(mean(x^2) + eps) per row before the epilogue
     int a_norm; float norm_eps;
+    // SK_RESID: optional copy of the updated rows in `dtype` (the A operand of the next fused-norm GEMM)
+    void* out2; int ldo2;
+    int w_narrow;                 // SK_RESID: W is packed [N/4][K/128][64][8] (packing.pack_narrow4) for the 4-column workgroup form
 };
 int launch_skinny(const SkinnyArgs& a, hipStream_t s);
 
@@ -140,7 +143,7 @@ int launch_gather_rows_f32(const float* x, int ldx, const int* idx, float* y, in
 // embedding: x[r,:] = table[tok[r],:] as f32 (tok < 0 -> zeros); table dtype f32/bf16
 int launch_embed(const void* table, int table_dtype, const int* tok, float* x, int ldx, int rows, int H, hipStream_t s);
 // LLM input rows: tok >= 0 -> speech[tok]; tok <= -2 -> text[-tok-2]; tok == -1 -> zeros   (llm_multi_head_v3.py:941-952)
-int launch_embed2(const void* speech, const void* text, int dtype, const int* tok, float* x, int ldx, int rows, int H, hipStream_t s);
+int launch_embed2(const void* speech, const void* text, int dtype, const int* tok, float* x, int ldx, void* x_copy, int rows, int H, hipStream_t s);
 // logits -> log_softmax (fp32, in place) over V columns, one block per row
 int launch_log_softmax(float* x, int ld, int rows, int V, hipStream_t s);
 // DiT: y = dtype( LN(x; eps, no affine) * (1 + scale[b]) + shift[b] ); x f32 [B][T][D]; shift/scale f32 [B][.] with stride mod_bs

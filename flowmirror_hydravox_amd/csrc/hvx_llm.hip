@@ -47,7 +47,7 @@ struct hvx_llm {
     void* vTcache = nullptr;
     // workspace carve
     float* x = nullptr;          // [R][H]
-    void* a = nullptr;           // [R][H]      dtype
+    void* a = nullptr;           // [R][H]      dtype: copy of x for the fused-norm GEMMs (bf16 mode)
     void* qbuf = nullptr;        // [R][q*64]   dtype
     void* attn = nullptr;        // [R][q*64]   dtype
     void* hmlp = nullptr;        // [R][inter]  dtype
@@ -129,7 +129,7 @@ int hvx_llm_create(const hvx_llm_config* cfg, const void* const* weights, int32_
     if (!cfg || !weights || !out) return set_error("hvx_llm_create: null argument"), -1;
     const int expect = 6 + 7 * cfg->layers + 7;
     if (n_weights != expect) return set_error("hvx_llm_create: expected %d weight pointers, got %d", expect, n_weights), -1;
-    if (cfg->hidden % 32 || cfg->inter % 16 || cfg->mtp_inter % 16 || cfg->mtp_attn_dim % 32 || cfg->vocab_pad % 16 ||
+    if (cfg->hidden % 32 || cfg->inter % 128 || (cfg->q_heads * 64) % 128 || cfg->mtp_inter % 16 || cfg->mtp_attn_dim % 32 || cfg->vocab_pad % 16 ||
         cfg->q_heads % cfg->kv_heads || cfg->vocab_pad < cfg->vocab)
         return set_error("hvx_llm_create: unsupported dimensions"), -1;
     for (int i = 0; i < n_weights; ++i)
@@ -236,7 +236,11 @@ static int forward_impl(hvx_llm* h, hipStream_t s, int32_t n_seq, int32_t kn, co
     const float* rope_sin = (const float*)w[1];
 
     // ---- embeddings: speech ids (>= 0) and text ids (<= -2) come from different tables -----------------------
-    if (launch_embed2(w[4], w[5], dt, tok, h->x, H, R, H, s)) return -1;
+    // the fused-norm GEMMs read the residual stream in the operand type: fp32 mode reads x itself, bf16 mode a bf16 copy (h->a) that
+    // the embedding and the residual epilogues keep beside the fp32 stream (half the bytes per workgroup)
+    void* const xa = dt == DT_F32 ? (void*)h->x : h->a;
+    void* const xcopy = dt == DT_F32 ? nullptr : h->a;
+    if (launch_embed2(w[4], w[5], dt, tok, h->x, H, xcopy, R, H, s)) return -1;
     // Five launches per layer: both RMSNorms ride inside the GEMM that consumes them (gain folded into the weights, 1/rms applied to
     // the accumulator; gemm_skinny.hip) and both residual adds in the epilogue of the GEMM that produces them (x += ..., one writer
     // per element).
@@ -246,7 +250,7 @@ static int forward_impl(hvx_llm* h, hipStream_t s, int32_t n_seq, int32_t kn, co
         // 1. QKV + bias + RoPE + KV append
         SkinnyArgs g;
         memset(&g, 0, sizeof(g));
-        g.dtype = dt; g.M = R; g.N = (c.q_heads + 2 * c.kv_heads) * 64; g.K = H; g.A = h->x; g.lda = H; g.W = lw[1]; g.split_k = 1; g.nz = 1;
+        g.dtype = dt; g.M = R; g.N = (c.q_heads + 2 * c.kv_heads) * 64; g.K = H; g.A = xa; g.lda = H; g.W = lw[1]; g.split_k = 1; g.nz = 1;
         g.a_norm = 1; g.norm_eps = c.rms_eps;               // input_layernorm gain is folded into lw[1] (llm.py)
         g.epi = SK_QKV_ROPE; g.bias = (const float*)lw[2];
         g.kn = kn; g.q_heads = c.q_heads; g.kv_heads = c.kv_heads; g.slot = d_slot; g.pos0 = d_pos0; g.n_new = d_nnew;
@@ -276,18 +280,18 @@ static int forward_impl(hvx_llm* h, hipStream_t s, int32_t n_seq, int32_t kn, co
         // 3. x += o_proj(attn)
         memset(&g, 0, sizeof(g));
         g.dtype = dt; g.M = R; g.N = H; g.K = Q; g.A = h->attn; g.lda = Q; g.W = lw[3]; g.nz = 1; g.split_k = 1;
-        g.epi = SK_RESID; g.out = h->x; g.out_f32 = 1; g.ldo = H;
+        g.epi = SK_RESID; g.out = h->x; g.out_f32 = 1; g.ldo = H; g.out2 = xcopy; g.ldo2 = H; g.w_narrow = 1;
         if (launch_skinny(g, s)) return -1;
         // 4. hmlp = SwiGLU(RMSNorm(x) * ln2)
         memset(&g, 0, sizeof(g));
-        g.dtype = dt; g.M = R; g.N = 2 * c.inter; g.K = H; g.A = h->x; g.lda = H; g.W = lw[5]; g.split_k = 1; g.nz = 1;
+        g.dtype = dt; g.M = R; g.N = 2 * c.inter; g.K = H; g.A = xa; g.lda = H; g.W = lw[5]; g.split_k = 1; g.nz = 1;
         g.a_norm = 1; g.norm_eps = c.rms_eps;               // post_attention_layernorm gain is folded into lw[5]
         g.epi = SK_SWIGLU; g.out = h->hmlp; g.ldo = c.inter;
         if (launch_skinny(g, s)) return -1;
         // 5. x += down(hmlp)
         memset(&g, 0, sizeof(g));
         g.dtype = dt; g.M = R; g.N = H; g.K = c.inter; g.A = h->hmlp; g.lda = c.inter; g.W = lw[6]; g.nz = 1; g.split_k = 1;
-        g.epi = SK_RESID; g.out = h->x; g.out_f32 = 1; g.ldo = H;
+        g.epi = SK_RESID; g.out = h->x; g.out_f32 = 1; g.ldo = H; g.out2 = xcopy; g.ldo2 = H; g.w_narrow = 1;
         if (launch_skinny(g, s)) return -1;
     }
     if (head_k <= 0) return 0;

@@ -18,7 +18,7 @@ import torch
 from . import _lib, ops
 from ._lib import check, ptr, stream_ptr
 from .config import LLMConfig
-from .packing import pack_frag, pack_gate_up, qkv_row_perm
+from .packing import pack_frag, pack_gate_up, pack_narrow4, qkv_row_perm
 from .sampling import NoiseStream, rep_threshold, sampling_params
 from .weights import llm_spec, check_state, DROP_KEYS
 
@@ -102,10 +102,10 @@ class HvxLLM:
             # RMSNorm gains are folded into the columns of the GEMM that consumes the normalised rows (the kernel applies 1/rms to its
             # accumulator, csrc/gemm_skinny.hip): norm(x) @ W^T == (x / rms) @ (W * gain)^T
             ln1, ln2 = W(p + 'input_layernorm.weight'), W(p + 'post_attention_layernorm.weight')
-            ws += [vec(ln1), mat(pack_frag(wqkv * ln1[None, :])), vec(bqkv), mat(pack_frag(W(p + 'self_attn.o_proj.weight'))),
+            ws += [vec(ln1), mat(pack_frag(wqkv * ln1[None, :])), vec(bqkv), mat(pack_narrow4(W(p + 'self_attn.o_proj.weight'))),
                    vec(ln2),
                    mat(pack_gate_up(W(p + 'mlp.gate_proj.weight') * ln2[None, :], W(p + 'mlp.up_proj.weight') * ln2[None, :])),
-                   mat(pack_frag(W(p + 'mlp.down_proj.weight')))]
+                   mat(pack_narrow4(W(p + 'mlp.down_proj.weight')))]
         hn = c.head_num
 
         def stack(fn):
@@ -164,7 +164,7 @@ class HvxLLM:
         wsb = self.lib.hvx_llm_workspace_bytes(self._h, S, R, self.max_ctx)
         kvb = self.lib.hvx_llm_kv_bytes(self._h, S, self.max_ctx)
         self._ws = torch.empty(wsb, dtype=torch.uint8, device=self.device)
-        self._kv = torch.empty(kvb, dtype=torch.uint8, device=self.device)
+        self._kv = torch.zeros(kvb, dtype=torch.uint8, device=self.device)      # masked keys contribute 0 * V: V must be finite
         check(self.lib.hvx_llm_bind(self._h, ptr(self._ws), wsb, S, R, ptr(self._kv), kvb, S, self.max_ctx, stream_ptr()), 'hvx_llm_bind')
         self._bound = (S, R)
 

@@ -27,6 +27,14 @@ def pack_frag(w):
     return w.view(N // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous().view(N, K)
 
 
+def pack_narrow4(w):
+    """[N][K] -> flat tensor in [N/4][K/128][g=4][ksub=4][c=4][8] order (N % 4 == 0, K % 128 == 0): lane (c + 4*ksub, g) of the
+    4-column workgroup form (csrc/gemm_skinny.hip: gemm_narrow_resid_kernel) holds W[4*nt + c][128*kb + 32*ksub + 8*g ..+8]."""
+    assert w.dim() == 2 and w.shape[0] % 4 == 0 and w.shape[1] % 128 == 0, w.shape
+    N, K = w.shape
+    return w.view(N // 4, 4, K // 128, 4, 4, 8).permute(0, 2, 4, 3, 1, 5).contiguous().view(N, K)
+
+
 def qkv_row_perm(n_heads, head_dim=64):
     """Row order of the fused [q | k | v] projection consumed by the SK_QKV_ROPE epilogue: inside every 64-row head, 16-row tile t
     holds d = 8t..8t+7 followed by their rotate-half partners d + 32, so a RoPE pair sits in one MFMA tile (lanes fr and fr ^ 8)."""
