@@ -57,6 +57,14 @@ class LLMConfig(C.Structure):
                 ('rms_eps', c_f32), ('mtp_rms_eps', c_f32), ('max_pos', c_i32)]
 
 
+class DecodeArgs(C.Structure):
+    _fields_ = [('n_seq', c_i32), ('head_k', c_i32), ('win_cap', c_i32), ('max_out', c_i32),
+                ('tok', c_vp), ('ctrl', c_vp), ('hist', c_vp), ('hist_len', c_vp), ('min_adj', c_vp), ('active', c_vp),
+                ('seq_state', c_vp), ('out_tokens', c_vp), ('ids', c_vp), ('logp', c_vp),
+                ('top_k', c_i32), ('top_p', c_f32), ('win_size', c_i32), ('rep_thresh', c_i32), ('max_trials', c_i32),
+                ('noise', c_vp), ('noise_seq_stride', c_i64), ('noise_len', c_i32), ('cursor', c_vp)]
+
+
 class FlowConfig(C.Structure):
     _fields_ = [('dtype', c_i32), ('vocab', c_i32), ('mel', c_i32), ('spk_dim', c_i32), ('pla_channels', c_i32), ('pla_len', c_i32),
                 ('dim', c_i32), ('depth', c_i32), ('heads', c_i32), ('ff', c_i32), ('conv_kernel', c_i32), ('conv_groups', c_i32),
@@ -90,6 +98,7 @@ SYMBOLS = {
     'hvx_llm_kv_bytes': (c_sz, [c_vp, c_i32, c_i32]),
     'hvx_llm_bind': (c_i32, [c_vp, c_vp, c_sz, c_i32, c_i32, c_vp, c_sz, c_i32, c_i32, c_vp]),
     'hvx_llm_forward': (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp]),
+    'hvx_llm_decode_steps': (c_i32, [c_vp, c_vp, C.POINTER(DecodeArgs), c_i32]),
     'hvx_llm_use_graph': (c_i32, [c_vp, c_i32]),
     'hvx_llm_last_hidden': (c_i32, [c_vp, c_vp, c_i32, c_vp]),
     'hvx_flow_create': (c_i32, [C.POINTER(FlowConfig), C.POINTER(c_vp), c_i32, C.POINTER(c_vp)]),

@@ -178,6 +178,18 @@ struct SampleArgs {
 };
 int launch_ras_sample(const SampleArgs& a, hipStream_t s);
 
+// Between two decode steps (llm_multi_head_v3.py:890-905 and the feedback of inference_wrapper): accept the sampled ids, append
+// them to the utterance and the repetition window, decide whether the sequence stops, and write the next step's tok / ctrl.
+struct AdvanceArgs {
+    int n_seq, head_k, win_cap, max_out, speech_tokens;
+    const int* ids;                         // [n_seq][head_k] from the sampler
+    int* tok; int* ctrl;                    // next step's [n_seq][head_k] tokens and [5][n_seq] control
+    int* hist; int* hist_len; int* min_adj; int* active;
+    int* seq_state;                         // [n_seq][8]: pos, out_len, done, min_len, max_len, steps, err, -
+    int* out_tokens;                        // [n_seq][max_out]
+};
+int launch_decode_advance(const AdvanceArgs& a, hipStream_t s);
+
 // ------------------------------------------------------------------------------------------------
 // HiFT source / STFT / iSTFT
 // ------------------------------------------------------------------------------------------------

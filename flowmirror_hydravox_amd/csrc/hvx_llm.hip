@@ -35,9 +35,17 @@ struct hvx_llm {
     std::vector<const void*> w;
     bool use_graph = false;
     std::map<GraphKey, hipGraphExec_t> graphs;
+    struct StepGraph {
+        hvx_decode_args a;
+        hipStream_t s;
+        hipGraphExec_t ex;
+    };
+    std::vector<StepGraph> step_graphs;      // whole decode steps (forward + sampler + advance), keyed on the argument block
     void drop_graphs() {
         for (auto& kv : graphs) hipGraphExecDestroy(kv.second);
         graphs.clear();
+        for (auto& g : step_graphs) hipGraphExecDestroy(g.ex);
+        step_graphs.clear();
     }
     // bound buffers
     char* ws = nullptr;
@@ -208,6 +216,69 @@ int hvx_llm_forward(hvx_llm* h, hvx_stream stream, int32_t n_seq, int32_t kn, co
         it = h->graphs.emplace(key, ex).first;
     }
     if (hipGraphLaunch(it->second, s) != hipSuccess) return set_error("hvx_llm_forward: graph launch failed"), -1;
+    return 0;
+}
+
+static int decode_step_impl(hvx_llm* h, hipStream_t s, const hvx_decode_args& a) {
+    if (forward_impl(h, s, a.n_seq, a.head_k, a.tok, a.ctrl, a.head_k, a.logp)) return -1;
+    SampleArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.n_seq = a.n_seq; sa.head_k = a.head_k; sa.V = h->c.vocab; sa.Vs = h->c.speech_tokens;
+    sa.logp = a.logp; sa.logp_ss = (long long)a.head_k * h->c.vocab; sa.logp_hs = h->c.vocab;
+    sa.hist = a.hist; sa.hist_ss = a.win_cap; sa.hist_len = a.hist_len; sa.min_len = a.min_adj; sa.active = a.active;
+    sa.top_k = a.top_k; sa.top_p = a.top_p; sa.win_size = a.win_size; sa.rep_thresh = a.rep_thresh;
+    sa.noise = a.noise; sa.noise_ss = a.noise_seq_stride; sa.noise_len = a.noise_len; sa.cursor = (long long*)a.cursor;
+    sa.out_ids = a.ids; sa.max_trials = a.max_trials;
+    if (launch_ras_sample(sa, s)) return -1;
+    AdvanceArgs aa;
+    memset(&aa, 0, sizeof(aa));
+    aa.n_seq = a.n_seq; aa.head_k = a.head_k; aa.win_cap = a.win_cap; aa.max_out = a.max_out; aa.speech_tokens = h->c.speech_tokens;
+    aa.ids = a.ids; aa.tok = a.tok; aa.ctrl = a.ctrl; aa.hist = a.hist; aa.hist_len = a.hist_len; aa.min_adj = a.min_adj; aa.active = a.active;
+    aa.seq_state = a.seq_state; aa.out_tokens = a.out_tokens;
+    return launch_decode_advance(aa, s);
+}
+
+int hvx_llm_decode_steps(hvx_llm* h, hvx_stream stream, const hvx_decode_args* a, int32_t n_steps) {
+    if (!h || !h->ws || !a) return set_error("hvx_llm_decode_steps: handle not bound / null argument"), -1;
+    if (a->n_seq < 1 || a->head_k < 1 || a->head_k > 8 || a->win_cap < 1 || a->max_out < 1 || !a->tok || !a->ctrl || !a->hist || !a->hist_len ||
+        !a->min_adj || !a->active || !a->seq_state || !a->out_tokens || !a->ids || !a->logp || !a->noise || !a->cursor)
+        return set_error("hvx_llm_decode_steps: bad argument block"), -1;
+    hipStream_t s = (hipStream_t)stream;
+    if (!h->use_graph || prof_enabled() || s == nullptr) {
+        for (int i = 0; i < n_steps; ++i)
+            if (decode_step_impl(h, s, *a)) return -1;
+        return 0;
+    }
+    hipGraphExec_t ex = nullptr;
+    for (auto& g : h->step_graphs)
+        if (g.s == s && memcmp(&g.a, a, sizeof(*a)) == 0) ex = g.ex;
+    if (!ex) {
+        hipGraph_t g = nullptr;
+        if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) return set_error("hvx_llm_decode_steps: begin capture failed"), -1;
+        const int rc = decode_step_impl(h, s, *a);
+        const hipError_t e = hipStreamEndCapture(s, &g);
+        if (rc != 0 || e != hipSuccess || !g) {
+            if (g) hipGraphDestroy(g);
+            if (rc == 0) set_error("hvx_llm_decode_steps: graph capture failed: %s", hipGetErrorString(e));
+            return -1;
+        }
+        if (hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) != hipSuccess) {
+            hipGraphDestroy(g);
+            return set_error("hvx_llm_decode_steps: graph instantiate failed"), -1;
+        }
+        hipGraphDestroy(g);
+        if (h->step_graphs.size() >= 8) {                     // callers re-bind control blocks per utterance batch: keep the cache small
+            hipGraphExecDestroy(h->step_graphs.front().ex);
+            h->step_graphs.erase(h->step_graphs.begin());
+        }
+        hvx_llm::StepGraph sg;
+        memcpy(&sg.a, a, sizeof(*a));                         // (byte copy: padding is compared too, callers pass a zeroed block)
+        sg.s = s;
+        sg.ex = ex;
+        h->step_graphs.push_back(sg);
+    }
+    for (int i = 0; i < n_steps; ++i)
+        if (hipGraphLaunch(ex, s) != hipSuccess) return set_error("hvx_llm_decode_steps: graph launch failed"), -1;
     return 0;
 }
 

@@ -233,4 +233,65 @@ int launch_ras_sample(const SampleArgs& a, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? 0 : (set_error("ras_sample launch failed"), -1);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// decode_advance: the reference's host logic between two steps, one thread per sequence (K <= 8 tokens each).
+//   for t in ids: t == -1 -> RuntimeError (err = 1); t >= speech_token_size -> stop; else append; len(out) >= max_len -> stop
+//   an empty accepted group stops the sequence; the accepted group is what the next step feeds (llm_multi_head_v3.py:898-905)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void decode_advance_kernel(AdvanceArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_seq) return;
+    int* st = a.seq_state + i * 8;
+    const int K = a.head_k;
+    int pos = st[0], out_len = st[1], done = st[2];
+    const int min_len = st[3], max_len = st[4];
+    int n_next = 0;
+    if (!done) {
+        pos += a.ctrl[2 * a.n_seq + i];                      // rows fed by the step that just ran
+        for (int j = 0; j < K; ++j) {
+            const int t = a.ids[i * K + j];
+            if (t < 0) {                                     // -1: max_trials exhausted, -2: noise window exhausted
+                st[6] = (t == -1) ? 1 : 2;
+                done = 1;
+                break;
+            }
+            if (t >= a.speech_tokens) {                      // any stop id
+                done = 1;
+                break;
+            }
+            if (out_len < a.max_out) a.out_tokens[(long long)i * a.max_out + out_len] = t;
+            a.hist[(long long)i * a.win_cap + (out_len % a.win_cap)] = t;
+            a.tok[i * K + n_next] = t;
+            ++out_len;
+            ++n_next;
+            if (out_len >= max_len) {
+                done = 1;
+                break;
+            }
+        }
+        if (n_next == 0) done = 1;
+        st[5] += 1;
+    }
+    const int nn = done ? 0 : n_next;
+    for (int j = nn; j < K; ++j) a.tok[i * K + j] = -1;
+    a.ctrl[0 * a.n_seq + i] = i;
+    a.ctrl[1 * a.n_seq + i] = pos;
+    a.ctrl[2 * a.n_seq + i] = nn;
+    a.ctrl[3 * a.n_seq + i] = pos + nn;
+    a.ctrl[4 * a.n_seq + i] = nn ? (i * K + nn - 1) : -1;
+    const int hl = out_len < a.win_cap ? out_len : a.win_cap;
+    a.hist_len[i] = hl;
+    a.min_adj[i] = min_len - (out_len - hl);
+    a.active[i] = done ? 0 : 1;
+    st[0] = pos;
+    st[1] = out_len;
+    st[2] = done;
+}
+
+int launch_decode_advance(const AdvanceArgs& a, hipStream_t s) {
+    if (a.n_seq <= 0) return 0;
+    hipLaunchKernelGGL(decode_advance_kernel, dim3((a.n_seq + 63) / 64), dim3(64), 0, s, a);
+    return hipGetLastError() == hipSuccess ? 0 : (set_error("decode_advance launch failed"), -1);
+}
+
 }  // namespace hvx

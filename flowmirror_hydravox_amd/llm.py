@@ -228,7 +228,7 @@ class HvxLLM:
     # ------------------------------------------------------------------------------------------------------------
     # engine
     # ------------------------------------------------------------------------------------------------------------
-    def _run(self, reqs, stream_first):
+    def _run(self, reqs, stream_first, sync_every=None):
         """Generator over the tokens of request 0 (stream_first) that drives all requests to completion.
         Device work runs on a private stream (hipGraph capture is illegal on the legacy default stream); nothing
         stays selected as torch's current stream across a yield."""
@@ -250,9 +250,8 @@ class HvxLLM:
         t_start = time.time()
         W = sp['win_size'] if sp['win_size'] > 0 else max(r.max_len for r in reqs)
         W = max(W, 1)
-        n_ctl = S * K + 5 * S + S * W + 3 * S
-        o_tok, o_ctrl, o_hist = 0, S * K, S * K + 5 * S
-        o_hlen, o_min, o_act = o_hist + S * W, o_hist + S * W + S, o_hist + S * W + 2 * S
+        if sync_every is None:
+            sync_every = 4 if stream_first else 8          # steps enqueued per host round trip (tokens surface in bursts of this many steps)
         d = type('DecodeState', (), {})()
         with torch.cuda.stream(stream):
             self._bind(S, max(longest, S * K))
@@ -265,56 +264,59 @@ class HvxLLM:
                     self._forward(1, n, tok, ctrl, 0, None)
                 r.pos = n
                 r.next = [r.prefix[-1]]
-            # ---- decode buffers (fixed addresses: the step graph is captured once and replayed) -----------------------------
-            ctl_host = torch.empty(n_ctl, dtype=torch.int32).pin_memory()
-            ctl_dev = torch.empty(n_ctl, dtype=torch.int32, device=dev)
+            # ---- decode state (fixed device addresses: the step graph is captured once and replayed) ---------------------------
+            # The loop itself lives on the device (hvx_llm_decode_steps): forward, sampling of the K heads and the bookkeeping the
+            # reference does in Python between two steps (accept / append / stop, llm_multi_head_v3.py:890-905) are one graph per
+            # step, `sync_every` steps are enqueued per host round trip and only the per-sequence state words come back.
+            max_trials = 100
+            ncap = self.noise_cap
+            while sync_every * K * max_trials > ncap // 2:          # a block of steps can never run out of pre-generated noise
+                ncap *= 2
+            max_out = max(max(r.max_len for r in reqs), 1)
+            o_tok, o_ctrl, o_hist = 0, S * K, S * K + 5 * S
+            o_hlen, o_min, o_act = o_hist + S * W, o_hist + S * W + S, o_hist + S * W + 2 * S
+            o_state, o_ids = o_act + S, o_act + S + 8 * S
+            n_ctl = o_ids + S * K
+            ctl_host = torch.zeros(n_ctl, dtype=torch.int32).pin_memory()
+            ch = ctl_host.numpy()
+            ch[o_tok:o_tok + S * K] = -1
+            for i, r in enumerate(reqs):
+                ch[o_tok + i * K] = r.next[0]
+                ch[o_ctrl + 0 * S + i] = i
+                ch[o_ctrl + 1 * S + i] = r.pos
+                ch[o_ctrl + 2 * S + i] = 1
+                ch[o_ctrl + 3 * S + i] = r.pos + 1
+                ch[o_ctrl + 4 * S + i] = i * K
+                ch[o_min + i] = r.min_len
+                ch[o_act + i] = 1
+                ch[o_state + 8 * i:o_state + 8 * i + 5] = [r.pos, 0, 0, r.min_len, r.max_len]
+            ctl_dev = ctl_host.to(dev, non_blocking=True)
+            out_dev = torch.zeros(S, max_out, dtype=torch.int32, device=dev)
             logp = torch.empty(S, K, c.vocab, dtype=torch.float32, device=dev)
-            d.ncap = self.noise_cap
+            d.ncap = ncap
             d.noise_host = torch.empty(S, d.ncap, dtype=torch.float32).pin_memory()
-            d.noise_dev = torch.empty(S, d.ncap, dtype=torch.float32, device=dev)
-            d.cur_dev = torch.zeros(S, dtype=torch.int64, device=dev)
-            d.nbase = [0] * S                    # absolute stream position of noise_dev[i, 0]
             for i, r in enumerate(reqs):
                 d.noise_host[i].copy_(torch.from_numpy(r.noise.window(0, d.ncap)))
-            d.noise_dev.copy_(d.noise_host, non_blocking=True)
-            ids_host = torch.empty(S * K, dtype=torch.int32).pin_memory()
+            d.noise_dev = d.noise_host.to(dev, non_blocking=True)
+            d.cur_dev = torch.zeros(S, dtype=torch.int64, device=dev)
+            d.nbase = [0] * S                    # absolute stream position of noise_dev[i, 0]
+            state_host = torch.zeros(S, 8, dtype=torch.int32).pin_memory()
             d.cur_host = torch.zeros(S, dtype=torch.int64).pin_memory()
-        ch = ctl_host.numpy()
+            first_host = torch.zeros(max_out, dtype=torch.int32).pin_memory()
+            stream.synchronize()
 
-        def device_step():
-            """upload the control block, run the step, sample (re-sampling sequences that ran out of noise)"""
-            ctl_dev.copy_(ctl_host, non_blocking=True)
-            self._forward(S, K, ctl_dev[o_tok:], ctl_dev[o_ctrl:], K, logp)
-            act = ctl_dev[o_act:o_act + S]
-            idl, short = None, []
-            while True:
-                ids = ops.ras_sample(logp, ctl_dev[o_hist:o_hist + S * W].view(S, W), ctl_dev[o_hlen:o_hlen + S], ctl_dev[o_min:o_min + S],
-                                     d.noise_dev, d.cur_dev, speech_tokens=c.speech_tokens, top_k=sp['top_k'], top_p=sp['top_p'],
-                                     win_size=sp['win_size'], rep_thresh=thr, active=act)
-                ids_host.copy_(ids.view(-1), non_blocking=True)
-                d.cur_host.copy_(d.cur_dev, non_blocking=True)
-                stream.synchronize()
-                new = ids_host.view(S, K).tolist()
-                if idl is None:
-                    idl = new
-                else:
-                    for i in short:
-                        idl[i] = new[i]
-                short = [i for i, r in enumerate(reqs) if not r.done and idl[i][0] == -2]
-                if not short:
-                    return idl
-                # these sequences ran out of pre-generated noise inside the step (their cursor was left untouched):
-                # enlarge the window and sample them again; everyone else keeps the ids already drawn
-                act = torch.zeros(S, dtype=torch.int32)
-                act[short] = 1
-                act = act.to(dev)
-                d.ncap *= 4
-                refill_noise()
+        def decode_args():
+            a = _lib.DecodeArgs()
+            a.n_seq, a.head_k, a.win_cap, a.max_out = S, K, W, max_out
+            base = ctl_dev.data_ptr()
+            a.tok, a.ctrl, a.hist, a.hist_len = base + 4 * o_tok, base + 4 * o_ctrl, base + 4 * o_hist, base + 4 * o_hlen
+            a.min_adj, a.active, a.seq_state, a.ids = base + 4 * o_min, base + 4 * o_act, base + 4 * o_state, base + 4 * o_ids
+            a.out_tokens, a.logp = out_dev.data_ptr(), logp.data_ptr()
+            a.top_k, a.top_p, a.win_size, a.rep_thresh, a.max_trials = sp['top_k'], sp['top_p'], sp['win_size'], thr, max_trials
+            a.noise, a.noise_seq_stride, a.noise_len, a.cursor = d.noise_dev.data_ptr(), d.ncap, d.ncap, d.cur_dev.data_ptr()
+            return a
 
         def refill_noise():
-            if d.noise_host.shape[1] != d.ncap:
-                d.noise_host = torch.empty(S, d.ncap, dtype=torch.float32).pin_memory()
-                d.noise_dev = torch.empty(S, d.ncap, dtype=torch.float32, device=dev)
             for i, r in enumerate(reqs):
                 d.nbase[i] += int(d.cur_host[i])
                 d.noise_host[i].copy_(torch.from_numpy(r.noise.window(d.nbase[i], d.ncap)))
@@ -323,59 +325,41 @@ class HvxLLM:
             d.cur_host.zero_()
             stream.synchronize()
 
-        steps = 0
-        n_llm_tokens = 0
-        while not all(r.done for r in reqs):
-            ch[o_tok:o_tok + S * K] = -1
-            for i, r in enumerate(reqs):
-                nn = 0 if r.done else len(r.next)
-                if nn:
-                    ch[o_tok + i * K:o_tok + i * K + nn] = r.next
-                ch[o_ctrl + 0 * S + i] = i
-                ch[o_ctrl + 1 * S + i] = r.pos
-                ch[o_ctrl + 2 * S + i] = nn
-                ch[o_ctrl + 3 * S + i] = r.pos + nn
-                ch[o_ctrl + 4 * S + i] = (i * K + nn - 1) if nn else -1
-                hw = r.out[-W:]
-                ch[o_hist + i * W:o_hist + i * W + len(hw)] = hw
-                ch[o_hlen + i] = len(hw)
-                ch[o_min + i] = r.min_len - (len(r.out) - len(hw))       # (len(snapshot)+j < min_len) in window coordinates
-                ch[o_act + i] = 0 if r.done else 1
+        args = decode_args()
+        emitted = 0
+        while True:
             with torch.cuda.stream(stream):
-                idl = device_step()
-            steps += 1
-            emitted = []
-            for i, r in enumerate(reqs):
-                if r.done:
-                    continue
-                r.pos += len(r.next)
-                group = []
-                for t in idl[i]:
-                    if t == -1:
-                        raise RuntimeError('sampling reaches max_trials {} and still get eos when ignore_eos is True, check your input!'.format(100))
-                    if t >= c.speech_tokens:                # any stop id (:683, :904)
-                        r.done = True
-                        break
-                    r.out.append(t)
-                    group.append(t)
-                    n_llm_tokens += 1
-                    if i == 0:
-                        emitted.append(t)
-                    if len(r.out) >= r.max_len:
-                        r.done = True
-                        break
-                if not group:
-                    r.done = True
-                r.next = group
-            if max(int(v) for v in d.cur_host.tolist()) > d.ncap // 2 and not all(r.done for r in reqs):
+                check(self.lib.hvx_llm_decode_steps(self._h, C.c_void_p(stream.cuda_stream), C.byref(args), sync_every), 'hvx_llm_decode_steps')
+                state_host.copy_(ctl_dev[o_state:o_state + 8 * S].view(S, 8), non_blocking=True)
+                d.cur_host.copy_(d.cur_dev, non_blocking=True)
+                if stream_first:
+                    first_host.copy_(out_dev[0], non_blocking=True)
+                stream.synchronize()
+            st = state_host.tolist()
+            if any(row[6] == 1 for row in st):
+                raise RuntimeError('sampling reaches max_trials {} and still get eos when ignore_eos is True, check your input!'.format(max_trials))
+            if any(row[6] != 0 for row in st):
+                raise _lib.HvxError('decode loop: pre-generated sampler noise exhausted inside a block of %d steps' % sync_every)
+            if stream_first:
+                n0 = st[0][1]
+                for t in first_host[emitted:n0].tolist():
+                    yield t
+                emitted = n0
+            if all(row[2] for row in st):
+                break
+            if max(int(v) for v in d.cur_host.tolist()) > d.ncap // 2:
                 with torch.cuda.stream(stream):
                     refill_noise()
-            if stream_first:
-                for t in emitted:
-                    yield t
+        with torch.cuda.stream(stream):
+            out_host = out_dev.cpu()
+        n_llm_tokens = 0
         for i, r in enumerate(reqs):
+            r.out = out_host[i, :st[i][1]].tolist()
+            r.done = True
+            n_llm_tokens += len(r.out)
             r.cursor = d.nbase[i] + int(d.cur_host[i])
             r.noise.finalize(r.cursor)
+        steps = max(row[5] for row in st)
         torch.cuda.current_stream().wait_stream(stream)
         dt = time.time() - t_start
         self.last_stats = dict(steps=steps, tokens=n_llm_tokens, seconds=dt, tps=n_llm_tokens / dt if dt > 0 else 0.0, head_k=K, batch=S)

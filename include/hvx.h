@@ -133,6 +133,29 @@ int hvx_llm_forward(hvx_llm* h, hvx_stream s, int32_t n_seq, int32_t kn, const i
                     int32_t head_k, float* logp);
 /* replay the decode-step launches (head_k > 0) as one cached hipGraph per (grid, control/logp addresses, stream) */
 int hvx_llm_use_graph(hvx_llm* h, int32_t enable);
+/* Device-resident decode loop — replaces the per-step host logic of CosyVoice3LM.inference_wrapper (llm_multi_head_v3.py:871-905):
+ * one call enqueues `n_steps` repetitions of { forward over the [n_seq][head_k] grid, RAS sampling of the K heads, advance }, where
+ * `advance` does on the device what the reference's Python loop does between two steps: feed the accepted tokens back (tok / ctrl
+ * of the next step), append them to the utterance, slide the repetition window, stop a sequence on a stop id / max_len / an empty
+ * group.  Nothing is read back between steps; the caller looks at `seq_state` whenever it wants (e.g. every 8 steps).
+ *   tok / ctrl                  as in hvx_llm_forward (kn = head_k); rewritten by every step
+ *   hist [n_seq][win_cap]       ring of the last tokens (slot = out_len % win_cap), hist_len = min(out_len, win_cap)
+ *   min_adj [n_seq]             min_len - (out_len - hist_len): head j ignores stop ids while hist_len + j < min_adj
+ *   active [n_seq]              0 once a sequence is finished
+ *   seq_state [n_seq][8]        pos, out_len, done, min_len, max_len, steps, err (1 = sampler max_trials exhausted, 2 = noise window
+ *                               exhausted), reserved
+ *   out_tokens [n_seq][max_out] the utterance so far (out_len valid entries)
+ *   ids [n_seq][head_k]         scratch: the ids sampled by the last step
+ * Sampler fields as in hvx_sample_args.  The step is replayed from a cached hipGraph keyed on the argument block. */
+typedef struct {
+    int32_t n_seq, head_k, win_cap, max_out;
+    int32_t* tok; int32_t* ctrl; int32_t* hist; int32_t* hist_len; int32_t* min_adj; int32_t* active;
+    int32_t* seq_state; int32_t* out_tokens; int32_t* ids;
+    float* logp;
+    int32_t top_k; float top_p; int32_t win_size; int32_t rep_thresh; int32_t max_trials;
+    const float* noise; int64_t noise_seq_stride; int32_t noise_len; int64_t* cursor;
+} hvx_decode_args;
+int hvx_llm_decode_steps(hvx_llm* h, hvx_stream s, const hvx_decode_args* a, int32_t n_steps);
 /* debugging / parity: copy the post-final-norm hidden of the last rows of the previous forward (fp32 [n_seq][H]) */
 int hvx_llm_last_hidden(hvx_llm* h, hvx_stream s, int32_t n_seq, float* out);
 
