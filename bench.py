@@ -235,8 +235,22 @@ def main():
         return
     assert world > 1 or len(got) == B
 
-    est = sorted(((p['est_total_ms'], n) for n, p in prof.items()), reverse=True)
-    dominant = est[0][1] if est else None
+    # The dominant "kernel" is the decode step: one hipGraph replay of forward + sampler + advance (~160 launches of 5-9 us, which a
+    # per-launch event bracket would distort), timed over the timed region itself by hipEvents around every block of 8 replays on
+    # the decode stream.  Its algorithmic bytes are every LM weight once plus the cached K/V rows (HvxLLM.decode_step_bytes).
+    def step_roofline(sts):
+        sts = [x.llm for x in sts if x.llm.get('decode_steps_timed')]
+        if not sts:
+            return None
+        n = sum(x['decode_steps_timed'] for x in sts)
+        us = sum(x['decode_step_us'] * x['decode_steps_timed'] for x in sts) / n
+        by = sum(x['decode_step_bytes'] * x['decode_steps_timed'] for x in sts) / n
+        ach = by / us / 1e3
+        return dict(achieved=round(ach, 1), frac=round(ach / HBM_PEAK_GBS, 4), avg_launch_us=round(us, 1), algorithmic_bytes_per_launch=round(by),
+                    launches=n)
+    rl_timed = step_roofline(stats)
+    rl_alone = step_roofline([serial]) if serial is not None else None
+    est = sorted(((p['est_total_ms'], n) for n, p in prof.items() if n not in ('llm_decode_gemm', 'llm_attention', 'ras_sampler')), reverse=True)
     line = {
         'metric': 'speech-tokens/sec + RTF, HydraVox-CV3 head_num=%d, %d-char batch' % (K, chars),
         'value': round(tokens / elapsed, 2), 'unit': 'speech-tokens/s',
@@ -255,9 +269,18 @@ def main():
         'audio_seconds_per_step': round(audio / args.steps, 2),
         'setup_seconds': round(t_build, 1),
     }
-    if dominant:
-        line['roofline'] = roofline_of(dominant, prof[dominant])
-        line['roofline_other'] = [roofline_of(n, prof[n]) for _, n in est[1:] if prof[n]['work_per_launch'] > 0]
+    if rl_timed:
+        line['roofline'] = dict(kernel='llm_decode_step (hipGraph: %d-layer backbone + %d MTP heads + sampler, one launch = one step of %d sequences)'
+                                       % (cfg.llm.layers, K, B), bound='hbm', achieved=rl_timed['achieved'], peak=HBM_PEAK_GBS, unit='GB/s',
+                                frac=rl_timed['frac'], traffic=pmc_traffic('llm_decode_step'), avg_launch_us=rl_timed['avg_launch_us'],
+                                algorithmic_bytes_per_launch=rl_timed['algorithmic_bytes_per_launch'], launches_per_timed_region=rl_timed['launches'],
+                                measured='hipEvents around every 8 replays on the decode stream, all timed steps' +
+                                         ('' if args.serial else '; the flow decoder + vocoder of the previous step share the GPU meanwhile'))
+        if rl_alone and not args.serial:
+            line['roofline']['alone'] = dict(achieved=rl_alone['achieved'], frac=rl_alone['frac'], avg_launch_us=rl_alone['avg_launch_us'],
+                                             measured='same brackets in the warm-up step (stages back to back, nothing else on the GPU)')
+    if est:
+        line['roofline_other'] = [roofline_of(n, prof[n]) for _, n in est if prof[n]['work_per_launch'] > 0]
         line['kernel_time_share_ms'] = {n: round(t, 1) for t, n in est}
     if world == 1 and not args.no_cpu_baseline:
         try:

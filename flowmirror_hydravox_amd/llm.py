@@ -327,9 +327,15 @@ class HvxLLM:
 
         args = decode_args()
         emitted = 0
+        blocks = []                                   # hipEvent brackets around every block of steps (2 events per sync_every steps)
+        pos_start = [r.pos for r in reqs]
         while True:
             with torch.cuda.stream(stream):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
                 check(self.lib.hvx_llm_decode_steps(self._h, C.c_void_p(stream.cuda_stream), C.byref(args), sync_every), 'hvx_llm_decode_steps')
+                e1.record(stream)
+                blocks.append((e0, e1))
                 state_host.copy_(ctl_dev[o_state:o_state + 8 * S].view(S, 8), non_blocking=True)
                 d.cur_host.copy_(d.cur_dev, non_blocking=True)
                 if stream_first:
@@ -362,7 +368,24 @@ class HvxLLM:
         steps = max(row[5] for row in st)
         torch.cuda.current_stream().wait_stream(stream)
         dt = time.time() - t_start
-        self.last_stats = dict(steps=steps, tokens=n_llm_tokens, seconds=dt, tps=n_llm_tokens / dt if dt > 0 else 0.0, head_k=K, batch=S)
+        step_ms = sum(a.elapsed_time(b) for a, b in blocks) / (len(blocks) * sync_every)
+        mean_ctx = sum(0.5 * (p0 + row[0]) for p0, row in zip(pos_start, st)) / S
+        self.last_stats = dict(steps=steps, tokens=n_llm_tokens, seconds=dt, tps=n_llm_tokens / dt if dt > 0 else 0.0, head_k=K, batch=S,
+                               decode_step_us=1e3 * step_ms, decode_steps_timed=len(blocks) * sync_every, mean_ctx=mean_ctx,
+                               decode_step_bytes=self.decode_step_bytes(S, K, mean_ctx))
+
+    def decode_step_bytes(self, n_seq, head_k, ctx):
+        """Algorithmic HBM bytes of one decode step: every weight of the backbone, of the head_k MTP blocks and of
+        llm_decoder once, plus the K and V rows of `ctx` cached positions per sequence and layer; activations are noise next to it."""
+        c = self.cfg
+        es = 2 if self.dtype == torch.bfloat16 else 4
+        H, Q, KV = c.hidden, c.q_heads * c.head_dim, c.kv_heads * c.head_dim
+        layer = H * (Q + 2 * KV) + Q * H + 3 * H * c.inter
+        mtp = 2 * c.mtp_attn_dim * H + 3 * H * c.mtp_inter
+        vpad = (c.vocab + 15) // 16 * 16
+        weights = (c.layers * layer + head_k * mtp + vpad * H) * es
+        kv = c.layers * n_seq * 2 * KV * ctx * es
+        return float(weights + kv)
 
     @torch.inference_mode()
     def prefill_logp(self, prefix_encoded, head_k=None):

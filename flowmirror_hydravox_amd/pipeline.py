@@ -37,6 +37,7 @@ class SynthStats:
     hift_seconds: float = 0.0
     total_seconds: float = 0.0
     per_utt_tokens: List[int] = field(default_factory=list)
+    llm: dict = field(default_factory=dict)               # HvxLLM.last_stats of this batch (decode-step timing)
 
     @property
     def tps(self):
@@ -123,6 +124,7 @@ class HvxPipeline:
         torch.cuda.synchronize()
         t1 = time.time()
         st.llm_seconds = t1 - t0
+        st.llm = dict(self.llm.last_stats)
         st.per_utt_tokens = [len(t) for t in toks]
         st.tokens = sum(st.per_utt_tokens)
         mels = self._mels(utts, toks)
@@ -169,6 +171,7 @@ class HvxPipeline:
             t0 = time.time()
             toks = self._speech_tokens(utts, max_token_text_ratio, min_token_text_ratio)
             st.llm_seconds = time.time() - t0
+            st.llm = dict(self.llm.last_stats)
             st.per_utt_tokens = [len(t) for t in toks]
             st.tokens = sum(st.per_utt_tokens)
             if pending is not None:
