@@ -19,6 +19,10 @@ FLAGS = ['-O3', '-std=c++17', '-fPIC', '--offload-arch=' + ARCH, '-Wall', '-Wno-
          '-I', CSRC, '-I', INCLUDE]
 
 
+# per-file additions: the attention softmax takes maxima of values that are never NaN (scores, -inf masks)
+FILE_FLAGS = {'attention.hip': ['-fno-honor-nans']}
+
+
 def _hipcc():
     for c in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
         if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
@@ -40,7 +44,7 @@ def _headers_mtime():
 
 
 def _compile(src, obj, verbose):
-    cmd = [_hipcc()] + FLAGS + ['-c', src, '-o', obj]
+    cmd = [_hipcc()] + FLAGS + FILE_FLAGS.get(os.path.basename(src), []) + ['-c', src, '-o', obj]
     t0 = time.time()
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if verbose or r.returncode != 0:

@@ -14,6 +14,8 @@
 // Used by: DiT self-attention (non-causal, key padding via kv_len), LLM prefill and decode (causal,
 // GQA-packed: the 7 query heads of a KV head are stacked as rows so each K/V byte is read once,
 // optional key splits with (m, l, o) partials combined by attn_combine_kernel).
+#include <type_traits>
+
 #include "hvx_device.h"
 #include "hvx_kernels.h"
 
@@ -24,6 +26,12 @@ template <> struct Vec4<bf16_t> { typedef bf16x4 type; };
 template <> struct Vec4<float> { typedef f32x4 type; };
 __device__ __forceinline__ bf16x4 load4(const bf16_t* p) { return *reinterpret_cast<const bf16x4*>(p); }
 __device__ __forceinline__ f32x4 load4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// maxima of values that are never NaN here (scores and -inf masks): this file is built with -fno-honor-nans (build.py) so that
+// they become plain v_max / v_max3 without a canonicalising self-max in front of every operand
+__device__ __forceinline__ float fmax2(float a, float b) { return __builtin_fmaxf(a, b); }
+__device__ __forceinline__ float fmax3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 
 template <class T, int QT>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
@@ -306,7 +314,8 @@ __global__ void attn_combine_kernel(AttnArgs a) {
 // wave from L2.  Same register-resident S^T / P^T orientation as above.  Softmax runs on exp2 with the scale folded into one
 // fma per score, and the key-padding mask is only evaluated on the last tile.
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_dit_kernel(AttnArgs a) {
+template <int QR>                        // 16-row query tiles per wave: every K / V^T fragment read from LDS feeds QR MFMAs
+__global__ __launch_bounds__(256, 2) void attn_dit_kernel(AttnArgs a) {
     typedef bf16_t T;
     constexpr int KT = 64;                 // keys per tile
     constexpr int LD = 72;                 // LDS row stride (elements): 144 B keeps the 16 rows of a lane group on distinct 16-B slots
@@ -315,14 +324,14 @@ __global__ __launch_bounds__(256) void attn_dit_kernel(AttnArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     const int b = blockIdx.z, h = blockIdx.y;
-    const int row0 = blockIdx.x * 128 + wave * 32;
+    const int row0 = blockIdx.x * (64 * QR) + wave * (16 * QR);
     const int kv_len = a.kv_len ? a.kv_len[b] : a.kv_len_const;
     const T* __restrict__ kb = reinterpret_cast<const T*>(a.k) + (long long)b * a.k_bs + (long long)h * a.k_hs;
     const T* __restrict__ vb = reinterpret_cast<const T*>(a.vT) + (long long)b * a.v_bs + (long long)h * a.v_hs;
 
-    bf16x8 qf[2][2];
+    bf16x8 qf[QR][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < QR; ++i) {
         const int r = row0 + i * 16 + fr;
         if (r < a.n_rows) {
             const T* qp = reinterpret_cast<const T*>(a.q) + (long long)b * a.q_bs + (long long)h * a.q_hs + (long long)r * a.q_lo + fg * 8;
@@ -345,21 +354,115 @@ __global__ __launch_bounds__(256) void attn_dit_kernel(AttnArgs a) {
             rv[i] = load8(vb + (long long)(lrow + i * 32) * a.v_ld + key0 + lchunk);
         }
     };
+    // V^T goes into LDS with the keys of every 32-key MFMA step permuted so that the 8 keys a lane needs for its P^T k-slots
+    // (4g..4g+3 of the first 16-key score tile and of the second) are adjacent: position = 32m + 8g + 4h + r for key = 32m + 16h +
+    // 4g + r.  The PV operand is then one conflict-free 16-byte LDS read instead of two 8-byte reads with 2-way bank conflicts.
+    const int vc = tid & 7;                                              // 8-key chunk: m = vc / 4, h = (vc % 4) / 2, g0 = 2 * (vc % 2)
+    const int vpos = (vc >> 2) * 32 + ((vc & 1) * 2) * 8 + ((vc >> 1) & 1) * 4;
     auto stash = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             store8(&Ks[buf][(lrow + i * 32) * LD + lchunk], rk[i]);
-            store8(&Vs[buf][(lrow + i * 32) * LD + lchunk], rv[i]);
+            bf16x4 lo, hi;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                lo[j] = rv[i][j];
+                hi[j] = rv[i][4 + j];
+            }
+            *reinterpret_cast<bf16x4*>(&Vs[buf][(lrow + i * 32) * LD + vpos]) = lo;
+            *reinterpret_cast<bf16x4*>(&Vs[buf][(lrow + i * 32) * LD + vpos + 8]) = hi;
         }
     };
 
-    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.0f, 0.0f};
-    f32x4 o_acc[2][4];
+    float m_run[QR];
+    f32x4 o_acc[QR][4], l_acc[QR];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < QR; ++i) {
+        m_run[i] = -INFINITY;
+        l_acc[i] = f32x4{0, 0, 0, 0};
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o_acc[i][dt] = f32x4{0, 0, 0, 0};
+    }
     const float c = a.scale * 1.4426950408889634f;                      // softmax(s * scale) == exp2(s * c - m * c)
+    const f32x2 c2 = {c, c};
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = f32_to_bf16(1.0f);
+
+    // One 64-key tile.  The softmax is the bottleneck of this kernel, not the matrix cores (head_dim 64: 32 MFMAs against ~32
+    // exp2 + ~100 other VALU instructions per wave and tile), so everything that can leave the vector ALU does: the row sums are
+    // one more MFMA against a fragment of ones (which also sums exactly the bf16 probabilities that multiply V), the key-padding
+    // mask exists only in the peeled last tile, scale and max subtraction are packed fp32 FMAs.
+    auto tile = [&](int buf, int key0, auto tail_tag) {
+        constexpr bool TAIL = decltype(tail_tag)::value;
+        // S^T = K Q^T for all query tiles of the wave; each K fragment is read from LDS once and used QR times
+        f32x4 s[QR][4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            const bf16x8 k0 = load8(&Ks[buf][(kt * 16 + fr) * LD + fg * 8]);
+            const bf16x8 k1 = load8(&Ks[buf][(kt * 16 + fr) * LD + 32 + fg * 8]);
+#pragma unroll
+            for (int i = 0; i < QR; ++i) {
+                s[i][kt] = f32x4{0, 0, 0, 0};
+                mma32(s[i][kt], k0, qf[i][0]);
+                mma32(s[i][kt], k1, qf[i][1]);
+            }
+        }
+        bf16x8 pf[QR][2];
+#pragma unroll
+        for (int i = 0; i < QR; ++i) {
+            if constexpr (TAIL) {
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (key0 + kt * 16 + fg * 4 + r >= kv_len) s[i][kt][r] = -INFINITY;
+            }
+            float mx = fmax3(fmax3(s[i][0][0], s[i][0][1], s[i][0][2]), fmax3(s[i][0][3], s[i][1][0], s[i][1][1]),
+                             fmax3(s[i][1][2], s[i][1][3], s[i][2][0]));
+            mx = fmax3(mx, fmax3(s[i][2][1], s[i][2][2], s[i][2][3]), fmax3(s[i][3][0], s[i][3][1], s[i][3][2]));
+            mx = fmax2(mx, s[i][3][3]);
+            mx = fmax2(mx, __shfl_xor(mx, 16, 64));                   // the four lanes of a row must end up with the same maximum
+            mx = fmax2(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmax2(m_run[i], mx * c);               // running max in scaled (log2) units; c > 0
+            const f32x2 nm = {-m_new, -m_new};
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                float p[8];
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const f32x4 sv = s[i][2 * m + hh];
+                    const f32x2 lo = f32x2{sv[0], sv[1]} * c2 + nm, hi = f32x2{sv[2], sv[3]} * c2 + nm;     // s == -inf -> exp2 -> 0
+                    p[4 * hh + 0] = __builtin_amdgcn_exp2f(lo[0]);
+                    p[4 * hh + 1] = __builtin_amdgcn_exp2f(lo[1]);
+                    p[4 * hh + 2] = __builtin_amdgcn_exp2f(hi[0]);
+                    p[4 * hh + 3] = __builtin_amdgcn_exp2f(hi[1]);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pf[i][m][e] = f32_to_bf16(p[e]);
+            }
+            if (__any(m_new != m_run[i])) {                              // wave-uniform: most tiles do not raise any row's maximum
+                const float alpha = __builtin_amdgcn_exp2f(m_run[i] - m_new);     // exp2(-inf) == 0 on the first tile
+                l_acc[i] *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) o_acc[i][dt] *= alpha;
+                m_run[i] = m_new;
+            }
+        }
+        // O^T += V^T P^T; each V^T fragment is read from LDS once and used for all query tiles.  l += 1^T P^T on the matrix cores.
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int i = 0; i < QR; ++i) mma32(l_acc[i], ones, pf[i][m]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const bf16x8 v = load8(&Vs[buf][(dt * 16 + fr) * LD + m * 32 + fg * 8]);
+#pragma unroll
+                for (int i = 0; i < QR; ++i) mma32(o_acc[i][dt], v, pf[i][m]);
+            }
+    };
 
     const int n_tiles = (kv_len + KT - 1) / KT;
     if (n_tiles > 0) {
@@ -367,85 +470,19 @@ __global__ __launch_bounds__(256) void attn_dit_kernel(AttnArgs a) {
         stash(0);
     }
     __syncthreads();
-    for (int it = 0; it < n_tiles; ++it) {
+    const int n_full = kv_len / KT;                                    // the loop holds full tiles only; the masked tile is peeled
+    for (int it = 0; it < n_full; ++it) {
         const int buf = it & 1, key0 = it * KT;
         const bool more = (it + 1) < n_tiles;
         if (more) gload(key0 + KT);
-        const bool tail = (key0 + KT) > kv_len;
-        // S^T = K Q^T for both query tiles; each K fragment is read from LDS once and used twice
-        f32x4 s[2][4];
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-            const bf16x8 k0 = load8(&Ks[buf][(kt * 16 + fr) * LD + fg * 8]);
-            const bf16x8 k1 = load8(&Ks[buf][(kt * 16 + fr) * LD + 32 + fg * 8]);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                s[i][kt] = f32x4{0, 0, 0, 0};
-                mma32(s[i][kt], k0, qf[i][0]);
-                mma32(s[i][kt], k1, qf[i][1]);
-            }
-        }
-        bf16x8 pf[2][2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            float mx = -INFINITY;
-            if (tail) {
-#pragma unroll
-                for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if (key0 + kt * 16 + fg * 4 + r >= kv_len) s[i][kt][r] = -INFINITY;
-                        mx = fmaxf(mx, s[i][kt][r]);
-                    }
-            } else {
-#pragma unroll
-                for (int kt = 0; kt < 4; ++kt) mx = fmaxf(mx, fmaxf(fmaxf(s[i][kt][0], s[i][kt][1]), fmaxf(s[i][kt][2], s[i][kt][3])));
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run[i], mx * c);               // running max in scaled (log2) units; c > 0
-            float psum = 0.0f;
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float p = __builtin_amdgcn_exp2f(fmaf(s[i][2 * m + (e >> 2)][e & 3], c, -m_new));      // s == -inf -> 0
-                    psum += p;
-                    pf[i][m][e] = f32_to_bf16(p);
-                }
-            if (__any(m_new != m_run[i])) {                              // wave-uniform: most tiles do not raise any row's maximum
-                const float alpha = __builtin_amdgcn_exp2f(m_run[i] - m_new);     // exp2(-inf) == 0 on the first tile
-                l_run[i] *= alpha;
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) o_acc[i][dt] *= alpha;
-                m_run[i] = m_new;
-            }
-            l_run[i] += psum;
-        }
-        // O^T += V^T P^T; each V^T fragment is read from LDS once and used for both query tiles
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                const T* vp = &Vs[buf][(dt * 16 + fr) * LD + m * 32 + fg * 4];
-                const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vp), hi = *reinterpret_cast<const bf16x4*>(vp + 16);
-                bf16x8 v;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    v[j] = lo[j];
-                    v[4 + j] = hi[j];
-                }
-#pragma unroll
-                for (int i = 0; i < 2; ++i) mma32(o_acc[i][dt], v, pf[i][m]);
-            }
+        tile(buf, key0, std::false_type{});
         if (more) stash(buf ^ 1);
         __syncthreads();
     }
+    if (n_full < n_tiles) tile(n_full & 1, n_full * KT, std::true_type{});
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        float l = l_run[i];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
+    for (int i = 0; i < QR; ++i) {
+        const float l = l_acc[i][0];                                   // every row of the ones-MFMA holds the column (query) sum
         const int r = row0 + i * 16 + fr;
         if (r >= a.n_rows) continue;
         const float inv = l > 0.0f ? 1.0f / l : 0.0f;
@@ -466,7 +503,11 @@ static int launch_t(const AttnArgs& a, hipStream_t s) {
         (a.v_ld & 63) == 0) {
         const double fl = 4.0 * a.n_rows * (double)a.kv_len_const * 64.0 * a.heads * a.batch;
         const int slot = prof_begin(PK_ATTN, a.kv_len ? 0.0 : fl, s);
-        hipLaunchKernelGGL(attn_dit_kernel, dim3((a.n_rows + 127) / 128, a.heads, a.batch), dim3(256), 0, s, a);
+        // 64 rows per wave halve the LDS reads and the K/V staging traffic per flop; shorter sequences keep 32 rows (more workgroups)
+        static const int force_qr = getenv("HVX_ATTN_QR") ? atoi(getenv("HVX_ATTN_QR")) : 0;
+        const int qr = force_qr ? force_qr : (a.n_rows * a.heads * a.batch >= 256 * 256 * 2 ? 4 : 2);
+        if (qr == 4) hipLaunchKernelGGL(attn_dit_kernel<4>, dim3((a.n_rows + 255) / 256, a.heads, a.batch), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(attn_dit_kernel<2>, dim3((a.n_rows + 127) / 128, a.heads, a.batch), dim3(256), 0, s, a);
         prof_end(slot, s);
         return hipGetLastError() == hipSuccess ? 0 : (set_error("attention launch failed"), -1);
     }

@@ -2,10 +2,10 @@
 //
 // Workgroup = 256 threads = 4 waves.  Block tile BM x BN, K-step 32.  Both operands are
 // K-contiguous, so one 16-byte (bf16) / 32-byte (f32) vector per lane is exactly an MFMA
-// fragment row; tiles are staged global -> registers -> LDS with the next K-step's global
-// loads issued before the current step's MFMAs (register prefetch).  LDS rows are padded
-// (bf16: 80 B, f32: 144 B) so that the 16 rows read by one ds_read_b128 lane group fall on
-// 16 distinct 16-byte slots.  The conv index map (tap, dilation, stride, nearest-upsample,
+// fragment row.  bf16 tiles are staged by LDS-DMA (global_load_lds_dwordx4, double-buffered,
+// swizzle on the source address); fp32 tiles go global -> registers -> LDS with the next
+// K-step's loads issued before the current step's MFMAs and LDS rows padded (144 B) so that
+// the 16 rows read by one ds_read_b128 lane group fall on 16 distinct 16-byte slots.  The conv index map (tap, dilation, stride, nearest-upsample,
 // zero padding) lives in the A-tile loader; every epilogue variant is fused.
 #include <stdlib.h>
 
@@ -18,11 +18,14 @@ namespace hvx {
 
 template <class T> struct LdsPad { static constexpr int value = (sizeof(T) == 2) ? 8 : 4; };
 
-template <class T, int BM, int BN, int WM, int WN, int EPI, int BK, int NBUF = 1>
+// a 64-byte row of zeros: where the LDS-DMA form needs a padding / out-of-range row it points the lane's source address here
+__device__ __attribute__((aligned(64))) const float g_zero_row[16] = {0};
+
+template <class T, int BM, int BN, int WM, int WN, int EPI, int BK, int NBUF = 1, int GLDS = 0>
 __global__ __launch_bounds__(256) void gemm_tiled_kernel(GemmArgs a) {
     // BK = 64 (bf16, 144-byte LDS rows) halves the barriers and global-load round trips per flop; BK = 32 serves fp32 and the
     // convs whose padded channel count is not a multiple of 64 (a K-step must not straddle two taps)
-    constexpr int LDK = BK + LdsPad<T>::value;
+    constexpr int LDK = GLDS ? BK : BK + LdsPad<T>::value;      // the LDS-DMA image is lane-linear: no padding, swizzled instead
     constexpr int MT = WM / 16, NT = WN / 16;
     constexpr int WAVES_N = BN / WN;
     static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
@@ -101,19 +104,13 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(GemmArgs a) {
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
 
     V8 ra[A_VECS], rb[B_VECS];
-    load_a(0, ra);
-    load_b(0, rb);
-    stash(0, ra, rb);
-    __syncthreads();
-
+    if constexpr (!GLDS) {
+        load_a(0, ra);
+        load_b(0, rb);
+        stash(0, ra, rb);
+    }
     const int fr = lane & 15, fg = lane >> 4;
-    for (int kc = 0; kc < nk; ++kc) {
-        const bool more = (kc + 1) < nk;
-        const int cur = (NBUF == 2) ? (kc & 1) : 0;
-        if (more) {
-            load_a(kc + 1, ra);
-            load_b(kc + 1, rb);
-        }
+    auto compute = [&](int cur) {
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 32) {
             V8 af[MT], bf[NT];
@@ -126,11 +123,89 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(GemmArgs a) {
 #pragma unroll
                 for (int j = 0; j < NT; ++j) mma32(acc[i][j], af[i], bf[j]);
         }
-        if constexpr (NBUF == 2) {
-            // the other buffer was last read one iteration ago and every wave has passed the barrier since: one barrier per K-step
-            if (more) stash(cur ^ 1, ra, rb);
+    };
+    if constexpr (GLDS) {
+        // LDS-DMA staging (global_load_lds_dwordx4): no staging registers, no ds_write pass.  A wave instruction deposits its 64 lanes'
+        // 16 bytes back to back, so the LDS image is lane-linear: [row][4 chunks of 8 bf16], 16 rows per instruction, and the bank
+        // spread that padding gives the register form comes from a swizzle applied to the SOURCE address instead: the lane that
+        // fills slot s of row r fetches chunk s ^ f(r), f(r) = (-(r >> 2)) & 3, which puts the 16 rows of every ds_read_b128 lane
+        // group on 16 distinct 16-byte slots; the four lanes of a row still fetch the same 64 contiguous bytes.
+        static_assert(!GLDS || (sizeof(T) == 2 && BK == 32 && NBUF == 2 && BM % 32 == 0 && BN % 32 == 0), "LDS-DMA form: bf16, BK = 32");
+        typedef __attribute__((address_space(3))) void* lds_ptr;
+        typedef const __attribute__((address_space(1))) void* glb_ptr;
+        const int lrow = lane >> 2, lslot = lane & 3;
+        const int gchunk = lslot ^ ((-(lrow >> 2)) & 3);
+        constexpr int A_INS = BM / 64, B_INS = BN / 64;            // instructions per wave and tile: 16 rows each, 4 waves
+        auto issue = [&](int kc, int buf) {
+            const int k0 = kc * BK;
+            const int tap = k0 / a.cin_pad;
+            const int ci = k0 - tap * a.cin_pad + gchunk * 8;
+#pragma unroll
+            for (int q = 0; q < A_INS; ++q) {
+                const int r16 = (wave * A_INS + q) * 16;
+                const int m = m0 + r16 + lrow;
+                const long long idx = (long long)m * a.conv_stride + (long long)tap * a.conv_dil - a.pad_left;
+                const bool ok = m < a.M && idx >= 0 && idx < in_span;
+                const long long src = (a.up == 1) ? idx : idx / a.up;
+                const void* gp = ok ? static_cast<const void*>(Ab + src * a.lda + ci) : static_cast<const void*>(g_zero_row);
+                __builtin_amdgcn_global_load_lds((glb_ptr)gp, (lds_ptr)(&As[buf][r16 * LDK]), 16, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < B_INS; ++q) {
+                const int r16 = (wave * B_INS + q) * 16;
+                const int n = n0 + r16 + lrow;
+                const void* gp = n < a.N ? static_cast<const void*>(Wb + (long long)n * a.K + k0 + gchunk * 8) : static_cast<const void*>(g_zero_row);
+                __builtin_amdgcn_global_load_lds((glb_ptr)gp, (lds_ptr)(&Bs[buf][r16 * LDK]), 16, 0, 0);
+            }
+        };
+        const int fsw = (fg ^ ((-(fr >> 2)) & 3)) * 8;               // slot of this lane's fragment chunk in its row
+        auto compute_swz = [&](int cur) {
+            V8 af[MT], bf[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) af[i] = load8(&As[cur][(wm0 + i * 16 + fr) * LDK + fsw]);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bf[j] = load8(&Bs[cur][(wn0 + j * 16 + fr) * LDK + fsw]);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) mma32(acc[i][j], af[i], bf[j]);
+        };
+        issue(0, 0);
+        for (int kc = 0; kc < nk; ++kc) {
+            __syncthreads();                                 // tile kc has landed (the barrier drains the DMA queue); buffer (kc+1)&1 is free
+            if (kc + 1 < nk) issue(kc + 1, (kc + 1) & 1);
+            compute_swz(kc & 1);
+        }
+        __syncthreads();                                     // the epilogue reuses the tile memory as staging
+    } else if constexpr (NBUF == 2) {
+        // One barrier per K-step, one register set: after the barrier (every wave has finished reading the buffer about to be
+        // overwritten, and the tile staged last step is visible) the registers holding tile t+1 go to LDS and are re-issued at once
+        // for tile t+2, whose global loads then have the whole MFMA phase of tile t and the next barrier to land.
+        if (nk > 1) {
+            load_a(1, ra);
+            load_b(1, rb);
+        }
+        for (int kc = 0; kc < nk; ++kc) {
             __syncthreads();
-        } else {
+            if (kc + 1 < nk) {
+                stash((kc + 1) & 1, ra, rb);
+                if (kc + 2 < nk) {
+                    load_a(kc + 2, ra);
+                    load_b(kc + 2, rb);
+                }
+            }
+            compute(kc & 1);
+        }
+        __syncthreads();                                 // the epilogue reuses the tile memory as staging
+    } else {
+        __syncthreads();
+        for (int kc = 0; kc < nk; ++kc) {
+            const bool more = (kc + 1) < nk;
+            if (more) {
+                load_a(kc + 1, ra);
+                load_b(kc + 1, rb);
+            }
+            compute(0);
             __syncthreads();
             if (more) {
                 stash(0, ra, rb);
@@ -360,23 +435,30 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(GemmArgs a) {
     }
 }
 
-template <class T, int BM, int BN, int WM, int WN, int BK, int NBUF = 1>
+template <class T, int BM, int BN, int WM, int WN, int BK, int NBUF = 1, int GLDS = 0>
 static int launch_cfg_bk(const GemmArgs& a, hipStream_t s) {
     dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, a.batch * a.groups);
     const int slot = prof_begin(sizeof(T) == 2 ? PK_GEMM : PK_GEMM_F32, 2.0 * a.M * a.N * (double)a.K * a.batch * a.groups, s);
     if (a.epi == EPI_GENERIC)
-        hipLaunchKernelGGL((gemm_tiled_kernel<T, BM, BN, WM, WN, EPI_GENERIC, BK, NBUF>), grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL((gemm_tiled_kernel<T, BM, BN, WM, WN, EPI_GENERIC, BK, NBUF, GLDS>), grid, dim3(256), 0, s, a);
     else
-        hipLaunchKernelGGL((gemm_tiled_kernel<T, BM, BN, WM, WN, EPI_QKV_DIT, BK, NBUF>), grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL((gemm_tiled_kernel<T, BM, BN, WM, WN, EPI_QKV_DIT, BK, NBUF, GLDS>), grid, dim3(256), 0, s, a);
     prof_end(slot, s);
     return hipGetLastError() == hipSuccess ? 0 : (set_error("gemm launch failed"), -1);
 }
 
 template <class T, int BM, int BN, int WM, int WN>
 static int launch_cfg(const GemmArgs& a, hipStream_t s) {
-    // Measured on MI355X (tools/bench_ops.py, DiT shapes): with this two-barrier structure BK = 64 is slower (180 vs 300 TF/s) and a
-    // double-buffered LDS (NBUF = 2, one barrier per K-step) changes nothing — the template keeps both knobs, only BK = 32 / NBUF = 1
-    // is instantiated.
+    // K-loop forms, measured on MI355X with tools/bench_ops.py on the DiT shapes (M = 11264, K = 1024..2048, 128x128 tiles):
+    //   registers -> LDS, two barriers per K-step            470-550 TF/s
+    //   registers -> LDS, double buffer, one barrier          480-575 TF/s   (write after the barrier, re-issue at once)
+    //   LDS-DMA (global_load_lds), double buffer              530-650 TF/s   <- bf16 default
+    //   BK = 64 with either register form                     340-460 TF/s   (LDS footprint halves the resident workgroups)
+    static const int v = getenv("HVX_GEMM_VAR") ? atoi(getenv("HVX_GEMM_VAR")) : 0;
+    if constexpr (sizeof(T) == 2) {
+        if (v == 0) return launch_cfg_bk<T, BM, BN, WM, WN, 32, 2, 1>(a, s);
+    }
+    if (v == 1) return launch_cfg_bk<T, BM, BN, WM, WN, 32, 2>(a, s);
     return launch_cfg_bk<T, BM, BN, WM, WN, 32>(a, s);
 }
 
