@@ -454,12 +454,10 @@ static int launch_cfg(const GemmArgs& a, hipStream_t s) {
     //   registers -> LDS, double buffer, one barrier          480-575 TF/s   (write after the barrier, re-issue at once)
     //   LDS-DMA (global_load_lds), double buffer              530-650 TF/s   <- bf16 default
     //   BK = 64 with either register form                     340-460 TF/s   (LDS footprint halves the resident workgroups)
-    static const int v = getenv("HVX_GEMM_VAR") ? atoi(getenv("HVX_GEMM_VAR")) : 0;
-    if constexpr (sizeof(T) == 2) {
-        if (v == 0) return launch_cfg_bk<T, BM, BN, WM, WN, 32, 2, 1>(a, s);
-    }
-    if (v == 1) return launch_cfg_bk<T, BM, BN, WM, WN, 32, 2>(a, s);
-    return launch_cfg_bk<T, BM, BN, WM, WN, 32>(a, s);
+    // fp32 (HiFT shapes): the two-barrier register form is the fastest of the three (the double buffer costs 10-25 % there).
+    // (only the chosen form of each dtype is instantiated: every extra one costs a minute of build time over the tile configurations)
+    if constexpr (sizeof(T) == 2) return launch_cfg_bk<T, BM, BN, WM, WN, 32, 2, 1>(a, s);
+    else return launch_cfg_bk<T, BM, BN, WM, WN, 32>(a, s);
 }
 
 template <class T>
