@@ -81,6 +81,16 @@ class HiftConfig(C.Structure):
                 ('lrelu_slope', c_f32), ('audio_limit', c_f32)]
 
 
+class MatchaConfig(C.Structure):
+    _fields_ = [('in_channels', c_i32), ('out_channels', c_i32), ('n_stages', c_i32), ('channels', c_i32 * 4),
+                ('n_blocks', c_i32), ('n_mid', c_i32), ('heads', c_i32), ('ff_mult', c_i32), ('cv_variant', c_i32), ('max_t', c_i32)]
+
+
+class HifiGanConfig(C.Structure):
+    _fields_ = [('mel', c_i32), ('initial_channel', c_i32), ('n_up', c_i32), ('up_rates', c_i32 * 4), ('up_kernels', c_i32 * 4),
+                ('n_rb', c_i32), ('rb_kernels', c_i32 * 4), ('rb_dils', (c_i32 * 3) * 4)]
+
+
 # every symbol include/hvx.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     'hvx_abi_version': (c_i32, []),
@@ -109,6 +119,18 @@ SYMBOLS = {
     'hvx_cfm_estimator': (c_i32, [c_vp, c_vp, c_vp, c_sz, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'hvx_flow_set_mod_cache': (c_i32, [c_vp, c_vp, c_sz]),
     'hvx_cfm_solve': (c_i32, [c_vp, c_vp, c_vp, c_sz, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, C.POINTER(c_f32), C.POINTER(c_f32)]),
+    'hvx_matcha_create': (c_i32, [C.POINTER(MatchaConfig), C.POINTER(c_vp), c_i32, C.POINTER(c_vp)]),
+    'hvx_matcha_destroy': (None, [c_vp]),
+    'hvx_matcha_workspace_bytes': (c_sz, [c_vp, c_i32, c_i32]),
+    'hvx_matcha_estimator': (c_i32, [c_vp, c_vp, c_vp, c_sz, c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    'hvx_matcha_solve': (c_i32, [c_vp, c_vp, c_vp, c_sz, c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, C.POINTER(c_f32), C.POINTER(c_f32)]),
+    'hvx_hifigan_create': (c_i32, [C.POINTER(HifiGanConfig), C.POINTER(c_vp), c_i32, C.POINTER(c_vp)]),
+    'hvx_hifigan_destroy': (None, [c_vp]),
+    'hvx_hifigan_workspace_bytes': (c_sz, [c_vp, c_i32]),
+    'hvx_hifigan_forward': (c_i32, [c_vp, c_vp, c_vp, c_sz, c_vp, c_i32, c_vp]),
+    'hvx_denoise_workspace_bytes': (c_sz, [c_i32, c_i32, c_i32]),
+    'hvx_stft_magnitude': (c_i32, [c_vp, c_vp, c_sz, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    'hvx_denoise': (c_i32, [c_vp, c_vp, c_sz, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp]),
     'hvx_hift_create': (c_i32, [C.POINTER(HiftConfig), C.POINTER(c_vp), c_i32, C.POINTER(c_vp)]),
     'hvx_hift_destroy': (None, [c_vp]),
     'hvx_hift_workspace_bytes': (c_sz, [c_vp, c_i32]),

@@ -117,6 +117,70 @@ class HiftConfig:
 
 
 @dataclass
+class MatchaConfig:
+    """Matcha-TTS flow decoder (matcha/models/components/decoder.py:201-300; CosyVoice variant cosyvoice/flow/decoder.py:88-208)."""
+    mel: int = 80
+    spk_dim: int = 0                    # width of the broadcast speaker vector packed after mu (0: none)
+    use_cond: bool = False              # CosyVoice variant: a (B, mel, T) `cond` packed last
+    channels: tuple = (256, 256)
+    n_blocks: int = 1
+    num_mid_blocks: int = 2
+    num_heads: int = 2
+    head_dim: int = 64
+    ff_mult: int = 4                    # FeedForward(mult=4) is fixed in BasicTransformerBlock (transformer.py:236)
+    cv_variant: bool = False            # key-padding masks + skip trimming (ConditionalDecoder.forward)
+    n_timesteps: int = 10
+    temperature: float = 0.667
+    max_t: int = 8192
+
+    @property
+    def in_channels(self):
+        return 2 * self.mel + self.spk_dim + (self.mel if self.use_cond else 0)
+
+
+@dataclass
+class HifiGanConfig:
+    """HiFi-GAN v1 (matcha/hifigan/config.py:1-28)."""
+    mel: int = 80
+    initial_channel: int = 512
+    upsample_rates: tuple = (8, 8, 2, 2)
+    upsample_kernel_sizes: tuple = (16, 16, 4, 4)
+    resblock_kernel_sizes: tuple = (3, 7, 11)
+    resblock_dilations: tuple = ((1, 3, 5), (1, 3, 5), (1, 3, 5))
+    sampling_rate: int = 22050
+    n_fft: int = 1024                   # Denoiser filter_length
+    n_overlap: int = 4                  # Denoiser hop = n_fft / n_overlap
+
+    @property
+    def upsample(self):
+        u = 1
+        for r in self.upsample_rates:
+            u *= r
+        return u
+
+
+def matcha_config() -> MatchaConfig:
+    return MatchaConfig()
+
+
+def cv2_decoder_config() -> MatchaConfig:
+    """CosyVoice-2 ConditionalDecoder dims (cosyvoice/flow/flow.py:36-40): in 320 = x + mu + spks(80) + cond."""
+    return MatchaConfig(spk_dim=80, use_cond=True, channels=(256,), n_blocks=4, num_mid_blocks=12, num_heads=8, cv_variant=True)
+
+
+def tiny_matcha_config(cv=False) -> MatchaConfig:
+    if cv:
+        return MatchaConfig(spk_dim=80, use_cond=True, channels=(64, 128), n_blocks=1, num_mid_blocks=1, num_heads=2, cv_variant=True,
+                            n_timesteps=3, max_t=512)
+    return MatchaConfig(spk_dim=64, channels=(64, 64), n_blocks=1, num_mid_blocks=1, num_heads=2, n_timesteps=3, max_t=512)
+
+
+def tiny_hifigan_config() -> HifiGanConfig:
+    return HifiGanConfig(initial_channel=128, upsample_rates=(4, 2), upsample_kernel_sizes=(8, 4), resblock_kernel_sizes=(3, 5),
+                         resblock_dilations=((1, 3, 5), (1, 3, 5)), n_fft=64, n_overlap=2)
+
+
+@dataclass
 class HvxConfig:
     llm: LLMConfig = field(default_factory=LLMConfig)
     flow: FlowConfig = field(default_factory=FlowConfig)

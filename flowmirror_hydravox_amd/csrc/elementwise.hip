@@ -374,4 +374,208 @@ int launch_rows_to_dtype(const float* src, int ld_src, void* dst, int dd, int ld
     return hipGetLastError() == hipSuccess ? 0 : (set_error("rows_to_dtype launch failed"), -1);
 }
 
+// =====================================================================================================================
+// Matcha-TTS / HiFi-GAN v1 family
+// =====================================================================================================================
+
+// ---- decoder input: pack [x, mu, spks, cond] (decoder.py:380-384; cv/flow/decoder.py:232-238) as time-major rows -------
+__global__ void pack_rows_kernel(PackRowsArgs a) {
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * blockDim.y + threadIdx.y;
+    if (t >= a.T) return;
+    float* y = a.dst + ((long long)b * a.T + t) * a.ld;
+    for (int c = threadIdx.x; c < a.ld; c += blockDim.x) {
+        float v = 0.0f;
+        int base = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ck = a.channels[k];
+            if (ck > 0 && c >= base && c < base + ck) {
+                const int ch = c - base;
+                v = a.broadcast[k] ? a.src[k][(long long)b * ck + ch] : a.src[k][((long long)b * ck + ch) * a.T + t];
+            }
+            base += ck;
+        }
+        y[c] = v;
+    }
+}
+int launch_pack_rows(const PackRowsArgs& a, int B, hipStream_t s) {
+    if (B <= 0 || a.T <= 0) return 0;
+    dim3 block(64, 4), grid((a.T + 3) / 4, B);
+    hipLaunchKernelGGL(pack_rows_kernel, grid, block, 0, s, a);
+    return hipGetLastError() == hipSuccess ? 0 : (set_error("pack_rows launch failed"), -1);
+}
+
+// ---- GroupNorm over (C / G channels x T rows) + Mish + row mask + per-(batch, channel) bias (decoder.py:40-75) ---------
+// pass 1: partial (sum, sum of squares) per (batch, group, 64-row chunk); pass 2: every workgroup folds the partials of its
+// batch in double (fixed order) and normalises its rows.  y = (act((x - mean) * rstd * gamma + beta) + tbias[b][c]) * [t < len]
+constexpr int GN_CHUNK = 64;
+__global__ __launch_bounds__(256) void groupnorm_partial_kernel(const float* x, int ld, int T, int C, int G, double* part) {
+    const int chunk = blockIdx.x, g = blockIdx.y, b = blockIdx.z;
+    const int Cg = C / G, n_chunks = gridDim.x;
+    // the statistics run over ALL T rows of the conv output, padded rows included: the reference masks the conv's input and the
+    // block's output, not what GroupNorm sees (decoder.py:52-54)
+    const int r0 = chunk * GN_CHUNK, r1 = min(r0 + GN_CHUNK, T);
+    float s1 = 0.0f, s2 = 0.0f;
+    const int n = max(r1 - r0, 0) * Cg;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int r = r0 + i / Cg, c = g * Cg + i % Cg;
+        const float v = x[((long long)b * T + r) * ld + c];
+        s1 += v;
+        s2 += v * v;
+    }
+    __shared__ float red[2][4];
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = s1;
+        red[1][threadIdx.x >> 6] = s2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double* p = part + (((long long)b * G + g) * n_chunks + chunk) * 2;
+        p[0] = (double)red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        p[1] = (double)red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    }
+}
+__global__ __launch_bounds__(256) void groupnorm_apply_kernel(const float* x, int ld, int T, int C, int G, const int* len, const double* part,
+                                                              int n_chunks, const float* gamma, const float* beta, float eps,
+                                                              const float* tbias, int act, float* y, int ldy) {
+    const int b = blockIdx.y;
+    const int Cg = C / G;
+    const int tlen = len ? min(len[b], T) : T;
+    __shared__ float s_mean[64], s_rstd[64];
+    if (threadIdx.x < G) {
+        double s1 = 0.0, s2 = 0.0;
+        const double* p = part + ((long long)b * G + threadIdx.x) * n_chunks * 2;
+        for (int i = 0; i < n_chunks; ++i) {
+            s1 += p[2 * i];
+            s2 += p[2 * i + 1];
+        }
+        const double cnt = (double)T * Cg;
+        const double mean = s1 / cnt;
+        const double var = s2 / cnt - mean * mean;
+        s_mean[threadIdx.x] = (float)mean;
+        s_rstd[threadIdx.x] = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + (double)eps));
+    }
+    __syncthreads();
+    const int rows_per_block = 8;
+    const int r0 = blockIdx.x * rows_per_block;
+    for (int i = threadIdx.x; i < rows_per_block * C; i += 256) {
+        const int r = r0 + i / C, c = i % C;
+        if (r >= T) break;
+        const int g = c / Cg;
+        const float xv = x[((long long)b * T + r) * ld + c];
+        float v = (xv - s_mean[g]) * s_rstd[g] * gamma[c] + beta[c];
+        v = act_apply(act, v, 0.0f, 1.0f);
+        if (tbias) v += tbias[(long long)b * C + c];       // h += mlp(t): the next block masks its input again, so masked rows stay 0
+        if (r >= tlen) v = 0.0f;
+        y[((long long)b * T + r) * ldy + c] = v;
+    }
+}
+size_t groupnorm_ws_bytes(int B, int T, int G) { return (size_t)B * G * ((T + GN_CHUNK - 1) / GN_CHUNK) * 2 * sizeof(double); }
+int launch_groupnorm_act(const float* x, int ld, int B, int T, int C, int G, const int* len, const float* gamma, const float* beta, float eps,
+                         const float* tbias, int act, float* y, int ldy, void* ws, hipStream_t s) {
+    if (B <= 0 || T <= 0) return 0;
+    if (G < 1 || G > 64 || C % G) return set_error("groupnorm: C=%d groups=%d", C, G), -1;
+    const int n_chunks = (T + GN_CHUNK - 1) / GN_CHUNK;
+    double* part = reinterpret_cast<double*>(ws);
+    hipLaunchKernelGGL(groupnorm_partial_kernel, dim3(n_chunks, G, B), dim3(256), 0, s, x, ld, T, C, G, part);
+    hipLaunchKernelGGL(groupnorm_apply_kernel, dim3((T + 7) / 8, B), dim3(256), 0, s, x, ld, T, C, G, len, part, n_chunks, gamma, beta, eps, tbias,
+                       act, y, ldy);
+    return hipGetLastError() == hipSuccess ? 0 : (set_error("groupnorm launch failed"), -1);
+}
+
+// ---- x * mask: zero the rows at and beyond len[b] (decoder.py:405, 441-443) ---------------------------------------------------
+__global__ void mask_rows_kernel(float* x, int ld, int T, int C, const int* len) {
+    const int b = blockIdx.y;
+    const int r = blockIdx.x * blockDim.y + threadIdx.y;
+    if (r >= T || r < len[b]) return;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) x[((long long)b * T + r) * ld + c] = 0.0f;
+}
+int launch_mask_rows(float* x, int ld, int B, int T, int C, const int* len, hipStream_t s) {
+    if (!len || B <= 0 || T <= 0) return 0;
+    hipLaunchKernelGGL(mask_rows_kernel, dim3((T + 3) / 4, B), dim3(64, 4), 0, s, x, ld, T, C, len);
+    return hipGetLastError() == hipSuccess ? 0 : (set_error("mask_rows launch failed"), -1);
+}
+
+// ---- x += dt * v on (mel, T) with v given as time-major rows [T][ldv] (flow_matching.py:78-81) ----------------------------
+__global__ void euler_rows_kernel(float* x, const float* v, int ldv, float dt, int T, int mel, long long x_bs, long long v_bs) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T * mel) return;
+    const int c = i / T, t = i - c * T;
+    x[b * x_bs + i] += dt * v[b * v_bs + (long long)t * ldv + c];
+}
+int launch_euler_rows(float* x, const float* v, int ldv, float dt, int B, int T, int mel, hipStream_t s) {
+    if (B <= 0 || T <= 0) return 0;
+    hipLaunchKernelGGL(euler_rows_kernel, dim3((T * mel + 255) / 256, B), dim3(256), 0, s, x, v, ldv, dt, T, mel, (long long)mel * T, (long long)T * ldv);
+    return hipGetLastError() == hipSuccess ? 0 : (set_error("euler_rows launch failed"), -1);
+}
+
+// ---- Denoiser (denoiser.py:57-64): reflect padding of torch.stft(center=True), spectral subtraction, overlap-add ---------------
+__global__ void reflect_pad_kernel(const float* x, float* y, int L, int pad, int total) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int j = i - pad;
+    if (j < 0) j = -j;
+    if (j >= L) j = 2 * (L - 1) - j;
+    y[i] = (j >= 0 && j < L) ? x[j] : 0.0f;
+}
+int launch_reflect_pad(const float* x, float* y, int L, int pad, int total, hipStream_t s) {
+    hipLaunchKernelGGL(reflect_pad_kernel, dim3((total + 255) / 256), dim3(256), 0, s, x, y, L, pad, total);
+    return hipGetLastError() == hipSuccess ? 0 : (set_error("reflect_pad launch failed"), -1);
+}
+// spec rows: [re 0..bins) | [im 0..bins).  |S| - strength * bias, clamped at 0, phase kept: S *= max(|S| - s*b, 0) / |S|
+__global__ void spectral_subtract_kernel(float* spec, int ld, int frames, int bins, const float* bias, float strength) {
+    const int f = blockIdx.y;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= bins) return;
+    float* row = spec + (long long)f * ld;
+    const float re = row[k], im = row[bins + k];
+    const float mag = sqrtf(re * re + im * im);
+    const float m2 = fmaxf(mag - bias[k] * strength, 0.0f);
+    // atan2(0, 0) == 0 in the reference: a zero bin comes back as (m2, 0)
+    const float fr = mag > 0.0f ? re * (m2 / mag) : m2, fi = mag > 0.0f ? im * (m2 / mag) : 0.0f;
+    row[k] = fr;
+    row[bins + k] = fi;
+}
+int launch_spectral_subtract(float* spec, int ld, int frames, int bins, const float* bias, float strength, hipStream_t s) {
+    if (frames <= 0) return 0;
+    hipLaunchKernelGGL(spectral_subtract_kernel, dim3((bins + 255) / 256, frames), dim3(256), 0, s, spec, ld, frames, bins, bias, strength);
+    return hipGetLastError() == hipSuccess ? 0 : (set_error("spectral_subtract launch failed"), -1);
+}
+__global__ void spectral_magnitude_kernel(const float* spec, int ld, int bins, float* mag) {
+    const int f = blockIdx.y;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= bins) return;
+    const float re = spec[(long long)f * ld + k], im = spec[(long long)f * ld + bins + k];
+    mag[(long long)f * bins + k] = sqrtf(re * re + im * im);
+}
+int launch_spectral_magnitude(const float* spec, int ld, int frames, int bins, float* mag, hipStream_t s) {
+    if (frames <= 0) return 0;
+    hipLaunchKernelGGL(spectral_magnitude_kernel, dim3((bins + 255) / 256, frames), dim3(256), 0, s, spec, ld, bins, mag);
+    return hipGetLastError() == hipSuccess ? 0 : (set_error("spectral_magnitude launch failed"), -1);
+}
+// torch.istft(center=True): y[n] = sum_f frame_f[n + n_fft/2 - f*hop] / sum_f w^2[...], n in [0, hop*(frames-1))
+__global__ void overlap_add_kernel(const float* fr, int ld, int frames, int n_fft, int hop, const float* wsq, float* y, int out_len) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= out_len) return;
+    const int p = n + n_fft / 2;
+    const int f1 = min(p / hop, frames - 1), f0 = max((p - n_fft) / hop + ((p - n_fft) >= 0 ? 1 : 0), 0);
+    float acc = 0.0f, env = 0.0f;
+    for (int f = f0; f <= f1; ++f) {
+        const int j = p - f * hop;
+        if (j < 0 || j >= n_fft) continue;
+        acc += fr[(long long)f * ld + j];
+        env += wsq[j];
+    }
+    y[n] = env > 1e-11f ? acc / env : acc;
+}
+int launch_overlap_add(const float* frames_buf, int ld, int frames, int n_fft, int hop, const float* wsq, float* y, int out_len, hipStream_t s) {
+    if (out_len <= 0) return 0;
+    hipLaunchKernelGGL(overlap_add_kernel, dim3((out_len + 255) / 256), dim3(256), 0, s, frames_buf, ld, frames, n_fft, hop, wsq, y, out_len);
+    return hipGetLastError() == hipSuccess ? 0 : (set_error("overlap_add launch failed"), -1);
+}
+
 }  // namespace hvx

@@ -279,10 +279,11 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(GemmArgs a) {
                     f32x4 v = {x[c4], x[c4 + 1], x[c4 + 2], x[c4 + 3]};
                     if (a.bias) v += ld4(a.bias + gc0 + c4);
                     if (a.act != ACT_NONE) {
-                        f32x4 al = {1.0f, 1.0f, 1.0f, 1.0f};
+                        f32x4 al = {1.0f, 1.0f, 1.0f, 1.0f}, be = {1.0f, 1.0f, 1.0f, 1.0f};
                         if (a.act_alpha) al = ld4(a.act_alpha + gc0 + c4);
+                        if (a.act == ACT_SNAKEBETA) be = ld4(a.act_alpha + a.groups * a.N + gc0 + c4);   // second half of the table
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = act_apply(a.act, v[e], a.act_param, al[e]);
+                        for (int e = 0; e < 4; ++e) v[e] = act_apply(a.act, v[e], a.act_param, al[e], be[e]);
                     }
                     if (a.gate) v *= ld4(a.gate + (long long)bz * a.gate_bs + gc0 + c4);
                     if (resp) v += ld4(resp + c4);
@@ -338,7 +339,8 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(GemmArgs a) {
                         const float al1 = a.act_alpha ? a.act_alpha[gc] : 1.0f;
                         al2 = a.act2_alpha ? a.act2_alpha[gc] : 1.0f;
                         const float gt = a.gate ? a.gate[(long long)bz * a.gate_bs + gc] : 1.0f;
-                        v = act_apply(a.act, x[c] + bi, a.act_param, al1) * gt;
+                        const float be1 = a.act == ACT_SNAKEBETA ? a.act_alpha[a.groups * a.N + gc] : 1.0f;
+                        v = act_apply(a.act, x[c] + bi, a.act_param, al1, be1) * gt;
                         if (a.res) v += a.res[(long long)bz * a.res_bs + (long long)(row + a.res_row_off) * a.ldres + gc];
                         if (a.res2) v += a.res2[(long long)bz * a.res2_bs + (long long)row * a.ldres2 + gc];
                         v *= a.scale;
@@ -386,7 +388,7 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(GemmArgs a) {
                 if (!wave_ok || row >= a.M) return;
 #pragma unroll
                 for (int c = 0; c < 16; ++c) x[c] += a.bias ? a.bias[cw + pcs + c] : 0.0f;
-                if (c0 < 64) {
+                if (c0 < 64 && a.rope_cos) {                 // (no table: plain multi-head QKV, e.g. the Matcha transformer blocks)
 #pragma unroll
                     for (int c = 0; c < 16; c += 2) {
                         const float cs = a.rope_cos[(long long)row * 32 + ((d0 + c) >> 1)], sn = a.rope_sin[(long long)row * 32 + ((d0 + c) >> 1)];

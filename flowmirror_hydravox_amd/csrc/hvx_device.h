@@ -88,9 +88,10 @@ enum Act : int {
     ACT_SNAKE = 6,       // x + sin^2(a x) / (a + 1e-9), a per col  (activation.py:73-84)
     ACT_TANH = 7,
     ACT_ABS = 8,         // |x|                                     (f0_predictor.py:103)
+    ACT_SNAKEBETA = 9,   // x + sin^2(a x) / (b + 1e-9); a = alpha[col], b = alpha[n_cols + col] (matcha transformer.py:17-80, exp() applied at load)
 };
 
-__device__ __forceinline__ float act_apply(int act, float x, float param, float alpha) {
+__device__ __forceinline__ float act_apply(int act, float x, float param, float alpha, float beta = 1.0f) {
     switch (act) {
         case ACT_GELU_TANH: {
             const float k0 = 0.7978845608028654f, k1 = 0.044715f;
@@ -107,6 +108,10 @@ __device__ __forceinline__ float act_apply(int act, float x, float param, float 
         case ACT_SNAKE: {
             const float s = sinf(x * alpha);
             return x + (1.0f / (alpha + 1e-9f)) * (s * s);
+        }
+        case ACT_SNAKEBETA: {
+            const float s = sinf(x * alpha);
+            return x + (1.0f / (beta + 1e-9f)) * (s * s);
         }
         case ACT_TANH: return tanhf(x);
         case ACT_ABS: return fabsf(x);

@@ -158,6 +158,23 @@ int launch_time_sinus(const float* t, void* y, int dtype, int B, int dim, hipStr
 int launch_cfg_euler(float* x, const float* v, int ldv, long long v_bs, float dt, float rate, int T, int mel, hipStream_t s);
 // generic strided f32 copy / cast helpers
 int launch_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long long n, hipStream_t s);
+
+// ---- Matcha / HiFi-GAN v1 family ----------------------------------------------------------------------
+struct PackRowsArgs {
+    const float* src[4]; int channels[4]; int broadcast[4];     // source k: (B, C_k, T) channel-major, or (B, C_k) broadcast over T
+    float* dst; int ld; int T;                                   // dst [B][T][ld], columns beyond the sources zero-filled
+};
+int launch_pack_rows(const PackRowsArgs& a, int B, hipStream_t s);
+size_t groupnorm_ws_bytes(int B, int T, int G);
+// y = (act(GroupNorm_G(x * mask)) + tbias[b][c]) * mask, mask = [t < len[b]]; x, y f32 time-major [B][T][ld]; ws >= groupnorm_ws_bytes
+int launch_groupnorm_act(const float* x, int ld, int B, int T, int C, int G, const int* len, const float* gamma, const float* beta, float eps,
+                         const float* tbias, int act, float* y, int ldy, void* ws, hipStream_t s);
+int launch_mask_rows(float* x, int ld, int B, int T, int C, const int* len, hipStream_t s);
+int launch_euler_rows(float* x, const float* v, int ldv, float dt, int B, int T, int mel, hipStream_t s);
+int launch_reflect_pad(const float* x, float* y, int L, int pad, int total, hipStream_t s);
+int launch_spectral_magnitude(const float* spec, int ld, int frames, int bins, float* mag, hipStream_t s);
+int launch_spectral_subtract(float* spec, int ld, int frames, int bins, const float* bias, float strength, hipStream_t s);
+int launch_overlap_add(const float* frames_buf, int ld, int frames, int n_fft, int hop, const float* wsq, float* y, int out_len, hipStream_t s);
 int launch_transpose_f32(const float* src, float* dst, int rows, int cols, int ld_src, int ld_dst, hipStream_t s);   // dst[c][r] = src[r][c]
 int launch_rows_to_dtype(const float* src, int ld_src, void* dst, int dst_dtype, int ld_dst, int rows, int cols, int cols_pad, hipStream_t s);
 

@@ -83,3 +83,45 @@ def fold_weight_norm(sd, name):
         v = sd[name + '.parametrizations.weight.original1'].float()
         return v * (g / v.norm(2, dim=(1, 2), keepdim=True))
     return sd[name + '.weight'].float()
+
+
+def convtranspose_phases(w, stride, padding):
+    """ConvTranspose1d weight [Cin][Cout][k] -> [stride][Cout][k/stride taps][Cin_pad32]: output phase p (rows t*stride + p) is a
+    convolution over the input rows t + c_p - (taps-1) .. t + c_p with c_p = (p + padding) // stride; tap tau multiplies
+    w[:, :, (p + padding) % stride + stride * (taps - 1 - tau)]   (y[n] = sum_i x[i] w[n - i*stride + padding])."""
+    cin, cout, k = w.shape
+    assert k % stride == 0
+    taps = k // stride
+    cp = (cin + 31) // 32 * 32
+    out = w.new_zeros(stride, cout, taps, cp)
+    for p in range(stride):
+        j0 = (p + padding) % stride
+        for tau in range(taps):
+            out[p, :, tau, :cin] = w[:, :, j0 + stride * (taps - 1 - tau)].t()
+    return out.reshape(stride, cout, taps * cp).contiguous()
+
+
+def stft_bases(n_fft, win_length=None):
+    """Windowed DFT bases of torch.stft / torch.istft (hann, periodic) as GEMM operands:
+    analysis [2*bins][n_fft] (rows re_0..re_{N/2}, im_0..im_{N/2}), synthesis [n_fft][pad32(2*bins)] (irfft, window and 1/N folded in),
+    wsq [n_fft] = window^2."""
+    import math
+    N = n_fft
+    bins = N // 2 + 1
+    win = torch.hann_window(win_length or N, dtype=torch.float64)
+    n = torch.arange(N, dtype=torch.float64)
+    k = torch.arange(bins, dtype=torch.float64)
+    ang = 2.0 * math.pi * k[:, None] * n[None, :] / N
+    ana = torch.cat([torch.cos(ang) * win[None, :], -torch.sin(ang) * win[None, :]], 0)           # X_k = sum_n w x e^{-i ang}
+    wk = torch.full((bins,), 2.0, dtype=torch.float64)
+    wk[0] = 1.0
+    wk[-1] = 1.0
+    syn_re = (torch.cos(ang) * wk[:, None]).t() / N                                                   # [N][bins]
+    syn_im = (-torch.sin(ang) * wk[:, None]).t() / N
+    syn_im[:, 0] = 0.0                                                                                # irfft ignores Im of DC and Nyquist
+    syn_im[:, -1] = 0.0
+    syn = torch.cat([syn_re, syn_im], 1) * win[:, None]
+    ld = (2 * bins + 31) // 32 * 32
+    syn_p = torch.zeros(N, ld, dtype=torch.float64)
+    syn_p[:, :2 * bins] = syn
+    return ana.float().contiguous(), syn_p.float().contiguous(), (win * win).float().contiguous()

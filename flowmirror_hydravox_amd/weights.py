@@ -145,6 +145,92 @@ def hift_spec(c: HiftConfig) -> Spec:
 
 
 # --------------------------------------------------------------------------------------------------
+# Matcha-TTS family: state-dict keys of matcha.models.components.decoder.Decoder /
+# cosyvoice.flow.decoder.ConditionalDecoder and matcha.hifigan.models.Generator
+# --------------------------------------------------------------------------------------------------
+def _matcha_resnet_spec(pre: str, cin: int, cout: int, te: int) -> Spec:
+    return [(pre + 'mlp.1.weight', (cout, te), 'w'), (pre + 'mlp.1.bias', (cout,), 'b'),
+            (pre + 'block1.block.0.weight', (cout, cin, 3), 'w'), (pre + 'block1.block.0.bias', (cout,), 'b'),
+            (pre + 'block1.block.1.weight', (cout,), 'g'), (pre + 'block1.block.1.bias', (cout,), 'b'),
+            (pre + 'block2.block.0.weight', (cout, cout, 3), 'w'), (pre + 'block2.block.0.bias', (cout,), 'b'),
+            (pre + 'block2.block.1.weight', (cout,), 'g'), (pre + 'block2.block.1.bias', (cout,), 'b'),
+            (pre + 'res_conv.weight', (cout, cin, 1), 'w'), (pre + 'res_conv.bias', (cout,), 'b')]
+
+
+def _matcha_tblock_spec(pre: str, dim: int, inner: int, ff: int) -> Spec:
+    return [(pre + 'norm1.weight', (dim,), 'g'), (pre + 'norm1.bias', (dim,), 'b'),
+            (pre + 'attn1.to_q.weight', (inner, dim), 'w'), (pre + 'attn1.to_k.weight', (inner, dim), 'w'), (pre + 'attn1.to_v.weight', (inner, dim), 'w'),
+            (pre + 'attn1.to_out.0.weight', (dim, inner), 'w'), (pre + 'attn1.to_out.0.bias', (dim,), 'b'),
+            (pre + 'norm3.weight', (dim,), 'g'), (pre + 'norm3.bias', (dim,), 'b'),
+            (pre + 'ff.net.0.proj.weight', (ff, dim), 'w'), (pre + 'ff.net.0.proj.bias', (ff,), 'b'),
+            (pre + 'ff.net.0.alpha', (ff,), 'z'), (pre + 'ff.net.0.beta', (ff,), 'z'),
+            (pre + 'ff.net.2.weight', (dim, ff), 'w'), (pre + 'ff.net.2.bias', (dim,), 'b')]
+
+
+def matcha_spec(c) -> Spec:
+    """Decoder.__init__ (decoder.py:201-300): module order down_blocks / mid_blocks / up_blocks / final_block / final_proj."""
+    ch = tuple(c.channels)
+    cin = c.in_channels
+    te = ch[0] * 4
+    inner = c.num_heads * c.head_dim
+    s: Spec = [('time_mlp.linear_1.weight', (te, cin), 'w'), ('time_mlp.linear_1.bias', (te,), 'b'),
+               ('time_mlp.linear_2.weight', (te, te), 'w'), ('time_mlp.linear_2.bias', (te,), 'b')]
+    out = cin
+    for i, co in enumerate(ch):
+        inp, out = out, co
+        p = 'down_blocks.%d.' % i
+        s += _matcha_resnet_spec(p + '0.', inp, out, te)
+        for j in range(c.n_blocks):
+            s += _matcha_tblock_spec(p + '1.%d.' % j, out, inner, c.ff_mult * out)
+        last = i == len(ch) - 1
+        s += [(p + ('2.weight' if last else '2.conv.weight'), (out, out, 3), 'w'), (p + ('2.bias' if last else '2.conv.bias'), (out,), 'b')]
+    for i in range(c.num_mid_blocks):
+        p = 'mid_blocks.%d.' % i
+        s += _matcha_resnet_spec(p + '0.', ch[-1], out, te)
+        for j in range(c.n_blocks):
+            s += _matcha_tblock_spec(p + '1.%d.' % j, out, inner, c.ff_mult * out)
+    rev = ch[::-1] + (ch[0],)
+    for i in range(len(rev) - 1):
+        inp, out = rev[i], rev[i + 1]
+        p = 'up_blocks.%d.' % i
+        s += _matcha_resnet_spec(p + '0.', 2 * inp, out, te)
+        for j in range(c.n_blocks):
+            s += _matcha_tblock_spec(p + '1.%d.' % j, out, inner, c.ff_mult * out)
+        last = i == len(rev) - 2
+        if last:
+            s += [(p + '2.weight', (out, out, 3), 'w'), (p + '2.bias', (out,), 'b')]
+        else:
+            s += [(p + '2.conv.weight', (out, out, 4), 'w'), (p + '2.conv.bias', (out,), 'b')]       # ConvTranspose1d: [Cin][Cout][k]
+    s += [('final_block.block.0.weight', (rev[-1], rev[-1], 3), 'w'), ('final_block.block.0.bias', (rev[-1],), 'b'),
+          ('final_block.block.1.weight', (rev[-1],), 'g'), ('final_block.block.1.bias', (rev[-1],), 'b'),
+          ('final_proj.weight', (c.mel, rev[-1], 1), 'w'), ('final_proj.bias', (c.mel,), 'b')]
+    return s
+
+
+def hifigan_spec(c) -> Spec:
+    s: Spec = []
+
+    def wn(name, shape, nbias):
+        s.extend([(name + '.weight_g', (shape[0], 1, 1), 'wn_g_old'), (name + '.weight_v', tuple(shape), 'w'), (name + '.bias', (nbias,), 'b')])
+
+    C = c.initial_channel
+    wn('conv_pre', (C, c.mel, 7), C)
+    for i, (u, k) in enumerate(zip(c.upsample_rates, c.upsample_kernel_sizes)):
+        wn('ups.%d' % i, (C // (2 ** i), C // (2 ** (i + 1)), k), C // (2 ** (i + 1)))               # ConvTranspose1d: [Cin][Cout][k]
+    n = 0
+    for i in range(len(c.upsample_rates)):
+        chn = C // (2 ** (i + 1))
+        for k in c.resblock_kernel_sizes:
+            for d in range(3):
+                wn('resblocks.%d.convs1.%d' % (n, d), (chn, chn, k), chn)
+            for d in range(3):
+                wn('resblocks.%d.convs2.%d' % (n, d), (chn, chn, k), chn)
+            n += 1
+    wn('conv_post', (1, C // (2 ** len(c.upsample_rates)), 7), 1)
+    return s
+
+
+# --------------------------------------------------------------------------------------------------
 # seeded synthetic checkpoints
 # --------------------------------------------------------------------------------------------------
 def _fill(spec: Spec, seed: int, init: str, head_dim: int = 64) -> Dict[str, torch.Tensor]:
@@ -176,16 +262,20 @@ def _fill(spec: Spec, seed: int, init: str, head_dim: int = 64) -> Dict[str, tor
             t = torch.ones(shape)
             if init == 'fan_in':
                 t = (t + 0.2 * torch.randn(shape, generator=g)).abs() + 0.05
-        elif kind == 'wn_g':
-            t = None          # filled after its v (original1) is drawn
+        elif kind in ('wn_g', 'wn_g_old'):
+            t = None          # filled after its v is drawn
+        elif kind == 'z':     # log-scale parameter initialised at 0 (SnakeBeta alpha / beta)
+            t = torch.zeros(shape)
+            if init == 'fan_in':
+                t = 0.2 * torch.randn(shape, generator=g)
         elif kind == 'inv_freq':
             t = 1.0 / (10000 ** (torch.arange(0, head_dim, 2).float() / head_dim))
         else:
             raise ValueError(kind)
         sd[key] = t
     for key, shape, kind in spec:
-        if kind == 'wn_g':
-            v = sd[key.replace('original0', 'original1')]
+        if kind in ('wn_g', 'wn_g_old'):
+            v = sd[key.replace('original0', 'original1') if kind == 'wn_g' else key.replace('weight_g', 'weight_v')]
             n = v.norm(2, dim=(1, 2), keepdim=True)
             sd[key] = n.clone() if init != 'fan_in' else n * (1.0 + 0.1 * torch.randn(shape, generator=g))
     return sd
@@ -211,6 +301,17 @@ def make_hift_state(c: HiftConfig, seed: int = 1988, init: str = 'normal02'):
         sd['conv_post.parametrizations.weight.original0'] = sd['conv_post.parametrizations.weight.original0'] * 0.3
         sd['conv_post.bias'] = sd['conv_post.bias'] - 1.5
         sd['f0_predictor.classifier.weight'] = sd['f0_predictor.classifier.weight'] * 200.0
+    return sd
+
+
+def make_matcha_state(c, seed: int = 1989, init: str = 'normal02'):
+    return _fill(matcha_spec(c), seed, init)
+
+
+def make_hifigan_state(c, seed: int = 1990, init: str = 'normal02'):
+    sd = _fill(hifigan_spec(c), seed, init)
+    if init == 'fan_in':
+        sd['conv_post.weight_g'] = sd['conv_post.weight_g'] * 0.5          # keep tanh out of saturation
     return sd
 
 

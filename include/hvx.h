@@ -227,6 +227,62 @@ int hvx_hift_source(hvx_hift* h, hvx_stream s, void* ws, size_t ws_bytes, const 
 /* mel (mel, T) + source [T*up] -> wav f32 [T*up] */
 int hvx_hift_decode(hvx_hift* h, hvx_stream s, void* ws, size_t ws_bytes, const float* mel, const float* source, int32_t t, float* wav);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Matcha-TTS family, fp32:
+ *   hvx_matcha_*   — matcha/models/components/decoder.py:363-443 Decoder.forward (and its CosyVoice variant
+ *                    cosyvoice/flow/decoder.py:210-291 when cv_variant = 1: `cond` input, key-padding masks) and
+ *                    flow_matching.py:32-85 BASECFM.solve_euler
+ *   hvx_hifigan_*  — matcha/hifigan/models.py:181-197 Generator.forward (config.py v1)
+ *   hvx_denoise    — matcha/hifigan/denoiser.py:57-64 Denoiser.forward
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t in_channels, out_channels;          /* packed [x | mu | spks | cond] width (multiple of 32); mel bins */
+    int32_t n_stages; int32_t channels[4];      /* U-Net widths (multiples of 64) */
+    int32_t n_blocks, n_mid, heads, ff_mult;    /* transformer blocks per stage, mid stages, heads of 64, FeedForward multiplier */
+    int32_t cv_variant;                         /* 0: Matcha (full-length masks only), 1: CosyVoice ConditionalDecoder (key-padding masks) */
+    int32_t max_t;
+} hvx_matcha_config;
+/* weights[] (all f32; Linear [N][K], Conv1d [Cout][tap][Cin_pad32]):
+ *   time_mlp: W1 [TE][Cin], b1, W2 [TE][TE], b2                                  (TE = 4 * channels[0])
+ *   units in execution order — n_stages down, n_mid mid, n_stages up — each:
+ *     resnet: mlp W [C][TE], b; block1 conv W, b, GroupNorm gamma, beta; block2 conv W, b, gamma, beta; res_conv W [C][Cin_pad], b
+ *     n_blocks x transformer: norm1 (gamma - 1), beta; Wqkv [3*heads*64][C]; Wo [C][heads*64], bo; norm3 (gamma - 1), beta;
+ *                             ff W1 [ff_mult*C][C], b1, snake table [2][ff_mult*C] = exp(alpha) | exp(beta); ff W2 [C][ff_mult*C], b2
+ *     down / up units only: resampler W, b — Conv1d k3 (stride 2, or 1 on the last stage) / ConvTranspose1d k4 s2 p1 as its two
+ *                           phase matrices [2][C][2 taps][C] (packing.convtranspose_phases), Conv1d k3 on the last up stage
+ *   final_block conv W, b, GroupNorm gamma, beta; final_proj W [mel][C], b */
+typedef struct hvx_matcha hvx_matcha;
+int hvx_matcha_create(const hvx_matcha_config* cfg, const void* const* weights, int32_t n_weights, hvx_matcha** out);
+void hvx_matcha_destroy(hvx_matcha* h);
+size_t hvx_matcha_workspace_bytes(const hvx_matcha* h, int32_t batch, int32_t t);
+/* x, mu, cond: f32 (B, mel, T); spks f32 (B, spk_dim) or null; lens: device int32 [n_stages][B] valid lengths per U-Net level or null;
+ * t: device f32 [B]; out: f32 (B, mel, T) */
+int hvx_matcha_estimator(hvx_matcha* h, hvx_stream s, void* ws, size_t ws_bytes, int32_t batch, int32_t t_len, const float* x, const float* mu,
+                         const float* spks, int32_t spk_dim, const float* cond, const int32_t* lens, const float* t, float* out);
+/* x holds z on entry and the sample on return; ts / dts: host arrays, the fp32 values solve_euler's loop visits */
+int hvx_matcha_solve(hvx_matcha* h, hvx_stream s, void* ws, size_t ws_bytes, int32_t batch, int32_t t_len, float* x, const float* mu,
+                     const float* spks, int32_t spk_dim, const float* cond, const int32_t* lens, int32_t n_steps, const float* ts, const float* dts);
+
+typedef struct {
+    int32_t mel, initial_channel;
+    int32_t n_up; int32_t up_rates[4]; int32_t up_kernels[4];
+    int32_t n_rb; int32_t rb_kernels[4]; int32_t rb_dils[4][3];
+} hvx_hifigan_config;
+/* weights[] (f32, weight-norm folded): conv_pre W [C0][7][mel_pad32], b; per upsample: ConvTranspose phases [rate][C/2][k/rate][C], b,
+ * then n_rb x 3 x (convs1 W, b, convs2 W, b); conv_post W [1][7][C], b */
+typedef struct hvx_hifigan hvx_hifigan;
+int hvx_hifigan_create(const hvx_hifigan_config* cfg, const void* const* weights, int32_t n_weights, hvx_hifigan** out);
+void hvx_hifigan_destroy(hvx_hifigan* h);
+size_t hvx_hifigan_workspace_bytes(const hvx_hifigan* h, int32_t t);
+int hvx_hifigan_forward(hvx_hifigan* h, hvx_stream s, void* ws, size_t ws_bytes, const float* mel, int32_t T, float* wav);
+
+size_t hvx_denoise_workspace_bytes(int32_t L, int32_t n_fft, int32_t hop);
+/* |torch.stft(audio, n_fft, hop, window=hann, center=True)|: mag f32 [1 + L/hop][n_fft/2 + 1] */
+int hvx_stft_magnitude(hvx_stream s, void* ws, size_t ws_bytes, const float* audio, int32_t L, int32_t n_fft, int32_t hop, const float* stft_basis,
+                       float* mag);
+int hvx_denoise(hvx_stream s, void* ws, size_t ws_bytes, const float* audio, int32_t L, int32_t n_fft, int32_t hop, const float* stft_basis,
+                const float* istft_basis, const float* wsq, const float* bias, float strength, float* out);
+
 #ifdef __cplusplus
 }
 #endif

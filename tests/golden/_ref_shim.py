@@ -6,7 +6,13 @@ This shim installs the minimal stand-in *modules* needed so the reference's own 
 import unmodified.  Nothing here is shipped, nothing here is imported by the product or by the
 `-m gpu` tests; it only serves tests/golden/make_golden.py.
 
-The only arithmetic restated here is x_transformers' RotaryEmbedding / apply_rotary_pos_emb
+Arithmetic restated here (third-party packages the reference imports but this image lacks):
+  * diffusers.models.attention_processor.Attention (diffusers==0.25.0 in the reference's requirements; self-attention use only):
+    to_q / to_k / to_v Linear without bias, to_out = [Linear with bias, Dropout], heads of dim_head, scale dim_head**-0.5, the
+    `attention_mask` (2-D (B, T) or 3-D (B, T, T) float) is ADDED to the scores, broadcast over heads (prepare_attention_mask +
+    AttnProcessor2_0).  Used by matcha's BasicTransformerBlock; parity of that sub-step is therefore pinned on the reference's call
+    sites, not on diffusers itself.
+  * x_transformers' RotaryEmbedding / apply_rotary_pos_emb
 (third-party, pinned x_transformers==2.12.2 in the reference's requirements.txt:51, not installed):
     inv_freq = 1 / 10000^(2i/dim); freqs = pos (x) inv_freq, each value duplicated *interleaved*
     (f0,f0,f1,f1,...); rotate_half on interleaved pairs (-x2, x1); only the first rot_dim channels
@@ -79,7 +85,32 @@ def install():
     _mod('diffusers.models')
     _mod('diffusers.models.activations', get_activation=lambda n: {'silu': nn.SiLU(), 'swish': nn.SiLU(), 'mish': nn.Mish(), 'gelu': nn.GELU()}[n])
     _mod('diffusers.models.attention', GEGLU=_Dummy, GELU=_Dummy, AdaLayerNorm=_Dummy, AdaLayerNormZero=_Dummy, ApproximateGELU=_Dummy)
-    _mod('diffusers.models.attention_processor', Attention=_Dummy)
+    class Attention(nn.Module):
+        def __init__(self, query_dim, cross_attention_dim=None, heads=8, dim_head=64, dropout=0.0, bias=False, upcast_attention=False, **kw):
+            super().__init__()
+            assert cross_attention_dim is None
+            inner = heads * dim_head
+            self.heads, self.scale = heads, dim_head ** -0.5
+            self.to_q = nn.Linear(query_dim, inner, bias=bias)
+            self.to_k = nn.Linear(query_dim, inner, bias=bias)
+            self.to_v = nn.Linear(query_dim, inner, bias=bias)
+            self.to_out = nn.ModuleList([nn.Linear(inner, query_dim), nn.Dropout(dropout)])
+
+        def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None, **kw):
+            assert encoder_hidden_states is None
+            B, T, _ = hidden_states.shape
+            q, k, v = self.to_q(hidden_states), self.to_k(hidden_states), self.to_v(hidden_states)
+            d = q.shape[-1] // self.heads
+            q, k, v = (t.view(B, T, self.heads, d).transpose(1, 2) for t in (q, k, v))
+            s = torch.matmul(q, k.transpose(-1, -2)) * self.scale
+            if attention_mask is not None:
+                m = attention_mask
+                m = m[:, None, None, :] if m.dim() == 2 else m[:, None]
+                s = s + m.to(s.dtype)
+            o = torch.matmul(torch.softmax(s, dim=-1), v).transpose(1, 2).reshape(B, T, self.heads * d)
+            return self.to_out[1](self.to_out[0](o))
+
+    _mod('diffusers.models.attention_processor', Attention=Attention)
     _mod('diffusers.models.lora', LoRACompatibleLinear=nn.Linear)
     _mod('diffusers.utils')
     _mod('diffusers.utils.torch_utils', maybe_allow_in_graph=lambda c: c)

@@ -330,8 +330,104 @@ def gen_hift():
     np.savez_compressed(os.path.join(HERE, 'hift_tiny.npz'), **out)
 
 
+# ------------------------------------------------------------------------------------------------
+# Matcha-TTS family
+# ------------------------------------------------------------------------------------------------
+def gen_matcha():
+    from matcha.models.components.decoder import Decoder
+    from matcha.models.components.flow_matching import CFM
+    from cosyvoice.flow.decoder import ConditionalDecoder
+    from matcha.hifigan.models import Generator
+    from matcha.hifigan.denoiser import Denoiser
+    from omegaconf import DictConfig
+    from flowmirror_hydravox_amd.config import tiny_matcha_config, tiny_hifigan_config
+    from oracle import matcha_ref
+    out = {}
+    g = torch.Generator()
+    g.manual_seed(11)
+    # ---- M1-M3: Matcha Decoder inside CFM (n_spks > 1: the speaker vector is packed after mu) -----------------------------
+    c = tiny_matcha_config()
+    dec_params = dict(channels=c.channels, dropout=0.0, attention_head_dim=c.head_dim, n_blocks=c.n_blocks, num_mid_blocks=c.num_mid_blocks,
+                      num_heads=c.num_heads, act_fn='snakebeta')
+    cfm = CFM(in_channels=2 * c.mel, out_channel=c.mel, cfm_params=DictConfig(solver='euler', sigma_min=1e-4), decoder_params=dec_params,
+              n_spks=2, spk_emb_dim=c.spk_dim).eval()
+    assert isinstance(cfm.estimator, Decoder)
+    assert_spec(cfm.estimator, W.matcha_spec(c), 'matcha decoder')
+    sd = W.make_matcha_state(c, seed=21, init='fan_in')
+    cfm.estimator.load_state_dict(sd)
+    out['m_weight_seed'] = np.int64(21)
+    out['m_weight_sha'] = np.array(state_checksum(sd))
+    for r, T in enumerate([16, 40]):                      # multiples of 2^(stages-1): Matcha pads its inputs to that (fix_len_compatibility)
+        x, mu, spks = torch.randn(1, c.mel, T, generator=g), torch.randn(1, c.mel, T, generator=g), torch.randn(1, c.spk_dim, generator=g)
+        mask = torch.ones(1, 1, T)
+        t = torch.tensor([0.3 + 0.4 * r])
+        with torch.inference_mode():
+            y = cfm.estimator(x, mask, mu, t, spks)
+            torch.manual_seed(100 + r)
+            noise = torch.randn_like(mu)
+            torch.manual_seed(100 + r)
+            sample = cfm(mu, mask, c.n_timesteps, temperature=c.temperature, spks=spks)
+        o_y = matcha_ref.decoder_forward(sd, c, x, mask, mu, t, spks)
+        o_s = matcha_ref.solve_euler(sd, c, noise * c.temperature, mask, mu, c.n_timesteps, spks)
+        d = [(o_y - y).abs().max().item(), (o_s - sample).abs().max().item()]
+        assert d[0] < 1e-4 and d[1] < 1e-3, d
+        print('[matcha] T=%d: oracle-reference max abs diff estimator %.1e, %d-step sample %.1e (out std %.3f)' % (T, d[0], c.n_timesteps, d[1], y.std()))
+        p = 'm%d_' % r
+        out.update({p + 'x': x.numpy(), p + 'mu': mu.numpy(), p + 'spks': spks.numpy(), p + 't': t.numpy(), p + 'y': y.numpy(),
+                    p + 'noise': noise.numpy(), p + 'sample': sample.numpy()})
+    # ---- M2 (CosyVoice variant): padded batch, cond input, odd length (skip trimming) --------------------------------------------
+    cc = tiny_matcha_config(cv=True)
+    dec = ConditionalDecoder(in_channels=cc.in_channels, out_channels=cc.mel, channels=cc.channels, dropout=0.0, attention_head_dim=cc.head_dim,
+                             n_blocks=cc.n_blocks, num_mid_blocks=cc.num_mid_blocks, num_heads=cc.num_heads, act_fn='snakebeta').eval()
+    assert_spec(dec, W.matcha_spec(cc), 'conditional decoder')
+    sdc = W.make_matcha_state(cc, seed=22, init='fan_in')
+    dec.load_state_dict(sdc)
+    out['c_weight_seed'] = np.int64(22)
+    out['c_weight_sha'] = np.array(state_checksum(sdc))
+    T = 37
+    lens = [37, 29]
+    x, mu, cond = torch.randn(2, cc.mel, T, generator=g), torch.randn(2, cc.mel, T, generator=g), torch.randn(2, cc.mel, T, generator=g)
+    spks = torch.randn(2, cc.spk_dim, generator=g)
+    mask = torch.zeros(2, 1, T)
+    for b, n in enumerate(lens):
+        mask[b, :, :n] = 1.0
+    t = torch.tensor([0.25, 0.75])
+    with torch.inference_mode():
+        y = dec(x, mask, mu, t, spks, cond)
+    o_y = matcha_ref.decoder_forward(sdc, cc, x, mask, mu, t, spks, cond)
+    d = (o_y - y).abs().max().item()
+    assert d < 1e-4, d
+    print('[matcha] conditional decoder (B=2, lens %s): oracle-reference max abs diff %.1e' % (lens, d))
+    out.update({'c_x': x.numpy(), 'c_mu': mu.numpy(), 'c_cond': cond.numpy(), 'c_spks': spks.numpy(), 'c_mask': mask.numpy(), 'c_t': t.numpy(), 'c_y': y.numpy()})
+    # ---- M4 / M5: HiFi-GAN v1 generator + denoiser ---------------------------------------------------------------------------------
+    hc = tiny_hifigan_config()
+    h = DictConfig(resblock='1', upsample_rates=list(hc.upsample_rates), upsample_kernel_sizes=list(hc.upsample_kernel_sizes),
+                   upsample_initial_channel=hc.initial_channel, resblock_kernel_sizes=list(hc.resblock_kernel_sizes),
+                   resblock_dilation_sizes=[list(d) for d in hc.resblock_dilations])
+    gen = Generator(h).eval()
+    assert_spec(gen, W.hifigan_spec(hc), 'hifigan generator')
+    sdg = W.make_hifigan_state(hc, seed=23, init='fan_in')
+    gen.load_state_dict(sdg)
+    out['g_weight_seed'] = np.int64(23)
+    out['g_weight_sha'] = np.array(state_checksum(sdg))
+    mel = torch.randn(1, hc.mel, 30, generator=g)
+    with torch.inference_mode():
+        wav = gen(mel)
+        den = Denoiser(gen, filter_length=hc.n_fft, n_overlap=hc.n_overlap, win_length=hc.n_fft, mode='zeros')
+        clean = den(wav.squeeze(1), strength=0.05)
+    o_wav = matcha_ref.generator_forward(sdg, hc, mel)
+    o_bias = matcha_ref.denoiser_bias(sdg, hc)
+    o_clean = matcha_ref.denoise(wav.squeeze(1), o_bias, hc, 0.05)
+    d = [(o_wav - wav).abs().max().item(), (o_bias - den.bias_spec).abs().max().item(), (o_clean - clean).abs().max().item()]
+    assert max(d) < 1e-4, d
+    print('[matcha] hifigan: oracle-reference max abs diff wav %.1e bias %.1e denoised %.1e (wav std %.3f, bias max %.3f)'
+          % (d[0], d[1], d[2], wav.std(), den.bias_spec.max()))
+    out.update({'g_mel': mel.numpy(), 'g_wav': wav.numpy(), 'g_bias': den.bias_spec.numpy(), 'g_clean': clean.numpy(), 'g_strength': np.float32(0.05)})
+    np.savez_compressed(os.path.join(HERE, 'matcha_tiny.npz'), **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['sampler', 'llm', 'flow', 'hift']
+    which = sys.argv[1:] or ['sampler', 'llm', 'flow', 'hift', 'matcha']
     for w in which:
-        {'sampler': gen_sampler, 'llm': gen_llm, 'flow': gen_flow, 'hift': gen_hift}[w]()
+        {'sampler': gen_sampler, 'llm': gen_llm, 'flow': gen_flow, 'hift': gen_hift, 'matcha': gen_matcha}[w]()
     print('golden fixtures written to', HERE)

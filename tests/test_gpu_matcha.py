@@ -1,0 +1,120 @@
+"""Parity of the Matcha-TTS family through the C-ABI against the golden vectors minted from the reference's own
+modules (tests/golden/make_golden.py: gen_matcha) and against the CPU oracle on further seeded inputs.  fp32 throughout; tolerances are
+relative to the signal scale and written at each assertion."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, state_checksum
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-12)
+
+
+@pytest.fixture(scope='module')
+def golden():
+    return load_golden('matcha_tiny.npz')
+
+
+def test_matcha_decoder_and_euler_solver_vs_reference(golden):
+    from flowmirror_hydravox_amd import weights as W
+    from flowmirror_hydravox_amd.config import tiny_matcha_config
+    from flowmirror_hydravox_amd.matcha import HvxMatchaCFM
+    g = golden
+    c = tiny_matcha_config()
+    sd = W.make_matcha_state(c, seed=int(g['m_weight_seed']), init='fan_in')
+    assert state_checksum(sd) == str(g['m_weight_sha'])
+    cfm = HvxMatchaCFM(c, {'estimator.' + k: v for k, v in sd.items()})          # checkpoint keys as CFM.state_dict() has them
+    for r in range(2):
+        p = 'm%d_' % r
+        x, mu, spks, t = (torch.from_numpy(g[p + k]) for k in ('x', 'mu', 'spks', 't'))
+        mask = torch.ones(1, 1, x.shape[-1])
+        y = cfm.estimator(x, mask, mu, t, spks).cpu()
+        assert _rel(y.numpy(), g[p + 'y']) < 1e-3                                 # one estimator call (M2/M3)
+        s = cfm.forward(mu, mask, c.n_timesteps, temperature=c.temperature, spks=spks, noise=torch.from_numpy(g[p + 'noise'])).cpu()
+        assert _rel(s.numpy(), g[p + 'sample']) < 2e-3                            # BASECFM.solve_euler (M1)
+
+
+def test_matcha_decoder_rejects_padded_batches_in_matcha_mode(golden):
+    from flowmirror_hydravox_amd import _lib, weights as W
+    from flowmirror_hydravox_amd.config import tiny_matcha_config
+    from flowmirror_hydravox_amd.matcha import HvxMatchaDecoder
+    c = tiny_matcha_config()
+    dec = HvxMatchaDecoder(c, W.make_matcha_state(c, seed=3, init='fan_in'))
+    x = torch.randn(2, c.mel, 16)
+    mask = torch.ones(2, 1, 16)
+    mask[1, :, 10:] = 0
+    with pytest.raises(_lib.HvxError):       # the Matcha decoder ADDS its 0/1 mask to the scores: only full-length masks are served
+        dec(x, mask, x, torch.tensor([0.5, 0.5]), torch.randn(2, c.spk_dim))
+
+
+def test_conditional_decoder_padded_batch_vs_reference(golden):
+    from flowmirror_hydravox_amd import weights as W
+    from flowmirror_hydravox_amd.config import tiny_matcha_config
+    from flowmirror_hydravox_amd.matcha import HvxMatchaDecoder
+    g = golden
+    cc = tiny_matcha_config(cv=True)
+    sd = W.make_matcha_state(cc, seed=int(g['c_weight_seed']), init='fan_in')
+    assert state_checksum(sd) == str(g['c_weight_sha'])
+    dec = HvxMatchaDecoder(cc, sd)
+    x, mask, mu, t, spks, cond = (torch.from_numpy(g['c_' + k]) for k in ('x', 'mask', 'mu', 't', 'spks', 'cond'))
+    y = dec(x, mask, mu, t, spks, cond).cpu().numpy()            # B = 2, lengths 37 / 29 of 37 (odd: skip trimming), key-padding masks
+    assert _rel(y, g['c_y']) < 1e-3
+    assert np.abs(y[1, :, 29:]).max() == 0.0                     # output * mask
+
+
+def test_conditional_decoder_longer_input_vs_oracle():
+    from flowmirror_hydravox_amd import weights as W
+    from flowmirror_hydravox_amd.config import tiny_matcha_config
+    from flowmirror_hydravox_amd.matcha import HvxMatchaDecoder
+    from oracle import matcha_ref
+    cc = tiny_matcha_config(cv=True)
+    sd = W.make_matcha_state(cc, seed=31, init='fan_in')
+    dec = HvxMatchaDecoder(cc, sd)
+    gq = torch.Generator().manual_seed(32)
+    T = 301
+    x, mu, cond = (torch.randn(1, cc.mel, T, generator=gq) for _ in range(3))
+    spks = torch.randn(1, cc.spk_dim, generator=gq)
+    mask = torch.ones(1, 1, T)
+    t = torch.tensor([0.6])
+    ref = matcha_ref.decoder_forward(sd, cc, x, mask, mu, t, spks, cond)
+    y = dec(x, mask, mu, t, spks, cond).cpu()
+    assert _rel(y.numpy(), ref.numpy()) < 1e-3
+
+
+def test_hifigan_generator_and_denoiser_vs_reference(golden):
+    from flowmirror_hydravox_amd import weights as W
+    from flowmirror_hydravox_amd.config import tiny_hifigan_config
+    from flowmirror_hydravox_amd.matcha import HvxDenoiser, HvxHifiGan
+    g = golden
+    hc = tiny_hifigan_config()
+    sd = W.make_hifigan_state(hc, seed=int(g['g_weight_seed']), init='fan_in')
+    assert state_checksum(sd) == str(g['g_weight_sha'])
+    voc = HvxHifiGan(hc, sd)
+    wav = voc(torch.from_numpy(g['g_mel'])).cpu().numpy()
+    assert wav.shape == g['g_wav'].shape
+    assert _rel(wav, g['g_wav']) < 1e-3                          # Generator.forward (M4): ConvTranspose as phase convolutions
+    den = HvxDenoiser(voc)
+    assert _rel(den.bias_spec.cpu().numpy(), g['g_bias'][0, :, 0]) < 1e-3
+    clean = den(torch.from_numpy(g['g_wav']).squeeze(1), strength=float(g['g_strength'])).cpu().numpy()
+    assert clean.shape == g['g_clean'].shape
+    assert _rel(clean, g['g_clean']) < 1e-3                      # Denoiser.forward (M5)
+
+
+def test_hifigan_accepts_checkpoints_with_weight_norm_removed(golden):
+    from flowmirror_hydravox_amd import weights as W
+    from flowmirror_hydravox_amd.config import tiny_hifigan_config
+    from flowmirror_hydravox_amd.matcha import HvxHifiGan, _fold_wn_old
+    hc = tiny_hifigan_config()
+    sd = W.make_hifigan_state(hc, seed=40, init='fan_in')
+    names = sorted({k.rsplit('.', 1)[0] for k in sd})
+    folded = {}
+    for n in names:                                              # what Generator.remove_weight_norm() leaves behind
+        folded[n + '.weight'] = _fold_wn_old(sd, n)
+        folded[n + '.bias'] = sd[n + '.bias']
+    mel = torch.randn(1, hc.mel, 12, generator=torch.Generator().manual_seed(41))
+    assert torch.equal(HvxHifiGan(hc, sd)(mel), HvxHifiGan(hc, folded)(mel))

@@ -134,3 +134,71 @@ def test_hift_stages(tiny_cfg):
         assert np.allclose(s.numpy(), g[p + 'source'], atol=1e-3)
         # end to end the F0 -> phase accumulation amplifies fp32 rounding: looser bound
         assert np.abs(wav.numpy() - g[p + 'wav']).max() < 5e-3
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# Matcha-TTS family: oracle vs the vectors minted from the reference's own modules
+# ------------------------------------------------------------------------------------------------------------------------
+def test_matcha_decoder_cfm_hifigan_denoiser():
+    from flowmirror_hydravox_amd.config import tiny_matcha_config, tiny_hifigan_config
+    from oracle import matcha_ref
+    g = load_golden('matcha_tiny.npz')
+    c = tiny_matcha_config()
+    sd = W.make_matcha_state(c, seed=int(g['m_weight_seed']), init='fan_in')
+    assert state_checksum(sd) == str(g['m_weight_sha'])
+    for r in range(2):
+        p = 'm%d_' % r
+        x, mu, spks, t = (torch.from_numpy(g[p + k]) for k in ('x', 'mu', 'spks', 't'))
+        mask = torch.ones(1, 1, x.shape[-1])
+        y = matcha_ref.decoder_forward(sd, c, x, mask, mu, t, spks)
+        assert (y - torch.from_numpy(g[p + 'y'])).abs().max() < 1e-5
+        s = matcha_ref.solve_euler(sd, c, torch.from_numpy(g[p + 'noise']) * c.temperature, mask, mu, c.n_timesteps, spks)
+        assert (s - torch.from_numpy(g[p + 'sample'])).abs().max() < 1e-4
+    cc = tiny_matcha_config(cv=True)
+    sdc = W.make_matcha_state(cc, seed=int(g['c_weight_seed']), init='fan_in')
+    assert state_checksum(sdc) == str(g['c_weight_sha'])
+    y = matcha_ref.decoder_forward(sdc, cc, *(torch.from_numpy(g['c_' + k]) for k in ('x', 'mask', 'mu', 't', 'spks', 'cond')))
+    assert (y - torch.from_numpy(g['c_y'])).abs().max() < 1e-5
+    hc = tiny_hifigan_config()
+    sdg = W.make_hifigan_state(hc, seed=int(g['g_weight_seed']), init='fan_in')
+    assert state_checksum(sdg) == str(g['g_weight_sha'])
+    wav = matcha_ref.generator_forward(sdg, hc, torch.from_numpy(g['g_mel']))
+    assert (wav - torch.from_numpy(g['g_wav'])).abs().max() < 1e-5
+    bias = matcha_ref.denoiser_bias(sdg, hc)
+    assert (bias - torch.from_numpy(g['g_bias'])).abs().max() < 1e-5
+    clean = matcha_ref.denoise(torch.from_numpy(g['g_wav']).squeeze(1), bias, hc, float(g['g_strength']))
+    assert (clean - torch.from_numpy(g['g_clean'])).abs().max() < 1e-5
+
+
+def test_matcha_euler_schedule_matches_the_reference_loop():
+    from flowmirror_hydravox_amd.matcha import matcha_euler_schedule
+    from oracle import matcha_ref
+    for n in (1, 2, 10, 32):
+        assert matcha_euler_schedule(n) == matcha_ref.euler_schedule(n)
+        ts, dts = matcha_euler_schedule(n)
+        assert len(ts) == n and abs(ts[-1] + dts[-1] - 1.0) < 1e-6
+
+
+def test_convtranspose_phases_and_stft_bases_against_torch():
+    from flowmirror_hydravox_amd.packing import convtranspose_phases, stft_bases
+    import torch.nn.functional as F
+    gq = torch.Generator().manual_seed(5)
+    for (cin, cout, k, s) in [(6, 4, 4, 2), (5, 3, 16, 8), (3, 7, 8, 4)]:
+        pd = (k - s) // 2
+        w = torch.randn(cin, cout, k, generator=gq)
+        x = torch.randn(1, cin, 9, generator=gq)
+        ref = F.conv_transpose1d(x, w, stride=s, padding=pd)[0]             # (cout, 9*s)
+        ph = convtranspose_phases(w, s, pd).view(s, cout, k // s, -1)[..., :cin]
+        taps = k // s
+        for p in range(s):
+            c_p = (p + pd) // s
+            xp = F.pad(x[0], (taps - 1 - c_p, c_p + taps))                 # input index t + c_p - (taps-1) + tau
+            y = torch.stack([sum(ph[p, :, tau] @ xp[:, t + tau] for tau in range(taps)) for t in range(9)], 1)
+            assert (y - ref[:, p::s]).abs().max() < 1e-5
+    ana, syn, wsq = stft_bases(64)
+    x = torch.randn(64, generator=gq)
+    spec = torch.fft.rfft(x * torch.hann_window(64))
+    mine = ana @ x
+    assert (mine[:33] - spec.real).abs().max() < 1e-4 and (mine[33:] - spec.imag).abs().max() < 1e-4
+    back = syn[:, :66] @ mine
+    assert (back - torch.fft.irfft(spec, 64) * torch.hann_window(64)).abs().max() < 1e-4
