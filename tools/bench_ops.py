@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Micro-benchmarks of the building-block kernels on the DiT / HiFT / decode shapes (development aid, not the bench contract).
 
-    python tools/bench_ops.py [gemm] [attn] [skinny] [sampler]
+    python tools/bench_ops.py [gemm] [attn] [skinny] [sampler] [matcha]
 """
 import math
 import os
@@ -80,8 +80,46 @@ def bench_sampler():
     print('sampler S=%d K=%d V=%d  %7.2f us' % (S, K, V, t * 1e6))
 
 
+def hifigan_flops_per_frame(c):
+    """2 * MACs of Generator.forward per mel frame (matcha/hifigan/models.py:181-197)"""
+    f = 2.0 * 7 * c.mel * c.initial_channel
+    L, C = 1, c.initial_channel
+    for u, k in zip(c.upsample_rates, c.upsample_kernel_sizes):
+        f += 2.0 * L * k * C * (C // 2)                  # ConvTranspose1d: every input row meets k taps
+        L, C = L * u, C // 2
+        for kk in c.resblock_kernel_sizes:
+            f += 2.0 * L * 6 * kk * C * C
+    return f + 2.0 * L * 7 * C
+
+
+def bench_matcha():
+    from flowmirror_hydravox_amd import weights as W
+    from flowmirror_hydravox_amd.config import HifiGanConfig, cv2_decoder_config, matcha_config
+    from flowmirror_hydravox_amd.matcha import HvxDenoiser, HvxHifiGan, HvxMatchaDecoder
+    for name, c, T in (('matcha decoder (256,256) 1+2+1 blocks', matcha_config(), 1024), ('cosyvoice2 conditional decoder 256 x (4+12x4+4)', cv2_decoder_config(), 1024)):
+        dec = HvxMatchaDecoder(c, W.make_matcha_state(c, seed=1))
+        x, mu = torch.randn(2, c.mel, T, device=DEV), torch.randn(2, c.mel, T, device=DEV)
+        spks = torch.randn(2, c.spk_dim, device=DEV) if c.spk_dim else None
+        cond = torch.randn(2, c.mel, T, device=DEV) if c.use_cond else None
+        mask = torch.ones(2, 1, T, device=DEV)
+        t = torch.tensor([0.5, 0.5])
+        tm = timeit(lambda: dec(x, mask, mu, t, spks, cond), iters=5, warm=2)
+        print('%-52s B=2 T=%d  %8.1f us per estimator call' % (name, T, tm * 1e6))
+    hc = HifiGanConfig()
+    voc = HvxHifiGan(hc, W.make_hifigan_state(hc, seed=2))
+    T = 1000
+    mel = torch.randn(1, hc.mel, T, device=DEV)
+    tm = timeit(lambda: voc(mel), iters=5, warm=2)
+    fl = hifigan_flops_per_frame(hc) * T
+    print('hifigan v1 generator T=%d (%.1f s audio)  %8.1f us  %6.1f TF/s fp32 (%.0f MF per frame)' % (T, T * 256 / 22050.0, tm * 1e6, fl / tm / 1e12, fl / T / 1e6))
+    den = HvxDenoiser(voc)
+    wav = voc(mel).squeeze(1)
+    tm = timeit(lambda: den(wav), iters=5, warm=2)
+    print('denoiser L=%d  %8.1f us' % (wav.shape[1], tm * 1e6))
+
+
 if __name__ == '__main__':
     _lib.require_gpu()
     which = sys.argv[1:] or ['gemm', 'attn', 'skinny', 'sampler']
     for w in which:
-        {'gemm': bench_gemm, 'attn': bench_attn, 'skinny': bench_skinny, 'sampler': bench_sampler}[w]()
+        {'gemm': bench_gemm, 'attn': bench_attn, 'skinny': bench_skinny, 'sampler': bench_sampler, 'matcha': bench_matcha}[w]()
