@@ -122,6 +122,35 @@ def test_llm_batched_equals_single(tiny_cfg, llm_setup):
         assert all(0 <= t < cfg.speech_tokens for t in batch[i]) and len(batch[i]) <= 4 * len(texts[i])
 
 
+def test_llm_batch32_all_heads_mixed_lengths_vs_oracle(tiny_cfg, llm_setup):
+    """BASELINE configs[2]/[3] in miniature: 32 sequences in lock-step, every MTP head (K = head_num), mixed text / prompt lengths,
+    sequences finishing at different steps, win_size=32 / tau_r=0.2 repetition window — ids equal the oracle's per utterance."""
+    from functools import partial
+    from flowmirror_hydravox_amd.llm import HvxLLM
+    from flowmirror_hydravox_amd.sampling import ras_sampling
+    from oracle import llm_ref, sampler_ref
+    g, sd = llm_setup
+    cfg = tiny_cfg.llm
+    K = cfg.head_num
+    llm = HvxLLM(cfg, sd, dtype=torch.float32, max_batch=32, max_ctx=512, inference_head_num=K,
+                 sampling=partial(ras_sampling, top_p=0.8, top_k=25, win_size=32, tau_r=0.2))
+    gen = torch.Generator().manual_seed(99)
+    n = 32
+    texts = [torch.randint(0, cfg.text_vocab, (int(torch.randint(3, 20, (1,), generator=gen)),), generator=gen, dtype=torch.int32) for _ in range(n)]
+    prompts = [torch.randint(0, cfg.speech_tokens, (int(torch.randint(0, 9, (1,), generator=gen)),), generator=gen, dtype=torch.int32) for _ in range(n)]
+    seeds = list(range(500, 500 + n))
+    batch = llm.generate_batch(texts, prompt_speech_tokens=prompts, seeds=seeds, max_token_text_ratio=5, min_token_text_ratio=1)
+    assert llm.last_stats['head_k'] == K and llm.last_stats['batch'] == n
+    lens = set()
+    for i in (0, 5, 13, 21, 31):                       # a spread of the 32 (the oracle recomputes every utterance on the CPU)
+        ora = list(llm_ref.llm_inference(sd, cfg, texts[i], sampler_ref.NoiseStream(seed=seeds[i]), prompt_speech_token=prompts[i],
+                                         inference_head_num=K, max_token_text_ratio=5, min_token_text_ratio=1, use_kv_cache=True,
+                                         sampling=dict(top_p=0.8, top_k=25, win_size=32, tau_r=0.2)))
+        assert ora == batch[i], i
+        lens.add(len(ora))
+    assert len({len(b) for b in batch}) > 3            # the utterances really stop at different steps
+
+
 def test_llm_bf16_tracks_the_fp32_oracle(tiny_cfg, llm_setup):
     """bf16 production mode: the ids agree with the fp32 oracle until the first near-tie; report the common prefix."""
     from flowmirror_hydravox_amd.llm import HvxLLM
