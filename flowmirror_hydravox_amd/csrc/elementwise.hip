@@ -124,6 +124,52 @@ int launch_gather_rows_f32(const float* x, int ldx, const int* idx, float* y, in
     return hipGetLastError() == hipSuccess ? 0 : (set_error("gather_rows launch failed"), -1);
 }
 
+// ---- head prologue: last rows -> final RMSNorm y (hidden_states[-1]) -> per MTP head: residual copy and input RMSNorm ---------------
+// One launch instead of gather + norm + K copies + norm (llm_multi_head_v3.py:248-260, 886-887): y = gain_f * (x * rsqrt(mean x^2 + eps));
+// hx[j] = y; ha[j] = T(gain_j * T(y * rsqrt(mean y^2 + eps_mtp))) — the mean square of y is shared by the K heads.
+template <class T>
+__global__ __launch_bounds__(256) void heads_prologue_kernel(const float* x, int ldx, const int* idx, const float* gain_f, float eps_f,
+                                                             const float* gain_h, float eps_h, int K, int S, int H, float* ylast, float* hx, T* ha) {
+    __shared__ float red[4];
+    const int sq = blockIdx.x;
+    const int src = idx[sq];
+    const float* xr = x + (long long)(src >= 0 ? src : 0) * ldx;
+    float ss = 0.0f;
+    for (int c = threadIdx.x; c < H; c += 256) {
+        const float v = src >= 0 ? xr[c] : 0.0f;
+        ss += v * v;
+    }
+    ss = block_sum(ss, red);
+    const float inv = rsqrtf(ss / (float)H + eps_f);
+    float ss2 = 0.0f;
+    for (int c = threadIdx.x; c < H; c += 256) {
+        const float v = (src >= 0 ? xr[c] : 0.0f) * inv;
+        const float y = gain_f[c] * v;
+        ylast[(long long)sq * H + c] = y;
+        ss2 += y * y;
+    }
+    __syncthreads();
+    ss2 = block_sum(ss2, red);
+    const float inv2 = rsqrtf(ss2 / (float)H + eps_h);
+    for (int c = threadIdx.x; c < H; c += 256) {
+        const float y = gain_f[c] * ((src >= 0 ? xr[c] : 0.0f) * inv);
+        const float v = y * inv2;
+        for (int j = 0; j < K; ++j) {
+            hx[((long long)j * S + sq) * H + c] = y;
+            ha[((long long)j * S + sq) * H + c] = from_f32<T>(gain_h[(long long)j * H + c] * to_f32(from_f32<T>(v)));
+        }
+    }
+}
+int launch_heads_prologue(const float* x, int ldx, const int* idx, const float* gain_f, float eps_f, const float* gain_h, float eps_h, int K,
+                          int S, int H, float* ylast, float* hx, void* ha, int dtype, hipStream_t s) {
+    if (S <= 0 || K <= 0) return 0;
+    if (dtype == DT_BF16)
+        hipLaunchKernelGGL(heads_prologue_kernel<bf16_t>, dim3(S), dim3(256), 0, s, x, ldx, idx, gain_f, eps_f, gain_h, eps_h, K, S, H, ylast, hx, (bf16_t*)ha);
+    else
+        hipLaunchKernelGGL(heads_prologue_kernel<float>, dim3(S), dim3(256), 0, s, x, ldx, idx, gain_f, eps_f, gain_h, eps_h, K, S, H, ylast, hx, (float*)ha);
+    return hipGetLastError() == hipSuccess ? 0 : (set_error("heads_prologue launch failed"), -1);
+}
+
 template <class T>
 __global__ void embed_kernel(const T* table, const int* tok, float* x, int ldx, int H) {
     const int r = blockIdx.x;

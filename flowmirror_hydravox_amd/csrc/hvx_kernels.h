@@ -139,6 +139,8 @@ int launch_reduce_rmsnorm(const ReduceNormArgs& a, hipStream_t s);
 int launch_act_rows(const float* x, int ldx, void* y, int ldy, int dtype, int act, float param, const float* alpha, long long rows, int cols,
                     hipStream_t s);
 // gather rows: y[r,:] = x[idx[r],:] (idx[r] < 0 -> zeros)
+int launch_heads_prologue(const float* x, int ldx, const int* idx, const float* gain_f, float eps_f, const float* gain_h, float eps_h, int K,
+                          int S, int H, float* ylast, float* hx, void* ha, int dtype, hipStream_t s);
 int launch_gather_rows_f32(const float* x, int ldx, const int* idx, float* y, int ldy, int rows, int H, hipStream_t s);
 // embedding: x[r,:] = table[tok[r],:] as f32 (tok < 0 -> zeros); table dtype f32/bf16
 int launch_embed(const void* table, int table_dtype, const int* tok, float* x, int ldx, int rows, int H, hipStream_t s);

@@ -369,24 +369,15 @@ static int forward_impl(hvx_llm* h, hipStream_t s, int32_t n_seq, int32_t kn, co
 
     // ---- last rows -> final RMSNorm (hidden_states[-1], llm_multi_head_v3.py:248-260, 886) ---------------------
     const int S = n_seq;
-    if (launch_gather_rows_f32(h->x, H, d_last, h->ylast, H, S, H, s)) return -1;
-    ReduceNormArgs fn;
-    memset(&fn, 0, sizeof(fn));
-    fn.x = h->ylast; fn.ldx = H; fn.gain = (const float*)w[2]; fn.eps = c.rms_eps; fn.do_norm = 1; fn.y = h->ylast; fn.ldy = H; fn.dtype = DT_F32;
-    fn.M = S; fn.H = H; fn.rows_per_z = S;
-    if (launch_reduce_rmsnorm(fn, s)) return -1;
-
-    // ---- K MTP heads, batched over blockIdx.z ----------------------------------------------------------------
     const void* const* mw = w + 6 + 7 * c.layers;
     const int A = c.mtp_attn_dim, I = c.mtp_inter, K = head_k;
-    for (int j = 0; j < K; ++j)
-        if (hipMemcpyAsync(h->hx + (size_t)j * S * H, h->ylast, (size_t)S * H * 4, hipMemcpyDeviceToDevice, s) != hipSuccess)
-            return set_error("hvx_llm_forward: memcpy failed"), -1;
+    // ---- K MTP heads, batched over blockIdx.z; their residual copies and input norms come out of the same launch as the final norm ---
+    if (launch_heads_prologue(h->x, H, d_last, (const float*)w[2], c.rms_eps, (const float*)mw[0], c.mtp_rms_eps, K, S, H, h->ylast, h->hx, h->ha, dt, s))
+        return -1;
     ReduceNormArgs hn;
     memset(&hn, 0, sizeof(hn));
-    hn.x = h->hx; hn.ldx = H; hn.gain = (const float*)mw[0]; hn.gain_zs = H; hn.eps = c.mtp_rms_eps; hn.do_norm = 1; hn.y = h->ha; hn.ldy = H;
+    hn.x = h->hx; hn.ldx = H; hn.gain_zs = H; hn.eps = c.mtp_rms_eps; hn.do_norm = 1; hn.y = h->ha; hn.ldy = H;
     hn.dtype = dt; hn.M = K * S; hn.H = H; hn.rows_per_z = S;
-    if (launch_reduce_rmsnorm(hn, s)) return -1;
     SkinnyArgs g;
     // v = Wv n1 + bv
     memset(&g, 0, sizeof(g));

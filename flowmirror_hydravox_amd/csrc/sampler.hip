@@ -81,6 +81,14 @@ __global__ __launch_bounds__(256) void ras_sample_kernel(SampleArgs a) {
     const int min_len = a.min_len[s];
     const int win = (a.win_size == 0) ? hist_len : min(a.win_size, hist_len);
     bool overflow = false;
+    // Everything the trial loops will touch is requested up front, beside the first head's logits: the repetition window (shared by
+    // the K heads, llm_multi_head_v3.py:891-900) and the next NW noise values (a step without EOS retries consumes <= K * top_k).
+    constexpr int NW = 128, HW = 256;
+    __shared__ float s_noise[NW];
+    __shared__ int s_hist[HW];
+    if (tid < NW) s_noise[tid] = (cursor0 + tid < a.noise_len) ? noise[cursor0 + tid] : 1.0f;
+    if (tid < HW && tid < win) s_hist[tid] = hist[hist_len - win + tid];
+    auto noise_at = [&](long long i) -> float { return (i - cursor0) < NW ? s_noise[i - cursor0] : noise[i]; };
 
     for (int j = 0; j < a.head_k && !overflow; ++j) {
         const float* lp = a.logp + (long long)s * a.logp_ss + (long long)j * a.logp_hs;
@@ -153,7 +161,7 @@ __global__ __launch_bounds__(256) void ras_sample_kernel(SampleArgs a) {
             }
             if (tid < 64) {
                 Best b = {-1.0f, BIG_IDX};
-                if (tid < n) b = Best{cand_v[tid] / noise[cursor + tid], tid};
+                if (tid < n) b = Best{cand_v[tid] / noise_at(cursor + tid), tid};
                 b = wave_best(b);
                 if (tid == 0) sh_pick = cand_i[b.i];
             }
@@ -162,7 +170,7 @@ __global__ __launch_bounds__(256) void ras_sample_kernel(SampleArgs a) {
             cursor += n;
             // ---- repetition check over the shared history snapshot (common.py:140-142) ----------------
             int rep = 0;
-            for (int i = tid; i < win; i += 256) rep += (hist[hist_len - win + i] == c) ? 1 : 0;
+            for (int i = tid; i < win; i += 256) rep += ((i < HW ? s_hist[i] : hist[hist_len - win + i]) == c) ? 1 : 0;
             rep = (int)wave_sum((float)rep);
             __syncthreads();
             if ((tid & 63) == 0) red_i[tid >> 6] = rep;
