@@ -25,7 +25,7 @@ class SampleArgs(C.Structure):
                 ('min_len', c_vp), ('active', c_vp),
                 ('top_k', c_i32), ('top_p', c_f32), ('win_size', c_i32), ('rep_thresh', c_i32),
                 ('noise', c_vp), ('noise_seq_stride', c_i64), ('noise_len', c_i32),
-                ('cursor', c_vp), ('out_ids', c_vp), ('max_trials', c_i32)]
+                ('cursor', c_vp), ('out_ids', c_vp), ('max_trials', c_i32), ('noise_limit', c_vp)]
 
 
 class GemmArgs(C.Structure):
@@ -62,7 +62,7 @@ class DecodeArgs(C.Structure):
                 ('tok', c_vp), ('ctrl', c_vp), ('hist', c_vp), ('hist_len', c_vp), ('min_adj', c_vp), ('active', c_vp),
                 ('seq_state', c_vp), ('out_tokens', c_vp), ('ids', c_vp), ('logp', c_vp),
                 ('top_k', c_i32), ('top_p', c_f32), ('win_size', c_i32), ('rep_thresh', c_i32), ('max_trials', c_i32),
-                ('noise', c_vp), ('noise_seq_stride', c_i64), ('noise_len', c_i32), ('cursor', c_vp)]
+                ('noise', c_vp), ('noise_seq_stride', c_i64), ('noise_len', c_i32), ('cursor', c_vp), ('noise_limit', c_vp)]
 
 
 class FlowConfig(C.Structure):

@@ -109,7 +109,7 @@ int hvx_ras_sample(const hvx_sample_args* a, hvx_stream s) {
     k.hist = a->hist; k.hist_ss = a->hist_seq_stride; k.hist_len = a->hist_len;
     k.min_len = a->min_len; k.active = a->active;
     k.top_k = a->top_k; k.top_p = a->top_p; k.win_size = a->win_size; k.rep_thresh = a->rep_thresh;
-    k.noise = a->noise; k.noise_ss = a->noise_seq_stride; k.noise_len = a->noise_len;
+    k.noise = a->noise; k.noise_ss = a->noise_seq_stride; k.noise_len = a->noise_len; k.noise_limit = (const long long*)a->noise_limit;
     k.cursor = (long long*)a->cursor; k.out_ids = a->out_ids; k.max_trials = a->max_trials;
     return launch_ras_sample(k, (hipStream_t)s);
 }

@@ -190,7 +190,8 @@ struct SampleArgs {
     const int* min_len;                     // per seq: head j ignores EOS while hist_len + j < min_len
     const int* active;                      // optional per seq (0 -> skip)
     int top_k; float top_p; int win_size; int rep_thresh;   // rep_thresh = ceil(win_size * tau_r) computed on the host in double
-    const float* noise; long long noise_ss; int noise_len;  // Exp(1) stream per seq
+    const float* noise; long long noise_ss; int noise_len;  // Exp(1) stream per seq: ring of noise_len values, index = position % noise_len
+    const long long* noise_limit;           // optional per seq: positions < limit are valid (absent: the plain window [0, noise_len))
     long long* cursor;                      // in/out per seq: next unread noise value
     int* out_ids;                           // [n_seq][head_k]; -1 = max_trials exhausted, -2 = noise exhausted (cursor unchanged)
     int max_trials;

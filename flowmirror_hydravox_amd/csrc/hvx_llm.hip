@@ -227,7 +227,7 @@ static int decode_step_impl(hvx_llm* h, hipStream_t s, const hvx_decode_args& a)
     sa.logp = a.logp; sa.logp_ss = (long long)a.head_k * h->c.vocab; sa.logp_hs = h->c.vocab;
     sa.hist = a.hist; sa.hist_ss = a.win_cap; sa.hist_len = a.hist_len; sa.min_len = a.min_adj; sa.active = a.active;
     sa.top_k = a.top_k; sa.top_p = a.top_p; sa.win_size = a.win_size; sa.rep_thresh = a.rep_thresh;
-    sa.noise = a.noise; sa.noise_ss = a.noise_seq_stride; sa.noise_len = a.noise_len; sa.cursor = (long long*)a.cursor;
+    sa.noise = a.noise; sa.noise_ss = a.noise_seq_stride; sa.noise_len = a.noise_len; sa.noise_limit = (const long long*)a.noise_limit; sa.cursor = (long long*)a.cursor;
     sa.out_ids = a.ids; sa.max_trials = a.max_trials;
     if (launch_ras_sample(sa, s)) return -1;
     AdvanceArgs aa;

@@ -76,6 +76,10 @@ __global__ __launch_bounds__(256) void ras_sample_kernel(SampleArgs a) {
     const long long cursor0 = a.cursor[s];
     long long cursor = cursor0;
     const float* noise = a.noise + (long long)s * a.noise_ss;
+    // noise is a ring of noise_len values indexed by the ABSOLUTE stream position (position % noise_len); positions below `limit` are
+    // valid.  Without a limit array the buffer is a plain window [0, noise_len).
+    const long long cap = a.noise_len;
+    const long long limit = a.noise_limit ? a.noise_limit[s] : cap;
     const int hist_len = a.hist_len[s];
     const int* hist = a.hist + (long long)s * a.hist_ss;
     const int min_len = a.min_len[s];
@@ -86,9 +90,9 @@ __global__ __launch_bounds__(256) void ras_sample_kernel(SampleArgs a) {
     constexpr int NW = 128, HW = 256;
     __shared__ float s_noise[NW];
     __shared__ int s_hist[HW];
-    if (tid < NW) s_noise[tid] = (cursor0 + tid < a.noise_len) ? noise[cursor0 + tid] : 1.0f;
+    if (tid < NW) s_noise[tid] = (cursor0 + tid < limit) ? noise[(cursor0 + tid) % cap] : 1.0f;
     if (tid < HW && tid < win) s_hist[tid] = hist[hist_len - win + tid];
-    auto noise_at = [&](long long i) -> float { return (i - cursor0) < NW ? s_noise[i - cursor0] : noise[i]; };
+    auto noise_at = [&](long long i) -> float { return (i - cursor0) < NW ? s_noise[i - cursor0] : noise[i % cap]; };
 
     for (int j = 0; j < a.head_k && !overflow; ++j) {
         const float* lp = a.logp + (long long)s * a.logp_ss + (long long)j * a.logp_hs;
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(256) void ras_sample_kernel(SampleArgs a) {
         int result = -1;
         for (int trial = 0;; ++trial) {
             // ---- multinomial(1) over the candidates == first argmax of p / Exp(1) ---------------------
-            if (cursor + n > a.noise_len) {
+            if (cursor + n > limit) {
                 overflow = true;
                 break;
             }
@@ -178,7 +182,7 @@ __global__ __launch_bounds__(256) void ras_sample_kernel(SampleArgs a) {
             rep = red_i[0] + red_i[1] + red_i[2] + red_i[3];
             if (rep >= a.rep_thresh) {
                 // random_sampling: race over the full vocabulary (common.py:164-166)
-                if (cursor + V > a.noise_len) {
+                if (cursor + V > limit) {
                     overflow = true;
                     break;
                 }
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(256) void ras_sample_kernel(SampleArgs a) {
 #pragma unroll
                 for (int u = 0; u < VPT; ++u) {
                     const int i = u * 256 + tid;
-                    q[u] = i < V ? noise[cursor + i] : 1.0f;
+                    q[u] = i < V ? noise[(cursor + i) % cap] : 1.0f;
                 }
                 Best b = {-1.0f, BIG_IDX};
 #pragma unroll
@@ -254,12 +258,19 @@ __global__ void decode_advance_kernel(AdvanceArgs a) {
     int pos = st[0], out_len = st[1], done = st[2];
     const int min_len = st[3], max_len = st[4];
     int n_next = 0;
+    if (!done && a.ids[i * K] == -2) {
+        // the sampler ran out of pre-generated noise for this sequence (all K ids are -2, its cursor is untouched): the step is void.
+        // Nothing advances — the same rows are fed again (rewriting the same KV entries) until the host has refilled the window.
+        st[6] = 2;
+        return;
+    }
     if (!done) {
+        st[6] = 0;                                           // (a stall flag from an earlier void step is history once a step counts)
         pos += a.ctrl[2 * a.n_seq + i];                      // rows fed by the step that just ran
         for (int j = 0; j < K; ++j) {
             const int t = a.ids[i * K + j];
-            if (t < 0) {                                     // -1: max_trials exhausted, -2: noise window exhausted
-                st[6] = (t == -1) ? 1 : 2;
+            if (t < 0) {                                     // -1: max_trials exhausted (the reference raises RuntimeError)
+                st[6] = 1;
                 done = 1;
                 break;
             }

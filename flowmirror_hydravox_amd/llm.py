@@ -269,9 +269,7 @@ class HvxLLM:
             # reference does in Python between two steps (accept / append / stop, llm_multi_head_v3.py:890-905) are one graph per
             # step, `sync_every` steps are enqueued per host round trip and only the per-sequence state words come back.
             max_trials = 100
-            ncap = self.noise_cap
-            while sync_every * K * max_trials > ncap // 2:          # a block of steps can never run out of pre-generated noise
-                ncap *= 2
+            ncap = self.noise_cap          # a sequence that runs out of noise stalls on the device until the host refills (below)
             max_out = max(max(r.max_len for r in reqs), 1)
             o_tok, o_ctrl, o_hist = 0, S * K, S * K + 5 * S
             o_hlen, o_min, o_act = o_hist + S * W, o_hist + S * W + S, o_hist + S * W + 2 * S
@@ -293,17 +291,15 @@ class HvxLLM:
             ctl_dev = ctl_host.to(dev, non_blocking=True)
             out_dev = torch.zeros(S, max_out, dtype=torch.int32, device=dev)
             logp = torch.empty(S, K, c.vocab, dtype=torch.float32, device=dev)
+            # Exp(1) noise: a ring of `ncap` values per sequence addressed by ABSOLUTE stream position; the host tops it up behind the
+            # device cursor while the steps run (no stop-the-world refill)
             d.ncap = ncap
-            d.noise_host = torch.empty(S, d.ncap, dtype=torch.float32).pin_memory()
-            for i, r in enumerate(reqs):
-                d.noise_host[i].copy_(torch.from_numpy(r.noise.window(0, d.ncap)))
-            d.noise_dev = d.noise_host.to(dev, non_blocking=True)
+            d.noise_dev = torch.empty(S, d.ncap, dtype=torch.float32, device=dev)
+            d.head = [0] * S                     # absolute position up to which sequence i's ring is filled
+            d.limit_dev = torch.zeros(S, dtype=torch.int64, device=dev)
             d.cur_dev = torch.zeros(S, dtype=torch.int64, device=dev)
-            d.nbase = [0] * S                    # absolute stream position of noise_dev[i, 0]
-            state_host = torch.zeros(S, 8, dtype=torch.int32).pin_memory()
-            d.cur_host = torch.zeros(S, dtype=torch.int64).pin_memory()
-            first_host = torch.zeros(max_out, dtype=torch.int32).pin_memory()
-            stream.synchronize()
+            d.cur_host = torch.zeros(S, dtype=torch.int64)
+            d.last_fill = [0] * S
 
         def decode_args():
             a = _lib.DecodeArgs()
@@ -314,48 +310,124 @@ class HvxLLM:
             a.out_tokens, a.logp = out_dev.data_ptr(), logp.data_ptr()
             a.top_k, a.top_p, a.win_size, a.rep_thresh, a.max_trials = sp['top_k'], sp['top_p'], sp['win_size'], thr, max_trials
             a.noise, a.noise_seq_stride, a.noise_len, a.cursor = d.noise_dev.data_ptr(), d.ncap, d.ncap, d.cur_dev.data_ptr()
+            a.noise_limit = d.limit_dev.data_ptr()
             return a
 
-        def refill_noise():
+        def top_up(cursors, force=False):
+            """fill every ring up to cursor + ncap: the slots overwritten hold positions below a cursor the device has already reported,
+            so they are never read again; the new limits are published behind the data on the same stream"""
+            moved = [False] * S
             for i, r in enumerate(reqs):
-                d.nbase[i] += int(d.cur_host[i])
-                d.noise_host[i].copy_(torch.from_numpy(r.noise.window(d.nbase[i], d.ncap)))
-            d.noise_dev.copy_(d.noise_host, non_blocking=True)
-            d.cur_dev.zero_()
-            d.cur_host.zero_()
-            stream.synchronize()
+                target = int(cursors[i]) + d.ncap
+                n = target - d.head[i]
+                if n <= 0 or (not force and n < max(d.ncap // 8, 1)):
+                    continue
+                vals = torch.from_numpy(r.noise.window(d.head[i], n).copy()).pin_memory()
+                p0 = d.head[i] % d.ncap
+                first = min(n, d.ncap - p0)
+                d.noise_dev[i, p0:p0 + first].copy_(vals[:first], non_blocking=True)
+                if n > first:
+                    d.noise_dev[i, :n - first].copy_(vals[first:], non_blocking=True)
+                d.head[i] = target
+                moved[i] = True
+            if any(moved):
+                d.limit_dev.copy_(torch.tensor(d.head, dtype=torch.int64).pin_memory(), non_blocking=True)
+            return moved
 
-        args = decode_args()
+        def grow_ring(cursors):
+            """one step needs more values than the ring holds (toy capacities only): quadruple it, keeping the unread values"""
+            old, cap0 = d.noise_dev, d.ncap
+            d.ncap *= 4
+            d.noise_dev = torch.empty(S, d.ncap, dtype=torch.float32, device=dev)
+            for i in range(S):
+                j = torch.arange(int(cursors[i]), d.head[i], device=dev)
+                d.noise_dev[i, j % d.ncap] = old[i, j % cap0]
+
+        with torch.cuda.stream(stream):
+            top_up([0] * S, force=True)
+            stream.synchronize()
+        t_setup = time.time() - t_start
+
+        args = [decode_args()]
         emitted = 0
         blocks = []                                   # hipEvent brackets around every block of steps (2 events per sync_every steps)
         pos_start = [r.pos for r in reqs]
-        while True:
+        # The host runs AHEAD of the device: up to NS blocks of steps are enqueued before the oldest is waited for, so neither the wake-up
+        # latency of a wait nor a descheduled driver thread (tens of ms on a busy host) leaves the GPU without work.  Blocks beyond the
+        # second are only enqueued while some sequence is still short of its min_len by that many steps (it cannot stop before), so a
+        # finished batch costs at most one surplus block of inactive steps.
+        NS = 8
+        slots = [dict(state=torch.zeros(S, 8, dtype=torch.int32).pin_memory(), cur=torch.zeros(S, dtype=torch.int64).pin_memory(),
+                      first=torch.zeros(max_out, dtype=torch.int32).pin_memory(), done=torch.cuda.Event()) for _ in range(NS)]
+
+        def launch(slot):
             with torch.cuda.stream(stream):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(stream)
-                check(self.lib.hvx_llm_decode_steps(self._h, C.c_void_p(stream.cuda_stream), C.byref(args), sync_every), 'hvx_llm_decode_steps')
+                check(self.lib.hvx_llm_decode_steps(self._h, C.c_void_p(stream.cuda_stream), C.byref(args[0]), sync_every), 'hvx_llm_decode_steps')
                 e1.record(stream)
                 blocks.append((e0, e1))
-                state_host.copy_(ctl_dev[o_state:o_state + 8 * S].view(S, 8), non_blocking=True)
-                d.cur_host.copy_(d.cur_dev, non_blocking=True)
+                slot['state'].copy_(ctl_dev[o_state:o_state + 8 * S].view(S, 8), non_blocking=True)
+                slot['cur'].copy_(d.cur_dev, non_blocking=True)
                 if stream_first:
-                    first_host.copy_(out_dev[0], non_blocking=True)
-                stream.synchronize()
-            st = state_host.tolist()
+                    slot['first'].copy_(out_dev[0], non_blocking=True)
+                slot['done'].record(stream)
+
+        def steps_certainly_needed(st):
+            need = 0
+            for r, row in zip(reqs, st):
+                if not row[2]:
+                    need = max(need, -(-(min(r.min_len, r.max_len) - row[1]) // K))
+            return need
+
+        st = [[r.pos, 0, 0, r.min_len, r.max_len, 0, 0, 0] for r in reqs]
+        launched = processed = 0
+        draining = False                              # True while the queue is being emptied to re-allocate the noise ring
+        while True:
+            if not draining:
+                while launched - processed < NS:
+                    ahead = launched - processed
+                    if ahead >= 2 and (ahead + 1) * sync_every > steps_certainly_needed(st):
+                        break
+                    launch(slots[launched % NS])
+                    launched += 1
+            cur = slots[processed % NS]
+            while not cur['done'].query():            # polled (a blocking wait may wake up late); the sleep releases the GIL
+                time.sleep(0.0002)
+            processed += 1
+            st = cur['state'].tolist()
+            d.cur_host.copy_(cur['cur'])
             if any(row[6] == 1 for row in st):
                 raise RuntimeError('sampling reaches max_trials {} and still get eos when ignore_eos is True, check your input!'.format(max_trials))
-            if any(row[6] != 0 for row in st):
-                raise _lib.HvxError('decode loop: pre-generated sampler noise exhausted inside a block of %d steps' % sync_every)
             if stream_first:
                 n0 = st[0][1]
-                for t in first_host[emitted:n0].tolist():
+                for t in cur['first'][emitted:n0].tolist():
                     yield t
                 emitted = n0
             if all(row[2] for row in st):
                 break
-            if max(int(v) for v in d.cur_host.tolist()) > d.ncap // 2:
-                with torch.cuda.stream(stream):
-                    refill_noise()
+            cursors = d.cur_host.tolist()
+            stall = [row[6] == 2 for row in st]       # waiting for noise: that sequence's steps are void until its ring is topped up
+            if draining:
+                if launched == processed:             # the stream is idle: the ring can be re-allocated
+                    with torch.cuda.stream(stream):
+                        grow_ring(cursors)
+                        top_up(cursors, force=True)
+                        ctl_dev[o_state:o_state + 8 * S].view(S, 8)[:, 6] = 0
+                        args[0] = decode_args()
+                    draining = False
+                    d.last_fill = [launched] * S
+                continue
+            with torch.cuda.stream(stream):
+                moved = top_up(cursors, force=any(stall))
+                for i in range(S):
+                    if moved[i]:
+                        d.last_fill[i] = launched     # blocks enqueued from here on see sequence i's new limit
+                    elif stall[i] and processed - 1 >= d.last_fill[i]:
+                        # stalled in a block that was enqueued AFTER its ring had been filled up to cursor + ncap: one step needs
+                        # more values than the ring holds
+                        draining = True
+        stream.synchronize()                          # a surplus block of inactive steps may still be running: it changes nothing
         with torch.cuda.stream(stream):
             out_host = out_dev.cpu()
         n_llm_tokens = 0
@@ -363,14 +435,16 @@ class HvxLLM:
             r.out = out_host[i, :st[i][1]].tolist()
             r.done = True
             n_llm_tokens += len(r.out)
-            r.cursor = d.nbase[i] + int(d.cur_host[i])
+            r.cursor = int(d.cur_host[i])
             r.noise.finalize(r.cursor)
         steps = max(row[5] for row in st)
         torch.cuda.current_stream().wait_stream(stream)
         dt = time.time() - t_start
         step_ms = sum(a.elapsed_time(b) for a, b in blocks) / (len(blocks) * sync_every)
+        gaps = sorted(blocks[i][1].elapsed_time(blocks[i + 1][0]) for i in range(len(blocks) - 1))
         mean_ctx = sum(0.5 * (p0 + row[0]) for p0, row in zip(pos_start, st)) / S
         self.last_stats = dict(steps=steps, tokens=n_llm_tokens, seconds=dt, tps=n_llm_tokens / dt if dt > 0 else 0.0, head_k=K, batch=S,
+                               prefill_and_setup_seconds=t_setup, device_idle_ms_between_blocks=sum(gaps),
                                decode_step_us=1e3 * step_ms, decode_steps_timed=len(blocks) * sync_every, mean_ctx=mean_ctx,
                                decode_step_bytes=self.decode_step_bytes(S, K, mean_ctx))
 

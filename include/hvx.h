@@ -57,6 +57,7 @@ typedef struct {
     int64_t* cursor;
     int32_t* out_ids;
     int32_t max_trials;
+    const int64_t* noise_limit;   /* optional [n_seq]: `noise` is then a ring addressed by absolute stream position % noise_len, valid below the limit */
 } hvx_sample_args;
 int hvx_ras_sample(const hvx_sample_args* a, hvx_stream s);
 
@@ -142,8 +143,8 @@ int hvx_llm_use_graph(hvx_llm* h, int32_t enable);
  *   hist [n_seq][win_cap]       ring of the last tokens (slot = out_len % win_cap), hist_len = min(out_len, win_cap)
  *   min_adj [n_seq]             min_len - (out_len - hist_len): head j ignores stop ids while hist_len + j < min_adj
  *   active [n_seq]              0 once a sequence is finished
- *   seq_state [n_seq][8]        pos, out_len, done, min_len, max_len, steps, err (1 = sampler max_trials exhausted, 2 = noise window
- *                               exhausted), reserved
+ *   seq_state [n_seq][8]        pos, out_len, done, min_len, max_len, steps, err (1 = sampler max_trials exhausted, 2 = the sequence is
+ *                               waiting for noise: its steps are void, nothing advances, until the ring is topped up and the flag cleared), reserved
  *   out_tokens [n_seq][max_out] the utterance so far (out_len valid entries)
  *   ids [n_seq][head_k]         scratch: the ids sampled by the last step
  * Sampler fields as in hvx_sample_args.  The step is replayed from a cached hipGraph keyed on the argument block. */
@@ -154,6 +155,7 @@ typedef struct {
     float* logp;
     int32_t top_k; float top_p; int32_t win_size; int32_t rep_thresh; int32_t max_trials;
     const float* noise; int64_t noise_seq_stride; int32_t noise_len; int64_t* cursor;
+    const int64_t* noise_limit;   /* [n_seq] absolute positions up to which the noise ring is filled (the caller tops it up while steps run) */
 } hvx_decode_args;
 int hvx_llm_decode_steps(hvx_llm* h, hvx_stream s, const hvx_decode_args* a, int32_t n_steps);
 /* debugging / parity: copy the post-final-norm hidden of the last rows of the previous forward (fp32 [n_seq][H]) */

@@ -151,6 +151,26 @@ def test_llm_batch32_all_heads_mixed_lengths_vs_oracle(tiny_cfg, llm_setup):
     assert len({len(b) for b in batch}) > 3            # the utterances really stop at different steps
 
 
+def test_llm_noise_window_refill_and_growth_do_not_change_the_ids(tiny_cfg, llm_setup):
+    """A pre-generated noise window far too short for the run (refills every few steps; the RAS fallback alone needs more values than the
+    window holds, so it must also grow): sequences stall on the device until the host refills, and the ids are those of a roomy window."""
+    from functools import partial
+    from flowmirror_hydravox_amd.llm import HvxLLM
+    from flowmirror_hydravox_amd.sampling import ras_sampling
+    g, sd = llm_setup
+    cfg = tiny_cfg.llm
+    samp = partial(ras_sampling, top_p=0.9, top_k=10, win_size=8, tau_r=0.1)          # threshold 1: the fallback fires often
+    gen = torch.Generator().manual_seed(5)
+    texts = [torch.randint(0, cfg.text_vocab, (n,), generator=gen, dtype=torch.int32) for n in (12, 7, 15)]
+    seeds = [301, 302, 303]
+    roomy = HvxLLM(cfg, sd, dtype=torch.float32, max_batch=3, max_ctx=256, inference_head_num=2, sampling=samp)
+    want = roomy.generate_batch(texts, seeds=seeds, max_token_text_ratio=5, min_token_text_ratio=2)
+    tight = HvxLLM(cfg, sd, dtype=torch.float32, max_batch=3, max_ctx=256, inference_head_num=2, sampling=samp, noise_cap=48)
+    got = tight.generate_batch(texts, seeds=seeds, max_token_text_ratio=5, min_token_text_ratio=2)
+    assert got == want
+    assert sum(len(t) for t in got) > 20
+
+
 def test_llm_bf16_tracks_the_fp32_oracle(tiny_cfg, llm_setup):
     """bf16 production mode: the ids agree with the fp32 oracle until the first near-tie; report the common prefix."""
     from flowmirror_hydravox_amd.llm import HvxLLM
