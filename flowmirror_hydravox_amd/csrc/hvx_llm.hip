@@ -7,9 +7,10 @@
 // The reference recomputes the full prefix every step (cache=None, :873-882); with a causal mask that equals
 // this KV-cached evaluation of the new rows only.
 //
-// Per layer: QKV GEMM (+bias +RoPE +KV append) | GQA-packed attention (+split combine) | o_proj split-K |
-// reduce+residual+RMSNorm | gate/up GEMM (+SwiGLU) | down split-K | reduce+residual+RMSNorm(next).
-// Residual stream x stays fp32; GEMM operands are `dtype` (bf16 production / f32 parity).
+// Per layer, five GEMM / attention launches (+ the split combine): QKV (RMSNorm folded in, +bias +RoPE +KV append) | GQA-packed
+// attention | o_proj (+residual, in place) | gate/up (RMSNorm folded in, +SwiGLU) | down (+residual).  The residual stream x stays
+// fp32 (bf16 mode keeps a bf16 copy beside it for the fused-norm GEMMs); GEMM operands are `dtype` (bf16 production / f32 parity).
+// hvx_llm_decode_steps replays {forward, RAS sampler, advance} as one hipGraph per step: the decode loop lives on the device.
 #include <string.h>
 
 #include <map>
