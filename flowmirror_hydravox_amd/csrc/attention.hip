@@ -34,7 +34,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float fmax2(float a, float b) { return __builtin_fmaxf(a, b); }
 __device__ __forceinline__ float fmax3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 
-template <class T, int QT>
+template <class T, int QT, bool MERGE>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     typedef typename Vec8<T>::type V8;
     typedef typename Vec4<T>::type V4;
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     const int fr = lane & 15, fg = lane >> 4;
     const int b = blockIdx.z, h = blockIdx.y;
     const int n_qt = (a.n_rows + 16 * QT - 1) / (16 * QT);
-    const bool merge = (QT == 1) && a.sub_chunk > 0;          // decode form: workgroup = one split, waves = its four quarters
+    constexpr bool merge = MERGE;                             // decode form: workgroup = one split, waves = its four quarters
     const int w = merge ? blockIdx.x : blockIdx.x * 4 + wave;
     if (!merge && w >= n_qt * a.n_splits) return;
     const int qt = merge ? 0 : w / a.n_splits, sp = merge ? blockIdx.x : w - qt * a.n_splits;
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 
     // KS 32-key steps per trip.  The decode form (one q-tile) requests both steps of a wave's 64 keys before the first MFMA: the walk
     // is a chain of dependent round trips to L2 / HBM otherwise, and latency is all a decode step has to lose.
-    constexpr int KS = (QT == 1) ? 2 : 1;
+    constexpr int KS = (QT == 1 || MERGE) ? 2 : 1;
     for (int key0 = key_begin; key0 < key_end; key0 += 32 * KS) {
         // K fragments: 2 key tiles x 2 d-halves.  Rows past the end are clamped (their scores are masked by select).
         V8 kf[KS][2][2];
@@ -187,24 +187,29 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     }
 
     // ---- finish -------------------------------------------------------------------------------------
-    if constexpr (QT == 1) {
-        if (merge) {
-            // merge the four waves' partial softmax states in LDS (fixed wave order) and write ONE partial per workgroup
-            __shared__ float mo[4][16][64];
-            __shared__ float mml[4][16][2];
-            float l = l_run[0];
+    if constexpr (MERGE) {
+        // merge the four waves' partial softmax states in LDS (fixed wave order) and write ONE partial per workgroup
+        constexpr int RW = 16 * QT;
+        __shared__ float mo[4][RW][64];
+        __shared__ float mml[4][RW][2];
+#pragma unroll
+        for (int i = 0; i < QT; ++i) {
+            float l = l_run[i];
             l += __shfl_xor(l, 16, 64);
             l += __shfl_xor(l, 32, 64);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) mo[wave][fr][dt * 16 + fg * 4 + e] = o_acc[0][dt][e];
+                for (int e = 0; e < 4; ++e) mo[wave][i * 16 + fr][dt * 16 + fg * 4 + e] = o_acc[i][dt][e];
             if (fg == 0) {
-                mml[wave][fr][0] = m_run[0];
-                mml[wave][fr][1] = l;
+                mml[wave][i * 16 + fr][0] = m_run[i];
+                mml[wave][i * 16 + fr][1] = l;
             }
-            __syncthreads();
-            const int row = threadIdx.x >> 4, d0 = (threadIdx.x & 15) * 4;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int pass = 0; pass < QT; ++pass) {
+            const int row = pass * 16 + (threadIdx.x >> 4), d0 = (threadIdx.x & 15) * 4;
             const int rh = row / a.kn, rl = row - rh * a.kn;
             if (row < a.n_rows && rl < n_valid_lo) {
                 float m = -INFINITY;
@@ -226,8 +231,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
                     a.part_ml[base * 2 + 1] = ls;
                 }
             }
-            return;
         }
+        return;
     }
 #pragma unroll
     for (int i = 0; i < QT; ++i) {
@@ -514,12 +519,15 @@ static int launch_t(const AttnArgs& a, hipStream_t s) {
     const int rows_per_wave = big ? 32 : 16;
     const int n_qt = (a.n_rows + rows_per_wave - 1) / rows_per_wave;
     dim3 grid((n_qt * a.n_splits + 3) / 4, a.heads, a.batch);
-    if (!big && a.sub_chunk > 0) grid.x = a.n_splits;              // one workgroup per split, 4 waves merge in LDS
+    const bool merge = !big && a.sub_chunk > 0;
+    if (merge) grid.x = a.n_splits;                                // one workgroup per split, 4 waves merge in LDS
     // QK^T + PV flops when the key length is known on the host (DiT); 0 for the device-length LLM calls
     const double flops = a.kv_len ? 0.0 : 4.0 * a.n_rows * (double)a.kv_len_const * 64.0 * a.heads * a.batch * (a.causal ? 0.5 : 1.0);
     const int slot = prof_begin(a.kv_len ? PK_ATTN_LLM : PK_ATTN, flops, s);
-    if (big) hipLaunchKernelGGL((attn_fwd_kernel<T, 2>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((attn_fwd_kernel<T, 1>), grid, dim3(256), 0, s, a);
+    if (merge && a.n_rows > 16) hipLaunchKernelGGL((attn_fwd_kernel<T, 2, true>), grid, dim3(256), 0, s, a);      // decode, 17..32 rows (K = 3, 4)
+    else if (merge) hipLaunchKernelGGL((attn_fwd_kernel<T, 1, true>), grid, dim3(256), 0, s, a);
+    else if (big) hipLaunchKernelGGL((attn_fwd_kernel<T, 2, false>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<T, 1, false>), grid, dim3(256), 0, s, a);
     if (a.n_splits > 1) {
         dim3 g2((a.n_rows + 3) / 4, a.heads, a.batch);
         hipLaunchKernelGGL((attn_combine_kernel<T>), g2, dim3(256), 0, s, a);
@@ -533,7 +541,7 @@ int launch_attention(const AttnArgs& a_in, hipStream_t s) {
     if (a.n_rows <= 0 || a.batch <= 0) return 0;
     if (a.n_splits < 1) a.n_splits = 1;
     if (a.kn < 1) a.kn = a.n_rows;
-    if (a.n_splits == 1 || a.n_rows > 16 || a.sub_chunk * 4 != a.split_chunk || (a.sub_chunk & 31)) a.sub_chunk = 0;
+    if (a.n_splits == 1 || a.n_rows > 32 || a.sub_chunk * 4 != a.split_chunk || (a.sub_chunk & 31)) a.sub_chunk = 0;
     if ((a.v_ld & 31) || (a.n_splits > 1 && ((a.split_chunk & 31) || !a.part_o || !a.part_ml || a.n_rows_pad < a.n_rows))) {
         set_error("launch_attention: bad geometry v_ld=%d split_chunk=%d", a.v_ld, a.split_chunk);
         return -1;

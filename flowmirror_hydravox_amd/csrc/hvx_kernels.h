@@ -113,7 +113,7 @@ struct AttnArgs {
     float scale;
     void* out; long long o_bs, o_hs, o_hi, o_lo;      // dtype
     int n_splits; int split_chunk;                    // keys per split (multiple of 32) when n_splits > 1
-    int sub_chunk;                                    // > 0 (needs n_rows <= 16): one workgroup per split, its 4 waves take sub_chunk keys
+    int sub_chunk;                                    // > 0 (needs n_rows <= 32): one workgroup per split, its 4 waves take sub_chunk keys
                                                       // each and merge their (m, l, o) in LDS, so the combine reads 4x fewer partials
     float* part_o; float* part_ml;                    // [batch][heads][n_splits][n_rows_pad][64], [...][n_rows_pad][2]
     int n_rows_pad;

@@ -151,6 +151,27 @@ def test_llm_batch32_all_heads_mixed_lengths_vs_oracle(tiny_cfg, llm_setup):
     assert len({len(b) for b in batch}) > 3            # the utterances really stop at different steps
 
 
+def test_llm_wide_gqa_group_three_heads_vs_oracle(tiny_cfg):
+    """G * K = 8 query heads per KV head x 3 tokens per step = 24 packed rows: the two-tile form of the split decode attention
+    (the CV3 geometry at inference_head_num = 3 / 4: 21 / 28 rows)."""
+    import dataclasses
+    from flowmirror_hydravox_amd import weights as W
+    from flowmirror_hydravox_amd.llm import HvxLLM
+    from oracle import llm_ref, sampler_ref
+    cfg = dataclasses.replace(tiny_cfg.llm, q_heads=8, kv_heads=1)
+    sd = W.make_llm_state(cfg, seed=61, init='fan_in', with_lm_head=True)
+    llm = HvxLLM(cfg, sd, dtype=torch.float32, max_batch=2, max_ctx=1024, inference_head_num=3)      # 4 key splits of 256
+    gen = torch.Generator().manual_seed(62)
+    texts = [torch.randint(0, cfg.text_vocab, (n,), generator=gen, dtype=torch.int32) for n in (10, 6)]
+    prompts = [torch.randint(0, cfg.speech_tokens, (n,), generator=gen, dtype=torch.int32) for n in (300, 0)]   # a context that spans splits
+    batch = llm.generate_batch(texts, prompt_speech_tokens=prompts, seeds=[71, 72], max_token_text_ratio=4, min_token_text_ratio=2)
+    for i in range(2):
+        ora = list(llm_ref.llm_inference(sd, cfg, texts[i], sampler_ref.NoiseStream(seed=71 + i), prompt_speech_token=prompts[i],
+                                         inference_head_num=3, max_token_text_ratio=4, min_token_text_ratio=2, use_kv_cache=True))
+        assert ora == batch[i], i
+    assert sum(len(b) for b in batch) > 10
+
+
 def test_llm_noise_window_refill_and_growth_do_not_change_the_ids(tiny_cfg, llm_setup):
     """A pre-generated noise window far too short for the run (refills every few steps; the RAS fallback alone needs more values than the
     window holds, so it must also grow): sequences stall on the device until the host refills, and the ids are those of a roomy window."""
