@@ -129,6 +129,8 @@ SYMBOLS = {
     'hvx_hifigan_workspace_bytes': (c_sz, [c_vp, c_i32]),
     'hvx_hifigan_forward': (c_i32, [c_vp, c_vp, c_vp, c_sz, c_vp, c_i32, c_vp]),
     'hvx_denoise_workspace_bytes': (c_sz, [c_i32, c_i32, c_i32]),
+    'hvx_mel_workspace_bytes': (c_sz, [c_i32, c_i32, c_i32, c_i32]),
+    'hvx_mel_spectrogram': (c_i32, [c_vp, c_vp, c_sz, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp]),
     'hvx_stft_magnitude': (c_i32, [c_vp, c_vp, c_sz, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
     'hvx_denoise': (c_i32, [c_vp, c_vp, c_sz, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp]),
     'hvx_hift_create': (c_i32, [C.POINTER(HiftConfig), C.POINTER(c_vp), c_i32, C.POINTER(c_vp)]),

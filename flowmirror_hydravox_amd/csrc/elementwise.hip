@@ -591,16 +591,21 @@ int launch_spectral_subtract(float* spec, int ld, int frames, int bins, const fl
     hipLaunchKernelGGL(spectral_subtract_kernel, dim3((bins + 255) / 256, frames), dim3(256), 0, s, spec, ld, frames, bins, bias, strength);
     return hipGetLastError() == hipSuccess ? 0 : (set_error("spectral_subtract launch failed"), -1);
 }
-__global__ void spectral_magnitude_kernel(const float* spec, int ld, int bins, float* mag) {
+// mag[f][k] = sqrt(re^2 + im^2 + eps) for k < bins, 0 for the padding columns up to ld_mag
+__global__ void spectral_magnitude_kernel(const float* spec, int ld, int bins, float* mag, int ld_mag, float eps) {
     const int f = blockIdx.y;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= bins) return;
-    const float re = spec[(long long)f * ld + k], im = spec[(long long)f * ld + bins + k];
-    mag[(long long)f * bins + k] = sqrtf(re * re + im * im);
+    if (k >= ld_mag) return;
+    float v = 0.0f;
+    if (k < bins) {
+        const float re = spec[(long long)f * ld + k], im = spec[(long long)f * ld + bins + k];
+        v = sqrtf(re * re + im * im + eps);
+    }
+    mag[(long long)f * ld_mag + k] = v;
 }
-int launch_spectral_magnitude(const float* spec, int ld, int frames, int bins, float* mag, hipStream_t s) {
+int launch_spectral_magnitude(const float* spec, int ld, int frames, int bins, float* mag, int ld_mag, float eps, hipStream_t s) {
     if (frames <= 0) return 0;
-    hipLaunchKernelGGL(spectral_magnitude_kernel, dim3((bins + 255) / 256, frames), dim3(256), 0, s, spec, ld, bins, mag);
+    hipLaunchKernelGGL(spectral_magnitude_kernel, dim3((ld_mag + 255) / 256, frames), dim3(256), 0, s, spec, ld, bins, mag, ld_mag, eps);
     return hipGetLastError() == hipSuccess ? 0 : (set_error("spectral_magnitude launch failed"), -1);
 }
 // torch.istft(center=True): y[n] = sum_f frame_f[n + n_fft/2 - f*hop] / sum_f w^2[...], n in [0, hop*(frames-1))

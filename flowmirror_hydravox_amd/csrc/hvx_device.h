@@ -88,6 +88,7 @@ enum Act : int {
     ACT_SNAKE = 6,       // x + sin^2(a x) / (a + 1e-9), a per col  (activation.py:73-84)
     ACT_TANH = 7,
     ACT_ABS = 8,         // |x|                                     (f0_predictor.py:103)
+    ACT_LOG_CLAMP = 10,  // log(max(x, param))                      (matcha/utils/audio.py:23-24)
     ACT_SNAKEBETA = 9,   // x + sin^2(a x) / (b + 1e-9); a = alpha[col], b = alpha[n_cols + col] (matcha transformer.py:17-80, exp() applied at load)
 };
 
@@ -113,6 +114,7 @@ __device__ __forceinline__ float act_apply(int act, float x, float param, float 
             const float s = sinf(x * alpha);
             return x + (1.0f / (beta + 1e-9f)) * (s * s);
         }
+        case ACT_LOG_CLAMP: return logf(fmaxf(x, param));
         case ACT_TANH: return tanhf(x);
         case ACT_ABS: return fabsf(x);
         default: return x;

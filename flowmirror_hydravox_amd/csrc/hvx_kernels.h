@@ -174,7 +174,7 @@ int launch_groupnorm_act(const float* x, int ld, int B, int T, int C, int G, con
 int launch_mask_rows(float* x, int ld, int B, int T, int C, const int* len, hipStream_t s);
 int launch_euler_rows(float* x, const float* v, int ldv, float dt, int B, int T, int mel, hipStream_t s);
 int launch_reflect_pad(const float* x, float* y, int L, int pad, int total, hipStream_t s);
-int launch_spectral_magnitude(const float* spec, int ld, int frames, int bins, float* mag, hipStream_t s);
+int launch_spectral_magnitude(const float* spec, int ld, int frames, int bins, float* mag, int ld_mag, float eps, hipStream_t s);
 int launch_spectral_subtract(float* spec, int ld, int frames, int bins, const float* bias, float strength, hipStream_t s);
 int launch_overlap_add(const float* frames_buf, int ld, int frames, int n_fft, int hop, const float* wsq, float* y, int out_len, hipStream_t s);
 int launch_transpose_f32(const float* src, float* dst, int rows, int cols, int ld_src, int ld_dst, hipStream_t s);   // dst[c][r] = src[r][c]

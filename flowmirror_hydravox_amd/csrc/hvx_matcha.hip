@@ -548,7 +548,42 @@ int hvx_stft_magnitude(hvx_stream stream, void* ws, size_t ws_bytes, const float
     g.conv_stride = hop / 32;
     g.out = spec; g.ldo = ldspec; g.out_cols = ldspec;
     HVX_CHECK(launch_gemm(g, s));
-    return launch_spectral_magnitude(spec, ldspec, frames, bins, mag, s);
+    return launch_spectral_magnitude(spec, ldspec, frames, bins, mag, bins, 0.0f, s);
+}
+
+/* mel_spectrogram (matcha/utils/audio.py:45-82; the prompt-feature extractor of cosyvoice/cli/frontend.py:119): reflect pad by
+ * (n_fft - hop) / 2, STFT(center=False, hann), sqrt(re^2 + im^2 + 1e-9), mel filterbank, log(clamp(., 1e-5)).
+ * mel_basis f32 [n_mels][pad32(n_fft/2 + 1)] (zero padded); out f32 (n_mels, frames), frames = (L + (n_fft - hop)/2*2 - n_fft) / hop + 1. */
+size_t hvx_mel_workspace_bytes(int32_t L, int32_t n_fft, int32_t hop, int32_t n_mels) {
+    const size_t padded = (size_t)L + n_fft, frames = padded / hop + 1, ldspec = (size_t)pad32(n_fft + 2), ldmag = (size_t)pad32(n_fft / 2 + 1);
+    return align_up((padded + 64) * 4) + align_up(frames * ldspec * 4) + align_up(frames * ldmag * 4) + align_up(frames * pad32(n_mels) * 4);
+}
+int hvx_mel_spectrogram(hvx_stream stream, void* ws, size_t ws_bytes, const float* audio, int32_t L, int32_t n_fft, int32_t hop,
+                        const float* stft_basis, const float* mel_basis, int32_t n_mels, float* out) {
+    if (!ws || !audio || !stft_basis || !mel_basis || !out) return set_error("hvx_mel_spectrogram: null argument"), -1;
+    const int pad = (n_fft - hop) / 2;
+    if (n_fft % 32 || hop % 32 || hop > n_fft || L <= pad) return set_error("hvx_mel_spectrogram: n_fft=%d hop=%d L=%d", n_fft, hop, L), -1;
+    if (hvx_mel_workspace_bytes(L, n_fft, hop, n_mels) > ws_bytes) return set_error("hvx_mel_spectrogram: workspace too small"), -1;
+    hipStream_t s = (hipStream_t)stream;
+    const int padded = L + 2 * pad, frames = (padded - n_fft) / hop + 1;
+    const int bins = n_fft / 2 + 1, ldspec = pad32(2 * bins), ldmag = pad32(bins), ldm = pad32(n_mels);
+    if (frames < 1) return set_error("hvx_mel_spectrogram: signal shorter than one frame"), -1;
+    Carve cv((char*)ws);
+    float* xp = cv.take((size_t)L + n_fft + 64);
+    float* spec = cv.take((size_t)frames * ldspec);
+    float* mag = cv.take((size_t)frames * ldmag);
+    float* mel = cv.take((size_t)frames * ldm);
+    HVX_CHECK(launch_reflect_pad(audio, xp, L, pad, padded + 32, s));
+    GemmArgs g = conv(frames, 2 * bins, n_fft / 32, 32, xp, 32, (padded + 31) / 32, stft_basis, nullptr);
+    g.conv_stride = hop / 32;
+    g.out = spec; g.ldo = ldspec; g.out_cols = ldspec;
+    HVX_CHECK(launch_gemm(g, s));
+    HVX_CHECK(launch_spectral_magnitude(spec, ldspec, frames, bins, mag, ldmag, 1e-9f, s));
+    g = conv(frames, n_mels, 1, ldmag, mag, ldmag, frames, mel_basis, nullptr);
+    g.act = ACT_LOG_CLAMP; g.act_param = 1e-5f;
+    g.out = mel; g.ldo = ldm; g.out_cols = ldm;
+    HVX_CHECK(launch_gemm(g, s));
+    return launch_transpose_f32(mel, out, frames, n_mels, ldm, frames, s);
 }
 
 int hvx_denoise(hvx_stream stream, void* ws, size_t ws_bytes, const float* audio, int32_t L, int32_t n_fft, int32_t hop, const float* stft_basis,

@@ -125,3 +125,32 @@ def stft_bases(n_fft, win_length=None):
     syn_p = torch.zeros(N, ld, dtype=torch.float64)
     syn_p[:, :2 * bins] = syn
     return ana.float().contiguous(), syn_p.float().contiguous(), (win * win).float().contiguous()
+
+
+def mel_filterbank(sr, n_fft, n_mels, fmin=0.0, fmax=None):
+    """librosa.filters.mel(sr, n_fft, n_mels, fmin, fmax) with its defaults htk=False, norm='slaney' (librosa is what
+    matcha/utils/audio.py:53 calls; it is not installed here, this is its published algorithm): triangular filters on the Slaney mel
+    scale (linear below 1 kHz at 200/3 Hz per mel, logarithmic above with step ln(6.4)/27), each scaled by 2 / (its band width in Hz).
+    -> float32 [n_mels][n_fft // 2 + 1]"""
+    import numpy as np
+    fmax = sr / 2.0 if fmax is None else fmax
+    f_sp, min_log_hz = 200.0 / 3, 1000.0
+    min_log_mel, logstep = min_log_hz / f_sp, np.log(6.4) / 27.0
+
+    def hz_to_mel(f):
+        f = np.asarray(f, dtype=np.float64)
+        return np.where(f >= min_log_hz, min_log_mel + np.log(np.maximum(f, 1e-30) / min_log_hz) / logstep, f / f_sp)
+
+    def mel_to_hz(m):
+        m = np.asarray(m, dtype=np.float64)
+        return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), f_sp * m)
+
+    fftfreqs = np.linspace(0, sr / 2.0, 1 + n_fft // 2)
+    mel_f = mel_to_hz(np.linspace(hz_to_mel(fmin), hz_to_mel(fmax), n_mels + 2))
+    fdiff = np.diff(mel_f)
+    ramps = mel_f[:, None] - fftfreqs[None, :]
+    w = np.zeros((n_mels, 1 + n_fft // 2))
+    for i in range(n_mels):
+        w[i] = np.maximum(0, np.minimum(-ramps[i] / fdiff[i], ramps[i + 2] / fdiff[i + 1]))
+    w *= (2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels]))[:, None]
+    return torch.from_numpy(w.astype(np.float32))

@@ -278,6 +278,12 @@ void hvx_hifigan_destroy(hvx_hifigan* h);
 size_t hvx_hifigan_workspace_bytes(const hvx_hifigan* h, int32_t t);
 int hvx_hifigan_forward(hvx_hifigan* h, hvx_stream s, void* ws, size_t ws_bytes, const float* mel, int32_t T, float* wav);
 
+/* mel_spectrogram (matcha/utils/audio.py:45-82), the prompt-feature extractor the zero-shot frontend calls (cosyvoice/cli/frontend.py:119;
+ * SURVEY.md §8(f) N2): audio f32 [L] -> out f32 (n_mels, frames), frames = (L + 2*((n_fft - hop)/2) - n_fft) / hop + 1.
+ * stft_basis [2*(n_fft/2+1)][n_fft] (hann window folded in), mel_basis [n_mels][pad32(n_fft/2+1)] */
+size_t hvx_mel_workspace_bytes(int32_t L, int32_t n_fft, int32_t hop, int32_t n_mels);
+int hvx_mel_spectrogram(hvx_stream s, void* ws, size_t ws_bytes, const float* audio, int32_t L, int32_t n_fft, int32_t hop,
+                        const float* stft_basis, const float* mel_basis, int32_t n_mels, float* out);
 size_t hvx_denoise_workspace_bytes(int32_t L, int32_t n_fft, int32_t hop);
 /* |torch.stft(audio, n_fft, hop, window=hann, center=True)|: mag f32 [1 + L/hop][n_fft/2 + 1] */
 int hvx_stft_magnitude(hvx_stream s, void* ws, size_t ws_bytes, const float* audio, int32_t L, int32_t n_fft, int32_t hop, const float* stft_basis,

@@ -204,3 +204,14 @@ def denoise(audio, bias_spec, c, strength=0.0005):
     mag, ang = torch.sqrt(spec.pow(2).sum(-1)), torch.atan2(spec[..., -1], spec[..., 0])
     mag = torch.clamp(mag - bias_spec * strength, 0.0)
     return torch.istft(torch.complex(mag * torch.cos(ang), mag * torch.sin(ang)), c.n_fft, hop, c.n_fft, win)
+
+
+def mel_spectrogram(y, n_fft, num_mels, sampling_rate, hop_size, win_size, fmin, fmax, mel_basis):
+    """matcha/utils/audio.py:45-82 with the librosa filterbank passed in (librosa is absent from this image; its table is restated in
+    flowmirror_hydravox_amd.packing.mel_filterbank): (B, L) -> (B, num_mels, frames)"""
+    p = int((n_fft - hop_size) / 2)
+    y = F.pad(y.unsqueeze(1), (p, p), mode='reflect').squeeze(1)
+    spec = torch.view_as_real(torch.stft(y, n_fft, hop_length=hop_size, win_length=win_size, window=torch.hann_window(win_size), center=False,
+                                         pad_mode='reflect', normalized=False, onesided=True, return_complex=True))
+    spec = torch.sqrt(spec.pow(2).sum(-1) + 1e-9)
+    return torch.log(torch.clamp(torch.matmul(mel_basis, spec), min=1e-5))

@@ -123,6 +123,14 @@ def install():
                 raise AttributeError(k)
     _mod('omegaconf', DictConfig=DictConfig)
 
+    # librosa (absent): matcha/utils/audio.py only needs filters.mel — the restated table of flowmirror_hydravox_amd.packing.mel_filterbank
+    def _librosa_mel(sr, n_fft, n_mels, fmin, fmax):
+        sys.path.insert(0, '/root/repo') if '/root/repo' not in sys.path else None
+        from flowmirror_hydravox_amd.packing import mel_filterbank
+        return mel_filterbank(sr, n_fft, n_mels, fmin, fmax).numpy()
+    _mod('librosa')
+    _mod('librosa.filters', mel=_librosa_mel)
+
     import matcha  # real package root (namespace only)
     _mod('matcha.utils', __path__=[])
     _mod('matcha.utils.pylogger', get_pylogger=lambda name=None: logging.getLogger(name))

@@ -423,6 +423,24 @@ def gen_matcha():
     print('[matcha] hifigan: oracle-reference max abs diff wav %.1e bias %.1e denoised %.1e (wav std %.3f, bias max %.3f)'
           % (d[0], d[1], d[2], wav.std(), den.bias_spec.max()))
     out.update({'g_mel': mel.numpy(), 'g_wav': wav.numpy(), 'g_bias': den.bias_spec.numpy(), 'g_clean': clean.numpy(), 'g_strength': np.float32(0.05)})
+    # ---- N2: prompt log-mel (matcha/utils/audio.py: mel_spectrogram) at the CosyVoice3 settings and at toy settings ------------------
+    import importlib.util
+    spec_ = importlib.util.spec_from_file_location('ref_matcha_audio', '/root/reference/matcha/utils/audio.py')
+    audio = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(audio)
+    from flowmirror_hydravox_amd.packing import mel_filterbank
+    for tag, kw, L in (('cv3', dict(n_fft=1920, num_mels=80, sampling_rate=24000, hop_size=480, win_size=1920, fmin=0, fmax=8000), 24000),
+                       ('toy', dict(n_fft=64, num_mels=8, sampling_rate=800, hop_size=32, win_size=64, fmin=0, fmax=400), 1000)):
+        y = (torch.rand(2, L, generator=g) * 1.6 - 0.8)
+        audio.mel_basis.clear()
+        audio.hann_window.clear()
+        ref = audio.mel_spectrogram(y, center=False, **kw)
+        mb = mel_filterbank(kw['sampling_rate'], kw['n_fft'], kw['num_mels'], kw['fmin'], kw['fmax'])
+        ora = matcha_ref.mel_spectrogram(y, mel_basis=mb, **kw)
+        d = (ora - ref).abs().max().item()
+        assert d < 1e-4, d
+        print('[mel] %s: oracle-reference max abs diff %.1e, shape %s (filterbank = restated librosa table)' % (tag, d, tuple(ref.shape)))
+        out.update({'mel_%s_y' % tag: y.numpy(), 'mel_%s_out' % tag: ref.numpy()})
     np.savez_compressed(os.path.join(HERE, 'matcha_tiny.npz'), **out)
 
 

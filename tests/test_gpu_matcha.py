@@ -118,3 +118,17 @@ def test_hifigan_accepts_checkpoints_with_weight_norm_removed(golden):
         folded[n + '.bias'] = sd[n + '.bias']
     mel = torch.randn(1, hc.mel, 12, generator=torch.Generator().manual_seed(41))
     assert torch.equal(HvxHifiGan(hc, sd)(mel), HvxHifiGan(hc, folded)(mel))
+
+
+def test_prompt_mel_spectrogram_vs_reference(golden):
+    """the frontend's prompt log-mel on the device (STFT and mel projection as fp32-MFMA GEMMs)"""
+    from flowmirror_hydravox_amd.frontend import HvxMelSpectrogram
+    g = golden
+    for tag, kw in (('cv3', dict(n_fft=1920, num_mels=80, sampling_rate=24000, hop_size=480, win_size=1920, fmin=0, fmax=8000)),
+                    ('toy', dict(n_fft=64, num_mels=8, sampling_rate=800, hop_size=32, win_size=64, fmin=0, fmax=400))):
+        mel = HvxMelSpectrogram(**kw)
+        out = mel(torch.from_numpy(g['mel_%s_y' % tag])).cpu().numpy()
+        ref = g['mel_%s_out' % tag]
+        assert out.shape == ref.shape
+        # log domain: absolute tolerance (values span about [-11.5, 3]); 1e-3 abs is 0.1 % in the linear domain
+        assert np.abs(out - ref).max() < 2e-3

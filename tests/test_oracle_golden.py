@@ -202,3 +202,16 @@ def test_convtranspose_phases_and_stft_bases_against_torch():
     assert (mine[:33] - spec.real).abs().max() < 1e-4 and (mine[33:] - spec.imag).abs().max() < 1e-4
     back = syn[:, :66] @ mine
     assert (back - torch.fft.irfft(spec, 64) * torch.hann_window(64)).abs().max() < 1e-4
+
+
+def test_mel_spectrogram_oracle_vs_reference_vectors():
+    from flowmirror_hydravox_amd.packing import mel_filterbank
+    from oracle import matcha_ref
+    g = load_golden('matcha_tiny.npz')
+    for tag, kw in (('cv3', dict(n_fft=1920, num_mels=80, sampling_rate=24000, hop_size=480, win_size=1920, fmin=0, fmax=8000)),
+                    ('toy', dict(n_fft=64, num_mels=8, sampling_rate=800, hop_size=32, win_size=64, fmin=0, fmax=400))):
+        mb = mel_filterbank(kw['sampling_rate'], kw['n_fft'], kw['num_mels'], kw['fmin'], kw['fmax'])
+        # shape and partition-of-energy sanity of the restated librosa table: every filter has support, Slaney area normalisation
+        assert mb.shape == (kw['num_mels'], kw['n_fft'] // 2 + 1) and bool((mb.sum(1) > 0).all()) and float(mb.min()) >= 0.0
+        out = matcha_ref.mel_spectrogram(torch.from_numpy(g['mel_%s_y' % tag]), mel_basis=mb, **kw)
+        assert (out - torch.from_numpy(g['mel_%s_out' % tag])).abs().max() < 1e-5
