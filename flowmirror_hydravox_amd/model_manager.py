@@ -137,6 +137,48 @@ def _synthesize(model_manager, model_input, speed, zero_shot):
     return tts_speech.cpu()
 
 
+def synthesize_many(model_manager, model_inputs, zero_shot, speeds=None, seeds=None):
+    """Batched form of `_synthesize`: the frontend outputs of several requests are decoded by the LM in lock-step
+    (one weight stream serves every request of the batch, which is where the decode roofline is), then each goes through flow and the
+    vocoder.  `zero_shot[i]` says whether request i carries a prompt.  Every request samples from its OWN generator: `seeds[i]`, or a
+    seed drawn here from torch's global generator (with one global generator the draws of concurrent requests would interleave; the
+    per-request result equals `_synthesize` run alone with that seed).  -> list of cpu waveforms (1, L)"""
+    n = len(model_inputs)
+    speeds = [1.0] * n if speeds is None else list(speeds)
+    if any(s <= 0 for s in speeds):
+        raise ValueError('Invalid speed: %s' % min(speeds))
+    if seeds is None:
+        seeds = [int(v) for v in torch.randint(0, 2 ** 31 - 1, (n,)).tolist()]
+    llm, flow, hift = (model_manager.models[k] for k in ('llm', 'flow', 'hift'))
+    dev = model_manager.device
+    texts = [mi['text'].reshape(-1) for mi in model_inputs]
+    ptexts = [mi['prompt_text'].reshape(-1) if z else None for mi, z in zip(model_inputs, zero_shot)]
+    pspeech = [mi['llm_prompt_speech_token'].reshape(-1) if z else None for mi, z in zip(model_inputs, zero_shot)]
+    start = time.time()
+    toks = llm.generate_batch(texts, prompt_texts=ptexts if any(zero_shot) else None, prompt_speech_tokens=pspeech if any(zero_shot) else None,
+                              seeds=seeds)
+    llm_time = time.time() - start
+    outs = []
+    for mi, z, t, speed in zip(model_inputs, zero_shot, toks, speeds):
+        token = torch.tensor(t).unsqueeze(0).to(dev)
+        fkw = dict(token=token, token_len=torch.tensor([token.shape[1]], dtype=torch.int32), streaming=False, finalize=True)
+        if z:
+            fkw.update(prompt_token=mi['flow_prompt_speech_token'], prompt_token_len=mi['flow_prompt_speech_token_len'],
+                       prompt_feat=mi['prompt_speech_feat'], prompt_feat_len=mi['prompt_speech_feat_len'], embedding=mi['flow_embedding'])
+        else:
+            fkw.update(embedding=mi['flow_embedding'].unsqueeze(0))
+        mel, _ = flow.inference(**fkw)
+        if speed != 1.0:
+            mel = F.interpolate(mel, size=max(1, int(mel.shape[2] / speed)), mode='linear')
+        wav, _ = hift.inference(speech_feat=mel)
+        outs.append(wav.cpu())
+    total = time.time() - start
+    audio = sum(o.shape[-1] for o in outs) / 24000
+    logger.info('batched inference done: %d requests, total %.2fs, TPS %.2f, RTF %.4f', n, total,
+                sum(len(t) for t in toks) / llm_time if llm_time > 0 else 0.0, total / audio if audio else 0.0)
+    return outs
+
+
 def inference_zero_shot(model_manager, tts_text, prompt_text, prompt_audio, prompt_sample_rate, speed=1.0):
     if not model_manager.is_loaded:
         raise ValueError('models are not loaded')

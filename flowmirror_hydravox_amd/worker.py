@@ -64,3 +64,98 @@ def worker_process_tts(num_workers_gpu, task_queue, result_dict, worker_id, fron
             logger.error('[TTS Worker-%d] Error: %s', worker_id, e)
             result = {'error': str(e)}
         result_dict[task['id']] = result
+
+
+def worker_process_tts_batched(num_workers_gpu, task_queue, result_dict, worker_id, frontend_factory=None, max_batch=8):
+    """Same wire format as worker_process_tts, with real batching: whatever `tts` / `zero_shot` tasks are already waiting
+    (up to `max_batch`, same sampling parameters) are decoded together by `synthesize_many`; everything else is served one by one."""
+    import queue as _queue
+    os.environ['CUDA_VISIBLE_DEVICES'] = str(worker_id % num_workers_gpu)
+    from .model_manager import HvxModelManager, synthesize_many, text_to_speech, inference_zero_shot
+    from .sampling import ras_sampling
+
+    mm = HvxModelManager(frontend_factory=frontend_factory)
+    mm.load_models(argparse.Namespace(config=os.getenv('TTS_CONFIG'), model_dir=os.getenv('TTS_MODEL_DIR'), bf16=_env_flag('TTS_BF_16'),
+                                      fp16=_env_flag('TTS_FP_16'), cpu=_env_flag('TTS_CPU', False)))
+    pending = []
+    stop = False
+    while not stop:
+        if not pending:
+            pending.append(task_queue.get())
+        while len(pending) < max_batch:
+            try:
+                pending.append(task_queue.get_nowait())
+            except _queue.Empty:
+                break
+        if any(t is None for t in pending):
+            stop = True
+            pending = [t for t in pending if t is not None]
+        batch, rest = group_batchable(pending)
+        pending = []
+        if len(batch) > 1:
+            try:
+                apply_extra_params(mm, batch[0], ras_sampling)
+                fe = mm.frontend
+                inputs, zs = [], []
+                for t in batch:
+                    if t['task_type'] == 'tts':
+                        inputs.append(fe.frontend_sft(fe.text_normalize(t['text'], split=True, text_frontend=True)[0], t['speaker_id']))
+                        zs.append(False)
+                    else:
+                        p_text = fe.text_normalize(t.get('prompt_text', ''), split=False, text_frontend=True)
+                        inputs.append(fe.frontend_zero_shot(fe.text_normalize(t['tts_text'], split=True, text_frontend=True)[0], p_text,
+                                                            (t['prompt_audio'], t['prompt_sample_rate']), mm.configs['sample_rate'], zero_shot_spk_id=''))
+                        zs.append(True)
+                speeds = [float(t.get('extra_params', {}).get('speed', 1.0)) for t in batch]
+                sr = mm.configs['sample_rate']
+                for t, out in zip(batch, synthesize_many(mm, inputs, zs, speeds=speeds)):
+                    result_dict[t['id']] = {'output_audio': out, 'sample_rate': sr, 'format': t.get('output_format', 'wav'), 'duration': out.shape[-1] / sr}
+            except Exception as e:
+                logger.error('[TTS Worker-%d] batch error: %s', worker_id, e)
+                for t in batch:
+                    result_dict[t['id']] = {'error': str(e)}
+        else:
+            rest = batch + rest
+        for t in rest:
+            try:
+                speed = apply_extra_params(mm, t, ras_sampling)
+                if t['task_type'] == 'zero_shot':
+                    out = inference_zero_shot(mm, t['tts_text'], t.get('prompt_text', ''), t['prompt_audio'], t['prompt_sample_rate'], speed=speed)
+                    sr = mm.configs['sample_rate']
+                    result = {'output_audio': out, 'sample_rate': sr, 'format': t.get('output_format', 'wav'), 'duration': out.shape[-1] / sr}
+                elif t['task_type'] == 'tts':
+                    result = text_to_speech(mm, t['text'], t['speaker_id'], speed=speed)
+                elif t['task_type'] == 'load_pt':
+                    result = mm.load_pt(t['llm_pt'], t['flow_pt'])
+                else:
+                    result = {'error': 'unknown task_type %r' % (t['task_type'],)}
+            except Exception as e:
+                logger.error('[TTS Worker-%d] Error: %s', worker_id, e)
+                result = {'error': str(e)}
+            result_dict[t['id']] = result
+
+
+def group_batchable(tasks):
+    """-> (tasks that can be decoded together, the others in arrival order): synthesis tasks whose sampling parameters equal those of the
+    first synthesis task (llm.sampling / inference_head_num are per-model state, server/worker.py:57-65)"""
+    def key(t):
+        ep = t.get('extra_params') or {}
+        return tuple(ep.get(k) for k in ('top_p', 'top_k', 'win_size', 'tau_r', 'inference_head_num'))
+    batch, rest, k0 = [], [], None
+    for t in tasks:
+        if t.get('task_type') in ('tts', 'zero_shot') and (k0 is None or key(t) == k0):
+            k0 = key(t)
+            batch.append(t)
+        else:
+            rest.append(t)
+    return batch, rest
+
+
+def apply_extra_params(mm, task, ras_sampling):
+    """per-request knobs, exactly as server/worker.py:57-65 applies them; returns the speed"""
+    ep = task.get('extra_params')
+    if not ep:
+        return 1.0
+    mm.models['llm'].sampling = partial(ras_sampling, top_p=ep['top_p'], top_k=ep['top_k'], win_size=ep['win_size'], tau_r=ep['tau_r'])
+    mm.models['llm'].inference_head_num = ep['inference_head_num']
+    return float(ep.get('speed', 1.0))

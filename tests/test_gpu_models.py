@@ -339,3 +339,37 @@ def test_pipelined_batches_equal_serial(tiny_cfg):
         assert s1.audio_seconds == s0.audio_seconds and s1.total_seconds > 0
         for a, b in zip(w0, w1):
             assert a.shape == b.shape and torch.equal(a, b)
+
+
+def test_synthesize_many_equals_one_by_one(tiny_cfg):
+    """§8(f) N1: several requests decoded in lock-step by the batching entry return what the per-request path returns (same seeds)."""
+    import types
+    from flowmirror_hydravox_amd import weights as W
+    from flowmirror_hydravox_amd.flow import HvxFlow
+    from flowmirror_hydravox_amd.hift import HvxHift, make_tables
+    from flowmirror_hydravox_amd.llm import HvxLLM
+    from flowmirror_hydravox_amd.model_manager import synthesize_many
+    c = tiny_cfg
+    llm = HvxLLM(c.llm, W.make_llm_state(c.llm, seed=5, init='fan_in'), dtype=torch.float32, max_batch=3, max_ctx=512, inference_head_num=2)
+    flow = HvxFlow(c.flow, W.make_flow_state(c.flow, seed=6, init='fan_in'), dtype=torch.float32)
+    hift = HvxHift(c.hift, W.make_hift_state(c.hift, seed=7, init='fan_in'), tables=make_tables(c.hift, seed=1))
+    mm = types.SimpleNamespace(models={'llm': llm, 'flow': flow, 'hift': hift}, device='cuda', configs={'sample_rate': 24000})
+    g = torch.Generator().manual_seed(3)
+    inputs, zs = [], [False, True, False]
+    for i, z in enumerate(zs):
+        n = 6 + 3 * i
+        mi = dict(text=torch.randint(0, c.llm.text_vocab, (1, n), generator=g, dtype=torch.int32), flow_embedding=torch.randn(192, generator=g))
+        if z:
+            mi.update(prompt_text=torch.randint(0, c.llm.text_vocab, (1, 4), generator=g, dtype=torch.int32),
+                      llm_prompt_speech_token=torch.randint(0, c.llm.speech_tokens, (1, 5), generator=g, dtype=torch.int32),
+                      flow_prompt_speech_token=torch.randint(0, c.llm.speech_tokens, (1, 5), generator=g, dtype=torch.int32),
+                      flow_prompt_speech_token_len=torch.tensor([5], dtype=torch.int32),
+                      prompt_speech_feat=torch.randn(1, 10, 80, generator=g), prompt_speech_feat_len=torch.tensor([10], dtype=torch.int32),
+                      flow_embedding=torch.randn(1, 192, generator=g))
+        inputs.append(mi)
+    seeds = [41, 42, 43]
+    many = synthesize_many(mm, inputs, zs, seeds=seeds)
+    for i, (mi, z) in enumerate(zip(inputs, zs)):
+        one = synthesize_many(mm, [mi], [z], seeds=[seeds[i]])[0]
+        assert one.shape == many[i].shape and torch.equal(one, many[i]), i
+        assert many[i].shape[-1] > 0

@@ -229,3 +229,17 @@ def test_model_manager_surface_and_load_pt_never_raises():
     if not torch.cuda.is_available():
         with pytest.raises(ValueError):
             mm.load_models(argparse.Namespace(config=None, model_dir='/tmp', bf16=True, fp16=False, cpu=True))
+
+
+def test_batching_worker_groups_tasks_by_sampling_parameters():
+    from flowmirror_hydravox_amd.worker import group_batchable
+    ep = dict(top_p=0.8, top_k=25, win_size=10, tau_r=0.1, inference_head_num=2)
+    tasks = [dict(id=1, task_type='tts', text='a', speaker_id='s', extra_params=ep),
+             dict(id=2, task_type='load_pt', llm_pt='x', flow_pt='y'),
+             dict(id=3, task_type='zero_shot', tts_text='b', extra_params=dict(ep)),
+             dict(id=4, task_type='tts', text='c', speaker_id='s', extra_params=dict(ep, top_k=10)),
+             dict(id=5, task_type='tts', text='d', speaker_id='s', extra_params=dict(ep))]
+    batch, rest = group_batchable(tasks)
+    assert [t['id'] for t in batch] == [1, 3, 5] and [t['id'] for t in rest] == [2, 4]
+    batch, rest = group_batchable([dict(id=9, task_type='load_pt')])
+    assert batch == [] and len(rest) == 1
