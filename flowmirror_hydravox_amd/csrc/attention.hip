@@ -509,9 +509,12 @@ static int launch_t(const AttnArgs& a, hipStream_t s) {
         (a.v_ld & 63) == 0) {
         const double fl = 4.0 * a.n_rows * (double)a.kv_len_const * 64.0 * a.heads * a.batch;
         const int slot = prof_begin(PK_ATTN, a.kv_len ? 0.0 : fl, s);
-        // 32 query rows per wave (QR = 2).  QR = 4 (64 rows, half the LDS reads and K/V staging traffic per flop, 254 VGPRs -> two waves
-        // per SIMD) measures the same within 1-2 % on T = 5632 and slower on short sequences, so only QR = 2 is instantiated.
-        hipLaunchKernelGGL(attn_dit_kernel<2>, dim3((a.n_rows + 127) / 128, a.heads, a.batch), dim3(256), 0, s, a);
+        // Query rows per wave: 32 (QR = 2, three waves per SIMD) or 64 (QR = 4, 254 VGPRs, two waves per SIMD, half the K / V^T staging
+        // traffic per flop).  Alone the two tie on long sequences (415 vs 419 us at T = 5632) and QR = 2 wins on short ones (45 vs 53 us at
+        // T = 1408); beside the decode stream of the pipelined synthesis QR = 4 leaves room on every SIMD and halves the L2 traffic:
+        // the decode step next to it takes 2.6 ms instead of 4.1 ms (tools/contention_probe.py).
+        if (a.n_rows >= 2048) hipLaunchKernelGGL(attn_dit_kernel<4>, dim3((a.n_rows + 255) / 256, a.heads, a.batch), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(attn_dit_kernel<2>, dim3((a.n_rows + 127) / 128, a.heads, a.batch), dim3(256), 0, s, a);
         prof_end(slot, s);
         return hipGetLastError() == hipSuccess ? 0 : (set_error("attention launch failed"), -1);
     }
