@@ -22,17 +22,36 @@ struct Best {
 };
 __device__ __forceinline__ bool better(float v, int i, float v2, int i2) { return (v > v2) || (v == v2 && i < i2); }
 
+// Wave-wide best on the DPP network instead of 12 ds_bpermute round trips: (value, index) becomes one 64-bit key whose unsigned order is
+// the `better` order (values here are -1 or >= 0, so the float bits + 1 are monotonic; the inverted index breaks ties towards the lower
+// index), the maximum is folded to lane 63 with row shifts and row broadcasts (max is idempotent: overlapping contributions are
+// harmless) and read back through a scalar register.
+__device__ __forceinline__ unsigned long long best_key(Best b) {
+    const unsigned hi = b.v < 0.0f ? 0u : __float_as_uint(b.v) + 1u;
+    return ((unsigned long long)hi << 32) | (unsigned)(~b.i);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long dpp_max_step(unsigned long long k) {
+    const unsigned lo = (unsigned)k, hi = (unsigned)(k >> 32);
+    const unsigned lo2 = (unsigned)__builtin_amdgcn_update_dpp((int)lo, (int)lo, CTRL, ROW_MASK, 0xf, false);
+    const unsigned hi2 = (unsigned)__builtin_amdgcn_update_dpp((int)hi, (int)hi, CTRL, ROW_MASK, 0xf, false);
+    const unsigned long long k2 = ((unsigned long long)hi2 << 32) | lo2;
+    return k2 > k ? k2 : k;
+}
 __device__ __forceinline__ Best wave_best(Best b) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float v2 = __shfl_xor(b.v, o, 64);
-        const int i2 = __shfl_xor(b.i, o, 64);
-        if (better(v2, i2, b.v, b.i)) {
-            b.v = v2;
-            b.i = i2;
-        }
-    }
-    return b;
+    unsigned long long k = best_key(b);
+    k = dpp_max_step<0x111, 0xf>(k);          // row_shr:1
+    k = dpp_max_step<0x112, 0xf>(k);          // row_shr:2
+    k = dpp_max_step<0x114, 0xf>(k);          // row_shr:4
+    k = dpp_max_step<0x118, 0xf>(k);          // row_shr:8   -> lane 15 of every row holds its row's maximum
+    k = dpp_max_step<0x142, 0xa>(k);          // row_bcast:15 into rows 1 and 3
+    k = dpp_max_step<0x143, 0xc>(k);          // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's maximum
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)k, 63);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(k >> 32), 63);
+    Best r;
+    r.v = hi == 0u ? -1.0f : __uint_as_float(hi - 1u);
+    r.i = (int)~lo;
+    return r;
 }
 
 // block-wide best; every thread returns the same winner.  red_v/red_i: LDS [4]
