@@ -47,7 +47,7 @@ class AttnArgs(C.Structure):
     _fields_ = [('dtype', c_i32), ('batch', c_i32), ('heads', c_i32), ('t', c_i32), ('t_pad', c_i32),
                 ('q', c_vp), ('k', c_vp), ('vT', c_vp), ('out', c_vp), ('kv_len', c_vp),
                 ('causal', c_i32), ('scale', c_f32),
-                ('n_splits', c_i32), ('split_chunk', c_i32), ('part_o', c_vp), ('part_ml', c_vp)]
+                ('n_splits', c_i32), ('split_chunk', c_i32), ('part_o', c_vp), ('part_ml', c_vp), ('chunk', c_i32)]
 
 
 class LLMConfig(C.Structure):
@@ -117,6 +117,10 @@ SYMBOLS = {
     'hvx_flow_encode': (c_i32, [c_vp, c_vp, c_vp, c_sz, c_vp, c_i32, c_vp, c_vp, c_vp]),
     'hvx_flow_prelookahead': (c_i32, [c_vp, c_vp, c_vp, c_sz, c_vp, c_i32, c_vp]),
     'hvx_cfm_estimator': (c_i32, [c_vp, c_vp, c_vp, c_sz, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'hvx_cfm_estimator_streaming': (c_i32, [c_vp, c_vp, c_vp, c_sz, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),
+    'hvx_flow_prelookahead_context': (c_i32, [c_vp, c_vp, c_vp, c_sz, c_vp, c_i32, c_vp]),
+    'hvx_flow_encode_chunk': (c_i32, [c_vp, c_vp, c_vp, c_sz, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp]),
+    'hvx_cfm_solve_streaming': (c_i32, [c_vp, c_vp, c_vp, c_sz, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, C.POINTER(c_f32), C.POINTER(c_f32), c_i32]),
     'hvx_flow_set_mod_cache': (c_i32, [c_vp, c_vp, c_sz]),
     'hvx_cfm_solve': (c_i32, [c_vp, c_vp, c_vp, c_sz, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, C.POINTER(c_f32), C.POINTER(c_f32)]),
     'hvx_matcha_create': (c_i32, [C.POINTER(MatchaConfig), C.POINTER(c_vp), c_i32, C.POINTER(c_vp)]),
@@ -139,6 +143,7 @@ SYMBOLS = {
     'hvx_hift_f0': (c_i32, [c_vp, c_vp, c_vp, c_sz, c_vp, c_i32, c_vp]),
     'hvx_hift_source': (c_i32, [c_vp, c_vp, c_vp, c_sz, c_vp, c_i32, c_vp, c_vp]),
     'hvx_hift_decode': (c_i32, [c_vp, c_vp, c_vp, c_sz, c_vp, c_vp, c_i32, c_vp]),
+    'hvx_hift_decode_chunk': (c_i32, [c_vp, c_vp, c_vp, c_sz, c_vp, c_vp, c_i32, c_i32, c_vp]),
 }
 
 _lib = None

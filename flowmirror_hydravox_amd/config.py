@@ -74,6 +74,7 @@ class FlowConfig:
     conv_kernel: int = 31
     conv_groups: int = 16
     time_freq_dim: int = 256
+    static_chunk_size: int = 50      # mel frames per chunk of the streaming attention mask (dit.py:119; 2 x token_hop_len 25, cli/model.py:396)
 
     @property
     def ff(self) -> int:

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     int r_lo[QT];
     bool r_ok[QT];
     V8 qf[QT][2];
-    int max_pos = -1;
+    int max_pos = -1, max_lim = 0;
 #pragma unroll
     for (int i = 0; i < QT; ++i) {
         const int r = (qt * QT + i) * 16 + fr;
@@ -77,6 +77,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
             qf[i][0] = load8(qp);
             qf[i][1] = load8(qp + 32);
             max_pos = max(max_pos, pos0 + r_lo[i]);
+            if (a.chunk > 0) max_lim = max(max_lim, (r_lo[i] / a.chunk + 1) * a.chunk);
         } else {
             qf[i][0] = zero8<T>();
             qf[i][1] = zero8<T>();
@@ -87,6 +88,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) max_pos = max(max_pos, __shfl_xor(max_pos, o, 64));
         key_end = min(key_end, max_pos + 1);
+    }
+    if (a.chunk > 0) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) max_lim = max(max_lim, __shfl_xor(max_lim, o, 64));
+        key_end = min(key_end, max_lim);
     }
 
     const int slot = a.kv_slot ? a.kv_slot[b] : b;
@@ -150,7 +156,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
                     mma32(s[kt], kf[ks][kt][1], qf[i][1]);
                 }
                 // scale, mask, running max
-                const int lim = a.causal ? min(key_end, pos0 + r_lo[i] + 1) : key_end;
+                int lim = a.causal ? min(key_end, pos0 + r_lo[i] + 1) : key_end;
+                if (a.chunk > 0) lim = min(lim, (r_lo[i] / a.chunk + 1) * a.chunk);
                 float sv[8];
                 float mx = -INFINITY;
 #pragma unroll
@@ -334,6 +341,14 @@ __global__ __launch_bounds__(256, 2) void attn_dit_kernel(AttnArgs a) {
     const int kv_len = a.kv_len ? a.kv_len[b] : a.kv_len_const;
     const T* __restrict__ kb = reinterpret_cast<const T*>(a.k) + (long long)b * a.k_bs + (long long)h * a.k_hs;
     const T* __restrict__ vb = reinterpret_cast<const T*>(a.vT) + (long long)b * a.v_bs + (long long)h * a.v_hs;
+    // Static chunk mask (streaming synthesis): row r sees the keys below the end of its chunk.  The workgroup walks the keys that
+    // its last row sees; tiles below the limit of its first row need no mask, the rest take the masked form with per-row limits.
+    const int wg_row0 = blockIdx.x * (64 * QR), wg_row1 = min(wg_row0 + 64 * QR, a.n_rows) - 1;
+    const int lim_hi = a.chunk > 0 ? min(kv_len, (wg_row1 / a.chunk + 1) * a.chunk) : kv_len;
+    const int lim_lo = a.chunk > 0 ? min(kv_len, (wg_row0 / a.chunk + 1) * a.chunk) : kv_len;
+    int lim[QR];
+#pragma unroll
+    for (int i = 0; i < QR; ++i) lim[i] = a.chunk > 0 ? min(kv_len, ((row0 + i * 16 + fr) / a.chunk + 1) * a.chunk) : kv_len;
 
     bf16x8 qf[QR][2];
 #pragma unroll
@@ -422,7 +437,7 @@ __global__ __launch_bounds__(256, 2) void attn_dit_kernel(AttnArgs a) {
                 for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (key0 + kt * 16 + fg * 4 + r >= kv_len) s[i][kt][r] = -INFINITY;
+                        if (key0 + kt * 16 + fg * 4 + r >= lim[i]) s[i][kt][r] = -INFINITY;
             }
             float mx = fmax3(fmax3(s[i][0][0], s[i][0][1], s[i][0][2]), fmax3(s[i][0][3], s[i][1][0], s[i][1][1]),
                              fmax3(s[i][1][2], s[i][1][3], s[i][2][0]));
@@ -470,13 +485,13 @@ __global__ __launch_bounds__(256, 2) void attn_dit_kernel(AttnArgs a) {
             }
     };
 
-    const int n_tiles = (kv_len + KT - 1) / KT;
+    const int n_tiles = (lim_hi + KT - 1) / KT;
     if (n_tiles > 0) {
         gload(0);
         stash(0);
     }
     __syncthreads();
-    const int n_full = kv_len / KT;                                    // the loop holds full tiles only; the masked tile is peeled
+    const int n_full = lim_lo / KT;                                    // this loop holds unmasked tiles only
     for (int it = 0; it < n_full; ++it) {
         const int buf = it & 1, key0 = it * KT;
         const bool more = (it + 1) < n_tiles;
@@ -485,7 +500,15 @@ __global__ __launch_bounds__(256, 2) void attn_dit_kernel(AttnArgs a) {
         if (more) stash(buf ^ 1);
         __syncthreads();
     }
-    if (n_full < n_tiles) tile(n_full & 1, n_full * KT, std::true_type{});
+    // masked tiles: one (the ragged end) without a chunk mask, the tiles between the first and the last row's chunk end with one
+    for (int it = n_full; it < n_tiles; ++it) {
+        const int buf = it & 1, key0 = it * KT;
+        const bool more = (it + 1) < n_tiles;
+        if (more) gload(key0 + KT);
+        tile(buf, key0, std::true_type{});
+        if (more) stash(buf ^ 1);
+        __syncthreads();
+    }
 #pragma unroll
     for (int i = 0; i < QR; ++i) {
         const float l = l_acc[i][0];                                   // every row of the ones-MFMA holds the column (query) sum

@@ -149,20 +149,22 @@ __global__ void fill_kernel(float* p, int n, float v) {
 #define HVX_CHECK(x) do { if (x) return -1; } while (0)
 #define HIP_OK(x) do { if ((x) != hipSuccess) return set_error("hip call failed: %s", #x), -1; } while (0)
 
-int prelookahead(const hvx_flow* h, hipStream_t s, EstBufs& b, const float* x, int n, float* y) {
+// n rows in, n_out rows out: n_out == n zero-pads the look-ahead on the right (finalize), n_out == n - pla_len takes the last pla_len
+// rows of x as the look-ahead context (upsample_encoder.py:90-95)
+int prelookahead(const hvx_flow* h, hipStream_t s, EstBufs& b, const float* x, int n, int n_out, float* y) {
     const hvx_flow_config& c = h->c;
     const int melp = (c.mel + 31) & ~31;
     const void* const* w = h->w.data();
     HVX_CHECK(launch_rows_to_dtype(x, c.mel, b.e_h0t, c.dtype, melp, n, c.mel, melp, s));
     // conv1: Conv1d(mel -> C, k = len+1), input right-padded by `len` zeros, LeakyReLU(0.01)
-    GemmArgs g = linear(c.dtype, n, c.pla_channels, (c.pla_len + 1) * melp, b.e_h0t, melp, w[5], (const float*)w[6]);
+    GemmArgs g = linear(c.dtype, n_out, c.pla_channels, (c.pla_len + 1) * melp, b.e_h0t, melp, w[5], (const float*)w[6]);
     g.cin_pad = melp; g.rows_in = n;
     g.act = ACT_LRELU; g.act_param = 0.01f;
     g.out = b.e_c1; g.out_f32 = 0; g.ldo = c.pla_channels; g.out_cols = c.pla_channels;
     HVX_CHECK(launch_gemm(g, s));
     // conv2: left pad 2, Conv1d(C -> mel, k = 3), + residual
-    g = linear(c.dtype, n, c.mel, 3 * c.pla_channels, b.e_c1, c.pla_channels, w[7], (const float*)w[8]);
-    g.cin_pad = c.pla_channels; g.rows_in = n; g.pad_left = 2;
+    g = linear(c.dtype, n_out, c.mel, 3 * c.pla_channels, b.e_c1, c.pla_channels, w[7], (const float*)w[8]);
+    g.cin_pad = c.pla_channels; g.rows_in = n_out; g.pad_left = 2;
     g.res = x; g.ldres = c.mel;
     g.out = y; g.out_f32 = 1; g.ldo = c.mel; g.out_cols = c.mel;
     HVX_CHECK(launch_gemm(g, s));
@@ -171,7 +173,7 @@ int prelookahead(const hvx_flow* h, hipStream_t s, EstBufs& b, const float* x, i
 
 // estimator on time-major rows; leaves v in b.outrow [B][T][mel]
 int estimator_core(const hvx_flow* h, hipStream_t s, EstBufs& b, int B, int T, const float* x, const int* kv_len, const float* mu,
-                   const float* t, const float* spks, const float* cond, bool skip_mods = false) {
+                   const float* t, const float* spks, const float* cond, bool skip_mods = false, int chunk = 0) {
     const hvx_flow_config& c = h->c;
     const int dt = c.dtype, D = c.dim, H = c.heads, Tp = b.t_pad, mel = c.mel;
     const size_t es = dtype_size(dt);
@@ -239,7 +241,7 @@ int estimator_core(const hvx_flow* h, hipStream_t s, EstBufs& b, int B, int T, c
         at.q = b.q; at.q_bs = (long long)H * Tp * 64; at.q_hs = (long long)Tp * 64; at.q_lo = 64;
         at.k = b.k; at.k_bs = at.q_bs; at.k_hs = at.q_hs;
         at.vT = b.vT; at.v_bs = at.q_bs; at.v_hs = (long long)64 * Tp; at.v_ld = Tp;
-        at.kv_len = kv_len; at.kv_len_const = T; at.causal = 0; at.scale = 0.125f;
+        at.kv_len = kv_len; at.kv_len_const = T; at.causal = 0; at.chunk = chunk; at.scale = 0.125f;
         at.out = b.att; at.o_bs = (long long)T * D; at.o_hs = 64; at.o_lo = D; at.n_splits = 1;
         HVX_CHECK(launch_attention(at, s));
         g = linear(dt, T, D, D, b.att, D, bw[4], (const float*)bw[5]);
@@ -298,33 +300,58 @@ size_t hvx_flow_workspace_bytes(const hvx_flow* h, int32_t batch, int32_t t) {
 int hvx_flow_prelookahead(hvx_flow* h, hvx_stream s, void* ws, size_t ws_bytes, const float* x, int32_t n, float* y) {
     EstBufs b;
     if (carve_enc(h->c, (char*)ws, n, b) > ws_bytes) return set_error("hvx_flow_prelookahead: workspace too small"), -1;
-    return prelookahead(h, (hipStream_t)s, b, x, n, y);
+    return prelookahead(h, (hipStream_t)s, b, x, n, n, y);
 }
 
-int hvx_flow_encode(hvx_flow* h, hvx_stream stream, void* ws, size_t ws_bytes, const int32_t* token, int32_t n, const float* embedding,
-                    float* mu, float* spk) {
+int hvx_flow_prelookahead_context(hvx_flow* h, hvx_stream s, void* ws, size_t ws_bytes, const float* x, int32_t n, float* y) {
+    EstBufs b;
+    if (n <= h->c.pla_len) return set_error("hvx_flow_prelookahead_context: needs more than %d rows", h->c.pla_len), -1;
+    if (carve_enc(h->c, (char*)ws, n, b) > ws_bytes) return set_error("hvx_flow_prelookahead_context: workspace too small"), -1;
+    return prelookahead(h, (hipStream_t)s, b, x, n, n - h->c.pla_len, y);
+}
+
+static int encode_impl(hvx_flow* h, hvx_stream stream, void* ws, size_t ws_bytes, const int32_t* token, int32_t n, const float* embedding,
+                       int finalize, float* mu, float* spk) {
     hipStream_t s = (hipStream_t)stream;
+    const int n_out = finalize ? n : n - h->c.pla_len;
+    if (n_out <= 0) return set_error("hvx_flow_encode: %d tokens leave nothing after the look-ahead", n), -1;
     const hvx_flow_config& c = h->c;
     EstBufs b;
     if (carve_enc(c, (char*)ws, n, b) > ws_bytes) return set_error("hvx_flow_encode: workspace too small"), -1;
     hipLaunchKernelGGL(spk_affine_kernel, dim3(1), dim3(256), 0, s, embedding, (const float*)h->w[3], (const float*)h->w[4], spk, c.spk_dim, c.mel);
     hipLaunchKernelGGL(token_embed_kernel, dim3(n), dim3(128), 0, s, (const float*)h->w[2], token, b.e_h0, n, c.mel);
-    HVX_CHECK(prelookahead(h, s, b, b.e_h0, n, b.e_out));
-    const int T = 2 * n;
-    hipLaunchKernelGGL(mu_expand_kernel, dim3((T + 255) / 256, c.mel), dim3(256), 0, s, b.e_out, mu, n, c.mel, 2);
+    HVX_CHECK(prelookahead(h, s, b, b.e_h0, n, n_out, b.e_out));
+    const int T = 2 * n_out;
+    hipLaunchKernelGGL(mu_expand_kernel, dim3((T + 255) / 256, c.mel), dim3(256), 0, s, b.e_out, mu, n_out, c.mel, 2);
     HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int hvx_flow_encode(hvx_flow* h, hvx_stream stream, void* ws, size_t ws_bytes, const int32_t* token, int32_t n, const float* embedding,
+                    float* mu, float* spk) {
+    return encode_impl(h, stream, ws, ws_bytes, token, n, embedding, 1, mu, spk);
+}
+int hvx_flow_encode_chunk(hvx_flow* h, hvx_stream stream, void* ws, size_t ws_bytes, const int32_t* token, int32_t n, const float* embedding,
+                          int32_t finalize, float* mu, float* spk) {
+    return encode_impl(h, stream, ws, ws_bytes, token, n, embedding, finalize, mu, spk);
+}
+
+int hvx_cfm_estimator_streaming(hvx_flow* h, hvx_stream stream, void* ws, size_t ws_bytes, int32_t batch, int32_t t_len, const float* x,
+                                const int32_t* kv_len, const float* mu, const float* t, const float* spks, const float* cond,
+                                int32_t static_chunk_size, float* out) {
+    hipStream_t s = (hipStream_t)stream;
+    EstBufs b;
+    if (static_chunk_size < 0) return set_error("hvx_cfm_estimator: negative chunk size"), -1;
+    if (carve_est(h->c, (char*)ws, batch, t_len, b) > ws_bytes) return set_error("hvx_cfm_estimator: workspace too small"), -1;
+    HVX_CHECK(estimator_core(h, s, b, batch, t_len, x, kv_len, mu, t, spks, cond, false, static_chunk_size));
+    for (int bi = 0; bi < batch; ++bi)
+        HVX_CHECK(launch_transpose_f32(b.outrow + (size_t)bi * t_len * h->c.mel, out + (size_t)bi * t_len * h->c.mel, t_len, h->c.mel, h->c.mel, t_len, s));
     return 0;
 }
 
 int hvx_cfm_estimator(hvx_flow* h, hvx_stream stream, void* ws, size_t ws_bytes, int32_t batch, int32_t t_len, const float* x,
                       const int32_t* kv_len, const float* mu, const float* t, const float* spks, const float* cond, float* out) {
-    hipStream_t s = (hipStream_t)stream;
-    EstBufs b;
-    if (carve_est(h->c, (char*)ws, batch, t_len, b) > ws_bytes) return set_error("hvx_cfm_estimator: workspace too small"), -1;
-    HVX_CHECK(estimator_core(h, s, b, batch, t_len, x, kv_len, mu, t, spks, cond));
-    for (int bi = 0; bi < batch; ++bi)
-        HVX_CHECK(launch_transpose_f32(b.outrow + (size_t)bi * t_len * h->c.mel, out + (size_t)bi * t_len * h->c.mel, t_len, h->c.mel, h->c.mel, t_len, s));
-    return 0;
+    return hvx_cfm_estimator_streaming(h, stream, ws, ws_bytes, batch, t_len, x, kv_len, mu, t, spks, cond, 0, out);
 }
 
 int hvx_flow_set_mod_cache(hvx_flow* h, void* buf, size_t bytes) {
@@ -335,9 +362,10 @@ int hvx_flow_set_mod_cache(hvx_flow* h, void* buf, size_t bytes) {
     return 0;
 }
 
-int hvx_cfm_solve(hvx_flow* h, hvx_stream stream, void* ws, size_t ws_bytes, int32_t T, float* x, const float* mu, const float* spks,
-                  const float* cond, int32_t n_steps, const float* t_steps, const float* dt_steps) {
+int hvx_cfm_solve_streaming(hvx_flow* h, hvx_stream stream, void* ws, size_t ws_bytes, int32_t T, float* x, const float* mu, const float* spks,
+                            const float* cond, int32_t n_steps, const float* t_steps, const float* dt_steps, int32_t static_chunk_size) {
     hipStream_t s = (hipStream_t)stream;
+    if (static_chunk_size < 0) return set_error("hvx_cfm_solve: negative chunk size"), -1;
     const hvx_flow_config& c = h->c;
     EstBufs b;
     if (carve_est(c, (char*)ws, 2, T, b) > ws_bytes) return set_error("hvx_cfm_solve: workspace too small"), -1;
@@ -370,13 +398,18 @@ int hvx_cfm_solve(hvx_flow* h, hvx_stream stream, void* ws, size_t ws_bytes, int
             }
         }
         if (!hit) hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(64), 0, s, b.t_in, 2, t_steps[st]);
-        const int rc = estimator_core(h, s, b, 2, T, b.x_in, nullptr, b.mu_in, b.t_in, b.spk_in, b.cond_in, hit);
+        const int rc = estimator_core(h, s, b, 2, T, b.x_in, nullptr, b.mu_in, b.t_in, b.spk_in, b.cond_in, hit, static_chunk_size);
         b.mods = ws_mods;
         b.fmod = ws_fmod;
         if (rc) return -1;
         HVX_CHECK(launch_cfg_euler(x, b.outrow, c.mel, (long long)T * c.mel, dt_steps[st], c.cfg_rate, T, c.mel, s));
     }
     return 0;
+}
+
+int hvx_cfm_solve(hvx_flow* h, hvx_stream stream, void* ws, size_t ws_bytes, int32_t T, float* x, const float* mu, const float* spks,
+                  const float* cond, int32_t n_steps, const float* t_steps, const float* dt_steps) {
+    return hvx_cfm_solve_streaming(h, stream, ws, ws_bytes, T, x, mu, spks, cond, n_steps, t_steps, dt_steps, 0);
 }
 
 }  // extern "C"

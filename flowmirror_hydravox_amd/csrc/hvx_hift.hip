@@ -198,28 +198,33 @@ int hvx_hift_source(hvx_hift* h, hvx_stream stream, void* ws, size_t ws_bytes, c
     return 0;
 }
 
-int hvx_hift_decode(hvx_hift* h, hvx_stream stream, void* ws, size_t ws_bytes, const float* mel, const float* source, int32_t T, float* wav) {
+// decode over T_in mel frames of which the last `look` are real right context of conv_pre instead of zero padding (generator.py:674-680,
+// finalize=False): T = T_in - look output frames; the source STFT is taken over all T_in * up samples and cut to 120 T + 1 frames.
+static int decode_impl(hvx_hift* h, hvx_stream stream, void* ws, size_t ws_bytes, const float* mel, const float* source, int32_t T_in, int look,
+                       float* wav) {
     hipStream_t s = (hipStream_t)stream;
     const hvx_hift_config& c = h->c;
+    const int T = T_in - look;
+    if (look < 0 || T <= 0) return set_error("hvx_hift_decode: %d frames with %d of look-ahead", T_in, look), -1;
     Bufs b;
-    if (carve(h, (char*)ws, T, b) > ws_bytes) return set_error("hvx_hift_decode: workspace too small"), -1;
+    if (carve(h, (char*)ws, T_in, b) > ws_bytes) return set_error("hvx_hift_decode: workspace too small"), -1;
     WCursor wc{h->w.data(), (int)h->w.size()};
     wc.i = 14;                                           // skip f0 predictor (12) + source linear (2)
     const int melp = pad32(c.mel);
     const long long Ls = (long long)T * h->up_total;
     const int frames = (int)(Ls / c.hop + 1);
     // source STFT -> [frames][32] (18 used)
-    HVX_CHECK(launch_hift_stft(source, b.spec, (int)Ls, 32, s));
+    HVX_CHECK(launch_hift_stft(source, b.spec, (int)((long long)T_in * h->up_total), 32, s));
     // conv_pre (right-looking k) + LeakyReLU(slope) of stage 0
-    HIP_OK(hipMemsetAsync(b.melT, 0, (size_t)T * melp * 4, s));
-    HVX_CHECK(launch_transpose_f32(mel, b.melT, c.mel, T, T, melp, s));
+    HIP_OK(hipMemsetAsync(b.melT, 0, (size_t)T_in * melp * 4, s));
+    HVX_CHECK(launch_transpose_f32(mel, b.melT, c.mel, T_in, T_in, melp, s));
     float** P = b.pool;
     float* xin = P[0];
     {
         const float* W = wc.next();
         const float* bias = wc.next();
         const int C0 = c.base_channels;
-        GemmArgs g = conv(T, C0, c.conv_pre_kernel, melp, b.melT, melp, T, W, bias);
+        GemmArgs g = conv(T, C0, c.conv_pre_kernel, melp, b.melT, melp, T_in, W, bias);
         g.act = ACT_LRELU; g.act_param = c.lrelu_slope;
         g.out = xin; g.out_f32 = 1; g.ldo = pad32(C0); g.out_cols = pad32(C0);
         HVX_CHECK(launch_gemm(g, s));
@@ -310,6 +315,14 @@ int hvx_hift_decode(hvx_hift* h, hvx_stream stream, void* ws, size_t ws_bytes, c
     if (Lprev != frames) return set_error("hvx_hift_decode: %lld conv frames vs %d stft frames", Lprev, frames), -1;
     HVX_CHECK(launch_hift_istft(b.post, 32, wav, frames, c.audio_limit, s));
     return 0;
+}
+
+int hvx_hift_decode(hvx_hift* h, hvx_stream stream, void* ws, size_t ws_bytes, const float* mel, const float* source, int32_t T, float* wav) {
+    return decode_impl(h, stream, ws, ws_bytes, mel, source, T, 0, wav);
+}
+int hvx_hift_decode_chunk(hvx_hift* h, hvx_stream stream, void* ws, size_t ws_bytes, const float* mel, const float* source, int32_t t_in,
+                          int32_t look_right, float* wav) {
+    return decode_impl(h, stream, ws, ws_bytes, mel, source, t_in, look_right, wav);
 }
 
 }  // extern "C"

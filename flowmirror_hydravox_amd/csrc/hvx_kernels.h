@@ -110,6 +110,7 @@ struct AttnArgs {
     int kv_len_const;
     int causal; const int* pos0;  // key j visible to row r iff j <= pos0[b] + r_lo  (pos0 may be null -> 0)
     const int* n_valid_lo;        // optional: rows with r_lo >= n_valid_lo[b] are skipped (inactive)
+    int chunk;                    // > 0: static chunk mask (cosyvoice/utils/mask.py:128-158): row r also needs j < (r_lo / chunk + 1) * chunk
     float scale;
     void* out; long long o_bs, o_hs, o_hi, o_lo;      // dtype
     int n_splits; int split_chunk;                    // keys per split (multiple of 32) when n_splits > 1

@@ -53,6 +53,7 @@ class HvxFlow:
         self.fp16 = False
         self.token_mel_ratio = cfg.token_mel_ratio
         self.pre_lookahead_len = cfg.pre_lookahead_len
+        self.static_chunk_size = cfg.static_chunk_size            # DiT(static_chunk_size=...), dit.py:119,142
         self.output_size = cfg.mel
         self.max_t = max_t or cfg.noise_frames
         g = torch.Generator()
@@ -140,28 +141,40 @@ class HvxFlow:
         return self._ws
 
     # ---- stage entry points (also used by the parity tests) ----------------------------------------------------------------
-    def prelookahead(self, x):
-        """x f32 [n][mel] -> [n][mel] (upsample_encoder.py:82-103, finalize path)"""
+    def prelookahead(self, x, context=False):
+        """x f32 [n][mel] -> [n][mel] (upsample_encoder.py:82-103); context=True: the last pre_lookahead_len rows are the look-ahead
+        context of the rest (`forward(inputs[:-len], context=inputs[-len:])`) -> [n - len][mel]"""
         x = x.to(self.device, torch.float32).contiguous()
         n = x.shape[0]
-        y = torch.empty_like(x)
         ws = self._workspace(2, max(n, 32))
+        if context:
+            y = torch.empty(n - self.pre_lookahead_len, x.shape[1], dtype=torch.float32, device=self.device)
+            check(self.lib.hvx_flow_prelookahead_context(self._h, stream_ptr(), ptr(ws), ws.numel(), ptr(x), n, ptr(y)),
+                  'hvx_flow_prelookahead_context')
+            return y
+        y = torch.empty_like(x)
         check(self.lib.hvx_flow_prelookahead(self._h, stream_ptr(), ptr(ws), ws.numel(), ptr(x), n, ptr(y)), 'hvx_flow_prelookahead')
         return y
 
-    def encode(self, token, embedding):
-        """token int [n] (prompt already prepended), embedding f32 [spk_dim] -> mu (mel, 2n), spk (mel,)"""
+    def encode(self, token, embedding, finalize=True):
+        """token int [n] (prompt already prepended), embedding f32 [spk_dim] -> mu (mel, 2n), spk (mel,); finalize=False: the last
+        pre_lookahead_len tokens are context only (flow.py:401-404) -> mu (mel, 2 (n - len))"""
         token = token.to(self.device, torch.int32).contiguous().view(-1)
         emb = embedding.to(self.device, torch.float32).contiguous().view(-1)
         n = token.numel()
-        mu = torch.empty(self.cfg.mel, self.token_mel_ratio * n, dtype=torch.float32, device=self.device)
+        n_out = n if finalize else n - self.pre_lookahead_len
+        if n_out <= 0:
+            raise ValueError('a non-final chunk needs more than %d tokens' % self.pre_lookahead_len)
+        mu = torch.empty(self.cfg.mel, self.token_mel_ratio * n_out, dtype=torch.float32, device=self.device)
         spk = torch.empty(self.cfg.mel, dtype=torch.float32, device=self.device)
         ws = self._workspace(2, max(2 * n, 32))
-        check(self.lib.hvx_flow_encode(self._h, stream_ptr(), ptr(ws), ws.numel(), ptr(token), n, ptr(emb), ptr(mu), ptr(spk)), 'hvx_flow_encode')
+        check(self.lib.hvx_flow_encode_chunk(self._h, stream_ptr(), ptr(ws), ws.numel(), ptr(token), n, ptr(emb), 1 if finalize else 0, ptr(mu),
+                                             ptr(spk)), 'hvx_flow_encode_chunk')
         return mu, spk
 
-    def estimator(self, x, mask, mu, t, spks, cond):
-        """TensorRT-order estimator call (flow_matching.py:126-153): x, mu, cond (B,80,T); mask (B,1,T); t (B,); spks (B,80)."""
+    def estimator(self, x, mask, mu, t, spks, cond, streaming=False):
+        """TensorRT-order estimator call (flow_matching.py:126-153): x, mu, cond (B,80,T); mask (B,1,T); t (B,); spks (B,80);
+        streaming=True adds the static chunk mask (dit.py:163-164)."""
         B, mel, T = x.shape
         f = lambda a: a.to(self.device, torch.float32).contiguous()
         x, mu, cond, spks, t = f(x), f(mu), f(cond), f(spks), f(t).view(-1)
@@ -172,11 +185,12 @@ class HvxFlow:
             kv_len = mask.to(self.device).reshape(B, T).ne(0).sum(dim=1).to(torch.int32).contiguous()
         out = torch.empty(B, mel, T, dtype=torch.float32, device=self.device)
         ws = self._workspace(B, T)
-        check(self.lib.hvx_cfm_estimator(self._h, stream_ptr(), ptr(ws), ws.numel(), B, T, ptr(x), ptr(kv_len), ptr(mu), ptr(t), ptr(spks),
-                                         ptr(cond), ptr(out)), 'hvx_cfm_estimator')
+        check(self.lib.hvx_cfm_estimator_streaming(self._h, stream_ptr(), ptr(ws), ws.numel(), B, T, ptr(x), ptr(kv_len), ptr(mu), ptr(t),
+                                                   ptr(spks), ptr(cond), self.static_chunk_size if streaming else 0, ptr(out)),
+              'hvx_cfm_estimator_streaming')
         return out
 
-    def solve(self, mu, spks, cond, n_timesteps=None, noise=None):
+    def solve(self, mu, spks, cond, n_timesteps=None, noise=None, streaming=False):
         """CausalConditionalCFM.forward (flow_matching.py:204-228): mu, cond (mel,T) f32; spks (mel,) -> mel (mel,T)"""
         T = mu.shape[-1]
         n = n_timesteps or self.cfg.n_timesteps
@@ -185,8 +199,9 @@ class HvxFlow:
         ta = (C.c_float * n)(*ts)
         da = (C.c_float * n)(*dts)
         ws = self._workspace(2, T)
-        check(self.lib.hvx_cfm_solve(self._h, stream_ptr(), ptr(ws), ws.numel(), T, ptr(z), ptr(mu.contiguous()), ptr(spks.contiguous()),
-                                     ptr(cond.contiguous()), n, ta, da), 'hvx_cfm_solve')
+        check(self.lib.hvx_cfm_solve_streaming(self._h, stream_ptr(), ptr(ws), ws.numel(), T, ptr(z), ptr(mu.contiguous()),
+                                               ptr(spks.contiguous()), ptr(cond.contiguous()), n, ta, da,
+                                               self.static_chunk_size if streaming else 0), 'hvx_cfm_solve_streaming')
         return z
 
     # ---- reference surface ---------------------------------------------------------------------------------------------------
@@ -194,18 +209,16 @@ class HvxFlow:
     def inference(self, token, token_len, embedding, finalize=True, prompt_token=None, prompt_token_len=None, prompt_feat=None,
                   prompt_feat_len=None, streaming=False):
         assert token.shape[0] == 1                                       # flow.py:387
-        if streaming or not finalize:
-            raise NotImplementedError('streaming / chunked synthesis is outside the drop-in scope (server uses streaming=False, finalize=True)')
         if prompt_token is not None and prompt_token_len is not None:
             token = torch.concat([prompt_token.to(token.device), token], dim=1)
-        mu, spk = self.encode(token[0], embedding.reshape(-1))
+        mu, spk = self.encode(token[0], embedding.reshape(-1), finalize=finalize)
         T = mu.shape[-1]
         mel_len1 = 0
         cond = torch.zeros(self.cfg.mel, T, dtype=torch.float32, device=self.device)
         if prompt_feat is not None and prompt_feat_len is not None:
             mel_len1 = prompt_feat.shape[1]
             cond[:, :mel_len1] = prompt_feat[0].to(self.device, torch.float32).t()
-        feat = self.solve(mu, spk, cond)
+        feat = self.solve(mu, spk, cond, streaming=streaming)
         feat = feat[:, mel_len1:]
         assert feat.shape[1] == T - mel_len1
         return feat.unsqueeze(0).float(), None

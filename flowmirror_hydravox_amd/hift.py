@@ -167,13 +167,37 @@ class HvxHift:
         check(self.lib.hvx_hift_decode(self._h, stream_ptr(), ptr(ws), ws.numel(), ptr(mel), ptr(source), T, ptr(out)), 'hvx_hift_decode')
         return out
 
+    def decode_chunk(self, mel, source):
+        """finalize=False (generator.py:672-711): the last conv_pre_look_right frames of mel (80, T_in) are look-ahead context;
+        source [T_in*up] -> wav [(T_in - look_right - 1) * up] (the last up samples are dropped, generator.py:708-709)"""
+        mel = mel.to(self.device, torch.float32).contiguous()
+        source = source.to(self.device, torch.float32).contiguous().view(-1)
+        T_in, look = mel.shape[-1], self.cfg.conv_pre_look_right
+        if T_in - look - 1 <= 0:
+            raise ValueError('a non-final chunk needs more than %d mel frames' % (look + 1 + self.f0_look_right))
+        out = torch.empty((T_in - look) * self.up, dtype=torch.float32, device=self.device)
+        ws = self._workspace(T_in)
+        check(self.lib.hvx_hift_decode_chunk(self._h, stream_ptr(), ptr(ws), ws.numel(), ptr(mel), ptr(source), T_in, look, ptr(out)),
+              'hvx_hift_decode_chunk')
+        return out[:(T_in - look - 1) * self.up]
+
+    # the F0 predictor's first conv looks (kernel 4, causal_type 'right') 3 frames ahead: convolution.py:172, f0_predictor.py:97-100
+    f0_look_right = 3
+
     @torch.inference_mode()
     def inference(self, speech_feat, finalize=True):
-        if not finalize:
-            raise NotImplementedError('chunked synthesis is outside the drop-in scope (server calls hift.inference(speech_feat=mel))')
         assert speech_feat.shape[0] == 1
         mel = speech_feat[0]
         f0 = self.f0(mel)
-        s = self.source(f0)
-        wav = self.decode(mel, s)
+        if finalize:
+            s = self.source(f0)
+            wav = self.decode(mel, s)
+        else:
+            # f0_predictor.py:97-100: the last 3 frames are real right context, so the f0 of the frames before them is what the full
+            # (zero-padded) pass gives for them; source and decode then run on mel[:, :-3] (generator.py:717-725)
+            n = mel.shape[-1] - self.f0_look_right
+            if n <= 0:
+                raise ValueError('a non-final chunk needs more than %d mel frames' % self.f0_look_right)
+            s = self.source(f0[:n])
+            wav = self.decode_chunk(mel[:, :n], s)
         return wav.unsqueeze(0), s.view(1, 1, -1)

@@ -86,6 +86,7 @@ typedef struct {
     const int32_t* kv_len;                     /* optional [batch] */
     int32_t causal; float scale;
     int32_t n_splits, split_chunk; float* part_o; float* part_ml;   /* optional key splits (workspace) */
+    int32_t chunk;                             /* > 0: static chunk mask, row i sees keys j < (i / chunk + 1) * chunk (cosyvoice/utils/mask.py:128-158) */
 } hvx_attn_args;
 /* F.scaled_dot_product_attention (cosyvoice/flow/DiT/modules.py:391) */
 int hvx_op_attention(const hvx_attn_args* a, hvx_stream s);
@@ -189,10 +190,21 @@ int hvx_flow_encode(hvx_flow* h, hvx_stream s, void* ws, size_t ws_bytes, const 
                     float* mu, float* spk);
 /* pre-lookahead only (parity): x f32 [n][mel] -> y f32 [n][mel] */
 int hvx_flow_prelookahead(hvx_flow* h, hvx_stream s, void* ws, size_t ws_bytes, const float* x, int32_t n, float* y);
+/* Chunked synthesis (finalize=False, flow.py:401-404; upsample_encoder.py:90-95): the last pla_len rows / tokens are the look-ahead
+ * context of the rows before them instead of zero padding, and produce no output: y f32 [n - pla_len][mel], mu (mel, 2 (n - pla_len)).
+ * finalize != 0 is hvx_flow_encode. */
+int hvx_flow_prelookahead_context(hvx_flow* h, hvx_stream s, void* ws, size_t ws_bytes, const float* x, int32_t n, float* y);
+int hvx_flow_encode_chunk(hvx_flow* h, hvx_stream s, void* ws, size_t ws_bytes, const int32_t* token, int32_t n, const float* embedding,
+                          int32_t finalize, float* mu, float* spk);
 /* estimator, TensorRT argument order (flow_matching.py:130-153): x, mu, cond f32 (B, mel, T); mask -> kv_len int32 [B] (NULL: all T);
  * t f32 [B]; spks f32 (B, mel); out f32 (B, mel, T) */
 int hvx_cfm_estimator(hvx_flow* h, hvx_stream s, void* ws, size_t ws_bytes, int32_t batch, int32_t t_len, const float* x,
                       const int32_t* kv_len, const float* mu, const float* t, const float* spks, const float* cond, float* out);
+/* streaming=True (dit.py:163-164): attention row i additionally sees only keys j < (i / static_chunk_size + 1) * static_chunk_size
+ * (cosyvoice/utils/mask.py:128-158, 223-230); static_chunk_size == 0 is hvx_cfm_estimator. */
+int hvx_cfm_estimator_streaming(hvx_flow* h, hvx_stream s, void* ws, size_t ws_bytes, int32_t batch, int32_t t_len, const float* x,
+                                const int32_t* kv_len, const float* mu, const float* t, const float* spks, const float* cond,
+                                int32_t static_chunk_size, float* out);
 /* optional persistent device buffer in which hvx_cfm_solve keeps the adaLN modulation vectors of each distinct step time t
  * (they depend on t and the weights only); pass NULL to disable.  Must be re-set after the weights change. */
 int hvx_flow_set_mod_cache(hvx_flow* h, void* buf, size_t bytes);
@@ -200,6 +212,9 @@ int hvx_flow_set_mod_cache(hvx_flow* h, void* buf, size_t bytes);
  * (computed exactly as the reference accumulates them) */
 int hvx_cfm_solve(hvx_flow* h, hvx_stream s, void* ws, size_t ws_bytes, int32_t t_len, float* x, const float* mu, const float* spks,
                   const float* cond, int32_t n_steps, const float* t_steps, const float* dt_steps);
+/* the same with the static chunk mask of streaming=True (flow_matching.py:204-228 -> dit.py:163-164) */
+int hvx_cfm_solve_streaming(hvx_flow* h, hvx_stream s, void* ws, size_t ws_bytes, int32_t t_len, float* x, const float* mu, const float* spks,
+                            const float* cond, int32_t n_steps, const float* t_steps, const float* dt_steps, int32_t static_chunk_size);
 
 /* ---------------------------------------------------------------------------------------------------
  * HiFT — replaces CausalHiFTGenerator.inference / decode (cosyvoice/hifigan/generator.py:713-726, 672-711),
@@ -228,6 +243,11 @@ int hvx_hift_source(hvx_hift* h, hvx_stream s, void* ws, size_t ws_bytes, const 
                     float* source);
 /* mel (mel, T) + source [T*up] -> wav f32 [T*up] */
 int hvx_hift_decode(hvx_hift* h, hvx_stream s, void* ws, size_t ws_bytes, const float* mel, const float* source, int32_t t, float* wav);
+/* finalize=False (generator.py:672-711): the last look_right of the t_in mel frames are real right context of conv_pre and the source STFT
+ * is cut to match: mel (mel, t_in) + source [t_in*up] -> wav f32 [(t_in - look_right)*up] (the caller drops its last up*... hop samples,
+ * generator.py:708-709).  Workspace: hvx_hift_workspace_bytes(h, t_in). */
+int hvx_hift_decode_chunk(hvx_hift* h, hvx_stream s, void* ws, size_t ws_bytes, const float* mel, const float* source, int32_t t_in,
+                          int32_t look_right, float* wav);
 
 /* ---------------------------------------------------------------------------------------------------
  * Matcha-TTS family, fp32:

@@ -20,10 +20,14 @@ import torch
 import torch.nn.functional as F
 
 
-def pre_lookahead(x, sd, cfg, pre='pre_lookahead_layer.'):
-    """x: (1, N, 80) -> (1, N, 80); finalize=True path (zero right pad)."""
+def pre_lookahead(x, sd, cfg, pre='pre_lookahead_layer.', context=None):
+    """x: (1, N, 80) -> (1, N, 80); zero right pad, or `context` (1, pre_lookahead_len, 80) as the look-ahead (finalize=False)."""
     o = x.transpose(1, 2).contiguous()
-    o = F.pad(o, (0, cfg.pre_lookahead_len), value=0.0)
+    if context is None:
+        o = F.pad(o, (0, cfg.pre_lookahead_len), value=0.0)
+    else:
+        assert context.shape[1] == cfg.pre_lookahead_len
+        o = torch.cat([o, context.transpose(1, 2)], dim=2)
     o = F.leaky_relu(F.conv1d(o, sd[pre + 'conv1.weight'], sd[pre + 'conv1.bias']))
     k2 = sd[pre + 'conv2.weight'].shape[-1]
     o = F.pad(o, (k2 - 1, 0), value=0.0)
@@ -71,7 +75,7 @@ def causal_conv_pos_embed(x, sd, cfg, pre):
     return h.permute(0, 2, 1)
 
 
-def dit_block(x, t_emb, sd, cfg, pre, freqs, key_mask):
+def dit_block(x, t_emb, sd, cfg, pre, freqs, key_mask, attn_mask=None):
     B, T, D = x.shape
     H, dh = cfg.heads, cfg.head_dim
     emb = F.linear(F.silu(t_emb), sd[pre + 'attn_norm.linear.weight'], sd[pre + 'attn_norm.linear.bias'])
@@ -86,6 +90,8 @@ def dit_block(x, t_emb, sd, cfg, pre, freqs, key_mask):
     k = k.view(B, T, H, dh).transpose(1, 2)
     v = v.view(B, T, H, dh).transpose(1, 2)
     am = key_mask[:, None, None, :].expand(B, H, T, T)           # (B,1,T,T) repeated pad mask (dit.py:166)
+    if attn_mask is not None:
+        am = attn_mask[:, None].expand(B, H, T, T)                # streaming: pad mask & static chunk mask (dit.py:163-164)
     a = F.scaled_dot_product_attention(q, k, v, attn_mask=am, dropout_p=0.0, is_causal=False)
     a = a.transpose(1, 2).reshape(B, T, H * dh)
     a = F.linear(a, sd[pre + 'attn.to_out.0.weight'], sd[pre + 'attn.to_out.0.bias'])
@@ -97,9 +103,20 @@ def dit_block(x, t_emb, sd, cfg, pre, freqs, key_mask):
     return x + g_m.unsqueeze(1) * f
 
 
-def dit_forward(x, mask, mu, t, spks, cond, sd, cfg, pre='decoder.estimator.', n_blocks=None, taps=None):
+def chunk_attn_mask(key_mask, chunk):
+    """add_optional_chunk_mask(xs, masks, False, False, 0, static_chunk_size, -1) (cosyvoice/utils/mask.py:161-236 with
+    subsequent_chunk_mask :128-158): key j visible to row i iff mask[j] and j < (i // chunk + 1) * chunk; all-false rows -> all true."""
+    T = key_mask.shape[1]
+    pos = torch.arange(T)
+    cm = pos[None, :] < ((pos // chunk + 1) * chunk)[:, None]
+    am = key_mask[:, None, :] & cm[None]
+    am[am.sum(dim=-1) == 0] = True
+    return am
+
+
+def dit_forward(x, mask, mu, t, spks, cond, sd, cfg, pre='decoder.estimator.', n_blocks=None, taps=None, streaming=False):
     """Estimator call, TRT argument order (flow_matching.py:126-153): x,mu,cond (B,80,T); mask (B,1,T);
-    t (B,); spks (B,80) -> (B,80,T).  Non-streaming mask."""
+    t (B,); spks (B,80) -> (B,80,T).  streaming=True: static chunk mask of cfg.static_chunk_size frames."""
     x = x.transpose(1, 2)
     mu = mu.transpose(1, 2)
     cond = cond.transpose(1, 2)
@@ -115,8 +132,9 @@ def dit_forward(x, mask, mu, t, spks, cond, sd, cfg, pre='decoder.estimator.', n
     freqs = rope_freqs(T, cfg.head_dim)
     key_mask = mask.bool()[:, 0, :]
     nb = cfg.depth if n_blocks is None else n_blocks
+    attn_mask = chunk_attn_mask(key_mask, cfg.static_chunk_size) if streaming else None
     for i in range(nb):
-        h = dit_block(h, t_emb, sd, cfg, pre + 'transformer_blocks.%d.' % i, freqs, key_mask)
+        h = dit_block(h, t_emb, sd, cfg, pre + 'transformer_blocks.%d.' % i, freqs, key_mask, attn_mask)
         if taps is not None:
             taps['block%d' % i] = h.clone()
     emb = F.linear(F.silu(t_emb), sd[pre + 'norm_out.linear.weight'], sd[pre + 'norm_out.linear.bias'])
@@ -167,7 +185,7 @@ def solve_euler(x, t_span, mu, mask, spks, cond, estimator, cfg_rate):
     return traj[-1].float(), traj
 
 
-def cfm_forward(mu, mask, spks, cond, sd, cfg, noise=None, estimator=None, n_timesteps=None):
+def cfm_forward(mu, mask, spks, cond, sd, cfg, noise=None, estimator=None, n_timesteps=None, streaming=False):
     """CausalConditionalCFM.forward (flow_matching.py:204-228)."""
     noise = cfm_noise(cfg) if noise is None else noise
     z = noise[:, :, :mu.size(2)].to(mu.dtype)
@@ -175,20 +193,21 @@ def cfm_forward(mu, mask, spks, cond, sd, cfg, noise=None, estimator=None, n_tim
     t_span = cosine_t_span(n, mu.dtype)
     if estimator is None:
         def estimator(x, m, mu_, t, s, c):
-            return dit_forward(x, m, mu_, t, s, c, sd, cfg)
+            return dit_forward(x, m, mu_, t, s, c, sd, cfg, streaming=streaming)
     out, _ = solve_euler(z, t_span, mu, mask, spks, cond, estimator, cfg.cfg_rate)
     return out
 
 
-def flow_inference(token, embedding, sd, cfg, prompt_token=None, prompt_feat=None, noise=None):
-    """flow.py:367-430, fp32, finalize=True, streaming=False.
+def flow_inference(token, embedding, sd, cfg, prompt_token=None, prompt_feat=None, noise=None, finalize=True, streaming=False):
+    """flow.py:367-430, fp32; finalize=False: the last pre_lookahead_len tokens are look-ahead context only.
     token (1,N) int, embedding (1,192), prompt_token (1,Np) int, prompt_feat (1,Tp,80) -> mel (1,80,2N)."""
     emb = F.normalize(embedding.float(), dim=1)
     emb = F.linear(emb, sd['spk_embed_affine_layer.weight'], sd['spk_embed_affine_layer.bias'])
     if prompt_token is not None:
         token = torch.cat([prompt_token, token], dim=1)
     h = sd['input_embedding.weight'][torch.clamp(token.long(), min=0)]          # mask is all ones for B=1
-    h = pre_lookahead(h, sd, cfg)
+    L = cfg.pre_lookahead_len
+    h = pre_lookahead(h, sd, cfg) if finalize else pre_lookahead(h[:, :-L], sd, cfg, context=h[:, -L:])
     h = h.repeat_interleave(cfg.token_mel_ratio, dim=1)
     T = h.shape[1]
     mel_len1 = prompt_feat.shape[1] if prompt_feat is not None else 0
@@ -196,5 +215,5 @@ def flow_inference(token, embedding, sd, cfg, prompt_token=None, prompt_feat=Non
     if prompt_feat is not None:
         cond[:, :mel_len1] = prompt_feat
     mask = torch.ones(1, 1, T)
-    feat = cfm_forward(h.transpose(1, 2).contiguous(), mask, emb, cond.transpose(1, 2), sd, cfg, noise=noise)
+    feat = cfm_forward(h.transpose(1, 2).contiguous(), mask, emb, cond.transpose(1, 2), sd, cfg, noise=noise, streaming=streaming)
     return feat[:, :, mel_len1:].float()

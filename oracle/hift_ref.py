@@ -29,11 +29,17 @@ def fold_weight_norm(sd, name):
     return sd[name + '.weight']
 
 
-def causal_conv(x, w, b, dilation=1, causal_type='left'):
-    """CausalConv1d (convolution.py:150-187)."""
-    k = w.shape[-1]
-    pad = int((k * dilation - dilation) / 2) * 2 + (k + 1) % 2
-    x = F.pad(x, (pad, 0)) if causal_type == 'left' else F.pad(x, (0, pad))
+def causal_padding(k, dilation=1):
+    return int((k * dilation - dilation) / 2) * 2 + (k + 1) % 2
+
+
+def causal_conv(x, w, b, dilation=1, causal_type='left', cache=None):
+    """CausalConv1d (convolution.py:150-187); `cache` replaces the zero padding (left or right context)."""
+    pad = causal_padding(w.shape[-1], dilation)
+    if cache is None:
+        cache = torch.zeros(x.shape[0], x.shape[1], pad, dtype=x.dtype)
+    assert cache.shape[2] == pad
+    x = torch.cat([cache, x], dim=2) if causal_type == 'left' else torch.cat([x, cache], dim=2)
     return F.conv1d(x, w, b, dilation=dilation)
 
 
@@ -63,9 +69,14 @@ def resblock(x, sd, pre, dilations):
     return x
 
 
-def f0_predictor(mel, sd, pre='f0_predictor.'):
-    """mel (1,80,T) -> f0 (1,T) (f0_predictor.py:95-103)."""
-    x = causal_conv(mel, fold_weight_norm(sd, pre + 'condnet.0'), sd[pre + 'condnet.0.bias'], causal_type='right')
+def f0_predictor(mel, sd, pre='f0_predictor.', finalize=True):
+    """mel (1,80,T) -> f0 (1,T), or (1,T-3) with finalize=False where the last 3 frames are right context (f0_predictor.py:95-103)."""
+    w0 = fold_weight_norm(sd, pre + 'condnet.0')
+    if finalize:
+        x = causal_conv(mel, w0, sd[pre + 'condnet.0.bias'], causal_type='right')
+    else:
+        p = causal_padding(w0.shape[-1])
+        x = causal_conv(mel[:, :, :-p], w0, sd[pre + 'condnet.0.bias'], causal_type='right', cache=mel[:, :, -p:])
     x = F.elu(x)
     for i in (2, 4, 6, 8):
         x = F.elu(causal_conv(x, fold_weight_norm(sd, pre + 'condnet.%d' % i), sd[pre + 'condnet.%d.bias' % i]))
@@ -127,11 +138,18 @@ def istft(mag, phase, cfg):
     return torch.istft(torch.complex(real, img), cfg.n_fft, cfg.hop, cfg.n_fft, window=hann_window(cfg.n_fft))
 
 
-def decode(mel, s, sd, cfg, taps=None):
-    """CausalHiFTGenerator.decode, finalize=True (generator.py:672-711). mel (1,80,T), s (1,1,480T)."""
+def decode(mel, s, sd, cfg, taps=None, finalize=True):
+    """CausalHiFTGenerator.decode (generator.py:672-711). mel (1,80,T), s (1,1,480T); finalize=False: the last conv_pre_look_right
+    frames are context, the source spectrogram is cut to match and the last 480 samples are dropped."""
     sr, si = stft(s.squeeze(1), cfg)
+    if finalize:
+        x = causal_conv(mel, fold_weight_norm(sd, 'conv_pre'), sd['conv_pre.bias'], causal_type='right')
+    else:
+        look = cfg.conv_pre_look_right
+        x = causal_conv(mel[:, :, :-look], fold_weight_norm(sd, 'conv_pre'), sd['conv_pre.bias'], causal_type='right', cache=mel[:, :, -look:])
+        cut = int(np.prod(cfg.upsample_rates) * look)
+        sr, si = sr[:, :, :-cut], si[:, :, :-cut]
     s_stft = torch.cat([sr, si], dim=1)
-    x = causal_conv(mel, fold_weight_norm(sd, 'conv_pre'), sd['conv_pre.bias'], causal_type='right')
     nk = len(cfg.resblock_kernel_sizes)
     nu = len(cfg.upsample_rates)
     down_rates = [1] + cfg.upsample_rates[::-1][:-1]
@@ -161,15 +179,21 @@ def decode(mel, s, sd, cfg, taps=None):
     mag = torch.exp(x[:, :nb, :])
     phase = torch.sin(x[:, nb:, :])
     w = istft(mag, phase, cfg)
+    if not finalize:
+        w = w[:, :-int(np.prod(cfg.upsample_rates) * cfg.hop)]
     return torch.clamp(w, -cfg.audio_limit, cfg.audio_limit)
 
 
-def hift_inference(mel, sd, cfg, tables, taps=None):
-    """CausalHiFTGenerator.inference, finalize=True (generator.py:713-726). mel (1,80,T) fp32 -> (wav (1,480T), source)."""
-    f0 = f0_predictor(mel, sd)
+def hift_inference(mel, sd, cfg, tables, taps=None, finalize=True):
+    """CausalHiFTGenerator.inference (generator.py:713-726). mel (1,80,T) fp32 -> (wav (1,480T), source); finalize=False is the
+    non-final chunk of streaming synthesis: (wav (1, 480 (T - 8)), source (1, 1, 480 (T - 3)))."""
+    f0 = f0_predictor(mel, sd, finalize=finalize)
     s = F.interpolate(f0[:, None], scale_factor=float(cfg.upsample_total), mode='nearest').transpose(1, 2)
     s = source_module(s, sd, cfg, tables).transpose(1, 2)
     if taps is not None:
         taps['f0'] = f0.clone()
         taps['source'] = s.clone()
+    if not finalize:
+        p = causal_padding(fold_weight_norm(sd, 'f0_predictor.condnet.0').shape[-1])
+        return decode(mel[:, :, :-p], s, sd, cfg, taps, finalize=False), s
     return decode(mel, s, sd, cfg, taps), s

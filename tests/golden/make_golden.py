@@ -444,8 +444,130 @@ def gen_matcha():
     np.savez_compressed(os.path.join(HERE, 'matcha_tiny.npz'), **out)
 
 
+# ------------------------------------------------------------------------------------------------
+# streaming synthesis: static chunk mask in the DiT, finalize=False in flow and HiFT
+# ------------------------------------------------------------------------------------------------
+def gen_stream():
+    import dataclasses
+    from cosyvoice.flow.flow import CausalMaskedDiffWithDiT
+    from cosyvoice.flow.flow_matching import CausalConditionalCFM
+    from cosyvoice.flow.DiT.dit import DiT
+    from cosyvoice.transformer.upsample_encoder import PreLookaheadLayer
+    from cosyvoice.hifigan.generator import CausalHiFTGenerator
+    from cosyvoice.hifigan.f0_predictor import CausalConvRNNF0Predictor
+    CHUNK = 16
+    c = dataclasses.replace(tiny_config().flow, static_chunk_size=CHUNK)
+    dit = DiT(dim=c.dim, depth=c.depth, heads=c.heads, dim_head=c.head_dim, ff_mult=c.ff_mult, mel_dim=c.mel, mu_dim=c.mel,
+              spk_dim=c.mel, out_channels=c.mel, static_chunk_size=CHUNK)
+    cfm = CausalConditionalCFM(in_channels=240, cfm_params=DictConfig(sigma_min=1e-6, solver='euler', t_scheduler='cosine',
+                                                                     training_cfg_rate=0.2, inference_cfg_rate=c.cfg_rate, reg_loss_type='l1'),
+                               n_spks=1, spk_emb_dim=80, estimator=dit)
+    pla = PreLookaheadLayer(in_channels=80, channels=c.pre_lookahead_channels, pre_lookahead_len=c.pre_lookahead_len)
+    flow = CausalMaskedDiffWithDiT(input_size=80, output_size=80, spk_embed_dim=192, vocab_size=c.vocab, token_mel_ratio=2,
+                                   pre_lookahead_len=3, pre_lookahead_layer=pla, decoder=cfm).eval()
+    seed_w = 11
+    sd = W.make_flow_state(c, seed=seed_w, init='fan_in')
+    flow.load_state_dict(sd)
+    out = dict(chunk=np.int32(CHUNK), flow_weight_seed=np.int64(seed_w), flow_weight_sha=np.array(state_checksum(sd)))
+    g = torch.Generator()
+    g.manual_seed(17)
+    # ---- estimator with the chunk mask, padded batch -----------------------------------------------------------------------
+    T, lens = 70, [70, 45]
+    x_in = torch.randn(2, 80, T, generator=g)
+    mu_in = torch.randn(2, 80, T, generator=g)
+    t_in = torch.tensor([0.3, 0.7])
+    sp_in = torch.randn(2, 80, generator=g)
+    c_in = torch.randn(2, 80, T, generator=g)
+    mask = (torch.arange(T)[None, :] < torch.tensor(lens)[:, None]).float()[:, None, :]
+    est = dit(x_in, mask, mu_in, t_in, sp_in, c_in, streaming=True)
+    o_est = flow_ref.dit_forward(x_in, mask, mu_in, t_in, sp_in, c_in, sd, c, streaming=True)
+    d = ((o_est - est) * mask).abs().max().item()
+    assert d < 1e-4, d
+    full = dit(x_in, mask, mu_in, t_in, sp_in, c_in, streaming=False)
+    print('[stream] estimator chunk=%d lens=%s: oracle-reference max abs diff %.1e (streaming vs full mask differ by %.2f)'
+          % (CHUNK, lens, d, ((full - est) * mask).abs().max().item()))
+    out.update(est_x=x_in.numpy(), est_mu=mu_in.numpy(), est_t=t_in.numpy(), est_spk=sp_in.numpy(), est_cond=c_in.numpy(),
+               est_mask=mask.numpy(), est_out=est.numpy())
+
+    # ---- flow.inference(streaming=True) whole and in chunks (the check of the reference's own __main__, flow.py:436-459) ----
+    def ref_flow(token, ptoken, pfeat, emb, finalize):
+        # flow.py:388-430 in fp32 (the shipped method casts to bf16/fp16 and cannot run on CPU; SURVEY.md finding 7)
+        e = flow.spk_embed_affine_layer(F.normalize(emb, dim=1))
+        h0 = flow.input_embedding(torch.cat([ptoken, token], dim=1))
+        h = flow.pre_lookahead_layer(h0) if finalize else flow.pre_lookahead_layer(h0[:, :-3], context=h0[:, -3:])
+        h = h.repeat_interleave(2, dim=1)
+        Tm = h.shape[1]
+        cond = torch.zeros(1, Tm, 80)
+        cond[:, :pfeat.shape[1]] = pfeat
+        feat, _ = flow.decoder(mu=h.transpose(1, 2).contiguous(), mask=torch.ones(1, 1, Tm), spks=e, cond=cond.transpose(1, 2),
+                               n_timesteps=10, streaming=True)
+        return feat[:, :, pfeat.shape[1]:]
+
+    N, Np, hop = 4 * (CHUNK // 2), CHUNK // 2, CHUNK // 2              # token hop = chunk / token_mel_ratio, prompt = one chunk
+    token = torch.randint(0, c.vocab, (1, N), generator=g)
+    ptoken = torch.randint(0, c.vocab, (1, Np), generator=g)
+    pfeat = torch.randn(1, 2 * Np, 80, generator=g)
+    emb = torch.randn(1, 192, generator=g)
+    whole = ref_flow(token, ptoken, pfeat, emb, True)
+    o_whole = flow_ref.flow_inference(token, emb, sd, c, prompt_token=ptoken, prompt_feat=pfeat, streaming=True)
+    assert (o_whole - whole).abs().max().item() < 1e-4
+    out.update(token=token.numpy(), ptoken=ptoken.numpy(), pfeat=pfeat.numpy(), emb=emb.numpy(), mel_whole=whole.numpy())
+    worst = 0.0
+    for k, i in enumerate(range(0, N, hop)):
+        fin = i + hop + 3 >= N
+        part = ref_flow(token[:, :i + hop + 3], ptoken, pfeat, emb, fin)
+        o_part = flow_ref.flow_inference(token[:, :i + hop + 3], emb, sd, c, prompt_token=ptoken, prompt_feat=pfeat, streaming=True, finalize=fin)
+        assert (o_part - part).abs().max().item() < 1e-4
+        new = part[:, :, 2 * i:]
+        worst = max(worst, (whole[:, :, 2 * i:2 * i + new.shape[2]] - new).abs().max().item())
+        out['mel_chunk%d' % k] = part.numpy()
+        out['mel_chunk%d_final' % k] = np.int32(fin)
+    out['n_chunks'] = np.int32(k + 1)
+    out['hop'] = np.int32(hop)
+    print('[stream] flow N=%d prompt=%d hop=%d: %d chunks, chunked vs whole streaming mel max abs diff %.1e' % (N, Np, hop, k + 1, worst))
+
+    # ---- HiFT finalize=False ------------------------------------------------------------------------------------------------
+    hc = tiny_config().hift
+    f0p = CausalConvRNNF0Predictor(num_class=1, in_channels=80, cond_channels=hc.f0_channels)
+    gen = CausalHiFTGenerator(
+        in_channels=80, base_channels=hc.base_channels, nb_harmonics=hc.nb_harmonics, sampling_rate=hc.sampling_rate,
+        nsf_alpha=hc.nsf_alpha, nsf_sigma=hc.nsf_sigma, nsf_voiced_threshold=hc.nsf_voiced_threshold,
+        upsample_rates=hc.upsample_rates, upsample_kernel_sizes=hc.upsample_kernel_sizes,
+        istft_params={'n_fft': hc.n_fft, 'hop_len': hc.hop}, resblock_kernel_sizes=hc.resblock_kernel_sizes,
+        resblock_dilation_sizes=hc.resblock_dilations, source_resblock_kernel_sizes=hc.source_resblock_kernel_sizes,
+        source_resblock_dilation_sizes=hc.source_resblock_dilations, lrelu_slope=hc.lrelu_slope, audio_limit=hc.audio_limit,
+        conv_pre_look_right=hc.conv_pre_look_right, f0_predictor=f0p).eval()
+    seed_h, seed_t = 3, 9
+    sdh = W.make_hift_state(hc, seed=seed_h, init='fan_in')
+    gen.load_state_dict(sdh)
+    tables = hift_ref.make_tables(hc, seed=seed_t)
+    gen.m_source.l_sin_gen.rand_ini = tables['rand_ini']
+    gen.m_source.l_sin_gen.sine_waves = tables['sine_waves']
+    gen.m_source.uv = tables['uv']
+    out.update(hift_weight_seed=np.int64(seed_h), hift_table_seed=np.int64(seed_t), hift_weight_sha=np.array(state_checksum(sdh)))
+    Tm = 60
+    mel = torch.randn(1, 80, Tm, generator=g)
+    with torch.inference_mode():
+        wav_whole, _ = gen.inference(speech_feat=mel)
+    out.update(h_mel=mel.numpy(), h_wav_whole=wav_whole.numpy())
+    worst, up = 0.0, hc.upsample_total
+    for k, n in enumerate([12, 31, 47]):
+        with torch.inference_mode():
+            wav, s = gen.inference(speech_feat=mel[:, :, :n], finalize=False)
+        o_wav, o_s = hift_ref.hift_inference(mel[:, :, :n], sdh, hc, tables, finalize=False)
+        d = [(o_s - s).abs().max().item(), (o_wav - wav).abs().max().item()]
+        assert wav.shape[1] == up * (n - 8) and s.shape[2] == up * (n - 3), (wav.shape, s.shape)
+        assert d[0] < 1e-3, d
+        worst = max(worst, (wav_whole[:, :wav.shape[1]] - wav).abs().max().item())
+        print('[stream] hift finalize=False T=%d: oracle-reference max abs diff source %.1e wav %.1e' % (n, *d))
+        out.update({'h%d_n' % k: np.int32(n), 'h%d_wav' % k: wav.numpy(), 'h%d_source' % k: s.numpy()})
+    out['h_runs'] = np.int32(3)
+    print('[stream] hift: chunk prefix vs whole-utterance wav max abs diff %.1e' % worst)
+    np.savez_compressed(os.path.join(HERE, 'stream_tiny.npz'), **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['sampler', 'llm', 'flow', 'hift', 'matcha']
+    which = sys.argv[1:] or ['sampler', 'llm', 'flow', 'hift', 'matcha', 'stream']
     for w in which:
-        {'sampler': gen_sampler, 'llm': gen_llm, 'flow': gen_flow, 'hift': gen_hift, 'matcha': gen_matcha}[w]()
+        {'sampler': gen_sampler, 'llm': gen_llm, 'flow': gen_flow, 'hift': gen_hift, 'matcha': gen_matcha, 'stream': gen_stream}[w]()
     print('golden fixtures written to', HERE)

@@ -324,6 +324,102 @@ def test_hift_matches_oracle_on_longer_input(tiny_cfg, hift_setup):
 
 
 # ------------------------------------------------------------------------------------------------------------------------
+# streaming synthesis: static chunk mask, finalize=False
+# ------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('dtype,tol', [(torch.float32, 1e-3), (torch.bfloat16, 5e-2)])
+def test_flow_streaming_vs_reference(tiny_cfg, dtype, tol):
+    import dataclasses
+    from flowmirror_hydravox_amd import weights as W
+    from flowmirror_hydravox_amd.flow import HvxFlow
+    g = load_golden('stream_tiny.npz')
+    c = dataclasses.replace(tiny_cfg.flow, static_chunk_size=int(g['chunk']))
+    sd = W.make_flow_state(c, seed=int(g['flow_weight_seed']), init='fan_in')
+    assert state_checksum(sd) == str(g['flow_weight_sha'])
+    flow = HvxFlow(c, sd, dtype=dtype, max_t=512)
+    t = lambda k: torch.from_numpy(g[k])
+    est = flow.estimator(t('est_x'), t('est_mask'), t('est_mu'), t('est_t'), t('est_spk'), t('est_cond'), streaming=True).cpu().numpy()
+    assert _rel(est * g['est_mask'], g['est_out'] * g['est_mask']) < tol, _rel(est * g['est_mask'], g['est_out'] * g['est_mask'])
+    token, hop = t('token'), int(g['hop'])
+    ptoken = t('ptoken')
+    kw = dict(embedding=t('emb').to(DEV), prompt_token=ptoken.to(DEV), prompt_token_len=torch.tensor([ptoken.shape[1]], dtype=torch.int32),
+              prompt_feat=t('pfeat').to(DEV), prompt_feat_len=torch.tensor([2 * ptoken.shape[1]], dtype=torch.int32), streaming=True)
+    mtol = tol if dtype == torch.float32 else 0.15
+    whole, _ = flow.inference(token=token.to(DEV), token_len=torch.tensor([token.shape[1]], dtype=torch.int32), finalize=True, **kw)
+    assert _rel(whole.cpu().numpy(), g['mel_whole']) < mtol
+    for k in range(int(g['n_chunks'])):
+        fin = bool(g['mel_chunk%d_final' % k])
+        piece = token[:, :k * hop + hop + 3]
+        part, _ = flow.inference(token=piece.to(DEV), token_len=torch.tensor([piece.shape[1]], dtype=torch.int32), finalize=fin, **kw)
+        assert tuple(part.shape) == g['mel_chunk%d' % k].shape
+        assert _rel(part.cpu().numpy(), g['mel_chunk%d' % k]) < mtol, (k, _rel(part.cpu().numpy(), g['mel_chunk%d' % k]))
+        # causality of the streaming model (the reference's own check, flow.py:436-459): a chunk is a prefix of the whole pass
+        assert _rel(part.cpu().numpy(), whole[:, :, :part.shape[2]].cpu().numpy()) < (1e-4 if dtype == torch.float32 else 0.1)
+
+
+def test_hift_chunk_vs_reference(tiny_cfg):
+    from flowmirror_hydravox_amd import weights as W
+    from flowmirror_hydravox_amd.hift import HvxHift
+    from oracle import hift_ref
+    g = load_golden('stream_tiny.npz')
+    c = tiny_cfg.hift
+    sd = W.make_hift_state(c, seed=int(g['hift_weight_seed']), init='fan_in')
+    assert state_checksum(sd) == str(g['hift_weight_sha'])
+    hift = HvxHift(c, sd, tables=hift_ref.make_tables(c, seed=int(g['hift_table_seed'])))
+    mel = torch.from_numpy(g['h_mel'])
+    for k in range(int(g['h_runs'])):
+        n = int(g['h%d_n' % k])
+        ref_wav, ref_s = g['h%d_wav' % k], g['h%d_source' % k]
+        wav = hift.decode_chunk(mel[0, :, :n - 3], torch.from_numpy(ref_s).reshape(-1)).cpu().numpy()     # decode on the reference's source
+        assert wav.shape == (480 * (n - 8),)
+        assert _rel(wav, ref_wav[0]) < 1e-3, (n, _rel(wav, ref_wav[0]))
+        wav2, s2 = hift.inference(speech_feat=mel[:, :, :n].to(DEV), finalize=False)
+        assert tuple(wav2.shape) == ref_wav.shape and tuple(s2.shape) == ref_s.shape
+        assert np.abs(s2.cpu().numpy() - ref_s).max() < 2e-3
+        assert np.abs(wav2.cpu().numpy() - ref_wav).max() < 2e-2                                           # F0 -> phase accumulation, DESIGN.md §3
+    with pytest.raises(ValueError):
+        hift.inference(speech_feat=mel[:, :, :8].to(DEV), finalize=False)
+
+
+def test_streaming_chunks_are_prefixes_at_production_chunk_size(tiny_cfg):
+    """static_chunk_size 50 / token_hop_len 25 with a few thousand frames: the LDS-staged bf16 attention with per-row chunk limits
+    (both tilings).  Size-independent property from the reference's own self-check (flow.py:436-459, generator.py:739-747): what a
+    non-final chunk returns is a prefix of the whole-utterance streaming result."""
+    from flowmirror_hydravox_amd import weights as W
+    from flowmirror_hydravox_amd.flow import HvxFlow
+    from flowmirror_hydravox_amd.hift import HvxHift
+    from flowmirror_hydravox_amd.streaming import stream_tts
+    from oracle import hift_ref
+    c = tiny_cfg.flow
+    assert c.static_chunk_size == 50
+    flow = HvxFlow(c, W.make_flow_state(c, seed=5, init='fan_in'), dtype=torch.bfloat16, max_t=4096)
+    gen = torch.Generator().manual_seed(12)
+    n_prompt, n_tok = 60, 1290
+    token = torch.randint(0, c.vocab, (1, n_tok), generator=gen)
+    ptoken = torch.randint(0, c.vocab, (1, n_prompt), generator=gen)
+    pfeat = torch.randn(1, 2 * n_prompt, 80, generator=gen)
+    emb = torch.randn(1, 192, generator=gen)
+    kw = dict(embedding=emb.to(DEV), prompt_token=ptoken.to(DEV), prompt_token_len=torch.tensor([n_prompt], dtype=torch.int32),
+              prompt_feat=pfeat.to(DEV), prompt_feat_len=torch.tensor([2 * n_prompt], dtype=torch.int32), streaming=True)
+    whole, _ = flow.inference(token=token.to(DEV), token_len=torch.tensor([n_tok], dtype=torch.int32), finalize=True, **kw)
+    full, _ = flow.inference(token=token.to(DEV), token_len=torch.tensor([n_tok], dtype=torch.int32), finalize=True, **dict(kw, streaming=False))
+    assert _rel(full.cpu().numpy(), whole.cpu().numpy()) > 1e-2                     # the chunk mask changes the result
+    for n in (15 + 25 * 3 + 3, 15 + 25 * 20 + 3, 15 + 25 * 47 + 3):               # prompt + hop = whole chunks: 60 + 15 = 75 tokens = 3 chunks
+        part, _ = flow.inference(token=token[:, :n].to(DEV), token_len=torch.tensor([n], dtype=torch.int32), finalize=False, **kw)
+        assert tuple(part.shape) == (1, 80, 2 * (n - 3))
+        assert _rel(part.cpu().numpy(), whole[:, :, :part.shape[2]].cpu().numpy()) < 0.1, n
+    # end to end through the chunk scheduler: pieces tile the utterance; every non-final piece equals the corresponding samples of HiFT run
+    # over the mel cache at that time (finalize=False results are prefixes of each other up to fp32 rounding in the F0 phase)
+    hc = tiny_cfg.hift
+    hift = HvxHift(hc, W.make_hift_state(hc, seed=3, init='fan_in'), tables=hift_ref.make_tables(hc, seed=9))
+    toks = token[0, :215].tolist()
+    pieces = list(stream_tts(iter(toks), flow, hift, ptoken, pfeat, emb, token_hop_len=25))
+    assert len(pieces) == 8                                                       # hops 40 (25 + prompt pad 15), 6 x 25, final 25
+    wav = torch.cat(pieces, dim=1)
+    assert wav.shape == (1, 480 * 2 * 215)
+    assert torch.isfinite(wav).all() and wav.abs().max() <= hc.audio_limit + 1e-6
+
+
+# ------------------------------------------------------------------------------------------------------------------------
 # end to end: the software pipeline over batches returns what the back-to-back stages return
 # ------------------------------------------------------------------------------------------------------------------------
 def test_pipelined_batches_equal_serial(tiny_cfg):

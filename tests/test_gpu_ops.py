@@ -144,7 +144,7 @@ def test_epilogue_activations_gate_and_second_output():
         torch.testing.assert_close(out2.cpu(), ref2, rtol=5e-4, atol=5e-4)
 
 
-def _attn_ref(q, k, v, kv_len=None, causal=False):
+def _attn_ref(q, k, v, kv_len=None, causal=False, chunk=0):
     B, H, T, d = q.shape
     s = q @ k.transpose(-1, -2) / math.sqrt(d)
     mask = torch.ones(B, 1, T, T, dtype=torch.bool)
@@ -152,6 +152,9 @@ def _attn_ref(q, k, v, kv_len=None, causal=False):
         mask = mask & (torch.arange(T)[None, None, None, :] < kv_len[:, None, None, None])
     if causal:
         mask = mask & torch.tril(torch.ones(T, T, dtype=torch.bool))[None, None]
+    if chunk:
+        pos = torch.arange(T)
+        mask = mask & (pos[None, :] < ((pos // chunk + 1) * chunk)[:, None])[None, None]       # subsequent_chunk_mask (utils/mask.py:128-158)
     s = s.masked_fill(~mask, float('-inf'))
     return (torch.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(B, T, H * d)
 
@@ -178,6 +181,20 @@ def test_attention_padding_mask(dtype, T):
     kv_len = torch.tensor([T, max(1, T - 5)], dtype=torch.int32)
     ref = _attn_ref(q.float(), k.float(), v.float(), kv_len=kv_len)
     out = ops.attention(qd, kd, vd, T, kv_len=kv_len.to(DEV))
+    tol = dict(rtol=3e-2, atol=3e-2) if dtype == torch.bfloat16 else dict(rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(out.float().cpu(), ref, **tol)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('T,chunk', [(70, 16), (333, 50), (700, 50), (1000, 64), (2200, 50), (2200, 600)])
+def test_attention_static_chunk_mask(dtype, T, chunk):
+    """streaming=True mask of the DiT (dit.py:163-164): pad mask & static chunk mask; covers the generic kernel (fp32, short) and both
+    tilings of the LDS-staged bf16 kernel (128 and 256 rows per workgroup), chunk ends inside and across 64-key tiles."""
+    _lib, ops, packing = _mods()
+    q, k, v, qd, kd, vd = _attn_inputs(2, 2, T, dtype, seed=60)
+    kv_len = torch.tensor([T, max(1, T - 37)], dtype=torch.int32)
+    ref = _attn_ref(q.float(), k.float(), v.float(), kv_len=kv_len, chunk=chunk)
+    out = ops.attention(qd, kd, vd, T, kv_len=kv_len.to(DEV), chunk=chunk)
     tol = dict(rtol=3e-2, atol=3e-2) if dtype == torch.bfloat16 else dict(rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(out.float().cpu(), ref, **tol)
 

@@ -243,3 +243,46 @@ def test_batching_worker_groups_tasks_by_sampling_parameters():
     assert [t['id'] for t in batch] == [1, 3, 5] and [t['id'] for t in rest] == [2, 4]
     batch, rest = group_batchable([dict(id=9, task_type='load_pt')])
     assert batch == [] and len(rest) == 1
+
+
+def test_stream_tts_chunk_schedule_matches_the_reference_loop():
+    """stream_tts (cli/model.py:316-362 + token2wav :405-430) with stand-in models: which token prefixes reach the flow, with which
+    flags, and that the pieces handed out tile the audio of the final mel cache exactly once."""
+    from flowmirror_hydravox_amd.streaming import stream_tts
+    calls = []
+
+    class Flow:
+        token_mel_ratio, pre_lookahead_len, device = 2, 3, 'cpu'
+
+        def inference(self, token, token_len, embedding, finalize, prompt_token=None, prompt_token_len=None, prompt_feat=None,
+                      prompt_feat_len=None, streaming=False):
+            n = token.shape[1] if finalize else token.shape[1] - self.pre_lookahead_len
+            calls.append((token.shape[1], bool(finalize), bool(streaming), None if prompt_token is None else prompt_token.shape[1]))
+            ids = token[0, :n].float().repeat_interleave(2)                       # "mel" frame value = its token id
+            return ids.view(1, 1, -1).expand(1, 80, -1).contiguous(), None
+
+    class Hift:
+        def inference(self, speech_feat, finalize=True):
+            T = speech_feat.shape[2]
+            wav = speech_feat[0, 0].repeat_interleave(480)                        # sample value = token id of its frame
+            return (wav[:480 * T] if finalize else wav[:480 * (T - 8)]).view(1, -1), None
+
+    hop, n_prompt, n_tok = 25, 40, 143
+    toks = list(range(1000, 1000 + n_tok))
+    pieces = list(stream_tts(iter(toks), Flow(), Hift(), torch.zeros(1, n_prompt, dtype=torch.int32), torch.zeros(1, 2 * n_prompt, 80),
+                             torch.zeros(1, 192), token_hop_len=hop))
+    pad = 50 - n_prompt                                                           # first hop is padded to a whole chunk with the prompt
+    want, off = [], 0
+    while n_tok - off >= (hop + pad if off == 0 else hop) + 3:
+        h = hop + pad if off == 0 else hop
+        want.append((off + h + 3, False, True, n_prompt))
+        off += h
+    want.append((n_tok, True, False, n_prompt))                                   # the reference's last call drops `stream`
+    assert calls == want
+    wav = torch.cat(pieces, dim=1)
+    assert wav.shape == (1, 480 * 2 * n_tok)
+    assert torch.equal(wav[0], torch.tensor(toks).float().repeat_interleave(960))
+    # non-streaming: one call, everything at once
+    calls.clear()
+    one = list(stream_tts(iter(toks), Flow(), Hift(), torch.zeros(1, 0, dtype=torch.int32), torch.zeros(1, 0, 80), torch.zeros(1, 192), stream=False))
+    assert calls == [(n_tok, True, False, None)] and len(one) == 1 and one[0].shape == (1, 480 * 2 * n_tok)

@@ -215,3 +215,44 @@ def test_mel_spectrogram_oracle_vs_reference_vectors():
         assert mb.shape == (kw['num_mels'], kw['n_fft'] // 2 + 1) and bool((mb.sum(1) > 0).all()) and float(mb.min()) >= 0.0
         out = matcha_ref.mel_spectrogram(torch.from_numpy(g['mel_%s_y' % tag]), mel_basis=mb, **kw)
         assert (out - torch.from_numpy(g['mel_%s_out' % tag])).abs().max() < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# streaming synthesis: static chunk mask, finalize=False in flow and HiFT
+# ------------------------------------------------------------------------------------------------------------------------
+def test_streaming_oracle_vs_reference_vectors(tiny_cfg):
+    import dataclasses
+    g = load_golden('stream_tiny.npz')
+    c = dataclasses.replace(tiny_cfg.flow, static_chunk_size=int(g['chunk']))
+    sd = W.make_flow_state(c, seed=int(g['flow_weight_seed']), init='fan_in')
+    assert state_checksum(sd) == str(g['flow_weight_sha'])
+    t = lambda k: torch.from_numpy(g[k])
+    mask = t('est_mask')
+    est = flow_ref.dit_forward(t('est_x'), mask, t('est_mu'), t('est_t'), t('est_spk'), t('est_cond'), sd, c, streaming=True)
+    assert np.allclose((est * mask).numpy(), g['est_out'] * g['est_mask'], atol=1e-4)
+    full = flow_ref.dit_forward(t('est_x'), mask, t('est_mu'), t('est_t'), t('est_spk'), t('est_cond'), sd, c, streaming=False)
+    assert np.abs((full * mask).numpy() - g['est_out'] * g['est_mask']).max() > 1e-2          # the chunk mask is not a no-op here
+    # chunked flow: every non-final chunk of the reference equals the oracle's, and is a prefix of the whole streaming pass
+    token, hop = t('token'), int(g['hop'])
+    kw = dict(prompt_token=t('ptoken'), prompt_feat=t('pfeat'), streaming=True)
+    whole = flow_ref.flow_inference(token, t('emb'), sd, c, **kw)
+    assert np.allclose(whole.numpy(), g['mel_whole'], atol=2e-4)
+    for k in range(int(g['n_chunks'])):
+        fin = bool(g['mel_chunk%d_final' % k])
+        part = flow_ref.flow_inference(token[:, :k * hop + hop + 3], t('emb'), sd, c, finalize=fin, **kw)
+        assert part.shape == g['mel_chunk%d' % k].shape == (1, 80, 2 * (k * hop + hop) if not fin else 2 * token.shape[1])
+        assert np.allclose(part.numpy(), g['mel_chunk%d' % k], atol=2e-4)
+        assert np.allclose(part.numpy(), g['mel_whole'][:, :, :part.shape[2]], atol=2e-4)      # the check of flow.py:436-459
+    # HiFT finalize=False
+    hc = tiny_cfg.hift
+    sdh = W.make_hift_state(hc, seed=int(g['hift_weight_seed']), init='fan_in')
+    assert state_checksum(sdh) == str(g['hift_weight_sha'])
+    tables = hift_ref.make_tables(hc, seed=int(g['hift_table_seed']))
+    mel = t('h_mel')
+    for k in range(int(g['h_runs'])):
+        n = int(g['h%d_n' % k])
+        wav, s = hift_ref.hift_inference(mel[:, :, :n], sdh, hc, tables, finalize=False)
+        assert wav.shape == (1, 480 * (n - 8)) and s.shape == (1, 1, 480 * (n - 3))
+        assert np.allclose(s.numpy(), g['h%d_source' % k], atol=1e-3)
+        assert np.abs(wav.numpy() - g['h%d_wav' % k]).max() < 5e-3
+        assert np.abs(g['h%d_wav' % k] - g['h_wav_whole'][:, :wav.shape[1]]).max() < 1e-3      # the check of generator.py:739-747
