@@ -410,7 +410,7 @@ def test_streaming_chunks_are_prefixes_at_production_chunk_size(tiny_cfg):
     # end to end through the chunk scheduler: pieces tile the utterance; every non-final piece equals the corresponding samples of HiFT run
     # over the mel cache at that time (finalize=False results are prefixes of each other up to fp32 rounding in the F0 phase)
     hc = tiny_cfg.hift
-    hift = HvxHift(hc, W.make_hift_state(hc, seed=3, init='fan_in'), tables=hift_ref.make_tables(hc, seed=9))
+    hift = HvxHift(hc, W.make_hift_state(hc, seed=3, init='fan_in'), tables=hift_ref.make_tables(hc, seed=9, n_samples=480 * 440))
     toks = token[0, :215].tolist()
     pieces = list(stream_tts(iter(toks), flow, hift, ptoken, pfeat, emb, token_hop_len=25))
     assert len(pieces) == 8                                                       # hops 40 (25 + prompt pad 15), 6 x 25, final 25

@@ -54,6 +54,10 @@ def bench_attn():
         vT = torch.randn(B, H, 64, Tp, device=DEV).to(torch.bfloat16)
         t = timeit(lambda: ops.attention(q, k, vT, T))
         print('attn bf16 T=%5d  %8.1f us  %7.1f TF/s' % (T, t * 1e6, 4.0 * T * T * 64 * H * B / t / 1e12))
+        # streaming mask (static chunk 50): flops counted over the visible (row, key) pairs only
+        t = timeit(lambda: ops.attention(q, k, vT, T, chunk=50))
+        vis = sum(min(T, (i // 50 + 1) * 50) for i in range(T))
+        print('attn bf16 T=%5d chunk=50  %8.1f us  %7.1f TF/s (visible pairs)' % (T, t * 1e6, 4.0 * vis * 64 * H * B / t / 1e12))
 
 
 def bench_skinny():
