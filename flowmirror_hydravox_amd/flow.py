@@ -65,6 +65,10 @@ class HvxFlow:
             self.load_state_dict(state_dict)
 
     def load_state_dict(self, sd, strict=True):
+        return self.load_packed(self.pack_state_dict(sd))
+
+    def pack_state_dict(self, sd):
+        """reference checkpoint -> the device tensors libhvx consumes, in the order include/hvx.h documents"""
         sd = {k: v for k, v in sd.items() if k not in DROP_KEYS}
         check_state(sd, flow_spec(self.cfg), 'CausalMaskedDiffWithDiT', optional=('decoder.estimator.rotary_embed.inv_freq',))
         c, dt, dev = self.cfg, self.dtype, self.device
@@ -100,6 +104,11 @@ class HvxFlow:
                    mat(W(p + 'attn.to_out.0.weight')), vec(W(p + 'attn.to_out.0.bias')),
                    mat(W(p + 'ff.ff.0.0.weight')), vec(W(p + 'ff.ff.0.0.bias')), mat(W(p + 'ff.ff.2.weight')), vec(W(p + 'ff.ff.2.bias'))]
         ws += [mat(W(e + 'norm_out.linear.weight')), vec(W(e + 'norm_out.linear.bias')), mat(W(e + 'proj_out.weight')), vec(W(e + 'proj_out.bias'))]
+        return ws
+
+    def load_packed(self, ws):
+        c, dt, dev = self.cfg, self.dtype, self.device
+        ws = [w.to(dev) for w in ws]
         self._weights = ws
         cc = _lib.FlowConfig(dtype=_lib.dtype_code(dt), vocab=c.vocab, mel=c.mel, spk_dim=c.spk_embed_dim, pla_channels=c.pre_lookahead_channels,
                              pla_len=c.pre_lookahead_len, dim=c.dim, depth=c.depth, heads=c.heads, ff=c.ff, conv_kernel=c.conv_kernel,

@@ -82,12 +82,18 @@ class HvxHift:
             self.load_state_dict(state_dict)
 
     def load_state_dict(self, sd, strict=True):
+        return self.load_packed(self.pack_state_dict(sd))
+
+    def pack_state_dict(self, sd):
         sd = {k: v for k, v in sd.items() if k not in DROP_KEYS}
+        check_state(sd, hift_spec(self.cfg), 'CausalHiFTGenerator')
+        return pack_hift_weights(sd, self.cfg, self.device)
+
+    def load_packed(self, ws):
         c = self.cfg
-        check_state(sd, hift_spec(c), 'CausalHiFTGenerator')
         if any(len(d) != 3 for d in c.resblock_dilations + c.source_resblock_dilations):
             raise _lib.HvxError('hvx_hift supports three dilations per ResBlock')
-        ws = pack_hift_weights(sd, c, self.device)
+        ws = [w.to(self.device) for w in ws]
         self._weights = ws
         cc = _lib.HiftConfig()
         cc.mel, cc.base_channels, cc.nb_harmonics, cc.f0_channels = c.mel, c.base_channels, c.nb_harmonics, c.f0_channels

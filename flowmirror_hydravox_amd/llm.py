@@ -76,6 +76,10 @@ class HvxLLM:
     # weights
     # ------------------------------------------------------------------------------------------------------------
     def load_state_dict(self, sd, strict=True):
+        return self.load_packed(self.pack_state_dict(sd))
+
+    def pack_state_dict(self, sd):
+        """reference checkpoint -> the device tensors libhvx consumes, in the order include/hvx.h documents (gains folded, MFMA fragment order)"""
         sd = {k: v for k, v in sd.items() if k not in DROP_KEYS}
         check_state(sd, llm_spec(self.cfg, with_lm_head=True), 'CosyVoice3LM', optional=('llm.model.lm_head.weight',))
         c, dt, dev = self.cfg, self.dtype, self.device
@@ -118,6 +122,14 @@ class HvxLLM:
                vec(stack(lambda p: W(p + 'post_attention_layernorm.weight'))),
                mat(stack(lambda p: pack_gate_up(W(p + 'mlp.gate_proj.weight'), W(p + 'mlp.up_proj.weight')))),
                mat(stack(lambda p: pack_frag(W(p + 'mlp.down_proj.weight'))))]
+        return ws
+
+    def load_packed(self, ws):
+        """create the native handle from already packed tensors (pack_state_dict, or checkpoint.load_packed)"""
+        c, dt = self.cfg, self.dtype
+        hn = c.head_num
+        vpad = (c.vocab + 15) // 16 * 16
+        ws = [w.to(self.device) for w in ws]
         self._weights = ws                                   # keep device tensors alive
         cc = _lib.LLMConfig(dtype=_lib.dtype_code(dt), hidden=c.hidden, layers=c.layers, q_heads=c.q_heads, kv_heads=c.kv_heads,
                             inter=c.inter, vocab=c.vocab, vocab_pad=vpad, speech_tokens=c.speech_tokens, text_vocab=c.text_vocab,

@@ -66,15 +66,18 @@ class HvxModelManager:
             raise ValueError('HvxModelManager runs on MI355X only: there is no CPU path (TTS_CPU is not supported)')
         cfg = _load_config(args.model_dir)
         self.hvx_config = cfg
-        llm_sd = _load_pt(os.path.join(args.model_dir, 'llm.pt'))
-        flow_sd = _load_pt(os.path.join(args.model_dir, 'flow.pt'))
-        hift_sd = _load_pt(os.path.join(args.model_dir, 'hift.pt'))
         self.device = 'cuda'
         # precision policy of the reference (:101-118): llm bf16 / flow half / hift fp32.  fp16 requests run in bf16 as well:
         # libhvx computes in bf16 (or fp32), with fp32 accumulation and an fp32 residual stream.
-        llm = HvxLLM(cfg.llm, llm_sd, dtype=torch.bfloat16)
-        flow = HvxFlow(cfg.flow, flow_sd, dtype=torch.bfloat16)
-        hift = HvxHift(cfg.hift, hift_sd)
+        llm = HvxLLM(cfg.llm, None, dtype=torch.bfloat16)
+        flow = HvxFlow(cfg.flow, None, dtype=torch.bfloat16)
+        hift = HvxHift(cfg.hift, None)
+        # optional packed-weight cache: args.packed_cache or $HVX_PACKED_CACHE names a directory that holds the
+        # device-ready tensors of each `.pt` (checkpoint.py); without it the `.pt` files are read and packed on every start
+        self.packed_cache = getattr(args, 'packed_cache', None) or os.environ.get('HVX_PACKED_CACHE') or None
+        self.load_report = {}
+        for name, model in (('llm', llm), ('flow', flow), ('hift', hift)):
+            self.load_report[name] = self._load_into(model, os.path.join(args.model_dir, name + '.pt'))
         llm.bf16, flow.bf16, llm.fp16, flow.fp16 = True, True, False, False
         self.models = {'llm': llm, 'flow': flow, 'hift': hift}
         self.configs = {'sample_rate': cfg.sample_rate}
@@ -85,11 +88,18 @@ class HvxModelManager:
         self.is_loaded = True
         logger.info('models loaded')
 
+    def _load_into(self, model, pt_path):
+        if getattr(self, 'packed_cache', None):
+            from .checkpoint import load_or_pack
+            return load_or_pack(model, pt_path, self.packed_cache, _load_pt)
+        model.load_state_dict(_load_pt(pt_path))
+        return 'packed'
+
     def load_pt(self, llm_pt, flow_pt):
         try:
-            self.models['llm'].load_state_dict(_load_pt(llm_pt))
+            self._load_into(self.models['llm'], llm_pt)
             self.models['llm'].bf16, self.models['llm'].fp16 = True, False
-            self.models['flow'].load_state_dict(_load_pt(flow_pt))
+            self._load_into(self.models['flow'], flow_pt)
             self.models['flow'].bf16, self.models['flow'].fp16 = True, False
             return {'status': 'success', 'message': 'model weights loaded'}
         except Exception as e:                               # never raises (:181-184)

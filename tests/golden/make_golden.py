@@ -566,8 +566,50 @@ def gen_stream():
     np.savez_compressed(os.path.join(HERE, 'stream_tiny.npz'), **out)
 
 
+# ------------------------------------------------------------------------------------------------
+# checkpoint tooling: the MTP graft script, run as shipped
+# ------------------------------------------------------------------------------------------------
+def gen_graft():
+    import subprocess
+    import tempfile
+    from flowmirror_hydravox_amd.checkpoint import graft_mtp_heads
+    script = '/root/reference/scripts/post_process/add_mtp_weights_to_cosyvoice3lm_ckpt.py'
+    out = {}
+    cases = [dict(hidden=128, vocab=296, head_num=2, mtp_head_num=2, seed=7), dict(hidden=96, vocab=260, head_num=3, mtp_head_num=3, seed=1986)]
+    for ci, cs in enumerate(cases):
+        g = torch.Generator()
+        g.manual_seed(100 + ci)
+        sd = {'speech_embedding.weight': torch.randn(cs['vocab'], cs['hidden'], generator=g),
+              'llm_decoder.weight': torch.randn(cs['vocab'], cs['hidden'], generator=g),
+              'llm_decoder.bias': torch.randn(cs['vocab'], generator=g), 'step': torch.tensor(5)}
+        if ci == 1:                                                      # an entry that already exists must survive untouched
+            sd['mtp_block.0.input_layernorm.weight'] = torch.full((cs['hidden'],), 0.5)
+        with tempfile.TemporaryDirectory() as d:
+            torch.save(sd if ci == 0 else {'state_dict': sd, 'epoch': 3}, os.path.join(d, 'old.pt'))
+            subprocess.run([sys.executable, script, '--src_ckpt', os.path.join(d, 'old.pt'), '--dst_ckpt', os.path.join(d, 'new.pt'),
+                            '--head_num', str(cs['head_num']), '--mtp_head_num', str(cs['mtp_head_num']), '--seed', str(cs['seed'])],
+                           check=True, capture_output=True)
+            ref = torch.load(os.path.join(d, 'new.pt'))
+        if ci == 1:
+            assert ref['epoch'] == 3
+            ref = ref['state_dict']
+        mine, added = graft_mtp_heads(sd, head_num=cs['head_num'], mtp_head_num=cs['mtp_head_num'], seed=cs['seed'])
+        assert set(mine) == set(ref) and all(torch.equal(mine[k], ref[k]) and mine[k].dtype == ref[k].dtype for k in ref)
+        keys = sorted(ref)
+        sha = [hashlib.sha256(ref[k].contiguous().view(torch.uint8).numpy().tobytes() if ref[k].dim() else ref[k].numpy().tobytes()).hexdigest()
+               for k in keys]
+        p = 'c%d_' % ci
+        out.update({p + 'keys': np.array(keys), p + 'sha': np.array(sha), p + 'shapes': np.array([str(tuple(ref[k].shape)) for k in keys]),
+                    p + 'dtypes': np.array([str(ref[k].dtype) for k in keys]), p + 'added': np.int32(added), p + 'input_seed': np.int32(100 + ci),
+                    p + 'container': np.int32(ci == 1)})
+        out.update({p + k: np.int32(v) for k, v in cs.items()})
+        print('[graft] case %d: %d entries added by the script, ours bit-identical (%d keys)' % (ci, added, len(keys)))
+    out['n_cases'] = np.int32(len(cases))
+    np.savez_compressed(os.path.join(HERE, 'graft_tiny.npz'), **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['sampler', 'llm', 'flow', 'hift', 'matcha', 'stream']
+    which = sys.argv[1:] or ['sampler', 'llm', 'flow', 'hift', 'matcha', 'stream', 'graft']
     for w in which:
-        {'sampler': gen_sampler, 'llm': gen_llm, 'flow': gen_flow, 'hift': gen_hift, 'matcha': gen_matcha, 'stream': gen_stream}[w]()
+        {'sampler': gen_sampler, 'llm': gen_llm, 'flow': gen_flow, 'hift': gen_hift, 'matcha': gen_matcha, 'stream': gen_stream, 'graft': gen_graft}[w]()
     print('golden fixtures written to', HERE)

@@ -469,3 +469,37 @@ def test_synthesize_many_equals_one_by_one(tiny_cfg):
         one = synthesize_many(mm, [mi], [z], seeds=[seeds[i]])[0]
         assert one.shape == many[i].shape and torch.equal(one, many[i]), i
         assert many[i].shape[-1] > 0
+
+
+def test_packed_weight_cache_gives_the_same_models(tiny_cfg, tmp_path):
+    """§8(f) N4: ModelManager with a packed-weight cache — the second start loads the device-ready tensors instead of the `.pt` files and
+    synthesises the same samples; load_pt goes through the cache too."""
+    import argparse
+    from flowmirror_hydravox_amd import weights as W
+    from flowmirror_hydravox_amd.model_manager import HvxModelManager, synthesize_many
+    import json, dataclasses
+    c = tiny_cfg
+    d = tmp_path / 'model'
+    d.mkdir()
+    torch.save(W.make_llm_state(c.llm, seed=5, init='fan_in'), d / 'llm.pt')
+    torch.save(W.make_flow_state(c.flow, seed=6, init='fan_in'), d / 'flow.pt')
+    torch.save(W.make_hift_state(c.hift, seed=7, init='fan_in'), d / 'hift.pt')
+    (d / 'hvx_config.json').write_text(json.dumps({'llm': dataclasses.asdict(c.llm), 'flow': dataclasses.asdict(c.flow),
+                                                   'hift': dataclasses.asdict(c.hift)}))
+    args = argparse.Namespace(config=None, model_dir=str(d), bf16=True, fp16=False, cpu=False, packed_cache=str(tmp_path / 'cache'))
+    g = torch.Generator().manual_seed(4)
+    mi = dict(text=torch.randint(0, c.llm.text_vocab, (1, 9), generator=g, dtype=torch.int32), flow_embedding=torch.randn(192, generator=g))
+    outs, reports = [], []
+    for _ in range(2):
+        mm = HvxModelManager()
+        mm.load_models(args)
+        reports.append(dict(mm.load_report))
+        outs.append(synthesize_many(mm, [mi], [False], seeds=[11])[0])
+    assert reports[0] == {'llm': 'packed', 'flow': 'packed', 'hift': 'packed'}
+    assert reports[1] == {'llm': 'cache', 'flow': 'cache', 'hift': 'cache'}
+    assert outs[0].shape[-1] > 0 and torch.equal(outs[0], outs[1])
+    torch.save(W.make_llm_state(c.llm, seed=8, init='fan_in'), d / 'llm2.pt')
+    assert mm.load_pt(str(d / 'llm2.pt'), str(d / 'flow.pt'))['status'] == 'success'
+    swapped = synthesize_many(mm, [mi], [False], seeds=[11])[0]
+    assert not torch.equal(swapped[..., :outs[0].shape[-1]], outs[0][..., :swapped.shape[-1]]) or swapped.shape != outs[0].shape
+    assert mm.load_pt(str(d / 'missing.pt'), str(d / 'flow.pt'))['status'] == 'error'

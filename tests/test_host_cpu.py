@@ -286,3 +286,81 @@ def test_stream_tts_chunk_schedule_matches_the_reference_loop():
     calls.clear()
     one = list(stream_tts(iter(toks), Flow(), Hift(), torch.zeros(1, 0, dtype=torch.int32), torch.zeros(1, 0, 80), torch.zeros(1, 192), stream=False))
     assert calls == [(n_tok, True, False, None)] and len(one) == 1 and one[0].shape == (1, 480 * 2 * n_tok)
+
+
+def test_mtp_graft_reproduces_the_reference_script():
+    """checkpoint.graft_mtp_heads vs the hashes of what scripts/post_process/add_mtp_weights_to_cosyvoice3lm_ckpt.py wrote for the same
+    input checkpoint (tests/golden/make_golden.py::gen_graft runs the script itself): keys, shapes, dtypes and every byte."""
+    import hashlib
+    from conftest import load_golden
+    from flowmirror_hydravox_amd.checkpoint import graft_mtp_heads
+    g = load_golden('graft_tiny.npz')
+    for ci in range(int(g['n_cases'])):
+        p = 'c%d_' % ci
+        hidden, vocab = int(g[p + 'hidden']), int(g[p + 'vocab'])
+        gen = torch.Generator().manual_seed(int(g[p + 'input_seed']))
+        sd = {'speech_embedding.weight': torch.randn(vocab, hidden, generator=gen), 'llm_decoder.weight': torch.randn(vocab, hidden, generator=gen),
+              'llm_decoder.bias': torch.randn(vocab, generator=gen), 'step': torch.tensor(5)}
+        if int(g[p + 'container']):
+            sd['mtp_block.0.input_layernorm.weight'] = torch.full((hidden,), 0.5)
+        before = {k: v.clone() for k, v in sd.items()}
+        out, added = graft_mtp_heads(sd, head_num=int(g[p + 'head_num']), mtp_head_num=int(g[p + 'mtp_head_num']), seed=int(g[p + 'seed']))
+        assert added == int(g[p + 'added'])
+        assert sorted(out) == list(g[p + 'keys'])
+        for k, sha, shp, dt in zip(g[p + 'keys'], g[p + 'sha'], g[p + 'shapes'], g[p + 'dtypes']):
+            t = out[str(k)]
+            assert str(tuple(t.shape)) == str(shp) and str(t.dtype) == str(dt), k
+            raw = t.contiguous().view(torch.uint8).numpy().tobytes() if t.dim() else t.numpy().tobytes()
+            assert hashlib.sha256(raw).hexdigest() == str(sha), k
+        assert all(torch.equal(sd[k], before[k]) for k in before)                # the input dict is not modified
+    with pytest.raises(KeyError):
+        graft_mtp_heads({'llm_decoder.weight': torch.zeros(4, 4)})
+    with pytest.raises(ValueError):
+        graft_mtp_heads({'speech_embedding.weight': torch.zeros(100, 8), 'llm_decoder.weight': torch.zeros(100, 8)})
+
+
+def test_packed_weight_cache_roundtrip_and_validation(tmp_path):
+    """save_packed / load_packed / load_or_pack with a stand-in model: tensors and dtypes survive, and a file written for another
+    configuration, dtype, layout or source checkpoint is refused (then rebuilt by load_or_pack)."""
+    import dataclasses
+    from flowmirror_hydravox_amd import checkpoint as ck
+
+    @dataclasses.dataclass
+    class Cfg:
+        dim: int = 8
+        depth: int = 2
+
+    class Model:
+        def __init__(self, cfg, dtype=torch.bfloat16):
+            self.cfg, self.dtype, self.max_t, self._weights, self.loads = cfg, dtype, 64, None, 0
+
+        def load_state_dict(self, sd):
+            self.loads += 1
+            return self.load_packed([sd['a'].to(self.dtype) * 2, sd['b'].float()])
+
+        def load_packed(self, ws):
+            self._weights = list(ws)
+            return self
+
+    pt = tmp_path / 'm.pt'
+    torch.save({'a': torch.arange(12.).view(3, 4), 'b': torch.ones(5)}, pt)
+    loader = lambda p: torch.load(p)
+    m = Model(Cfg())
+    assert ck.load_or_pack(m, str(pt), str(tmp_path / 'cache'), loader) == 'packed' and m.loads == 1
+    m2 = Model(Cfg())
+    assert ck.load_or_pack(m2, str(pt), str(tmp_path / 'cache'), loader) == 'cache' and m2.loads == 0
+    assert all(torch.equal(x, y) and x.dtype == y.dtype for x, y in zip(m._weights, m2._weights))
+    cache = next((tmp_path / 'cache').iterdir())
+    meta = ck.read_packed_meta(str(cache))
+    assert meta['kind'] == 'Model' and meta['layout'] == ck.PACK_LAYOUT and meta['n'] == '2'
+    for other in (Model(Cfg(depth=3)), Model(Cfg(), dtype=torch.float32)):
+        with pytest.raises(ValueError):
+            ck.load_packed(other, str(cache))
+    with pytest.raises(ValueError):
+        ck.load_packed(Model(Cfg()), str(cache), source='0:0:other')
+    # a changed checkpoint invalidates the cache
+    torch.save({'a': torch.zeros(3, 4), 'b': torch.ones(5)}, pt)
+    m3 = Model(Cfg())
+    assert ck.load_or_pack(m3, str(pt), str(tmp_path / 'cache'), loader) == 'packed' and float(m3._weights[0].sum()) == 0.0
+    with pytest.raises(ValueError):
+        ck.save_packed(Model(Cfg()), str(tmp_path / 'x.hvxpack'))
