@@ -337,13 +337,15 @@ __global__ __launch_bounds__(256, 2) void attn_dit_kernel(AttnArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     const int b = blockIdx.z, h = blockIdx.y;
-    const int row0 = blockIdx.x * (64 * QR) + wave * (16 * QR);
+    // with a chunk mask the work per workgroup grows with its row index: dispatch the long ones first
+    const int bx = a.chunk > 0 ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+    const int row0 = bx * (64 * QR) + wave * (16 * QR);
     const int kv_len = a.kv_len ? a.kv_len[b] : a.kv_len_const;
     const T* __restrict__ kb = reinterpret_cast<const T*>(a.k) + (long long)b * a.k_bs + (long long)h * a.k_hs;
     const T* __restrict__ vb = reinterpret_cast<const T*>(a.vT) + (long long)b * a.v_bs + (long long)h * a.v_hs;
     // Static chunk mask (streaming synthesis): row r sees the keys below the end of its chunk.  The workgroup walks the keys that
     // its last row sees; tiles below the limit of its first row need no mask, the rest take the masked form with per-row limits.
-    const int wg_row0 = blockIdx.x * (64 * QR), wg_row1 = min(wg_row0 + 64 * QR, a.n_rows) - 1;
+    const int wg_row0 = bx * (64 * QR), wg_row1 = min(wg_row0 + 64 * QR, a.n_rows) - 1;
     const int lim_hi = a.chunk > 0 ? min(kv_len, (wg_row1 / a.chunk + 1) * a.chunk) : kv_len;
     const int lim_lo = a.chunk > 0 ? min(kv_len, (wg_row0 / a.chunk + 1) * a.chunk) : kv_len;
     int lim[QR];
@@ -536,7 +538,9 @@ static int launch_t(const AttnArgs& a, hipStream_t s) {
         // traffic per flop).  Alone the two tie on long sequences (415 vs 419 us at T = 5632) and QR = 2 wins on short ones (45 vs 53 us at
         // T = 1408); beside the decode stream of the pipelined synthesis QR = 4 leaves room on every SIMD and halves the L2 traffic:
         // the decode step next to it takes 2.6 ms instead of 4.1 ms (tools/contention_probe.py).
-        if (a.n_rows >= 2048) hipLaunchKernelGGL(attn_dit_kernel<4>, dim3((a.n_rows + 255) / 256, a.heads, a.batch), dim3(256), 0, s, a);
+        // With a chunk mask the last workgroup of a head does twice the average work: 128-row workgroups (twice as many, three per SIMD)
+        // balance better than 256-row ones (T = 5632, chunk 50: 244 vs 288 us; the unmasked pass takes 392 us).
+        if (a.n_rows >= 2048 && a.chunk <= 0) hipLaunchKernelGGL(attn_dit_kernel<4>, dim3((a.n_rows + 255) / 256, a.heads, a.batch), dim3(256), 0, s, a);
         else hipLaunchKernelGGL(attn_dit_kernel<2>, dim3((a.n_rows + 127) / 128, a.heads, a.batch), dim3(256), 0, s, a);
         prof_end(slot, s);
         return hipGetLastError() == hipSuccess ? 0 : (set_error("attention launch failed"), -1);
