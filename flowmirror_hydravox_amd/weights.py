@@ -329,3 +329,17 @@ def check_state(sd: Dict[str, torch.Tensor], spec: Spec, what: str, optional=())
         if k in sd and tuple(sd[k].shape) != tuple(s):
             raise RuntimeError('size mismatch for %s.%s: checkpoint %s vs model %s'
                                % (what, k, tuple(sd[k].shape), tuple(s)))
+
+
+def accept_stress_llm_state(sd, decoder_scale=6.0, v_bias_scale=30.0):
+    """SURVEY.md §8(d) "accept-stress" variant of a synthetic LM checkpoint: low-entropy, context-insensitive logits so that the
+    repetition-aware sampler falls back to full-softmax resampling on roughly a third of its calls.  `llm_decoder` has no bias in
+    CosyVoice3 (llm_multi_head_v3.py:652), so the bias is built from what the model has: the V-projection biases pass through every
+    softmax-weighted average unchanged, i.e. they add a position-independent vector to the residual stream; scaled up they dominate
+    the final hidden state, and a scaled decoder turns that into a sharp, nearly constant distribution.  Returns a new dict."""
+    out = dict(sd)
+    out['llm_decoder.weight'] = sd['llm_decoder.weight'] * decoder_scale
+    for k in sd:
+        if k.startswith('llm.model.model.layers.') and k.endswith('self_attn.v_proj.bias'):
+            out[k] = sd[k] * v_bias_scale
+    return out

@@ -223,6 +223,58 @@ def gen_llm():
     np.savez_compressed(os.path.join(HERE, 'llm_tiny.npz'), **out)
 
 
+def gen_llm_stress():
+    """BASELINE configs[2] "multi-head accept-rate stress": the reference LM on the accept-stress checkpoint (W.accept_stress_llm_state),
+    K = 4 and K = 2, win_size 32 / tau_r 0.2; records the token streams and how often ras_sampling fell back to random_sampling."""
+    import cosyvoice.utils.common as common
+    cfg = tiny_config().llm
+    seed_w = 7
+    sd = W.accept_stress_llm_state(W.make_llm_state(cfg, seed=seed_w, init='fan_in', with_lm_head=True))
+    out = dict(weight_seed=np.int64(seed_w), weight_sha=np.array(state_checksum(sd)))
+    sampling = dict(top_p=0.9, top_k=10, win_size=32, tau_r=0.2)
+    lm = build_ref_llm(cfg, sd, sampling)
+    calls = dict(nucleus=0, random=0)
+    orig_n, orig_r = common.nucleus_sampling, common.random_sampling
+
+    def count_n(*a, **k):
+        calls['nucleus'] += 1
+        return orig_n(*a, **k)
+
+    def count_r(*a, **k):
+        calls['random'] += 1
+        return orig_r(*a, **k)
+
+    common.nucleus_sampling, common.random_sampling = count_n, count_r
+    try:
+        for r, (K, seed, n_text, n_ps) in enumerate([(4, 201, 12, 0), (2, 202, 10, 6), (4, 203, 9, 3)]):
+            lm.inference_head_num = K
+            calls.update(nucleus=0, random=0)
+            g = torch.Generator()
+            g.manual_seed(seed)
+            text = torch.randint(0, cfg.text_vocab, (1, n_text), dtype=torch.int32, generator=g)
+            pspeech = torch.randint(0, cfg.speech_tokens, (1, n_ps), dtype=torch.int32, generator=g)
+            torch.manual_seed(seed)
+            toks = list(lm.inference(text=text, text_len=torch.tensor([n_text], dtype=torch.int32), prompt_text=torch.zeros(1, 0, dtype=torch.int32),
+                                     prompt_text_len=torch.tensor([0], dtype=torch.int32), prompt_speech_token=pspeech if n_ps else None,
+                                     prompt_speech_token_len=torch.tensor([n_ps], dtype=torch.int32), embedding=torch.zeros(0, 192),
+                                     max_token_text_ratio=8, min_token_text_ratio=8))
+            for use_cache in (False, True):
+                otoks = list(llm_ref.llm_inference(sd, cfg, text[0], sampler_ref.NoiseStream(seed=seed), prompt_speech_token=pspeech[0],
+                                                   inference_head_num=K, sampling=sampling, max_token_text_ratio=8, min_token_text_ratio=8,
+                                                   use_kv_cache=use_cache))
+                assert otoks == [int(t) for t in toks], (r, otoks, toks)
+            print('[llm-stress] run %d K=%d: %d tokens, %d sampler calls of which %d fell back to the full softmax (%.0f %%); oracle == reference'
+                  % (r, K, len(toks), calls['nucleus'], calls['random'], 100.0 * calls['random'] / calls['nucleus']))
+            p = 'r%d_' % r
+            out.update({p + 'K': np.int32(K), p + 'seed': np.int64(seed), p + 'text': text[0].numpy(), p + 'pspeech': pspeech[0].numpy(),
+                        p + 'tokens': np.array(toks, dtype=np.int32), p + 'calls': np.int32(calls['nucleus']), p + 'fallbacks': np.int32(calls['random'])})
+    finally:
+        common.nucleus_sampling, common.random_sampling = orig_n, orig_r
+    out['sampling'] = np.array([sampling['top_p'], sampling['top_k'], sampling['win_size'], sampling['tau_r']], dtype=np.float64)
+    out['n_runs'] = np.int32(3)
+    np.savez_compressed(os.path.join(HERE, 'llm_stress_tiny.npz'), **out)
+
+
 # ------------------------------------------------------------------------------------------------
 # flow
 # ------------------------------------------------------------------------------------------------
@@ -609,7 +661,7 @@ def gen_graft():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['sampler', 'llm', 'flow', 'hift', 'matcha', 'stream', 'graft']
+    which = sys.argv[1:] or ['sampler', 'llm', 'flow', 'hift', 'matcha', 'stream', 'graft', 'llm_stress']
     for w in which:
-        {'sampler': gen_sampler, 'llm': gen_llm, 'flow': gen_flow, 'hift': gen_hift, 'matcha': gen_matcha, 'stream': gen_stream, 'graft': gen_graft}[w]()
+        {'sampler': gen_sampler, 'llm': gen_llm, 'flow': gen_flow, 'hift': gen_hift, 'matcha': gen_matcha, 'stream': gen_stream, 'graft': gen_graft, 'llm_stress': gen_llm_stress}[w]()
     print('golden fixtures written to', HERE)

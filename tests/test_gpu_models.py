@@ -58,6 +58,41 @@ def test_llm_fp32_token_streams_bit_exact(tiny_cfg, llm_setup):
         assert toks == g['r%d_tokens' % r].tolist(), r
 
 
+def test_llm_accept_stress_streams_bit_exact(tiny_cfg):
+    """BASELINE configs[2] "multi-head accept-rate stress" (K = 4, win_size 32, tau_r 0.2) in miniature: on the low-entropy checkpoint
+    the reference's sampler fell back to full-softmax resampling on 28-70 % of its calls; the HIP sampler (device-resident decode loop,
+    fp32) emits the same ids — alone and with the three utterances decoded in lock-step."""
+    from functools import partial
+    from flowmirror_hydravox_amd import weights as W
+    from flowmirror_hydravox_amd.llm import HvxLLM
+    from flowmirror_hydravox_amd.sampling import ras_sampling
+    g = load_golden('llm_stress_tiny.npz')
+    cfg = tiny_cfg.llm
+    sd = W.accept_stress_llm_state(W.make_llm_state(cfg, seed=int(g['weight_seed']), init='fan_in', with_lm_head=True))
+    assert state_checksum(sd) == str(g['weight_sha'])
+    top_p, top_k, win, tau = g['sampling']
+    llm = HvxLLM(cfg, sd, dtype=torch.float32, max_batch=4, max_ctx=256,
+                 sampling=partial(ras_sampling, top_p=float(top_p), top_k=int(top_k), win_size=int(win), tau_r=float(tau)))
+    n = int(g['n_runs'])
+    assert sum(int(g['r%d_fallbacks' % r]) for r in range(n)) > 0.3 * sum(int(g['r%d_calls' % r]) for r in range(n))
+    for r in range(n):
+        p = 'r%d_' % r
+        llm.inference_head_num = int(g[p + 'K'])
+        text, ps = torch.from_numpy(g[p + 'text'])[None], torch.from_numpy(g[p + 'pspeech'])[None]
+        toks = list(llm.inference(text=text, text_len=torch.tensor([text.shape[1]], dtype=torch.int32), prompt_text=torch.zeros(1, 0, dtype=torch.int32),
+                                  prompt_text_len=torch.tensor([0], dtype=torch.int32), prompt_speech_token=ps if ps.shape[1] else None,
+                                  prompt_speech_token_len=torch.tensor([ps.shape[1]], dtype=torch.int32), embedding=torch.zeros(0, 192),
+                                  max_token_text_ratio=8, min_token_text_ratio=8, seed=int(g[p + 'seed'])))
+        assert toks == g[p + 'tokens'].tolist(), r
+    llm.inference_head_num = 4
+    idx = [r for r in range(n) if int(g['r%d_K' % r]) == 4]
+    batch = llm.generate_batch([torch.from_numpy(g['r%d_text' % r]) for r in idx],
+                               prompt_speech_tokens=[torch.from_numpy(g['r%d_pspeech' % r]) for r in idx],
+                               seeds=[int(g['r%d_seed' % r]) for r in idx], max_token_text_ratio=8, min_token_text_ratio=8)
+    for b, r in zip(batch, idx):
+        assert b == g['r%d_tokens' % r].tolist(), r
+
+
 def test_llm_global_generator_is_left_where_the_reference_leaves_it(tiny_cfg, llm_setup):
     from flowmirror_hydravox_amd.llm import HvxLLM
     from oracle import sampler_ref

@@ -59,6 +59,40 @@ def test_llm_token_streams(tiny_cfg, llm_golden, use_cache):
         assert all(t < cfg.speech_tokens for t in toks)
 
 
+def test_llm_accept_stress_token_streams(tiny_cfg):
+    """BASELINE configs[2] "accept-rate stress": low-entropy checkpoint on which the reference's ras_sampling fell back to the full
+    softmax on 28-70 % of its calls (tests/golden/make_golden.py::gen_llm_stress); the oracle emits the reference's ids and takes the
+    fallback branch exactly as often."""
+    g = load_golden('llm_stress_tiny.npz')
+    cfg = tiny_cfg.llm
+    sd = W.accept_stress_llm_state(W.make_llm_state(cfg, seed=int(g['weight_seed']), init='fan_in', with_lm_head=True))
+    assert state_checksum(sd) == str(g['weight_sha'])
+    top_p, top_k, win, tau = g['sampling']
+    calls = [0, 0]
+    orig = sampler_ref.ras_sample_once
+
+    def counted(*a, **k):
+        top, info = orig(*a, **k)
+        calls[0] += 1
+        calls[1] += int(info['fallback'])
+        return top, info
+
+    sampler_ref.ras_sample_once = counted
+    try:
+        for r in range(int(g['n_runs'])):
+            p = 'r%d_' % r
+            calls[:] = [0, 0]
+            toks = list(llm_ref.llm_inference(sd, cfg, torch.from_numpy(g[p + 'text']), sampler_ref.NoiseStream(seed=int(g[p + 'seed'])),
+                                              prompt_speech_token=torch.from_numpy(g[p + 'pspeech']), inference_head_num=int(g[p + 'K']),
+                                              sampling=dict(top_p=float(top_p), top_k=int(top_k), win_size=int(win), tau_r=float(tau)),
+                                              max_token_text_ratio=8, min_token_text_ratio=8, use_kv_cache=True))
+            assert toks == g[p + 'tokens'].tolist(), r
+            assert calls == [int(g[p + 'calls']), int(g[p + 'fallbacks'])], (r, calls)
+            assert calls[1] / calls[0] > 0.25
+    finally:
+        sampler_ref.ras_sample_once = orig
+
+
 def test_llm_first_step_numerics(tiny_cfg, llm_golden):
     g, sd = llm_golden
     cfg = tiny_cfg.llm
