@@ -37,7 +37,7 @@ KINDS = {0: ('llm_decode_gemm', 'hbm'), 1: ('dit_gemm_bf16', 'mfma'), 2: ('dit_a
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=4)
+    ap.add_argument('--steps', type=int, default=8)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--batch', type=int, default=8, help='utterances per GPU per step')
     ap.add_argument('--chars', type=int, default=512, help='text tokens per utterance')
