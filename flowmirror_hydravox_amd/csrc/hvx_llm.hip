@@ -136,7 +136,7 @@ extern "C" {
 
 int hvx_llm_create(const hvx_llm_config* cfg, const void* const* weights, int32_t n_weights, hvx_llm** out) {
     if (!cfg || !weights || !out) return set_error("hvx_llm_create: null argument"), -1;
-    const int expect = 6 + 7 * cfg->layers + 7;
+    const int expect = 6 + 9 * cfg->layers + 7;
     if (n_weights != expect) return set_error("hvx_llm_create: expected %d weight pointers, got %d", expect, n_weights), -1;
     if (cfg->hidden % 32 || cfg->inter % 128 || (cfg->q_heads * 64) % 128 || cfg->mtp_inter % 16 || cfg->mtp_attn_dim % 32 || cfg->vocab_pad % 16 ||
         cfg->q_heads % cfg->kv_heads || cfg->vocab_pad < cfg->vocab)
@@ -182,6 +182,28 @@ int hvx_llm_bind(hvx_llm* h, void* workspace, size_t ws_bytes, int32_t max_seq, 
     if (hipMemsetAsync(kv, 0, kv_bytes, (hipStream_t)s) != hipSuccess) return set_error("hvx_llm_bind: memset failed"), -1;
     if (hipMemsetAsync(workspace, 0, need, (hipStream_t)s) != hipSuccess) return set_error("hvx_llm_bind: memset failed"), -1;
     return 0;
+}
+
+// Residual projection x += A W^T for more than 32 rows (prefill, large decode batches).  The 4-column kernel above re-reads the [16][K]
+// activation tile per (workgroup, 16-row chunk): at 128 rows down_proj moves 348 MB from L2 to the CUs and takes 40 us.  Here the
+// 16-column / 64-row form with the weights in MFMA fragment order reads them once per 64 rows; when that leaves too few workgroups K is
+// split across workgroups (fp32 partials) and the split reduce — fixed order, one writer per element — does the residual add and
+// the operand-type copy.
+static int resid_wide(hvx_llm* h, SkinnyArgs g, const void* w_frag, void* xcopy, hipStream_t s) {
+    const int groups = (g.N / 16) * ((g.M + 63) / 64);
+    int split = (512 + groups - 1) / groups;
+    const int kt = g.K / 32;
+    if (split > kt / 8) split = kt / 8;
+    if (split > MAX_SPLIT) split = MAX_SPLIT;
+    g.W = w_frag; g.w_narrow = 0;
+    if (split <= 1) return launch_skinny(g, s);                      // SK_RESID, one writer per element
+    g.split_k = split; g.epi = SK_PARTIAL; g.part = h->part; g.part_zs = 0; g.out = nullptr; g.out2 = nullptr;
+    if (launch_skinny(g, s)) return -1;
+    ReduceNormArgs r;
+    memset(&r, 0, sizeof(r));
+    r.x = h->x; r.ldx = g.N; r.part = h->part; r.split_k = split; r.part_stride = (long long)g.M * g.N; r.do_norm = 0;
+    r.y = xcopy; r.ldy = g.N; r.dtype = g.dtype; r.M = g.M; r.H = g.N; r.rows_per_z = g.M;
+    return launch_reduce_rmsnorm(r, s);
 }
 
 static int forward_impl(hvx_llm* h, hipStream_t s, int32_t n_seq, int32_t kn, const int32_t* tok, const int32_t* ctrl, int32_t head_k,
@@ -317,8 +339,11 @@ static int forward_impl(hvx_llm* h, hipStream_t s, int32_t n_seq, int32_t kn, co
     // the accumulator; gemm_skinny.hip) and both residual adds in the epilogue of the GEMM that produces them (x += ..., one writer
     // per element).
     const bool use_split = (G * kn <= h->att_rows_pad) && (kn <= 8) && h->att_splits > 1;
+    // more than two 16-row tiles (prefill; decode of >= 17 sequences x 2 heads): the 4-column form would re-read its activation rows per
+    // tile, see resid_wide
+    const bool wide = R > 32;
     for (int l = 0; l < c.layers; ++l) {
-        const void* const* lw = w + 6 + 7 * l;
+        const void* const* lw = w + 6 + 9 * l;
         // 1. QKV + bias + RoPE + KV append
         SkinnyArgs g;
         memset(&g, 0, sizeof(g));
@@ -353,7 +378,7 @@ static int forward_impl(hvx_llm* h, hipStream_t s, int32_t n_seq, int32_t kn, co
         memset(&g, 0, sizeof(g));
         g.dtype = dt; g.M = R; g.N = H; g.K = Q; g.A = h->attn; g.lda = Q; g.W = lw[3]; g.nz = 1; g.split_k = 1;
         g.epi = SK_RESID; g.out = h->x; g.out_f32 = 1; g.ldo = H; g.out2 = xcopy; g.ldo2 = H; g.w_narrow = 1;
-        if (launch_skinny(g, s)) return -1;
+        if (R > 256 ? resid_wide(h, g, lw[7], xcopy, s) : launch_skinny(g, s)) return -1;      // K = q*64 is short: the 4-column form holds up to 16 row tiles
         // 4. hmlp = SwiGLU(RMSNorm(x) * ln2)
         memset(&g, 0, sizeof(g));
         g.dtype = dt; g.M = R; g.N = 2 * c.inter; g.K = H; g.A = xa; g.lda = H; g.W = lw[5]; g.split_k = 1; g.nz = 1;
@@ -364,13 +389,13 @@ static int forward_impl(hvx_llm* h, hipStream_t s, int32_t n_seq, int32_t kn, co
         memset(&g, 0, sizeof(g));
         g.dtype = dt; g.M = R; g.N = H; g.K = c.inter; g.A = h->hmlp; g.lda = c.inter; g.W = lw[6]; g.nz = 1; g.split_k = 1;
         g.epi = SK_RESID; g.out = h->x; g.out_f32 = 1; g.ldo = H; g.out2 = xcopy; g.ldo2 = H; g.w_narrow = 1;
-        if (launch_skinny(g, s)) return -1;
+        if (wide ? resid_wide(h, g, lw[8], xcopy, s) : launch_skinny(g, s)) return -1;
     }
     if (head_k <= 0) return 0;
 
     // ---- last rows -> final RMSNorm (hidden_states[-1], llm_multi_head_v3.py:248-260, 886) ---------------------
     const int S = n_seq;
-    const void* const* mw = w + 6 + 7 * c.layers;
+    const void* const* mw = w + 6 + 9 * c.layers;
     const int A = c.mtp_attn_dim, I = c.mtp_inter, K = head_k;
     // ---- K MTP heads, batched over blockIdx.z; their residual copies and input norms come out of the same launch as the final norm ---
     if (launch_heads_prologue(h->x, H, d_last, (const float*)w[2], c.rms_eps, (const float*)mw[0], c.mtp_rms_eps, K, S, H, h->ylast, h->hx, h->ha, dt, s))

@@ -109,7 +109,9 @@ class HvxLLM:
             ws += [vec(ln1), mat(pack_frag(wqkv * ln1[None, :])), vec(bqkv), mat(pack_narrow4(W(p + 'self_attn.o_proj.weight'))),
                    vec(ln2),
                    mat(pack_gate_up(W(p + 'mlp.gate_proj.weight') * ln2[None, :], W(p + 'mlp.up_proj.weight') * ln2[None, :])),
-                   mat(pack_narrow4(W(p + 'mlp.down_proj.weight')))]
+                   mat(pack_narrow4(W(p + 'mlp.down_proj.weight'))),
+                   # the same two residual projections in 16-column fragment order for grids of more than 32 rows (prefill, large batches)
+                   mat(pack_frag(W(p + 'self_attn.o_proj.weight'))), mat(pack_frag(W(p + 'mlp.down_proj.weight')))]
         hn = c.head_num
 
         def stack(fn):

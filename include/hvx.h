@@ -112,9 +112,10 @@ typedef struct {
 /* weights[] order (device pointers; matrices in `dtype`, packed with hvx fragment order unless noted; vectors f32):
  *   0 rope_cos f32 [max_pos][32]    1 rope_sin f32 [max_pos][32]     2 final norm gain [H]
  *   3 llm_decoder packed [vocab_pad][H]   4 speech_embedding rows [vocab][H] (dtype)   5 text embedding rows [text_vocab][H] (dtype)
- *   per layer l, 7 entries from 6+7l: ln1 gain, Wqkv packed [(q+2kv)*64][H], bqkv, Wo [H][q*64] in the narrow order, ln2 gain,
+ *   per layer l, 9 entries from 6+9l: ln1 gain, Wqkv packed [(q+2kv)*64][H], bqkv, Wo [H][q*64] in the narrow order, ln2 gain,
  *                                     Wgate/up packed as alternating 16-row tiles [2*inter][H], Wdown [H][inter] in the narrow order
- *                                     ([N/4][K/128][64 lanes][8], packing.pack_narrow4; needs q*64 % 128 == 0 and inter % 128 == 0);
+ *                                     ([N/4][K/128][64 lanes][8], packing.pack_narrow4; needs q*64 % 128 == 0 and inter % 128 == 0),
+ *                                     then Wo and Wdown once more in the 16-column fragment order (used for grids of > 32 rows);
  *                                     the backbone's Wqkv / Wgate/up carry their RMSNorm gain folded in (W[n][k] * ln[k]): the
  *                                     kernels scale by 1/rms only, the ln1 / ln2 entries are kept for layout stability and not read
  *   then 7 entries stacked over the head_num MTP heads: ln1 [hn][H], Wv packed [hn][A][H], bv [hn][A], Wo packed [hn][H][A],
