@@ -307,6 +307,28 @@ def test_flow_estimator_key_padding_mask(tiny_cfg, flow_setup):
     assert _rel(out[1, :, :Tv].numpy(), ref[1, :, :Tv].numpy()) < 1e-3
 
 
+@pytest.mark.parametrize('dtype,tol', [(torch.float32, 1e-3), (torch.bfloat16, 5e-2)])
+def test_flow_estimator_long_sequence_vs_oracle(tiny_cfg, flow_setup, dtype, tol):
+    """T = 2304 frames (a 210-char utterance): the long-sequence forms of the DiT kernels — many-tile GEMMs with the QKV / RoPE / V^T and
+    gated-residual epilogues, LDS-staged attention with 256-row workgroups — against the oracle, padded second batch entry."""
+    from flowmirror_hydravox_amd.flow import HvxFlow
+    from oracle import flow_ref
+    g, sd = flow_setup
+    c = tiny_cfg.flow
+    flow = HvxFlow(c, sd, dtype=dtype, max_t=2400)
+    gen = torch.Generator().manual_seed(21)
+    T, Tv = 2304, 2100
+    x, mu, cond = (torch.randn(2, 80, T, generator=gen) for _ in range(3))
+    spk = torch.randn(2, 80, generator=gen)
+    t = torch.tensor([0.35, 0.35])
+    mask = torch.ones(2, 1, T)
+    mask[1, :, Tv:] = 0
+    out = flow.estimator(x, mask, mu, t, spk, cond).cpu()
+    ref = flow_ref.dit_forward(x, mask, mu, t, spk, cond, sd, c)
+    assert _rel(out[0].numpy(), ref[0].numpy()) < tol, _rel(out[0].numpy(), ref[0].numpy())
+    assert _rel(out[1, :, :Tv].numpy(), ref[1, :, :Tv].numpy()) < tol
+
+
 # ------------------------------------------------------------------------------------------------------------------------
 # HiFT
 # ------------------------------------------------------------------------------------------------------------------------

@@ -30,7 +30,8 @@ def _tol(dtype):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize('M,N,K', [(300, 200, 96), (1000, 1024, 1024), (5, 6144, 1024), (2000, 64, 704), (257, 80, 320), (4100, 64, 64)])
+@pytest.mark.parametrize('M,N,K', [(300, 200, 96), (1000, 1024, 1024), (5, 6144, 1024), (2000, 64, 704), (257, 80, 320), (4100, 64, 64),
+                                   (4500, 1024, 256), (2300, 2000, 128)])       # the last two: many 128x128 tiles, ragged edges
 def test_linear(dtype, M, N, K):
     _lib, ops, packing = _mods()
     x = _rand(1, M, K, seed=1).to(dtype)
