@@ -101,6 +101,7 @@ SYMBOLS = {
     'hvx_ras_sample': (c_i32, [C.POINTER(SampleArgs), c_vp]),
     'hvx_op_gemm': (c_i32, [C.POINTER(GemmArgs), c_vp]),
     'hvx_op_attention': (c_i32, [C.POINTER(AttnArgs), c_vp]),
+    'hvx_op_resample_linear': (c_i32, [c_vp, c_i32, c_i32, c_vp, c_i32, c_vp]),
     'hvx_op_skinny_gemm': (c_i32, [c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp]),
     'hvx_llm_create': (c_i32, [C.POINTER(LLMConfig), C.POINTER(c_vp), c_i32, C.POINTER(c_vp)]),
     'hvx_llm_destroy': (None, [c_vp]),

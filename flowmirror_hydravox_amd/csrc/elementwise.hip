@@ -407,6 +407,27 @@ int launch_transpose_f32(const float* src, float* dst, int rows, int cols, int l
     return hipGetLastError() == hipSuccess ? 0 : (set_error("transpose launch failed"), -1);
 }
 
+// ---- F.interpolate(x, size=T_out, mode='linear') over the last axis of (rows, T_in): speed change of a mel (infer_speech_model.py:583-588,
+// cli/model.py:424-426).  align_corners=False: src = (j + 0.5) * T_in / T_out - 0.5 clamped at 0, two-tap blend in fp32.
+__global__ void resample_linear_kernel(const float* x, int t_in, float* y, int t_out, float scale) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y;
+    if (j >= t_out) return;
+    float src = scale * ((float)j + 0.5f) - 0.5f;
+    src = src < 0.0f ? 0.0f : src;
+    const int i0 = min((int)src, t_in - 1);
+    const int i1 = min(i0 + 1, t_in - 1);
+    const float l1 = src - (float)i0, l0 = 1.0f - l1;
+    const float* xr = x + (long long)r * t_in;
+    y[(long long)r * t_out + j] = l0 * xr[i0] + l1 * xr[i1];
+}
+int launch_resample_linear(const float* x, int rows, int t_in, float* y, int t_out, hipStream_t s) {
+    if (rows <= 0 || t_out <= 0) return 0;
+    if (t_in <= 0) return set_error("resample_linear: empty input"), -1;
+    hipLaunchKernelGGL(resample_linear_kernel, dim3((t_out + 255) / 256, rows), dim3(256), 0, s, x, t_in, y, t_out, (float)t_in / (float)t_out);
+    return hipGetLastError() == hipSuccess ? 0 : (set_error("resample_linear launch failed"), -1);
+}
+
 template <class D>
 __global__ void rows_to_dtype_kernel(const float* src, int ld_src, D* dst, int ld_dst, int cols, int cols_pad) {
     const int r = blockIdx.x;

@@ -148,6 +148,11 @@ int hvx_op_attention(const hvx_attn_args* a, hvx_stream s) {
     return launch_attention(k, (hipStream_t)s);
 }
 
+int hvx_op_resample_linear(const float* x, int32_t rows, int32_t t_in, float* y, int32_t t_out, hvx_stream s) {
+    if (!x || !y) return set_error("hvx_op_resample_linear: null argument"), -1;
+    return launch_resample_linear(x, rows, t_in, y, t_out, (hipStream_t)s);
+}
+
 int hvx_op_skinny_gemm(int32_t dtype, int32_t M, int32_t N, int32_t K, const void* A, int32_t lda, const void* Wpacked, const float* bias,
                        int32_t split_k, float* part_ws, float* out_f32, int32_t ldo, hvx_stream s) {
     SkinnyArgs k;

@@ -178,6 +178,7 @@ int launch_reflect_pad(const float* x, float* y, int L, int pad, int total, hipS
 int launch_spectral_magnitude(const float* spec, int ld, int frames, int bins, float* mag, int ld_mag, float eps, hipStream_t s);
 int launch_spectral_subtract(float* spec, int ld, int frames, int bins, const float* bias, float strength, hipStream_t s);
 int launch_overlap_add(const float* frames_buf, int ld, int frames, int n_fft, int hop, const float* wsq, float* y, int out_len, hipStream_t s);
+int launch_resample_linear(const float* x, int rows, int t_in, float* y, int t_out, hipStream_t s);   // F.interpolate(mode='linear') along the last axis
 int launch_transpose_f32(const float* src, float* dst, int rows, int cols, int ld_src, int ld_dst, hipStream_t s);   // dst[c][r] = src[r][c]
 int launch_rows_to_dtype(const float* src, int ld_src, void* dst, int dst_dtype, int ld_dst, int rows, int cols, int cols_pad, hipStream_t s);
 

@@ -18,12 +18,12 @@ import os
 import time
 
 import torch
-import torch.nn.functional as F
 
 from .config import HvxConfig, LLMConfig, FlowConfig, HiftConfig, cv3_config
 from .flow import HvxFlow
 from .hift import HvxHift
 from .llm import HvxLLM
+from .ops import resample_linear
 from .weights import DROP_KEYS
 
 logger = logging.getLogger('hvx')
@@ -139,7 +139,7 @@ def _synthesize(model_manager, model_input, speed, zero_shot):
     if speed <= 0:
         raise ValueError('Invalid speed: %s' % speed)
     if speed != 1.0:
-        tts_mel = F.interpolate(tts_mel, size=max(1, int(tts_mel.shape[2] / speed)), mode='linear')
+        tts_mel = resample_linear(tts_mel, max(1, int(tts_mel.shape[2] / speed)))
     tts_speech, _ = model_manager.models['hift'].inference(speech_feat=tts_mel)
     total = time.time() - start
     audio_len = tts_speech.shape[-1] / 24000
@@ -179,7 +179,7 @@ def synthesize_many(model_manager, model_inputs, zero_shot, speeds=None, seeds=N
             fkw.update(embedding=mi['flow_embedding'].unsqueeze(0))
         mel, _ = flow.inference(**fkw)
         if speed != 1.0:
-            mel = F.interpolate(mel, size=max(1, int(mel.shape[2] / speed)), mode='linear')
+            mel = resample_linear(mel, max(1, int(mel.shape[2] / speed)))
         wav, _ = hift.inference(speech_feat=mel)
         outs.append(wav.cpu())
     total = time.time() - start

@@ -100,3 +100,14 @@ def ras_sample(logp, hist, hist_len, min_len, noise, cursor, *, speech_tokens, t
     a.cursor, a.out_ids, a.max_trials = ptr(cursor), ptr(out), max_trials
     check(lib.hvx_ras_sample(C.byref(a), stream_ptr()), 'hvx_ras_sample')
     return out
+
+
+def resample_linear(x, t_out):
+    """F.interpolate(x, size=t_out, mode='linear') for a float32 (..., T) tensor on the device (the `speed` knob of the synthesis calls)"""
+    lib = _lib.load()
+    x = x.to(torch.float32).contiguous()
+    t_in = x.shape[-1]
+    rows = x.numel() // max(t_in, 1)
+    y = torch.empty(*x.shape[:-1], t_out, dtype=torch.float32, device=x.device)
+    check(lib.hvx_op_resample_linear(ptr(x), rows, t_in, ptr(y), t_out, stream_ptr()), 'hvx_op_resample_linear')
+    return y

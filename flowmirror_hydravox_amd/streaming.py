@@ -10,7 +10,6 @@ libhvx (flow.py / hift.py); this file is bookkeeping only, so it is covered on C
 import math
 
 import torch
-import torch.nn.functional as F
 
 
 class StreamSession:
@@ -41,7 +40,8 @@ class StreamSession:
         self.mel = tts_mel
         if speed != 1.0:
             assert token_offset == 0 and finalize is True, 'speed change only support non-stream inference mode'
-            tts_mel = F.interpolate(tts_mel, size=int(tts_mel.shape[2] / speed), mode='linear')
+            from .ops import resample_linear                            # F.interpolate(mode='linear') in libhvx
+            tts_mel = resample_linear(tts_mel, int(tts_mel.shape[2] / speed))
         tts_speech, _ = self.hift.inference(speech_feat=tts_mel, finalize=finalize)
         tts_speech = tts_speech[:, self.speech_offset:]
         self.speech_offset += tts_speech.shape[1]

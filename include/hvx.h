@@ -91,6 +91,10 @@ typedef struct {
 /* F.scaled_dot_product_attention (cosyvoice/flow/DiT/modules.py:391) */
 int hvx_op_attention(const hvx_attn_args* a, hvx_stream s);
 
+/* F.interpolate(x, size=t_out, mode='linear') along the last axis of an f32 (rows, t_in) array: the `speed` knob of
+ * inference_zero_shot / text_to_speech (infer_speech_model.py:583-588) and token2wav (cosyvoice/cli/model.py:424-426) */
+int hvx_op_resample_linear(const float* x, int32_t rows, int32_t t_in, float* y, int32_t t_out, hvx_stream s);
+
 /* packs a row-major [N][K] weight into the MFMA fragment order used by the decode GEMMs: [N/16][K/32][64][8] */
 int hvx_op_skinny_gemm(int32_t dtype, int32_t M, int32_t N, int32_t K, const void* A, int32_t lda, const void* Wpacked,
                        const float* bias, int32_t split_k, float* part_ws, float* out_f32, int32_t ldo, hvx_stream s);

@@ -253,3 +253,16 @@ def test_sampler_bit_exact_vs_golden(fname):
             if ids[j] != want_id or (want_id >= 0 and cur[j] != want_c):
                 bad.append((i, ids[j], want_id, cur[j], want_c))
     assert not bad, bad[:10]
+
+
+@pytest.mark.parametrize('t_in,speed', [(100, 1.3), (333, 0.7), (5632, 1.1), (7, 2.0), (50, 0.5)])
+def test_resample_linear_matches_torch_interpolate(t_in, speed):
+    """the `speed` knob: F.interpolate(mel, size=int(T / speed), mode='linear') (infer_speech_model.py:583-588)"""
+    import torch.nn.functional as F
+    _lib, ops, packing = _mods()
+    x = _rand(1, 80, t_in, seed=70)
+    t_out = max(1, int(t_in / speed))
+    ref = F.interpolate(x, size=t_out, mode='linear')
+    out = ops.resample_linear(x.to(DEV), t_out)
+    assert out.shape == ref.shape
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-6, atol=1e-6)
