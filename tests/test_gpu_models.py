@@ -560,3 +560,33 @@ def test_packed_weight_cache_gives_the_same_models(tiny_cfg, tmp_path):
     swapped = synthesize_many(mm, [mi], [False], seeds=[11])[0]
     assert not torch.equal(swapped[..., :outs[0].shape[-1]], outs[0][..., :swapped.shape[-1]]) or swapped.shape != outs[0].shape
     assert mm.load_pt(str(d / 'missing.pt'), str(d / 'flow.pt'))['status'] == 'error'
+
+
+def test_smallest_inputs_vs_oracle(tiny_cfg, flow_setup, hift_setup):
+    """edge sizes: a one-token utterance through the flow (2 mel frames, attention over 2 keys, every conv narrower than its kernel) and
+    1-, 2- and 5-frame mels through HiFT (F0 predictor and conv_pre look further ahead than the input is long)."""
+    from flowmirror_hydravox_amd.flow import HvxFlow
+    from flowmirror_hydravox_amd.hift import HvxHift
+    from oracle import flow_ref, hift_ref
+    g, sd = flow_setup
+    c = tiny_cfg.flow
+    flow = HvxFlow(c, sd, dtype=torch.float32, max_t=64)
+    gen = torch.Generator().manual_seed(33)
+    for n in (1, 2, 5):
+        token = torch.randint(0, c.vocab, (1, n), generator=gen)
+        emb = torch.randn(1, 192, generator=gen)
+        mel, _ = flow.inference(token=token.to(DEV), token_len=torch.tensor([n], dtype=torch.int32), embedding=emb.to(DEV), finalize=True)
+        ref = flow_ref.flow_inference(token, emb, sd, c)
+        assert tuple(mel.shape) == (1, 80, 2 * n)
+        assert _rel(mel.cpu().numpy(), ref.numpy()) < 1e-3, (n, _rel(mel.cpu().numpy(), ref.numpy()))
+    gh, sdh, tables = hift_setup
+    hc = tiny_cfg.hift
+    hift = HvxHift(hc, sdh, tables=tables)
+    for T in (1, 2, 5):
+        mel = torch.randn(1, 80, T, generator=gen)
+        o_wav, o_s = hift_ref.hift_inference(mel, sdh, hc, tables)
+        wav = hift.decode(mel[0], o_s.reshape(-1)).cpu()                      # decode on the oracle's source
+        assert wav.shape == (480 * T,)
+        assert _rel(wav.numpy(), o_wav[0].numpy()) < 1e-3, (T, _rel(wav.numpy(), o_wav[0].numpy()))
+        wav2, s2 = hift.inference(speech_feat=mel.to(DEV))
+        assert tuple(wav2.shape) == (1, 480 * T) and (s2.cpu() - o_s).abs().max() < 2e-3
