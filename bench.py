@@ -44,6 +44,8 @@ def parse():
     ap.add_argument('--heads', type=int, default=2, help='inference_head_num')
     ap.add_argument('--tiny', action='store_true', help='toy dimensions (plumbing check only; INVALID as a benchmark)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--acoustic-chains', type=int, default=1, help='batches whose flow + vocoder run concurrently in the pipelined timed region')
+    ap.add_argument('--lm-chains', type=int, default=3, help='batches whose LM decode runs concurrently in the pipelined timed region')
     ap.add_argument('--serial', action='store_true', help='run the stages of a step back to back instead of overlapping neighbouring steps')
     ap.add_argument('--prof-period', type=int, default=16)
     ap.add_argument('--cpu-baseline-worker', action='store_true', help=argparse.SUPPRESS)
@@ -195,7 +197,8 @@ def main():
             st, got = step()
             stats.append(st)
     else:
-        for wavs, st in pipe.synthesize_pipelined([utts] * args.steps, max_token_text_ratio=ratio, min_token_text_ratio=ratio):
+        for wavs, st in pipe.synthesize_pipelined([utts] * args.steps, max_token_text_ratio=ratio, min_token_text_ratio=ratio,
+                                                  lm_chains=args.lm_chains, acoustic_chains=args.acoustic_chains):
             got = gather_waveforms(wavs, gids, dst=0)
             stats.append(st)
     barrier()
@@ -264,7 +267,7 @@ def main():
         'rtf': round(elapsed / audio, 6) if audio else None,
         'llm_tokens_per_s': round(tokens / llm_s, 2) if llm_s else None,
         'stage_seconds_per_step': ({'llm': round(llm_s / args.steps, 4), 'flow': round(flow_s / args.steps, 4), 'hift': round(hift_s / args.steps, 4)} if args.serial else
-                                   {'llm': round(llm_s / args.steps, 4), 'flow+hift': round(flow_s / args.steps, 4), 'overlap': 'flow+hift of step i runs beside llm of step i+1'}),
+                                   {'llm': round(llm_s / args.steps, 4), 'flow+hift': round(flow_s / args.steps, 4), 'overlap': 'flow+hift of step i runs beside the llm of the next %d step(s); llm = mean decode wall time of a step while %d decode at once' % (args.lm_chains, args.lm_chains)}),
         'stage_seconds_serial': None if serial is None else {'llm': round(serial.llm_seconds, 4), 'flow': round(serial.flow_seconds, 4), 'hift': round(serial.hift_seconds, 4)},
         'audio_seconds_per_step': round(audio / args.steps, 2),
         'setup_seconds': round(t_build, 1),
@@ -275,7 +278,11 @@ def main():
                                 frac=rl_timed['frac'], traffic=pmc_traffic('llm_decode_step'), avg_launch_us=rl_timed['avg_launch_us'],
                                 algorithmic_bytes_per_launch=rl_timed['algorithmic_bytes_per_launch'], launches_per_timed_region=rl_timed['launches'],
                                 measured='hipEvents around every 8 replays on the decode stream, all timed steps' +
-                                         ('' if args.serial else '; the flow decoder + vocoder of the previous step share the GPU meanwhile'))
+                                         ('' if args.serial else '; the flow decoder + vocoder of an earlier step and the decode chain of %d other step(s) share the GPU meanwhile' % (args.lm_chains - 1)))
+        if not args.serial and args.lm_chains > 1:
+            # launches of different steps overlap in time: per launch `achieved` is bytes / its own duration; the chains together move this much
+            line['roofline']['concurrent_decode_chains'] = args.lm_chains
+            line['roofline']['achieved_all_chains'] = round(rl_timed['achieved'] * args.lm_chains, 1)
         if rl_alone and not args.serial:
             line['roofline']['alone'] = dict(achieved=rl_alone['achieved'], frac=rl_alone['frac'], avg_launch_us=rl_alone['avg_launch_us'],
                                              measured='same brackets in the warm-up step (stages back to back, nothing else on the GPU)')

@@ -69,26 +69,31 @@ class HvxPipeline:
                  inference_head_num=2):
         self.cfg = cfg
         llm_sd = llm_sd if llm_sd is not None else W.make_llm_state(cfg.llm, seed=seed, init=init)
-        self.llm = HvxLLM(cfg.llm, llm_sd, dtype=llm_dtype, device=device, max_batch=max_batch, max_ctx=max_ctx, sampling=sampling,
-                          inference_head_num=inference_head_num)
+        self._llm_kw = dict(dtype=llm_dtype, device=device, max_batch=max_batch, max_ctx=max_ctx)
+        self.llm = HvxLLM(cfg.llm, llm_sd, sampling=sampling, inference_head_num=inference_head_num, **self._llm_kw)
+        self._llms = [self.llm]
         del llm_sd
         flow_sd = flow_sd if flow_sd is not None else W.make_flow_state(cfg.flow, seed=seed + 1, init=init)
-        self.flow = HvxFlow(cfg.flow, flow_sd, dtype=flow_dtype, device=device, max_t=max_t)
+        self._flow_kw = dict(dtype=flow_dtype, device=device, max_t=max_t)
+        self.flow = HvxFlow(cfg.flow, flow_sd, **self._flow_kw)
         del flow_sd
         hift_sd = hift_sd if hift_sd is not None else W.make_hift_state(cfg.hift, seed=seed + 2, init=init)
-        self.hift = HvxHift(cfg.hift, hift_sd, device=device, tables=hift_tables)
+        self._hift_kw = dict(device=device, tables=hift_tables)
+        self.hift = HvxHift(cfg.hift, hift_sd, **self._hift_kw)
+        self._acoustic = [(self.flow, self.hift)]
         self.device = torch.device(device)
 
     # ---- stages -----------------------------------------------------------------------------------------------------------------
-    def _speech_tokens(self, utts, max_token_text_ratio, min_token_text_ratio):
-        return self.llm.generate_batch([u.text for u in utts],
+    def _speech_tokens(self, utts, max_token_text_ratio, min_token_text_ratio, llm=None):
+        return (llm or self.llm).generate_batch([u.text for u in utts],
                                        prompt_texts=[u.prompt_text for u in utts] if any(u.prompt_text is not None for u in utts) else None,
                                        prompt_speech_tokens=[u.prompt_speech_token for u in utts] if any(u.prompt_speech_token is not None for u in utts) else None,
                                        seeds=[u.seed for u in utts], max_token_text_ratio=max_token_text_ratio,
                                        min_token_text_ratio=min_token_text_ratio)
 
-    def _mels(self, utts, toks):
+    def _mels(self, utts, toks, flow=None):
         dev = self.device
+        flow = flow or self.flow
         mels = []
         for u, t in zip(utts, toks):
             if not t:
@@ -99,18 +104,19 @@ class HvxPipeline:
             if u.prompt_speech_token is not None:
                 kw = dict(prompt_token=u.prompt_speech_token.to(dev)[None], prompt_token_len=torch.tensor([len(u.prompt_speech_token)]),
                           prompt_feat=u.prompt_feat.to(dev)[None], prompt_feat_len=torch.tensor([u.prompt_feat.shape[0]]))
-            mel, _ = self.flow.inference(token=token, token_len=torch.tensor([token.shape[1]], dtype=torch.int32), embedding=u.embedding[None].to(dev),
+            mel, _ = flow.inference(token=token, token_len=torch.tensor([token.shape[1]], dtype=torch.int32), embedding=u.embedding[None].to(dev),
                                          finalize=True, **kw)
             mels.append(mel)
         return mels
 
-    def _waves(self, mels):
+    def _waves(self, mels, hift=None):
         wavs = []
+        hift = hift or self.hift
         for mel in mels:
             if mel is None:
                 wavs.append(torch.zeros(0, device=self.device))
                 continue
-            wav, _ = self.hift.inference(speech_feat=mel)
+            wav, _ = hift.inference(speech_feat=mel)
             wavs.append(wav[0])
         return wavs
 
@@ -140,48 +146,98 @@ class HvxPipeline:
         return wavs, st
 
     # ---- software pipeline over batches ------------------------------------------------------------------------------------------
-    def _acoustic_worker(self, utts, toks, st):
-        """flow + vocoder of one batch on the background stream (runs in the worker thread; returns when the waveforms are complete)"""
-        torch.cuda.set_device(self._bg_stream.device)              # the current device is per thread
-        with torch.inference_mode(), torch.cuda.stream(self._bg_stream):
+    def _acoustic_chain(self, k):
+        """k-th acoustic chain: (flow, vocoder) handles with their own workspaces over the same packed weights, and a stream"""
+        while len(self._acoustic) <= k:
+            flow = HvxFlow(self.cfg.flow, None, **self._flow_kw)
+            flow.load_packed(self.flow._weights)
+            hift = HvxHift(self.cfg.hift, None, **self._hift_kw)
+            hift.load_packed(self.hift._weights)
+            self._acoustic.append((flow, hift))
+        while len(self._bg_streams) <= k:
+            self._bg_streams.append(torch.cuda.Stream(device=self.device, priority=0))
+        return self._acoustic[k] + (self._bg_streams[k],)
+
+    def _acoustic_worker(self, utts, toks, st, k=0):
+        """flow + vocoder of one batch on a background stream (runs in a worker thread; returns when the waveforms are complete)"""
+        flow, hift, stream = self._acoustic_chain(k)
+        torch.cuda.set_device(stream.device)                       # the current device is per thread
+        with torch.inference_mode(), torch.cuda.stream(stream):
             t0 = time.time()
-            mels = self._mels(utts, toks)
+            mels = self._mels(utts, toks, flow)
             t1 = time.time()                       # enqueue time only: the stream is not drained between the stages
-            wavs = self._waves(mels)
-            self._bg_stream.synchronize()
+            wavs = self._waves(mels, hift)
+            stream.synchronize()
             t2 = time.time()
         st.flow_seconds, st.hift_seconds = t1 - t0, t2 - t1
         st.audio_seconds = sum(w.numel() for w in wavs) / float(self.cfg.sample_rate)
         return wavs
 
+    def _lm_chain(self, k):
+        """k-th LM decode chain: a further native handle (own KV cache, workspace, stream, graphs) over the SAME packed weight tensors"""
+        while len(self._llms) <= k:
+            clone = HvxLLM(self.cfg.llm, None, **self._llm_kw)
+            clone.load_packed(self.llm._weights)
+            self._llms.append(clone)
+        llm = self._llms[k]
+        llm.sampling, llm.inference_head_num = self.llm.sampling, self.llm.inference_head_num       # per-request knobs live on self.llm
+        return llm
+
+    def _lm_worker(self, k, utts, max_token_text_ratio, min_token_text_ratio):
+        torch.cuda.set_device(self._bg_stream.device)              # the current device is per thread
+        with torch.inference_mode():
+            st = SynthStats()
+            llm = self._lm_chain(k)
+            t0 = time.time()
+            toks = self._speech_tokens(utts, max_token_text_ratio, min_token_text_ratio, llm=llm)
+            st.llm_seconds = time.time() - t0
+            st.llm = dict(llm.last_stats)
+            st.per_utt_tokens = [len(t) for t in toks]
+            st.tokens = sum(st.per_utt_tokens)
+            return toks, st, t0
+
+    def _acoustic_after(self, utts, lm_future, k=0):
+        toks, st, t0 = lm_future.result()
+        wavs = self._acoustic_worker(utts, toks, st, k)
+        st.total_seconds = time.time() - t0
+        return wavs, st
+
     @torch.inference_mode()
-    def synthesize_pipelined(self, batches, max_token_text_ratio=20, min_token_text_ratio=2):
-        """Generator over (waveforms, SynthStats) of successive batches, in order, with the stages of neighbouring batches overlapped:
-        while the multi-head LM decodes batch i (a chain of short, latency-bound launches that leaves most CUs idle) the flow decoder and
-        the vocoder of batch i-1 (MFMA-bound) run on a second, lower-priority stream driven by a worker thread.  Results are identical to
-        synthesize(): every utterance carries its own sampler seed and no stage depends on another batch.  In the stats llm_seconds is the
-        decode wall time and flow_seconds + hift_seconds the wall time of the acoustic stages, both measured while overlapped."""
+    def synthesize_pipelined(self, batches, max_token_text_ratio=20, min_token_text_ratio=2, lm_chains=3, acoustic_chains=1):
+        """Generator over (waveforms, SynthStats) of successive batches, in order, with the stages of neighbouring batches overlapped.
+        The multi-head LM decode is a chain of ~160 short dependent launches per step that leaves most of the GPU idle, so (a) the flow
+        decoder and the vocoder of batch i (MFMA-bound) run on a second, lower-priority stream driven by a worker thread while later
+        batches decode, and (b) `lm_chains` batches decode at the same time, each on its own native handle (KV cache, workspace, stream,
+        graphs) over the same weight tensors and driven by its own host thread: two chains fill each other's launch gaps and together
+        emit 1.63x the tokens of one (tools/two_chain_probe.py); with three the acoustic stage is the bottleneck of the bench workload.
+        `acoustic_chains` > 1 runs the flow + vocoder of several batches at once as well (measured: slower, they are throughput-bound).
+        At most max(lm_chains, acoustic_chains) + 1 batches are in flight.  Results are identical
+        to synthesize(): every utterance carries its own sampler seed and no stage depends on another batch.  In the stats llm_seconds
+        is the decode wall time of the batch and flow_seconds + hift_seconds the wall time of its acoustic stages, all while overlapped."""
+        from collections import deque
         from concurrent.futures import ThreadPoolExecutor
         if getattr(self, '_bg_stream', None) is None:
             self._bg_stream = torch.cuda.Stream(device=self.device, priority=0)
-            self._bg_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix='hvx-acoustic')
-        pending = None
-        for utts in batches:
-            st = SynthStats()
-            t0 = time.time()
-            toks = self._speech_tokens(utts, max_token_text_ratio, min_token_text_ratio)
-            st.llm_seconds = time.time() - t0
-            st.llm = dict(self.llm.last_stats)
-            st.per_utt_tokens = [len(t) for t in toks]
-            st.tokens = sum(st.per_utt_tokens)
-            if pending is not None:
-                fut, pst, pt0 = pending
-                wavs = fut.result()
-                pst.total_seconds = time.time() - pt0
-                yield wavs, pst
-            pending = (self._bg_pool.submit(self._acoustic_worker, utts, toks, st), st, t0)
-        if pending is not None:
-            fut, pst, pt0 = pending
-            wavs = fut.result()
-            pst.total_seconds = time.time() - pt0
-            yield wavs, pst
+            self._bg_streams = [self._bg_stream]
+            self._bg_pools = []
+        lm_chains, acoustic_chains = max(1, int(lm_chains)), max(1, int(acoustic_chains))
+        while len(self._bg_pools) < acoustic_chains:
+            self._bg_pools.append(ThreadPoolExecutor(max_workers=1, thread_name_prefix='hvx-acoustic%d' % len(self._bg_pools)))
+        for k in range(acoustic_chains):
+            self._acoustic_chain(k)
+        pools = getattr(self, '_lm_pools', [])
+        while len(pools) < lm_chains:                     # one single-thread pool per chain: a handle is never used by two threads
+            pools.append(ThreadPoolExecutor(max_workers=1, thread_name_prefix='hvx-lm%d' % len(pools)))
+        self._lm_pools = pools
+        for k in range(lm_chains):
+            self._lm_chain(k)                             # build the handles on this thread, before the clock of the first job
+        window = deque()
+        for idx, utts in enumerate(batches):
+            k = idx % lm_chains
+            lm_f = pools[k].submit(self._lm_worker, k, utts, max_token_text_ratio, min_token_text_ratio)
+            ka = idx % acoustic_chains
+            window.append(self._bg_pools[ka].submit(self._acoustic_after, utts, lm_f, ka))      # FIFO per chain, results taken in batch order
+            while len(window) > max(lm_chains, acoustic_chains):
+                yield window.popleft().result()
+        while window:
+            yield window.popleft().result()

@@ -483,15 +483,18 @@ def test_pipelined_batches_equal_serial(tiny_cfg):
     from flowmirror_hydravox_amd.pipeline import HvxPipeline, synthetic_utterance
     pipe = HvxPipeline(tiny_cfg, llm_dtype=torch.float32, flow_dtype=torch.float32, max_batch=3, max_ctx=512, max_t=1024, seed=7, init='fan_in',
                        inference_head_num=2)
-    batches = [[synthetic_utterance(tiny_cfg, 10 * b + i, 6 + i) for i in range(3)] for b in range(3)]
+    batches = [[synthetic_utterance(tiny_cfg, 10 * b + i, 6 + i) for i in range(3)] for b in range(5)]
     serial = [pipe.synthesize(b, max_token_text_ratio=5, min_token_text_ratio=5) for b in batches]
-    piped = list(pipe.synthesize_pipelined(batches, max_token_text_ratio=5, min_token_text_ratio=5))
-    assert len(piped) == len(serial)
-    for (w0, s0), (w1, s1) in zip(serial, piped):
-        assert s0.per_utt_tokens == s1.per_utt_tokens and s1.tokens > 0
-        assert s1.audio_seconds == s0.audio_seconds and s1.total_seconds > 0
-        for a, b in zip(w0, w1):
-            assert a.shape == b.shape and torch.equal(a, b)
+    # default (three concurrent LM decode chains + one acoustic chain), the plain two-stage overlap, and two acoustic chains
+    for kw in ({}, dict(lm_chains=1), dict(lm_chains=2, acoustic_chains=2)):
+        piped = list(pipe.synthesize_pipelined(batches, max_token_text_ratio=5, min_token_text_ratio=5, **kw))
+        assert len(piped) == len(serial)
+        for (w0, s0), (w1, s1) in zip(serial, piped):
+            assert s0.per_utt_tokens == s1.per_utt_tokens and s1.tokens > 0
+            assert s1.audio_seconds == s0.audio_seconds and s1.total_seconds > 0
+            for a, b in zip(w0, w1):
+                assert a.shape == b.shape and torch.equal(a, b)
+    assert len(pipe._llms) == 3 and pipe._llms[1]._weights[0].data_ptr() == pipe.llm._weights[0].data_ptr()      # chains share the weights
 
 
 def test_synthesize_many_equals_one_by_one(tiny_cfg):
