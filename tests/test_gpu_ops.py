@@ -200,6 +200,18 @@ def test_attention_static_chunk_mask(dtype, T, chunk):
     torch.testing.assert_close(out.float().cpu(), ref, **tol)
 
 
+def test_attention_long_sequence_many_workgroups():
+    """the production geometry of the DiT attention (16 heads, CFG batch 2, thousands of frames): 544 workgroups of 256 rows, ragged
+    last tile, padded second batch entry."""
+    _lib, ops, packing = _mods()
+    T = 4300
+    q, k, v, qd, kd, vd = _attn_inputs(2, 16, T, torch.bfloat16, seed=80)
+    kv_len = torch.tensor([T, T - 123], dtype=torch.int32)
+    ref = _attn_ref(q.float(), k.float(), v.float(), kv_len=kv_len)
+    out = ops.attention(qd, kd, vd, T, kv_len=kv_len.to(DEV))
+    torch.testing.assert_close(out.float().cpu(), ref, rtol=3e-2, atol=3e-2)
+
+
 @pytest.mark.parametrize('T,n_splits,chunk', [(50, 1, 0), (300, 1, 0), (200, 4, 64), (97, 5, 32)])
 def test_attention_causal_and_splits(T, n_splits, chunk):
     _lib, ops, packing = _mods()
