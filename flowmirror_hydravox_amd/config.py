@@ -197,6 +197,18 @@ def cv3_config() -> HvxConfig:
     return HvxConfig()
 
 
+def cv3w_config() -> HvxConfig:
+    """HydraVox-CV3 WIDTHS at 2 layers / 2 DiT blocks: every per-layer shape of the full-size model (hidden 896, 14:2 heads, inter 4864,
+    vocab 6761, 5 MTP heads of 22016; DiT 1024 x 16 heads, conv groups 16, ff 2048, pre-lookahead 1024; HiFT base 512), so the kernel
+    instantiations the benchmark dispatches are the ones the parity tests run, at a depth the CPU reference / oracle finishes in seconds.
+    Only the depth and the (gather-only) text vocabulary are reduced."""
+    return HvxConfig(
+        llm=LLMConfig(layers=2, text_vocab=1024),
+        flow=FlowConfig(depth=2),
+        hift=HiftConfig(noise_seconds=16),
+    )
+
+
 def tiny_config() -> HvxConfig:
     """Toy dimensions used by the parity tests and golden fixtures (same code paths)."""
     return HvxConfig(

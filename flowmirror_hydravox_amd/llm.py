@@ -225,7 +225,11 @@ class HvxLLM:
     def generate_batch(self, texts, prompt_texts=None, prompt_speech_tokens=None, seeds=None, max_token_text_ratio=20,
                        min_token_text_ratio=2):
         """Lock-step batched decoding of several utterances; returns one token list per utterance.  Utterance i uses its own
-        generator seeded with seeds[i], so results do not depend on the batch composition."""
+        generator seeded with seeds[i], so results do not depend on the batch composition.  The two length ratios may be sequences
+        (one value per utterance)."""
+        def per_utt(v):
+            return list(v) if isinstance(v, (list, tuple)) else [v] * len(texts)
+        maxr, minr = per_utt(max_token_text_ratio), per_utt(min_token_text_ratio)
         reqs = []
         for i, text in enumerate(texts):
             text = torch.as_tensor(text)
@@ -233,7 +237,7 @@ class HvxLLM:
             ps = None if prompt_speech_tokens is None else prompt_speech_tokens[i]
             n_text = int(text.numel())
             reqs.append(_Request(self._encode_prefix(text, None if pt is None else torch.as_tensor(pt), None if ps is None else torch.as_tensor(ps)),
-                                 n_text, int(n_text * min_token_text_ratio), int(n_text * max_token_text_ratio),
+                                 n_text, int(n_text * minr[i]), int(n_text * maxr[i]),
                                  NoiseStream(seed=None if seeds is None else seeds[i])))
         for _ in self._run(reqs, stream_first=False):
             pass

@@ -20,7 +20,22 @@ import torch
 import torch.nn.functional as F
 
 
-def pre_lookahead(x, sd, cfg, pre='pre_lookahead_layer.', context=None):
+# bf16-faithful mode (`emu=True`, see oracle/llm_ref.py): every GEMM / conv / attention operand rounded to bf16 where the product's bf16
+# path holds it in bf16 (weights, adaLN-modulated rows, q / k / v, probabilities, GELU / Mish / LeakyReLU outputs that feed the next
+# GEMM), fp32 accumulation, fp32 residual stream, fp32 Euler state (csrc/hvx_flow.hip).
+def bf16r(t):
+    return t.to(torch.bfloat16).float()
+
+
+def _r(t, emu):
+    return bf16r(t) if emu else t
+
+
+def _lin(x, w, b=None, emu=False):
+    return F.linear(bf16r(x), bf16r(w), b) if emu else F.linear(x, w, b)
+
+
+def pre_lookahead(x, sd, cfg, pre='pre_lookahead_layer.', context=None, emu=False):
     """x: (1, N, 80) -> (1, N, 80); zero right pad, or `context` (1, pre_lookahead_len, 80) as the look-ahead (finalize=False)."""
     o = x.transpose(1, 2).contiguous()
     if context is None:
@@ -28,10 +43,10 @@ def pre_lookahead(x, sd, cfg, pre='pre_lookahead_layer.', context=None):
     else:
         assert context.shape[1] == cfg.pre_lookahead_len
         o = torch.cat([o, context.transpose(1, 2)], dim=2)
-    o = F.leaky_relu(F.conv1d(o, sd[pre + 'conv1.weight'], sd[pre + 'conv1.bias']))
+    o = F.leaky_relu(F.conv1d(_r(o, emu), _r(sd[pre + 'conv1.weight'], emu), sd[pre + 'conv1.bias']))
     k2 = sd[pre + 'conv2.weight'].shape[-1]
     o = F.pad(o, (k2 - 1, 0), value=0.0)
-    o = F.conv1d(o, sd[pre + 'conv2.weight'], sd[pre + 'conv2.bias'])
+    o = F.conv1d(_r(o, emu), _r(sd[pre + 'conv2.weight'], emu), sd[pre + 'conv2.bias'])
     return o.transpose(1, 2).contiguous() + x
 
 
@@ -43,10 +58,10 @@ def sinus_pos_emb(t, dim, scale=1000.0):
     return torch.cat((e.sin(), e.cos()), dim=-1)
 
 
-def time_embed(t, sd, cfg, pre):
+def time_embed(t, sd, cfg, pre, emu=False):
     h = sinus_pos_emb(t, cfg.time_freq_dim).to(t.dtype)
-    h = F.linear(h, sd[pre + 'time_embed.time_mlp.0.weight'], sd[pre + 'time_embed.time_mlp.0.bias'])
-    return F.linear(F.silu(h), sd[pre + 'time_embed.time_mlp.2.weight'], sd[pre + 'time_embed.time_mlp.2.bias'])
+    h = _lin(h, sd[pre + 'time_embed.time_mlp.0.weight'], sd[pre + 'time_embed.time_mlp.0.bias'], emu)
+    return _lin(F.silu(h), sd[pre + 'time_embed.time_mlp.2.weight'], sd[pre + 'time_embed.time_mlp.2.bias'], emu)
 
 
 def rope_freqs(T, head_dim):
@@ -66,40 +81,52 @@ def apply_rope_first(x, freqs):
     return torch.cat((xr.to(x.dtype), xp), dim=-1)
 
 
-def causal_conv_pos_embed(x, sd, cfg, pre):
+def causal_conv_pos_embed(x, sd, cfg, pre, emu=False):
     k = cfg.conv_kernel
     h = x.permute(0, 2, 1)
     for name in ('conv1.0.', 'conv2.0.'):
         h = F.pad(h, (k - 1, 0))
-        h = F.mish(F.conv1d(h, sd[pre + name + 'weight'], sd[pre + name + 'bias'], groups=cfg.conv_groups))
+        h = F.mish(F.conv1d(_r(h, emu), _r(sd[pre + name + 'weight'], emu), sd[pre + name + 'bias'], groups=cfg.conv_groups))
     return h.permute(0, 2, 1)
 
 
-def dit_block(x, t_emb, sd, cfg, pre, freqs, key_mask, attn_mask=None):
+def _sdpa_emu(q, k, v, am):
+    """softmax(q k^T / sqrt(d)) v with bf16 operands: scores fp32, probabilities rounded to bf16 for both the value product and the row
+    sum (csrc/attention.hip: attn_dit_kernel sums the bf16 probabilities on the matrix cores), output rounded to bf16."""
+    s = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(q.shape[-1])
+    s = s.masked_fill(~am, float('-inf'))
+    e = bf16r(torch.exp(s - s.amax(dim=-1, keepdim=True)))
+    return bf16r(torch.matmul(e, v) / e.sum(dim=-1, keepdim=True))
+
+
+def dit_block(x, t_emb, sd, cfg, pre, freqs, key_mask, attn_mask=None, emu=False):
     B, T, D = x.shape
     H, dh = cfg.heads, cfg.head_dim
-    emb = F.linear(F.silu(t_emb), sd[pre + 'attn_norm.linear.weight'], sd[pre + 'attn_norm.linear.bias'])
+    emb = _lin(F.silu(t_emb), sd[pre + 'attn_norm.linear.weight'], sd[pre + 'attn_norm.linear.bias'], emu)
     sh_a, sc_a, g_a, sh_m, sc_m, g_m = torch.chunk(emb, 6, dim=1)
     n = F.layer_norm(x, (D,), eps=1e-6) * (1 + sc_a[:, None]) + sh_a[:, None]
-    q = F.linear(n, sd[pre + 'attn.to_q.weight'], sd[pre + 'attn.to_q.bias'])
-    k = F.linear(n, sd[pre + 'attn.to_k.weight'], sd[pre + 'attn.to_k.bias'])
-    v = F.linear(n, sd[pre + 'attn.to_v.weight'], sd[pre + 'attn.to_v.bias'])
+    q = _lin(n, sd[pre + 'attn.to_q.weight'], sd[pre + 'attn.to_q.bias'], emu)
+    k = _lin(n, sd[pre + 'attn.to_k.weight'], sd[pre + 'attn.to_k.bias'], emu)
+    v = _lin(n, sd[pre + 'attn.to_v.weight'], sd[pre + 'attn.to_v.bias'], emu)
     q = apply_rope_first(q, freqs)
     k = apply_rope_first(k, freqs)
-    q = q.view(B, T, H, dh).transpose(1, 2)
-    k = k.view(B, T, H, dh).transpose(1, 2)
-    v = v.view(B, T, H, dh).transpose(1, 2)
+    q = _r(q, emu).view(B, T, H, dh).transpose(1, 2)
+    k = _r(k, emu).view(B, T, H, dh).transpose(1, 2)
+    v = _r(v, emu).view(B, T, H, dh).transpose(1, 2)
     am = key_mask[:, None, None, :].expand(B, H, T, T)           # (B,1,T,T) repeated pad mask (dit.py:166)
     if attn_mask is not None:
         am = attn_mask[:, None].expand(B, H, T, T)                # streaming: pad mask & static chunk mask (dit.py:163-164)
-    a = F.scaled_dot_product_attention(q, k, v, attn_mask=am, dropout_p=0.0, is_causal=False)
+    if emu:
+        a = _sdpa_emu(q, k, v, am)
+    else:
+        a = F.scaled_dot_product_attention(q, k, v, attn_mask=am, dropout_p=0.0, is_causal=False)
     a = a.transpose(1, 2).reshape(B, T, H * dh)
-    a = F.linear(a, sd[pre + 'attn.to_out.0.weight'], sd[pre + 'attn.to_out.0.bias'])
+    a = _lin(a, sd[pre + 'attn.to_out.0.weight'], sd[pre + 'attn.to_out.0.bias'], emu)
     a = a.masked_fill(~key_mask[:, :, None], 0.0)                 # mask[:, 0, -1] row == pad mask (modules.py:400-405)
     x = x + g_a.unsqueeze(1) * a
     f = F.layer_norm(x, (D,), eps=1e-6) * (1 + sc_m[:, None]) + sh_m[:, None]
-    f = F.linear(f, sd[pre + 'ff.ff.0.0.weight'], sd[pre + 'ff.ff.0.0.bias'])
-    f = F.linear(F.gelu(f, approximate='tanh'), sd[pre + 'ff.ff.2.weight'], sd[pre + 'ff.ff.2.bias'])
+    f = _lin(f, sd[pre + 'ff.ff.0.0.weight'], sd[pre + 'ff.ff.0.0.bias'], emu)
+    f = _lin(F.gelu(f, approximate='tanh'), sd[pre + 'ff.ff.2.weight'], sd[pre + 'ff.ff.2.bias'], emu)
     return x + g_m.unsqueeze(1) * f
 
 
@@ -114,7 +141,7 @@ def chunk_attn_mask(key_mask, chunk):
     return am
 
 
-def dit_forward(x, mask, mu, t, spks, cond, sd, cfg, pre='decoder.estimator.', n_blocks=None, taps=None, streaming=False):
+def dit_forward(x, mask, mu, t, spks, cond, sd, cfg, pre='decoder.estimator.', n_blocks=None, taps=None, streaming=False, emu=False):
     """Estimator call, TRT argument order (flow_matching.py:126-153): x,mu,cond (B,80,T); mask (B,1,T);
     t (B,); spks (B,80) -> (B,80,T).  streaming=True: static chunk mask of cfg.static_chunk_size frames."""
     x = x.transpose(1, 2)
@@ -123,10 +150,10 @@ def dit_forward(x, mask, mu, t, spks, cond, sd, cfg, pre='decoder.estimator.', n
     B, T, _ = x.shape
     if t.ndim == 0:
         t = t.repeat(B)
-    t_emb = time_embed(t, sd, cfg, pre)
+    t_emb = time_embed(t, sd, cfg, pre, emu)
     h = torch.cat([x, cond, mu, spks[:, None, :].expand(B, T, spks.shape[-1])], dim=-1)
-    h = F.linear(h, sd[pre + 'input_embed.proj.weight'], sd[pre + 'input_embed.proj.bias'])
-    h = causal_conv_pos_embed(h, sd, cfg, pre + 'input_embed.conv_pos_embed.') + h
+    h = _lin(h, sd[pre + 'input_embed.proj.weight'], sd[pre + 'input_embed.proj.bias'], emu)
+    h = causal_conv_pos_embed(h, sd, cfg, pre + 'input_embed.conv_pos_embed.', emu) + h
     if taps is not None:
         taps['input_embed'] = h.clone()
     freqs = rope_freqs(T, cfg.head_dim)
@@ -134,13 +161,13 @@ def dit_forward(x, mask, mu, t, spks, cond, sd, cfg, pre='decoder.estimator.', n
     nb = cfg.depth if n_blocks is None else n_blocks
     attn_mask = chunk_attn_mask(key_mask, cfg.static_chunk_size) if streaming else None
     for i in range(nb):
-        h = dit_block(h, t_emb, sd, cfg, pre + 'transformer_blocks.%d.' % i, freqs, key_mask, attn_mask)
+        h = dit_block(h, t_emb, sd, cfg, pre + 'transformer_blocks.%d.' % i, freqs, key_mask, attn_mask, emu)
         if taps is not None:
             taps['block%d' % i] = h.clone()
-    emb = F.linear(F.silu(t_emb), sd[pre + 'norm_out.linear.weight'], sd[pre + 'norm_out.linear.bias'])
+    emb = _lin(F.silu(t_emb), sd[pre + 'norm_out.linear.weight'], sd[pre + 'norm_out.linear.bias'], emu)
     scale, shift = torch.chunk(emb, 2, dim=1)
     h = F.layer_norm(h, (h.shape[-1],), eps=1e-6) * (1 + scale)[:, None, :] + shift[:, None, :]
-    return F.linear(h, sd[pre + 'proj_out.weight'], sd[pre + 'proj_out.bias']).transpose(1, 2)
+    return _lin(h, sd[pre + 'proj_out.weight'], sd[pre + 'proj_out.bias'], emu).transpose(1, 2)
 
 
 def cosine_t_span(n_timesteps, dtype=torch.float32):
@@ -185,7 +212,7 @@ def solve_euler(x, t_span, mu, mask, spks, cond, estimator, cfg_rate):
     return traj[-1].float(), traj
 
 
-def cfm_forward(mu, mask, spks, cond, sd, cfg, noise=None, estimator=None, n_timesteps=None, streaming=False):
+def cfm_forward(mu, mask, spks, cond, sd, cfg, noise=None, estimator=None, n_timesteps=None, streaming=False, emu=False):
     """CausalConditionalCFM.forward (flow_matching.py:204-228)."""
     noise = cfm_noise(cfg) if noise is None else noise
     z = noise[:, :, :mu.size(2)].to(mu.dtype)
@@ -193,12 +220,12 @@ def cfm_forward(mu, mask, spks, cond, sd, cfg, noise=None, estimator=None, n_tim
     t_span = cosine_t_span(n, mu.dtype)
     if estimator is None:
         def estimator(x, m, mu_, t, s, c):
-            return dit_forward(x, m, mu_, t, s, c, sd, cfg, streaming=streaming)
+            return dit_forward(x, m, mu_, t, s, c, sd, cfg, streaming=streaming, emu=emu)
     out, _ = solve_euler(z, t_span, mu, mask, spks, cond, estimator, cfg.cfg_rate)
     return out
 
 
-def flow_inference(token, embedding, sd, cfg, prompt_token=None, prompt_feat=None, noise=None, finalize=True, streaming=False):
+def flow_inference(token, embedding, sd, cfg, prompt_token=None, prompt_feat=None, noise=None, finalize=True, streaming=False, emu=False):
     """flow.py:367-430, fp32; finalize=False: the last pre_lookahead_len tokens are look-ahead context only.
     token (1,N) int, embedding (1,192), prompt_token (1,Np) int, prompt_feat (1,Tp,80) -> mel (1,80,2N)."""
     emb = F.normalize(embedding.float(), dim=1)
@@ -207,7 +234,7 @@ def flow_inference(token, embedding, sd, cfg, prompt_token=None, prompt_feat=Non
         token = torch.cat([prompt_token, token], dim=1)
     h = sd['input_embedding.weight'][torch.clamp(token.long(), min=0)]          # mask is all ones for B=1
     L = cfg.pre_lookahead_len
-    h = pre_lookahead(h, sd, cfg) if finalize else pre_lookahead(h[:, :-L], sd, cfg, context=h[:, -L:])
+    h = pre_lookahead(h, sd, cfg, emu=emu) if finalize else pre_lookahead(h[:, :-L], sd, cfg, context=h[:, -L:], emu=emu)
     h = h.repeat_interleave(cfg.token_mel_ratio, dim=1)
     T = h.shape[1]
     mel_len1 = prompt_feat.shape[1] if prompt_feat is not None else 0
@@ -215,5 +242,5 @@ def flow_inference(token, embedding, sd, cfg, prompt_token=None, prompt_feat=Non
     if prompt_feat is not None:
         cond[:, :mel_len1] = prompt_feat
     mask = torch.ones(1, 1, T)
-    feat = cfm_forward(h.transpose(1, 2).contiguous(), mask, emb, cond.transpose(1, 2), sd, cfg, noise=noise, streaming=streaming)
+    feat = cfm_forward(h.transpose(1, 2).contiguous(), mask, emb, cond.transpose(1, 2), sd, cfg, noise=noise, streaming=streaming, emu=emu)
     return feat[:, :, mel_len1:].float()

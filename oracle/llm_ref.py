@@ -18,6 +18,52 @@ import torch.nn.functional as F
 from . import sampler_ref
 
 
+# ----------------------------------------------------------------------------------------------------------------------------------
+# bf16-faithful mode (`emu=True`): the arithmetic the product's bf16 path performs, restated on the CPU — every GEMM / attention operand
+# rounded to bf16 (weights, the bf16 copy of the residual stream, q / k / v as they sit in the KV cache, the probabilities that multiply
+# V, the SwiGLU product), fp32 accumulation, fp32 residual stream, fp32 RMSNorm statistics taken from the rounded operand, RMSNorm gains
+# folded into the weight columns BEFORE rounding (flowmirror_hydravox_amd/llm.py: pack_state_dict).  It separates rounding (which this
+# mode reproduces up to accumulation order) from error (which it does not): tests bound bf16 HIP output against it tightly.
+# The reference itself runs the LM under `.to(bfloat16)` on a GPU (infer_speech_model.py:101-109) with a bf16 residual stream; the fp32
+# path above is the parity target, this mode is the yardstick for the production dtype.
+# ----------------------------------------------------------------------------------------------------------------------------------
+def bf16r(t):
+    return t.to(torch.bfloat16).float()
+
+
+_W_CACHE = {}          # (weight storage, gain storage) -> bf16-rounded (gain-folded) weight, so a decode loop rounds each matrix once
+
+
+def _wb(w, gain=None):
+    key = (w.data_ptr(), tuple(w.shape), 0 if gain is None else gain.data_ptr())
+    hit = _W_CACHE.get(key)
+    if hit is None or hit[0] is not w:
+        if len(_W_CACHE) > 256:
+            _W_CACHE.clear()
+        hit = (w, bf16r(w if gain is None else w * gain[None, :]))
+        _W_CACHE[key] = hit
+    return hit[1]
+
+
+def _lin(x, w, b=None, emu=False):
+    return F.linear(bf16r(x), _wb(w), b) if emu else F.linear(x, w, b)
+
+
+def _norm_lin(x, gain, eps, ws, bs, emu):
+    """[Linear_i(RMSNorm(x) * gain)]: fp32 = HF order; emu = gain folded into the bf16 weight, 1/rms from the bf16 copy of x applied to
+    the fp32 accumulator (csrc/gemm_skinny.hip ANORM)."""
+    if not emu:
+        h = rms_norm(x, gain, eps)
+        return [F.linear(h, w, b) for w, b in zip(ws, bs)]
+    xb = bf16r(x)
+    inv = torch.rsqrt(xb.pow(2).mean(-1, keepdim=True) + eps)
+    out = []
+    for w, b in zip(ws, bs):
+        y = F.linear(xb, _wb(w, gain)) * inv
+        out.append(y if b is None else y + b)
+    return out
+
+
 def rms_norm(x, w, eps):
     xf = x.float()
     var = xf.pow(2).mean(-1, keepdim=True)
@@ -36,16 +82,19 @@ def rotate_half(x):
     return torch.cat([-x[..., h:], x[..., :h]], dim=-1)
 
 
-def qwen2_layer(x, sd, pre, cfg, cos, sin, kv_cache=None):
+def qwen2_layer(x, sd, pre, cfg, cos, sin, kv_cache=None, emu=False):
     """One Qwen2 decoder layer on x (L_new, H); causal over [cache | new].  Returns y (and appends to cache)."""
     L, H = x.shape
     nq, nkv, d = cfg.q_heads, cfg.kv_heads, cfg.head_dim
-    h = rms_norm(x, sd[pre + 'input_layernorm.weight'], cfg.rms_eps)
-    q = F.linear(h, sd[pre + 'self_attn.q_proj.weight'], sd[pre + 'self_attn.q_proj.bias']).view(L, nq, d).transpose(0, 1)
-    k = F.linear(h, sd[pre + 'self_attn.k_proj.weight'], sd[pre + 'self_attn.k_proj.bias']).view(L, nkv, d).transpose(0, 1)
-    v = F.linear(h, sd[pre + 'self_attn.v_proj.weight'], sd[pre + 'self_attn.v_proj.bias']).view(L, nkv, d).transpose(0, 1)
+    q, k, v = _norm_lin(x, sd[pre + 'input_layernorm.weight'], cfg.rms_eps,
+                        [sd[pre + 'self_attn.%s_proj.weight' % n] for n in 'qkv'], [sd[pre + 'self_attn.%s_proj.bias' % n] for n in 'qkv'], emu)
+    q = q.view(L, nq, d).transpose(0, 1)
+    k = k.view(L, nkv, d).transpose(0, 1)
+    v = v.view(L, nkv, d).transpose(0, 1)
     q = q * cos + rotate_half(q) * sin
     k = k * cos + rotate_half(k) * sin
+    if emu:                                                     # what the QKV epilogue stores (q buffer, K / V^T cache) is bf16
+        q, k, v = bf16r(q), bf16r(k), bf16r(v)
     past = 0
     if kv_cache is not None:
         if pre in kv_cache:
@@ -61,50 +110,64 @@ def qwen2_layer(x, sd, pre, cfg, cos, sin, kv_cache=None):
     Lk = kk.shape[1]
     causal = torch.arange(Lk)[None, :] <= (torch.arange(L)[:, None] + past)
     s = s.masked_fill(~causal[None], float('-inf'))
-    p = torch.softmax(s.float(), dim=-1).to(x.dtype)
-    o = torch.matmul(p, vv).transpose(0, 1).reshape(L, nq * d)
-    x = x + F.linear(o, sd[pre + 'self_attn.o_proj.weight'])
-    h = rms_norm(x, sd[pre + 'post_attention_layernorm.weight'], cfg.rms_eps)
-    g = F.linear(h, sd[pre + 'mlp.gate_proj.weight'])
-    u = F.linear(h, sd[pre + 'mlp.up_proj.weight'])
-    x = x + F.linear(F.silu(g) * u, sd[pre + 'mlp.down_proj.weight'])
+    if emu:
+        # probabilities multiply V as bf16 while the row sum keeps the fp32 values (csrc/attention.hip: attn_fwd_kernel)
+        e = torch.exp(s.float() - s.float().amax(dim=-1, keepdim=True))
+        o = torch.matmul(bf16r(e), vv) / e.sum(dim=-1, keepdim=True)
+        o = bf16r(o.transpose(0, 1).reshape(L, nq * d))
+    else:
+        p = torch.softmax(s.float(), dim=-1).to(x.dtype)
+        o = torch.matmul(p, vv).transpose(0, 1).reshape(L, nq * d)
+    x = x + _lin(o, sd[pre + 'self_attn.o_proj.weight'], None, emu)
+    g, u = _norm_lin(x, sd[pre + 'post_attention_layernorm.weight'], cfg.rms_eps,
+                     [sd[pre + 'mlp.gate_proj.weight'], sd[pre + 'mlp.up_proj.weight']], [None, None], emu)
+    x = x + _lin(F.silu(g) * u, sd[pre + 'mlp.down_proj.weight'], None, emu)
     return x
 
 
-def backbone(x, sd, cfg, pos0=0, kv_cache=None):
+def backbone(x, sd, cfg, pos0=0, kv_cache=None, emu=False):
     """Qwen2 stack on embeddings x (L, H) at absolute positions pos0..pos0+L-1.
     Returns hidden_states[-1] (after the final RMSNorm), as forward_one_step does (:248-260)."""
     L = x.shape[0]
     cos, sin = rope_cos_sin(torch.arange(pos0, pos0 + L), cfg.head_dim, cfg.rope_theta)
     for i in range(cfg.layers):
-        x = qwen2_layer(x, sd, 'llm.model.model.layers.%d.' % i, cfg, cos, sin, kv_cache)
+        x = qwen2_layer(x, sd, 'llm.model.model.layers.%d.' % i, cfg, cos, sin, kv_cache, emu)
     return rms_norm(x, sd['llm.model.model.norm.weight'], cfg.rms_eps)
 
 
-def mtp_head(y, sd, j, cfg):
+def _rms_norm_emu(x, w, eps):
+    """HF RMSNorm under a bf16 module: weight * (x * rsqrt(mean x^2 + eps)).to(bf16), result bf16 (csrc/elementwise.hip: heads_prologue /
+    reduce_rmsnorm write `T(gain * T(v))`)."""
+    xf = x.float()
+    v = bf16r(xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps))
+    return bf16r(w * v)
+
+
+def mtp_head(y, sd, j, cfg, emu=False):
     """mtp_block[j] applied to a length-1 sequence (:887).  With one key the softmax is 1 and
     RoPE/q/k drop out (SURVEY.md §0 finding 5): h1 = y + Wo(Wv n1 + bv); out = h1 + MLP(n2)."""
     pre = 'mtp_block.%d.' % j
-    n1 = rms_norm(y, sd[pre + 'input_layernorm.weight'], cfg.mtp_rms_eps)
-    v = F.linear(n1, sd[pre + 'self_attn.v_proj.weight'], sd[pre + 'self_attn.v_proj.bias'])
-    h1 = y + F.linear(v, sd[pre + 'self_attn.o_proj.weight'])
-    n2 = rms_norm(h1, sd[pre + 'post_attention_layernorm.weight'], cfg.mtp_rms_eps)
-    g = F.linear(n2, sd[pre + 'mlp.gate_proj.weight'])
-    u = F.linear(n2, sd[pre + 'mlp.up_proj.weight'])
-    return h1 + F.linear(F.silu(g) * u, sd[pre + 'mlp.down_proj.weight'])
+    norm = _rms_norm_emu if emu else rms_norm
+    n1 = norm(y, sd[pre + 'input_layernorm.weight'], cfg.mtp_rms_eps)
+    v = _lin(n1, sd[pre + 'self_attn.v_proj.weight'], sd[pre + 'self_attn.v_proj.bias'], emu)
+    h1 = y + _lin(v, sd[pre + 'self_attn.o_proj.weight'], None, emu)
+    n2 = norm(h1, sd[pre + 'post_attention_layernorm.weight'], cfg.mtp_rms_eps)
+    g = _lin(n2, sd[pre + 'mlp.gate_proj.weight'], None, emu)
+    u = _lin(n2, sd[pre + 'mlp.up_proj.weight'], None, emu)
+    return h1 + _lin(F.silu(g) * u, sd[pre + 'mlp.down_proj.weight'], None, emu)
 
 
-def head_logps(y_last, sd, cfg, head_k):
+def head_logps(y_last, sd, cfg, head_k, emu=False):
     """K log-prob vectors from the last hidden row (:886-888)."""
     out = []
     for j in range(head_k):
-        h = mtp_head(y_last, sd, j, cfg)
-        out.append(F.linear(h, sd['llm_decoder.weight']).log_softmax(dim=-1))
+        h = mtp_head(y_last, sd, j, cfg, emu)
+        out.append(_lin(h, sd['llm_decoder.weight'], None, emu).log_softmax(dim=-1))
     return out
 
 
-def build_prefix(sd, cfg, text, prompt_text=None, prompt_speech_token=None):
-    """[sos | text_emb | task_id | prompt_speech_emb] (:941-952). text/prompt_text: 1-D int tensors."""
+def build_prefix(sd, cfg, text, prompt_text=None, prompt_speech_token=None, emu=False):
+    """[sos | text_emb | task_id | prompt_speech_emb] (:941-952). text/prompt_text: 1-D int tensors.  emu: bf16 embedding tables."""
     if prompt_text is not None and len(prompt_text):
         text = torch.cat([torch.as_tensor(prompt_text).long(), torch.as_tensor(text).long()])
     text = torch.as_tensor(text).long()
@@ -113,7 +176,8 @@ def build_prefix(sd, cfg, text, prompt_text=None, prompt_speech_token=None):
     parts = [se[cfg.sos][None], emb, se[cfg.task_id][None]]
     if prompt_speech_token is not None and len(prompt_speech_token):
         parts.append(se[torch.as_tensor(prompt_speech_token).long()])
-    return torch.cat(parts, dim=0)
+    out = torch.cat(parts, dim=0)
+    return bf16r(out) if emu else out
 
 
 def effective_heads(cfg, inference_head_num):
@@ -123,7 +187,7 @@ def effective_heads(cfg, inference_head_num):
 
 def llm_inference(sd, cfg, text, noise, prompt_text=None, prompt_speech_token=None, inference_head_num=2,
                   sampling=None, max_token_text_ratio=20, min_token_text_ratio=2, use_kv_cache=False,
-                  max_steps=None, trace=None):
+                  max_steps=None, trace=None, emu=False):
     """Generator of speech-token ids, reference semantics (:926-960 + :861-922).
 
     use_kv_cache=False reproduces the reference literally (full-prefix recompute, cache=None);
@@ -132,7 +196,7 @@ def llm_inference(sd, cfg, text, noise, prompt_text=None, prompt_speech_token=No
     """
     sampling = dict(top_p=0.8, top_k=25, win_size=10, tau_r=0.1) if sampling is None else sampling
     n_text = len(text)
-    lm_input = build_prefix(sd, cfg, text, prompt_text, prompt_speech_token)
+    lm_input = build_prefix(sd, cfg, text, prompt_text, prompt_speech_token, emu)
     min_len = int(n_text * min_token_text_ratio)
     max_len = int(n_text * max_token_text_ratio)
     head_k = effective_heads(cfg, inference_head_num)
@@ -143,11 +207,11 @@ def llm_inference(sd, cfg, text, noise, prompt_text=None, prompt_speech_token=No
     steps = 0
     while len(out_tokens) < max_len:
         if use_kv_cache:
-            y = backbone(lm_input[done_rows:], sd, cfg, pos0=done_rows, kv_cache=kv)
+            y = backbone(lm_input[done_rows:], sd, cfg, pos0=done_rows, kv_cache=kv, emu=emu)
             done_rows = lm_input.shape[0]
         else:
-            y = backbone(lm_input, sd, cfg)
-        logps = head_logps(y[-1], sd, cfg, head_k)
+            y = backbone(lm_input, sd, cfg, emu=emu)
+        logps = head_logps(y[-1], sd, cfg, head_k, emu)
         if trace is not None:
             trace.append(dict(y_last=y[-1].clone(), logps=[lp.clone() for lp in logps], cursor=noise.cursor))
         ids = sampler_ref.sample_step([lp.numpy() for lp in logps], out_tokens, noise, cfg.speech_tokens, min_len, sampling)
@@ -165,7 +229,8 @@ def llm_inference(sd, cfg, text, noise, prompt_text=None, prompt_speech_token=No
                 break
         if stop or not group:
             break
-        lm_input = torch.cat([lm_input, sd['speech_embedding.weight'][torch.tensor(group)]], dim=0)
+        new = sd['speech_embedding.weight'][torch.tensor(group)]
+        lm_input = torch.cat([lm_input, bf16r(new) if emu else new], dim=0)
         steps += 1
         if max_steps is not None and steps >= max_steps:
             break

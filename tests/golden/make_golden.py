@@ -27,7 +27,7 @@ import _ref_shim  # noqa: E402
 
 DictConfig = _ref_shim.install()
 
-from flowmirror_hydravox_amd.config import tiny_config  # noqa: E402
+from flowmirror_hydravox_amd.config import tiny_config, cv3w_config  # noqa: E402
 from flowmirror_hydravox_amd import weights as W  # noqa: E402
 from oracle import sampler_ref, llm_ref, flow_ref, hift_ref  # noqa: E402
 
@@ -275,6 +275,66 @@ def gen_llm_stress():
     np.savez_compressed(os.path.join(HERE, 'llm_stress_tiny.npz'), **out)
 
 
+def gen_llm_cv3w():
+    """The reference LM at the HydraVox-CV3 WIDTHS (hidden 896, 14:2 heads, inter 4864, vocab 6761, 5 MTP heads of 22016; 2 layers):
+    first-step hidden / log-probs of all 5 heads, and token streams for K in {1, 2, 4, 5} — a set of 8 utterances at K = 2 (the batch
+    the benchmark decodes) whose contexts start below and cross the 256- and 512-key attention splits."""
+    import time
+    cfg = cv3w_config().llm
+    seed_w = 1986
+    sd = W.make_llm_state(cfg, seed=seed_w, init='fan_in', with_lm_head=True)
+    out = dict(weight_seed=np.int64(seed_w), weight_sha=np.array(state_checksum(sd)))
+    sampling = dict(top_p=0.9, top_k=10, win_size=32, tau_r=0.2)
+    lm = build_ref_llm(cfg, sd, sampling)
+    # (K, n_text, n_prompt_text, n_prompt_speech, max ratio, min ratio)
+    runs = [(2, 14, 0, 0, 3, 2), (2, 20, 6, 150, 3, 2), (2, 24, 0, 215, 3, 2), (2, 30, 8, 200, 2, 2), (2, 16, 0, 460, 4, 3), (2, 9, 0, 30, 5, 2),
+            (2, 40, 10, 180, 2, 1), (2, 12, 0, 236, 4, 2),
+            (1, 16, 0, 230, 3, 2), (1, 10, 4, 0, 4, 2), (4, 24, 0, 210, 4, 3), (4, 11, 5, 40, 5, 3), (5, 20, 0, 225, 4, 3)]
+    for r, (K, n_text, n_pt, n_ps, maxr, minr) in enumerate(runs):
+        t0 = time.time()
+        lm.inference_head_num = K
+        seed = 700 + r
+        g = torch.Generator()
+        g.manual_seed(seed)
+        text = torch.randint(0, cfg.text_vocab, (1, n_text), dtype=torch.int32, generator=g)
+        ptext = torch.randint(0, cfg.text_vocab, (1, n_pt), dtype=torch.int32, generator=g)
+        pspeech = torch.randint(0, cfg.speech_tokens, (1, n_ps), dtype=torch.int32, generator=g)
+        torch.manual_seed(seed)
+        toks = list(lm.inference(
+            text=text, text_len=torch.tensor([n_text], dtype=torch.int32), prompt_text=ptext, prompt_text_len=torch.tensor([n_pt], dtype=torch.int32),
+            prompt_speech_token=pspeech if n_ps else None, prompt_speech_token_len=torch.tensor([n_ps], dtype=torch.int32),
+            embedding=torch.zeros(0, 192), max_token_text_ratio=maxr, min_token_text_ratio=minr))
+        ns = sampler_ref.NoiseStream(seed=seed)
+        otoks = list(llm_ref.llm_inference(sd, cfg, text[0], ns, prompt_text=ptext[0], prompt_speech_token=pspeech[0], inference_head_num=K,
+                                           sampling=sampling, max_token_text_ratio=maxr, min_token_text_ratio=minr, use_kv_cache=True))
+        assert otoks == [int(t) for t in toks], (r, otoks[:8], toks[:8])
+        if r == 0:                                      # the literal (uncached) form once
+            o2 = list(llm_ref.llm_inference(sd, cfg, text[0], sampler_ref.NoiseStream(seed=seed), prompt_text=ptext[0], prompt_speech_token=pspeech[0],
+                                            inference_head_num=K, sampling=sampling, max_token_text_ratio=maxr, min_token_text_ratio=minr))
+            assert o2 == otoks
+        n_ctx0 = 2 + n_text + n_pt + n_ps
+        print('[llm-cv3w] run %d K=%d: prefix %d rows, %d tokens (context %d -> %d), oracle == reference; %.1f s'
+              % (r, K, n_ctx0, len(toks), n_ctx0, n_ctx0 + len(toks), time.time() - t0))
+        p = 'r%d_' % r
+        out.update({p + 'K': np.int32(K), p + 'seed': np.int64(seed), p + 'text': text[0].numpy(), p + 'ptext': ptext[0].numpy(),
+                    p + 'pspeech': pspeech[0].numpy(), p + 'ratios': np.array([maxr, minr], dtype=np.float64), p + 'tokens': np.array(toks, dtype=np.int32)})
+        if r in (1, 12):                                # numeric pin of the first step: all 5 heads
+            lm_input = llm_ref.build_prefix(sd, cfg, text[0], ptext[0], pspeech[0])[None]
+            L = lm_input.shape[1]
+            y, _ = lm.llm.forward_one_step(lm_input, masks=torch.tril(torch.ones(1, L, L)).bool(), cache=None)
+            last = y[:, -1:, :]
+            logps = torch.stack([lm.llm_decoder(lm.mtp_block[j](last)[0][:, -1]).log_softmax(dim=-1)[0] for j in range(cfg.head_num)])
+            oy = llm_ref.backbone(lm_input[0], sd, cfg)
+            ol = torch.stack(llm_ref.head_logps(oy[-1], sd, cfg, cfg.head_num))
+            d = [(oy - y[0]).abs().max().item(), (ol - logps).abs().max().item()]
+            assert d[0] < 5e-5 and d[1] < 5e-4, d
+            print('[llm-cv3w] run %d first step: oracle-reference max abs diff hidden %.1e logp %.1e (|y| max %.2f)' % (r, d[0], d[1], y.abs().max()))
+            out.update({p + 'y_last': last[0, 0].numpy(), p + 'logps': logps.numpy()})
+    out['sampling'] = np.array([sampling['top_p'], sampling['top_k'], sampling['win_size'], sampling['tau_r']], dtype=np.float64)
+    out['n_runs'] = np.int32(len(runs))
+    np.savez_compressed(os.path.join(HERE, 'llm_cv3w.npz'), **out)
+
+
 # ------------------------------------------------------------------------------------------------
 # flow
 # ------------------------------------------------------------------------------------------------
@@ -335,6 +395,117 @@ def gen_flow():
                     p + 'est_cond': c_in.numpy(), p + 'est_out': est.numpy()})
     out['n_runs'] = np.int32(2)
     np.savez_compressed(os.path.join(HERE, 'flow_tiny.npz'), **out)
+
+
+def cv3w_flow_inputs(seed, T, lens):
+    """seeded estimator inputs (regenerated by the tests from the seed; the fixture stores their checksum and the reference output)"""
+    g = torch.Generator()
+    g.manual_seed(seed)
+    x, mu, cond = (torch.randn(2, 80, T, generator=g) for _ in range(3))
+    spk = torch.randn(2, 80, generator=g)
+    mask = (torch.arange(T)[None, :] < torch.tensor(lens)[:, None]).float()[:, None, :]
+    return x, mask, mu, spk, cond
+
+
+def gen_flow_cv3w():
+    """The reference flow decoder at the HydraVox-CV3 WIDTHS (DiT 1024 x 16 heads x ff 2048, conv groups 16, pre-lookahead 1024; 2 blocks):
+    estimator at T = 2176 (padded second row), estimator with the chunk mask, pre-lookahead and a whole flow.inference with a prompt."""
+    from cosyvoice.flow.flow import CausalMaskedDiffWithDiT
+    from cosyvoice.flow.flow_matching import CausalConditionalCFM
+    from cosyvoice.flow.DiT.dit import DiT
+    from cosyvoice.transformer.upsample_encoder import PreLookaheadLayer
+    c = cv3w_config().flow
+    dit = DiT(dim=c.dim, depth=c.depth, heads=c.heads, dim_head=c.head_dim, ff_mult=c.ff_mult, mel_dim=c.mel, mu_dim=c.mel,
+              spk_dim=c.mel, out_channels=c.mel, static_chunk_size=c.static_chunk_size)
+    cfm = CausalConditionalCFM(in_channels=240, cfm_params=DictConfig(sigma_min=1e-6, solver='euler', t_scheduler='cosine',
+                                                                     training_cfg_rate=0.2, inference_cfg_rate=c.cfg_rate, reg_loss_type='l1'),
+                               n_spks=1, spk_emb_dim=80, estimator=dit)
+    pla = PreLookaheadLayer(in_channels=80, channels=c.pre_lookahead_channels, pre_lookahead_len=c.pre_lookahead_len)
+    flow = CausalMaskedDiffWithDiT(input_size=80, output_size=80, spk_embed_dim=192, vocab_size=c.vocab, token_mel_ratio=2,
+                                   pre_lookahead_len=3, pre_lookahead_layer=pla, decoder=cfm).eval()
+    assert_spec(flow, W.flow_spec(c), 'flow.pt (cv3 widths)')
+    seed_w = 1987
+    sd = W.make_flow_state(c, seed=seed_w, init='fan_in')
+    flow.load_state_dict(sd)
+    out = dict(weight_seed=np.int64(seed_w), weight_sha=np.array(state_checksum(sd)))
+    # ---- estimator, long padded batch ----------------------------------------------------------------------------------------
+    for tag, seed, T, lens, streaming in (('e0', 41, 2176, [2176, 1900], False), ('e1', 42, 330, [330, 275], True)):
+        x, mask, mu, spk, cond = cv3w_flow_inputs(seed, T, lens)
+        t = torch.tensor([0.3, 0.3]) if tag == 'e0' else torch.tensor([0.7, 0.15])
+        est = dit(x, mask, mu, t, spk, cond, streaming=streaming)
+        o_est = flow_ref.dit_forward(x, mask, mu, t, spk, cond, sd, c, streaming=streaming)
+        d = ((o_est - est) * mask).abs().max().item()
+        assert d < 2e-4, d
+        print('[flow-cv3w] estimator %s T=%d lens=%s streaming=%s: oracle-reference max abs diff %.1e (out absmax %.2f)' % (tag, T, lens, streaming, d, (est * mask).abs().max()))
+        out.update({tag + '_seed': np.int64(seed), tag + '_T': np.int32(T), tag + '_lens': np.array(lens, dtype=np.int32), tag + '_t': t.numpy(),
+                    tag + '_streaming': np.int32(streaming), tag + '_in_sha': np.array(state_checksum(dict(x=x, mu=mu, spk=spk, cond=cond))),
+                    tag + '_out': (est * mask).numpy()})
+    # ---- pre-lookahead + whole inference with a prompt -------------------------------------------------------------------------
+    g = torch.Generator()
+    g.manual_seed(43)
+    N, Np = 130, 45
+    token = torch.randint(0, c.vocab, (1, N), generator=g)
+    ptoken = torch.randint(0, c.vocab, (1, Np), generator=g)
+    pfeat = torch.randn(1, 2 * Np, 80, generator=g)
+    emb = torch.randn(1, 192, generator=g)
+    e = flow.spk_embed_affine_layer(F.normalize(emb, dim=1))
+    h0 = flow.input_embedding(torch.cat([ptoken, token], dim=1))
+    hp = flow.pre_lookahead_layer(h0)
+    h = hp.repeat_interleave(2, dim=1)
+    T = h.shape[1]
+    cond = torch.zeros(1, T, 80)
+    cond[:, :2 * Np] = pfeat
+    feat, _ = flow.decoder(mu=h.transpose(1, 2).contiguous(), mask=torch.ones(1, 1, T), spks=e, cond=cond.transpose(1, 2), n_timesteps=10, streaming=False)
+    feat = feat[:, :, 2 * Np:]
+    o_pla = flow_ref.pre_lookahead(h0, sd, c)
+    o_feat = flow_ref.flow_inference(token, emb, sd, c, prompt_token=ptoken, prompt_feat=pfeat)
+    d = [(o_pla - hp).abs().max().item(), (o_feat - feat).abs().max().item()]
+    assert max(d) < 5e-4, d
+    print('[flow-cv3w] inference N=%d prompt=%d: oracle-reference max abs diff pla %.1e mel %.1e (mel absmax %.2f)' % (N, Np, d[0], d[1], feat.abs().max()))
+    out.update(token=token.numpy(), ptoken=ptoken.numpy(), pfeat=pfeat.numpy(), emb=emb.numpy(), h0=h0.numpy(), pla=hp.numpy(), mel=feat.numpy())
+    np.savez_compressed(os.path.join(HERE, 'flow_cv3w.npz'), **out)
+
+
+def gen_hift_cv3w():
+    """The reference HiFT vocoder at full width (base 512, F0 predictor 512): stage outputs for T in {8, 50, 160}."""
+    from cosyvoice.hifigan.generator import CausalHiFTGenerator
+    from cosyvoice.hifigan.f0_predictor import CausalConvRNNF0Predictor
+    c = cv3w_config().hift
+    f0p = CausalConvRNNF0Predictor(num_class=1, in_channels=80, cond_channels=c.f0_channels)
+    gen = CausalHiFTGenerator(
+        in_channels=80, base_channels=c.base_channels, nb_harmonics=c.nb_harmonics, sampling_rate=c.sampling_rate,
+        nsf_alpha=c.nsf_alpha, nsf_sigma=c.nsf_sigma, nsf_voiced_threshold=c.nsf_voiced_threshold,
+        upsample_rates=c.upsample_rates, upsample_kernel_sizes=c.upsample_kernel_sizes,
+        istft_params={'n_fft': c.n_fft, 'hop_len': c.hop}, resblock_kernel_sizes=c.resblock_kernel_sizes,
+        resblock_dilation_sizes=c.resblock_dilations, source_resblock_kernel_sizes=c.source_resblock_kernel_sizes,
+        source_resblock_dilation_sizes=c.source_resblock_dilations, lrelu_slope=c.lrelu_slope, audio_limit=c.audio_limit,
+        conv_pre_look_right=c.conv_pre_look_right, f0_predictor=f0p).eval()
+    assert_spec(gen, W.hift_spec(c), 'hift.pt (full width)')
+    seed_w, seed_t = 1988, 9
+    sd = W.make_hift_state(c, seed=seed_w, init='fan_in')
+    gen.load_state_dict(sd)
+    tables = hift_ref.make_tables(c, seed=seed_t)
+    gen.m_source.l_sin_gen.rand_ini = tables['rand_ini']
+    gen.m_source.l_sin_gen.sine_waves = tables['sine_waves']
+    gen.m_source.uv = tables['uv']
+    out = dict(weight_seed=np.int64(seed_w), table_seed=np.int64(seed_t), weight_sha=np.array(state_checksum(sd)))
+    g = torch.Generator()
+    g.manual_seed(4)
+    for r, T in enumerate([8, 50, 160]):
+        mel = torch.randn(1, 80, T, generator=g)
+        with torch.inference_mode():
+            f0 = gen.f0_predictor(mel)
+            wav, s = gen.inference(speech_feat=mel)
+        o_f0 = hift_ref.f0_predictor(mel, sd)
+        o_wav_s = hift_ref.decode(mel, s, sd, c)
+        d = [(o_f0 - f0).abs().max().item(), (o_wav_s - wav).abs().max().item()]
+        assert d[0] < 2e-3 and d[1] < 5e-4, d
+        print('[hift-cv3w] T=%d: oracle-reference max abs diff f0 %.1e decode(ref source) %.1e (wav std %.3f, f0 max %.1f, voiced %.0f %%)'
+              % (T, d[0], d[1], wav.std(), f0.max(), 100.0 * (f0 > 10).float().mean()))
+        p = 'r%d_' % r
+        out.update({p + 'mel': mel.numpy(), p + 'f0': f0.numpy(), p + 'source': s.numpy(), p + 'wav': wav.numpy()})
+    out['n_runs'] = np.int32(3)
+    np.savez_compressed(os.path.join(HERE, 'hift_cv3w.npz'), **out)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -661,7 +832,7 @@ def gen_graft():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['sampler', 'llm', 'flow', 'hift', 'matcha', 'stream', 'graft', 'llm_stress']
+    which = sys.argv[1:] or ['sampler', 'llm', 'flow', 'hift', 'matcha', 'stream', 'graft', 'llm_stress', 'llm_cv3w', 'flow_cv3w', 'hift_cv3w']
     for w in which:
-        {'sampler': gen_sampler, 'llm': gen_llm, 'flow': gen_flow, 'hift': gen_hift, 'matcha': gen_matcha, 'stream': gen_stream, 'graft': gen_graft, 'llm_stress': gen_llm_stress}[w]()
+        {'llm_cv3w': gen_llm_cv3w, 'flow_cv3w': gen_flow_cv3w, 'hift_cv3w': gen_hift_cv3w, 'sampler': gen_sampler, 'llm': gen_llm, 'flow': gen_flow, 'hift': gen_hift, 'matcha': gen_matcha, 'stream': gen_stream, 'graft': gen_graft, 'llm_stress': gen_llm_stress}[w]()
     print('golden fixtures written to', HERE)

@@ -290,3 +290,81 @@ def test_streaming_oracle_vs_reference_vectors(tiny_cfg):
         assert np.allclose(s.numpy(), g['h%d_source' % k], atol=1e-3)
         assert np.abs(wav.numpy() - g['h%d_wav' % k]).max() < 5e-3
         assert np.abs(g['h%d_wav' % k] - g['h_wav_whole'][:, :wav.shape[1]]).max() < 1e-3      # the check of generator.py:739-747
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# HydraVox-CV3 WIDTHS (config.cv3w_config: every per-layer shape of the benchmarked model, 2 layers / 2 DiT blocks)
+# ------------------------------------------------------------------------------------------------------------------------------
+def cv3w_flow_inputs(seed, T, lens):
+    """the seeded estimator inputs of tests/golden/make_golden.py::cv3w_flow_inputs (fixtures hold their checksum and the reference's output)"""
+    g = torch.Generator()
+    g.manual_seed(seed)
+    x, mu, cond = (torch.randn(2, 80, T, generator=g) for _ in range(3))
+    spk = torch.randn(2, 80, generator=g)
+    mask = (torch.arange(T)[None, :] < torch.tensor(lens)[:, None]).float()[:, None, :]
+    return x, mask, mu, spk, cond
+
+
+@pytest.fixture(scope='module')
+def cv3w_cfg():
+    from flowmirror_hydravox_amd.config import cv3w_config
+    return cv3w_config()
+
+
+def test_cv3w_llm_oracle_vs_reference_vectors(cv3w_cfg):
+    g = load_golden('llm_cv3w.npz')
+    cfg = cv3w_cfg.llm
+    sd = W.make_llm_state(cfg, seed=int(g['weight_seed']), init='fan_in', with_lm_head=True)
+    assert state_checksum(sd) == str(g['weight_sha'])
+    top_p, top_k, win, tau = g['sampling']
+    sampling = dict(top_p=float(top_p), top_k=int(top_k), win_size=int(win), tau_r=float(tau))
+    for r in range(int(g['n_runs'])):
+        p = 'r%d_' % r
+        toks = list(llm_ref.llm_inference(sd, cfg, torch.from_numpy(g[p + 'text']), sampler_ref.NoiseStream(seed=int(g[p + 'seed'])),
+                                          prompt_text=torch.from_numpy(g[p + 'ptext']), prompt_speech_token=torch.from_numpy(g[p + 'pspeech']),
+                                          inference_head_num=int(g[p + 'K']), sampling=sampling, max_token_text_ratio=float(g[p + 'ratios'][0]),
+                                          min_token_text_ratio=float(g[p + 'ratios'][1]), use_kv_cache=True))
+        assert toks == g[p + 'tokens'].tolist(), r
+        if p + 'y_last' in g:
+            x = llm_ref.build_prefix(sd, cfg, torch.from_numpy(g[p + 'text']), torch.from_numpy(g[p + 'ptext']), torch.from_numpy(g[p + 'pspeech']))
+            y = llm_ref.backbone(x, sd, cfg)
+            assert np.abs(y[-1].numpy() - g[p + 'y_last']).max() < 5e-5
+            lp = torch.stack(llm_ref.head_logps(y[-1], sd, cfg, cfg.head_num)).numpy()
+            assert np.abs(lp - g[p + 'logps']).max() < 5e-4
+            # the bf16-faithful mode is the same function with rounded operands: close to, and different from, the fp32 result
+            yb = llm_ref.backbone(llm_ref.bf16r(x), sd, cfg, emu=True)
+            rel = (yb[-1] - y[-1]).abs().max().item() / y[-1].abs().max().item()
+            assert 1e-4 < rel < 3e-2, rel
+
+
+def test_cv3w_flow_oracle_vs_reference_vectors(cv3w_cfg):
+    g = load_golden('flow_cv3w.npz')
+    c = cv3w_cfg.flow
+    sd = W.make_flow_state(c, seed=int(g['weight_seed']), init='fan_in')
+    assert state_checksum(sd) == str(g['weight_sha'])
+    tag = 'e1'                                                                  # (e0, T = 2176, is checked on the GPU box; here the short one)
+    x, mask, mu, spk, cond = cv3w_flow_inputs(int(g[tag + '_seed']), int(g[tag + '_T']), g[tag + '_lens'].tolist())
+    assert state_checksum(dict(x=x, mu=mu, spk=spk, cond=cond)) == str(g[tag + '_in_sha'])
+    est = flow_ref.dit_forward(x, mask, mu, torch.from_numpy(g[tag + '_t']), spk, cond, sd, c, streaming=bool(g[tag + '_streaming']))
+    assert np.abs((est * mask).numpy() - g[tag + '_out']).max() < 2e-4
+    emu = flow_ref.dit_forward(x, mask, mu, torch.from_numpy(g[tag + '_t']), spk, cond, sd, c, streaming=bool(g[tag + '_streaming']), emu=True)
+    rel = np.abs((emu * mask).numpy() - g[tag + '_out']).max() / np.abs(g[tag + '_out']).max()
+    assert 1e-4 < rel < 5e-2, rel
+    pla = flow_ref.pre_lookahead(torch.from_numpy(g['h0']), sd, c)
+    assert np.abs(pla.numpy() - g['pla']).max() < 1e-4
+    mel = flow_ref.flow_inference(torch.from_numpy(g['token']), torch.from_numpy(g['emb']), sd, c, prompt_token=torch.from_numpy(g['ptoken']),
+                                  prompt_feat=torch.from_numpy(g['pfeat']))
+    assert np.abs(mel.numpy() - g['mel']).max() < 5e-4
+
+
+def test_cv3w_hift_oracle_vs_reference_vectors(cv3w_cfg):
+    g = load_golden('hift_cv3w.npz')
+    c = cv3w_cfg.hift
+    sd = W.make_hift_state(c, seed=int(g['weight_seed']), init='fan_in')
+    assert state_checksum(sd) == str(g['weight_sha'])
+    for r in range(int(g['n_runs'])):
+        p = 'r%d_' % r
+        mel = torch.from_numpy(g[p + 'mel'])
+        assert np.abs(hift_ref.f0_predictor(mel, sd).numpy() - g[p + 'f0']).max() < 2e-3
+        wav = hift_ref.decode(mel, torch.from_numpy(g[p + 'source']), sd, c)
+        assert np.abs(wav.numpy() - g[p + 'wav']).max() < 5e-4
