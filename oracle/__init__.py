@@ -6,8 +6,10 @@ call, link or execute anything in this directory; only `tests/`, `__graft_entry_
 
 The reference (jingzhunxue/FlowMirror_HydraVox) is pure Python on PyTorch, so the restatement is
 plain functional fp32 PyTorch-on-CPU (no nn.Module, weights in a flat dict that uses the
-reference's own state_dict key names) plus one plain-C restatement of the integer-exact sampler
-(`ras_sampler.c`).  Each function cites the reference file:line it follows.
+reference's own state_dict key names).  Each function cites the reference file:line it follows.
+`llm_ref` / `flow_ref` also have a bf16-faithful mode (`emu=True`): the same functions with every
+operand rounded to bf16 where the product's bf16 path holds it in bf16 and fp32 accumulation — the
+yardstick for the production dtype (tests/test_gpu_cv3w.py), never the parity target.
 
 Pinning status: the reference ships no tests or golden vectors for this path
 (SURVEY.md §4), so the oracle is pinned against outputs of the reference itself, produced in the

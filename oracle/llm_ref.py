@@ -45,8 +45,24 @@ def _wb(w, gain=None):
     return hit[1]
 
 
+_PERM = {}
+
+
+def _perm(K):
+    if K not in _PERM:
+        _PERM[K] = torch.randperm(K, generator=torch.Generator().manual_seed(K))
+    return _PERM[K]
+
+
 def _lin(x, w, b=None, emu=False):
-    return F.linear(bf16r(x), _wb(w), b) if emu else F.linear(x, w, b)
+    """emu='perm': the same bf16 operands summed in another order (columns permuted) — the values are mathematically identical, the fp32
+    accumulation order is not; used to measure how far two faithful bf16 evaluations drift apart through rounding-boundary flips."""
+    if not emu:
+        return F.linear(x, w, b)
+    if emu == 'perm':
+        idx = _perm(w.shape[1])
+        return F.linear(bf16r(x)[..., idx].contiguous(), _wb(w)[:, idx].contiguous(), b)
+    return F.linear(bf16r(x), _wb(w), b)
 
 
 def _norm_lin(x, gain, eps, ws, bs, emu):
@@ -59,9 +75,49 @@ def _norm_lin(x, gain, eps, ws, bs, emu):
     inv = torch.rsqrt(xb.pow(2).mean(-1, keepdim=True) + eps)
     out = []
     for w, b in zip(ws, bs):
-        y = F.linear(xb, _wb(w, gain)) * inv
+        if emu == 'perm':
+            idx = _perm(w.shape[1])
+            y = F.linear(xb[..., idx].contiguous(), _wb(w, gain)[:, idx].contiguous()) * inv
+        else:
+            y = F.linear(xb, _wb(w, gain)) * inv
         out.append(y if b is None else y + b)
     return out
+
+
+def _attn_emu(s, vv, decode):
+    """Online-softmax attention as csrc/attention.hip walks it, so that the bf16 rounding of the probabilities happens against the same
+    running maximum: keys in steps of 32; `decode` (<= 8 new rows: the split kernel) restarts the running state every 64 keys — one wave's
+    share of a 256-key split — and merges the segments in fp32, the prefill form keeps one running state over the whole key walk.
+    s: masked scaled scores (heads, L, Lk) fp32, vv: bf16-rounded values (heads, Lk, d).  Returns o (heads, L, d) fp32, normalised."""
+    Hh, L, Lk = s.shape
+    d = vv.shape[-1]
+    ninf = float('-inf')
+    seg = 64 if decode else Lk + 32
+    M = torch.full((Hh, L, 1), ninf)
+    O = torch.zeros(Hh, L, d)
+    Ls = torch.zeros(Hh, L, 1)
+    for s0 in range(0, Lk, seg):
+        m = torch.full((Hh, L, 1), ninf)
+        o = torch.zeros(Hh, L, d)
+        l = torch.zeros(Hh, L, 1)
+        for k0 in range(s0, min(Lk, s0 + seg), 32):
+            sb = s[:, :, k0:k0 + 32]
+            m_new = torch.maximum(m, sb.amax(dim=-1, keepdim=True))
+            m_safe = torch.where(m_new == ninf, torch.zeros_like(m_new), m_new)
+            alpha = torch.where(m == ninf, torch.zeros_like(m), torch.exp(m - m_safe))
+            pb = torch.where(sb == ninf, torch.zeros_like(sb), torch.exp(sb - m_safe))
+            l = l * alpha + pb.sum(dim=-1, keepdim=True)
+            o = o * alpha + torch.matmul(bf16r(pb), vv[:, k0:k0 + 32])
+            m = m_new
+        # fp32 merge of the segment into the running total (waves of a split, then splits: attn_fwd_kernel<MERGE>, attn_combine_kernel)
+        Mn = torch.maximum(M, m)
+        Ms = torch.where(Mn == ninf, torch.zeros_like(Mn), Mn)
+        wa = torch.where(M == ninf, torch.zeros_like(M), torch.exp(M - Ms))
+        wb = torch.where(m == ninf, torch.zeros_like(m), torch.exp(m - Ms))
+        O = O * wa + o * wb
+        Ls = Ls * wa + l * wb
+        M = Mn
+    return O / Ls
 
 
 def rms_norm(x, w, eps):
@@ -112,9 +168,7 @@ def qwen2_layer(x, sd, pre, cfg, cos, sin, kv_cache=None, emu=False):
     s = s.masked_fill(~causal[None], float('-inf'))
     if emu:
         # probabilities multiply V as bf16 while the row sum keeps the fp32 values (csrc/attention.hip: attn_fwd_kernel)
-        e = torch.exp(s.float() - s.float().amax(dim=-1, keepdim=True))
-        o = torch.matmul(bf16r(e), vv) / e.sum(dim=-1, keepdim=True)
-        o = bf16r(o.transpose(0, 1).reshape(L, nq * d))
+        o = bf16r(_attn_emu(s.float(), vv, decode=L <= 8).transpose(0, 1).reshape(L, nq * d))
     else:
         p = torch.softmax(s.float(), dim=-1).to(x.dtype)
         o = torch.matmul(p, vv).transpose(0, 1).reshape(L, nq * d)
@@ -207,6 +261,10 @@ def llm_inference(sd, cfg, text, noise, prompt_text=None, prompt_speech_token=No
     steps = 0
     while len(out_tokens) < max_len:
         if use_kv_cache:
+            if emu and done_rows == 0 and lm_input.shape[0] > 1:
+                # the product prefills all but the last prefix row and feeds that row through its first decode step (llm.py: _run)
+                backbone(lm_input[:-1], sd, cfg, pos0=0, kv_cache=kv, emu=True)
+                done_rows = lm_input.shape[0] - 1
             y = backbone(lm_input[done_rows:], sd, cfg, pos0=done_rows, kv_cache=kv, emu=emu)
             done_rows = lm_input.shape[0]
         else:

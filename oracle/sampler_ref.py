@@ -9,8 +9,9 @@ generator.  For a single draw PyTorch computes `argmax(p / q)`, `q = empty_like(
 (SURVEY.md §0 finding 6), and `exponential_` on the CPU generator is stream-consistent (drawing n
 then m values equals drawing n+m).  The oracle therefore consumes an explicit Exp(1) *noise stream*:
 `NoiseStream(seed)` wraps a torch CPU generator and hands out consecutive float32 values; the HIP
-sampler consumes the very same stream from a device buffer.  tests/test_oracle_sampler.py checks
-this oracle id-for-id against the reference functions driven by `torch.manual_seed`.
+sampler consumes the very same stream from a device buffer.  tests/test_oracle_golden.py checks
+this oracle id-for-id (and draw-for-draw) against vectors minted from the reference functions driven
+by `torch.manual_seed` (tests/golden/make_golden.py: gen_sampler).
 """
 import math
 import numpy as np

@@ -98,17 +98,43 @@ def test_llm_fp32_token_streams_bit_exact_vs_reference(cfg, llm_setup):
         assert toks == g['r%d_tokens' % r].tolist(), r
 
 
+def test_llm_bf16_one_layer_is_the_bf16_oracle(cfg, llm_setup):
+    """A 1-layer model at the CV3 widths: the bf16 path and the bf16-faithful oracle round at the same points, so the hidden state agrees to
+    fp32 accumulation order (measured 2e-7 .. 7e-6) unless an intermediate lands on a bf16 rounding boundary (one such flip: ~5e-4)."""
+    import dataclasses
+    from flowmirror_hydravox_amd import weights as W
+    from oracle import llm_ref
+    g, sd2, sampling = llm_setup
+    c = dataclasses.replace(cfg.llm, layers=1)
+    sd = W.make_llm_state(c, seed=1986, init='fan_in', with_lm_head=True)
+    llm = _make_llm(dataclasses.replace(cfg, llm=c), sd, sampling, torch.bfloat16, max_batch=2, max_ctx=512)
+    llm.inference_head_num = 5
+    gen = torch.Generator().manual_seed(5)
+    errs = []
+    for n_text, n_ps in ((3, 0), (6, 0), (20, 0), (20, 100), (20, 250)):          # 5 / 8 rows: the split decode attention; more: the prefill forms
+        text = torch.randint(0, c.text_vocab, (n_text,), generator=gen, dtype=torch.int32)
+        ps = torch.randint(0, c.speech_tokens, (n_ps,), generator=gen, dtype=torch.int32)
+        logp, y = llm.prefill_logp(llm._encode_prefix(text, None, ps))
+        yo = llm_ref.backbone(llm_ref.build_prefix(sd, c, text, None, ps, emu=True), sd, c, emu=True)[-1]
+        yf = llm_ref.backbone(llm_ref.build_prefix(sd, c, text, None, ps), sd, c)[-1]
+        errs.append((_rel(y.cpu().numpy(), yo.numpy()), _rel(y.cpu().numpy(), yf.numpy())))
+    print('1 layer, bf16: hidden vs the bf16-faithful oracle %s; vs fp32 arithmetic %s' % (['%.1e' % e[0] for e in errs], ['%.1e' % e[1] for e in errs]))
+    assert max(e[0] for e in errs) < 1e-3 and sorted(e[0] for e in errs)[len(errs) // 2] < 5e-5, errs
+    assert min(e[1] for e in errs) > 1e-3                           # bf16 rounding itself is 3 orders above that
+
+
 def test_llm_bf16_teacher_forced_vs_bf16_oracle(cfg, llm_setup):
     """Production dtype against the bf16-faithful oracle, free of sampling discontinuities: the prefix is the reference's own token stream cut
     at several lengths (contexts 178..313 rows, below and above a 256-key split), hidden and the log-probs of all 5 heads are compared.
-    Tolerances: hidden 1e-2 of its scale, log-probs 3e-2 abs (measured: see DESIGN.md §3); the same quantities against the fp32 reference
-    are printed — that gap is bf16 rounding, which the oracle mode reproduces."""
+    Two bf16 evaluations of the same arithmetic differ where an fp32 intermediate sits on a bf16 rounding boundary (~5 such flips per row
+    and layer at these widths, each one bf16 ulp of one operand element); through 2 layers and the 22016-wide MTP heads that floor measures
+    <= 3e-3 of the hidden scale and <= 4e-2 in the log-probs.  Bounds: hidden 1e-2, log-probs 6e-2 (the round-1 bounds were 6e-2 / 0.25)."""
     from oracle import llm_ref
     g, sd, sampling = llm_setup
     c = cfg.llm
     llm = _make_llm(cfg, sd, sampling, torch.bfloat16, max_batch=2, max_ctx=512)
     llm.inference_head_num = 5
-    worst = [0.0, 0.0, 0.0, 0.0]
+    worst = [0.0, 0.0, 0.0]
     for r, cuts in ((1, (0, 31, 60)), (2, (0, 14, 15, 72))):
         p = 'r%d_' % r
         text, ptext, ps, toks = (torch.from_numpy(g[p + k]) for k in ('text', 'ptext', 'pspeech', 'tokens'))
@@ -120,38 +146,60 @@ def test_llm_bf16_teacher_forced_vs_bf16_oracle(cfg, llm_setup):
             lo = torch.stack(llm_ref.head_logps(yo, sd, c, c.head_num, emu=True))
             yf = llm_ref.backbone(llm_ref.build_prefix(sd, c, text, ptext, pst), sd, c)[-1]
             e = [_rel(y.cpu().numpy(), yo.numpy()), (logp.cpu() - lo).abs().max().item(), _rel(y.cpu().numpy(), yf.numpy())]
-            worst = [max(worst[0], e[0]), max(worst[1], e[1]), max(worst[2], e[2]), 0.0]
+            worst = [max(a, b) for a, b in zip(worst, e)]
             assert e[0] < 1e-2, (r, n, 'hidden vs bf16 oracle', e)
-            assert e[1] < 3e-2, (r, n, 'logp vs bf16 oracle', e)
-    print('bf16 HIP vs bf16-faithful oracle: hidden rel %.2e, logp abs %.2e; vs the fp32 reference arithmetic: hidden rel %.2e' % tuple(worst[:3]))
+            assert e[1] < 6e-2, (r, n, 'logp vs bf16 oracle', e)
+    print('bf16 HIP vs bf16-faithful oracle: hidden rel %.2e, logp abs %.2e; vs the fp32 reference arithmetic: hidden rel %.2e' % tuple(worst))
     assert worst[2] > worst[0]                      # the oracle mode explains most of the distance to fp32
 
 
-def test_llm_bf16_token_streams_vs_bf16_oracle(cfg, llm_setup):
-    """bf16 ids against the bf16-faithful oracle on the golden runs (same text / prompt / seed).  Sampling is discontinuous in the logits:
-    a draw whose two best candidates are within accumulation-order noise may flip, and everything after a flip differs, so the assertion
-    is on the common-prefix rate (>= 90 % of all tokens) and exact-stream count, both printed."""
+def test_llm_bf16_sampling_decisions_vs_bf16_oracle(cfg, llm_setup):
+    """bf16 ids against the bf16-faithful oracle.  Sampling is discontinuous in the logits: a draw whose two best candidates lie within the
+    rounding floor flips, and a free-running stream differs from there on, so the assertion is per DECISION: at every step of the oracle's
+    stream (same history, same noise position) the ids drawn from the HIP log-probs are compared with the oracle's.  The floor is known:
+    two CPU evaluations of the very same bf16 arithmetic that differ only in fp32 summation order agree on 93 % of the draws / 87 % of the
+    steps of these runs (tests/test_oracle_golden.py::test_cv3w_bf16_rounding_floor); the HIP path must do as well: >= 88 % of the draws,
+    >= 80 % of the steps.  The free-running common prefix is printed."""
     from oracle import llm_ref, sampler_ref
     g, sd, sampling = llm_setup
+    c = cfg.llm
     llm = _make_llm(cfg, sd, sampling, torch.bfloat16, max_batch=8, max_ctx=1024)
-    runs = [0, 1, 2, 5, 7, 9, 11]
-    agree = total = exact = 0
-    for r in runs:
+    same = steps = draws = draws_same = agree = total = 0
+    for r in (0, 1, 2, 9, 11):
         p = 'r%d_' % r
+        K = int(g[p + 'K'])
+        text, ptext, ps = (torch.from_numpy(g[p + k]) for k in ('text', 'ptext', 'pspeech'))
+        maxr, minr = float(g[p + 'ratios'][0]), float(g[p + 'ratios'][1])
+        trace = []
+        ora = list(llm_ref.llm_inference(sd, c, text, sampler_ref.NoiseStream(seed=int(g[p + 'seed'])), prompt_text=ptext, prompt_speech_token=ps,
+                                         inference_head_num=K, sampling=sampling, max_token_text_ratio=maxr, min_token_text_ratio=minr,
+                                         use_kv_cache=True, emu=True, trace=trace))
+        llm.inference_head_num = K
+        hist = []
+        min_len = int(len(text) * minr)
+        for st in trace:
+            def draw(logps):
+                ns = sampler_ref.NoiseStream(seed=int(g[p + 'seed']))
+                ns.cursor = st['cursor']
+                return sampler_ref.sample_step(logps, hist, ns, c.speech_tokens, min_len, sampling)
+            want = draw([lp.numpy() for lp in st['logps']])
+            logp, _ = llm.prefill_logp(llm._encode_prefix(text, ptext, torch.cat([ps, torch.tensor(hist, dtype=torch.int32)])))
+            got = draw([lp for lp in logp.cpu().numpy()])
+            same += int(got == want)
+            steps += 1
+            draws_same += sum(int(a == b) for a, b in zip(got, want))
+            draws += len(want)
+            hist += [t for t in want if t < c.speech_tokens][:max(0, len(ora) - len(hist))]
+        assert hist == ora, r
         got = _single(llm, g, r)
-        ora = list(llm_ref.llm_inference(sd, cfg.llm, torch.from_numpy(g[p + 'text']), sampler_ref.NoiseStream(seed=int(g[p + 'seed'])),
-                                         prompt_text=torch.from_numpy(g[p + 'ptext']), prompt_speech_token=torch.from_numpy(g[p + 'pspeech']),
-                                         inference_head_num=int(g[p + 'K']), sampling=sampling, max_token_text_ratio=float(g[p + 'ratios'][0]),
-                                         min_token_text_ratio=float(g[p + 'ratios'][1]), use_kv_cache=True, emu=True))
-        assert all(0 <= t < cfg.llm.speech_tokens for t in got)
         n = 0
         while n < min(len(got), len(ora)) and got[n] == ora[n]:
             n += 1
         agree += n
         total += len(ora)
-        exact += int(got == ora)
-    print('bf16 ids vs the bf16-faithful oracle: %d / %d tokens in common prefixes, %d / %d streams identical' % (agree, total, exact, len(runs)))
-    assert agree >= 0.9 * total, (agree, total)
+    print('bf16 sampling decisions equal to the bf16-faithful oracle: %d / %d draws, %d / %d steps; free-running common prefix %d / %d tokens'
+          % (draws_same, draws, same, steps, agree, total))
+    assert draws_same >= 0.88 * draws and same >= 0.80 * steps, (draws_same, draws, same, steps)
 
 
 def test_llm_32_sequences_4_heads_wide_grid_vs_oracle(cfg, llm_setup):

@@ -121,18 +121,29 @@ def test_llm_global_generator_is_left_where_the_reference_leaves_it(tiny_cfg, ll
     assert nxt == float(ns.peek(ns.cursor, 1)[0])
 
 
-@pytest.mark.parametrize('dtype,tol', [(torch.float32, 2e-4), (torch.bfloat16, 6e-2)])
-def test_llm_first_step_numerics(tiny_cfg, llm_setup, dtype, tol):
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_llm_first_step_numerics(tiny_cfg, llm_setup, dtype):
+    """fp32: hidden / log-probs of the first step == the reference's (2e-4 rel / 5e-4 abs).  bf16: against the bf16-faithful oracle
+    (oracle/llm_ref.py emu=True: same rounding points, fp32 accumulation) within 1e-2 rel / 5e-2 abs — see tests/test_gpu_cv3w.py for the
+    rounding floor that sets these."""
     from flowmirror_hydravox_amd.llm import HvxLLM
+    from oracle import llm_ref
     g, sd = llm_setup
-    llm = HvxLLM(tiny_cfg.llm, sd, dtype=dtype, max_batch=2, max_ctx=128)
+    c = tiny_cfg.llm
+    llm = HvxLLM(c, sd, dtype=dtype, max_batch=2, max_ctx=128)
     for r in range(int(g['n_runs'])):
         p = 'r%d_' % r
         llm.inference_head_num = int(g[p + 'K'])
-        enc = llm._encode_prefix(torch.from_numpy(g[p + 'text']), torch.from_numpy(g[p + 'ptext']), torch.from_numpy(g[p + 'pspeech']))
-        logp, y = llm.prefill_logp(enc)
-        assert _rel(y.cpu().numpy(), g[p + 'y_last']) < tol, (r, 'hidden')
-        assert np.abs(logp.cpu().numpy() - g[p + 'logps']).max() < (5e-4 if dtype == torch.float32 else 0.25), (r, 'logp')
+        text, ptext, ps = (torch.from_numpy(g[p + k]) for k in ('text', 'ptext', 'pspeech'))
+        logp, y = llm.prefill_logp(llm._encode_prefix(text, ptext, ps))
+        if dtype == torch.float32:
+            assert _rel(y.cpu().numpy(), g[p + 'y_last']) < 2e-4, (r, 'hidden')
+            assert np.abs(logp.cpu().numpy() - g[p + 'logps']).max() < 5e-4, (r, 'logp')
+        else:
+            yo = llm_ref.backbone(llm_ref.build_prefix(sd, c, text, ptext, ps, emu=True), sd, c, emu=True)[-1]
+            lo = torch.stack(llm_ref.head_logps(yo, sd, c, llm.head_k(), emu=True)).numpy()
+            assert _rel(y.cpu().numpy(), yo.numpy()) < 1e-2, (r, 'hidden', _rel(y.cpu().numpy(), yo.numpy()))
+            assert np.abs(logp.cpu().numpy() - lo).max() < 5e-2, (r, 'logp', np.abs(logp.cpu().numpy() - lo).max())
 
 
 def test_llm_batched_equals_single(tiny_cfg, llm_setup):
@@ -227,25 +238,33 @@ def test_llm_noise_window_refill_and_growth_do_not_change_the_ids(tiny_cfg, llm_
     assert sum(len(t) for t in got) > 20
 
 
-def test_llm_bf16_tracks_the_fp32_oracle(tiny_cfg, llm_setup):
-    """bf16 production mode: the ids agree with the fp32 oracle until the first near-tie; report the common prefix."""
+def test_llm_bf16_ids_vs_the_bf16_faithful_oracle(tiny_cfg, llm_setup):
+    """bf16 production mode, free-running ids against the bf16-faithful oracle (same text / prompt / seed).  At these toy widths (hidden 128)
+    rounding-boundary flips are rare enough for long stretches of every stream to survive (measured 56 %; asserted >= 40 % of all tokens in
+    common prefixes, and at least one stream identical end to end) (the
+    CV3-width statement, per sampling decision, is tests/test_gpu_cv3w.py::test_llm_bf16_sampling_decisions_vs_bf16_oracle)."""
     from flowmirror_hydravox_amd.llm import HvxLLM
+    from oracle import llm_ref, sampler_ref
     g, sd = llm_setup
     llm = HvxLLM(tiny_cfg.llm, sd, dtype=torch.bfloat16, max_batch=4, max_ctx=256)
-    agree = total = 0
+    agree = total = exact = 0
     for r in range(int(g['n_runs'])):
+        p = 'r%d_' % r
         toks = _run_case(llm, g, r)
-        ref = g['r%d_tokens' % r].tolist()
+        top_p, top_k, win, tau = g[p + 'sampling']
+        ref = list(llm_ref.llm_inference(sd, tiny_cfg.llm, torch.from_numpy(g[p + 'text']), sampler_ref.NoiseStream(seed=int(g[p + 'seed'])),
+                                         prompt_text=torch.from_numpy(g[p + 'ptext']), prompt_speech_token=torch.from_numpy(g[p + 'pspeech']),
+                                         inference_head_num=int(g[p + 'K']), sampling=dict(top_p=float(top_p), top_k=int(top_k), win_size=int(win), tau_r=float(tau)),
+                                         max_token_text_ratio=float(g[p + 'ratios'][0]), min_token_text_ratio=float(g[p + 'ratios'][1]), use_kv_cache=True, emu=True))
         assert all(0 <= t < tiny_cfg.llm.speech_tokens for t in toks)
         n = 0
         while n < min(len(toks), len(ref)) and toks[n] == ref[n]:
             n += 1
         agree += n
         total += len(ref)
-    print('bf16 common-prefix agreement with the reference ids: %d / %d' % (agree, total))
-    # sampling decisions are discontinuous in the logits: one flipped draw ends the common prefix, so this is a report
-    # (DESIGN.md §3), not a bit-exactness claim; bit-exact ids are asserted in fp32 mode above
-    assert agree >= 1
+        exact += int(toks == ref)
+    print('bf16 ids vs the bf16-faithful oracle: %d / %d tokens in common prefixes, %d / %d streams identical' % (agree, total, exact, int(g['n_runs'])))
+    assert agree >= 0.4 * total and exact >= 1, (agree, total, exact)
 
 
 # ------------------------------------------------------------------------------------------------------------------------
@@ -284,7 +303,18 @@ def test_flow_stages_vs_reference(tiny_cfg, flow_setup, dtype, tol):
                                 prompt_feat=torch.from_numpy(g[p + 'pfeat']).to(DEV) if has_p else None,
                                 prompt_feat_len=torch.tensor([2 * ptoken.shape[1]], dtype=torch.int32) if has_p else None)
         assert mel.dtype == torch.float32 and tuple(mel.shape) == g[p + 'mel'].shape
-        assert _rel(mel.cpu().numpy(), g[p + 'mel']) < (tol if dtype == torch.float32 else 0.15), (r, 'mel', _rel(mel.cpu().numpy(), g[p + 'mel']))
+        if dtype == torch.float32:
+            assert _rel(mel.cpu().numpy(), g[p + 'mel']) < tol, (r, 'mel', _rel(mel.cpu().numpy(), g[p + 'mel']))
+        else:
+            # production dtype: against the bf16-faithful oracle (same rounding points), 2e-2 for the estimator and the 10-step mel
+            from oracle import flow_ref
+            o_est = flow_ref.dit_forward(torch.from_numpy(g[p + 'est_x']), torch.ones(2, 1, T), torch.from_numpy(g[p + 'est_mu']), torch.from_numpy(g[p + 'est_t']),
+                                         torch.from_numpy(g[p + 'est_spk']), torch.from_numpy(g[p + 'est_cond']), sd, tiny_cfg.flow, emu=True)
+            o_mel = flow_ref.flow_inference(token, torch.from_numpy(g[p + 'emb']), sd, tiny_cfg.flow, prompt_token=ptoken if has_p else None,
+                                            prompt_feat=torch.from_numpy(g[p + 'pfeat']) if has_p else None, emu=True)
+            e = [_rel(est.cpu().numpy(), o_est.numpy()), _rel(mel.cpu().numpy(), o_mel.numpy()), _rel(mel.cpu().numpy(), g[p + 'mel'])]
+            print('bf16 flow run %d: estimator %.2e, mel %.2e of the bf16-faithful oracle; mel %.2e of the fp32 reference' % (r, *e))
+            assert e[0] < 2e-2 and e[1] < 2e-2, (r, e)
 
 
 def test_flow_estimator_key_padding_mask(tiny_cfg, flow_setup):
