@@ -141,13 +141,27 @@ def main():
         from flowmirror_hydravox_amd.config import cv3_config, tiny_config
         print(json.dumps(cpu_baseline(tiny_config() if args.tiny else cv3_config(), 1986, args.chars, args.heads)))
         return
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` starts its own ranks, one process per GPU over RCCL, as the reference starts one worker per GPU
+        # (server/worker.py:104-127); under torch.distributed.run the environment is already there and this branch is skipped
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+               '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))).returncode)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node %d, or without torch.distributed.run)' % (args.gpus, world, args.gpus))
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        assert dist.get_world_size() == args.gpus and dist.get_backend() == 'nccl'        # "nccl" is RCCL on ROCm
     else:
         torch.cuda.set_device(0)
     from flowmirror_hydravox_amd import _lib, cv3_config, tiny_config

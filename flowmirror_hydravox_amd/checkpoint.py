@@ -16,6 +16,7 @@ Two things the reference does around its `.pt` files, restated for this build:
 import dataclasses
 import hashlib
 import json
+import logging
 import os
 
 import torch
@@ -24,6 +25,8 @@ import torch
 PACK_LAYOUT = 'hvx-pack-4'
 
 QWEN2_DEFAULT_INTERMEDIATE = 22016         # Qwen2Config() default used by the graft script (and by mtp_block, llm_multi_head_v3.py:657-665)
+
+logger = logging.getLogger('hvx.checkpoint')
 
 
 def graft_mtp_heads(state_dict, head_num=5, mtp_head_num=14, seed=1986, intermediate_size=QWEN2_DEFAULT_INTERMEDIATE):
@@ -128,7 +131,10 @@ def load_packed(model, path, source=None):
                 raise ValueError('packed file %s: %s is %r, this model needs %r' % (path, k, meta.get(k), v))
         if source is not None and meta.get('source') != source:
             raise ValueError('packed file %s was made from another checkpoint' % path)
-        n = int(meta['n'])
+        n = int(meta.get('n', -1))
+        keys = set(f.keys())
+        if n <= 0 or any('w%04d' % i not in keys for i in range(n)):
+            raise ValueError('packed file %s is incomplete (%d tensors announced, %d present)' % (path, n, len(keys)))
         ws = [f.get_tensor('w%04d' % i) for i in range(n)]
     return model.load_packed(ws)
 
@@ -143,8 +149,11 @@ def load_or_pack(model, pt_path, cache_dir, loader):
         try:
             load_packed(model, cache, source=src)
             return 'cache'
-        except ValueError:
-            pass
+        except Exception as e:          # stale / truncated / foreign file, or the native layer rejecting its contents: repack from the .pt
+            logger.warning('packed cache %s unusable (%s: %s); repacking from %s', cache, type(e).__name__, e, pt_path)
     model.load_state_dict(loader(pt_path))
-    save_packed(model, cache, source=src)
+    try:
+        save_packed(model, cache, source=src)
+    except Exception as e:              # a read-only or full cache directory must not fail the load
+        logger.warning('could not write packed cache %s (%s: %s)', cache, type(e).__name__, e)
     return 'packed'

@@ -25,9 +25,21 @@ struct hvx_flow {
     std::vector<const void*> w;
     // adaLN modulation cache for the CFG-2 solver: the Euler t-grid is a constant of the model (flow_matching.py:225-227),
     // so the 22 x 6D + 2D modulation vectors of each step are computed once and reused by every later utterance.
+    // A slot is registered only AFTER the launches that fill it have been enqueued without error (a failed solve must not leave a
+    // "valid" slot of garbage behind), and carries the event recorded behind those launches: a hit on another stream waits for it.
     float* mod_cache = nullptr;
     int mod_slots = 0;
-    std::vector<float> mod_t;
+    struct ModSlot {
+        float t;
+        hipStream_t s;
+        hipEvent_t ev;
+    };
+    std::vector<ModSlot> mod_t;
+    void drop_mods() {
+        for (auto& m : mod_t)
+            if (m.ev) hipEventDestroy(m.ev);
+        mod_t.clear();
+    }
     size_t mod_slot_floats() const { return (size_t)c.depth * 2 * 6 * c.dim + (size_t)2 * 2 * c.dim; }
 };
 
@@ -288,7 +300,10 @@ int hvx_flow_create(const hvx_flow_config* cfg, const void* const* weights, int3
     *out = h;
     return 0;
 }
-void hvx_flow_destroy(hvx_flow* h) { delete h; }
+void hvx_flow_destroy(hvx_flow* h) {
+    if (h) h->drop_mods();
+    delete h;
+}
 
 size_t hvx_flow_workspace_bytes(const hvx_flow* h, int32_t batch, int32_t t) {
     EstBufs b;
@@ -358,7 +373,7 @@ int hvx_flow_set_mod_cache(hvx_flow* h, void* buf, size_t bytes) {
     if (!h) return set_error("hvx_flow_set_mod_cache: null handle"), -1;
     h->mod_cache = (float*)buf;
     h->mod_slots = buf ? (int)(bytes / (h->mod_slot_floats() * 4)) : 0;
-    h->mod_t.clear();
+    h->drop_mods();
     return 0;
 }
 
@@ -367,6 +382,9 @@ int hvx_cfm_solve_streaming(hvx_flow* h, hvx_stream stream, void* ws, size_t ws_
     hipStream_t s = (hipStream_t)stream;
     if (static_chunk_size < 0) return set_error("hvx_cfm_solve: negative chunk size"), -1;
     const hvx_flow_config& c = h->c;
+    // everything that can be refused is refused before any state (workspace, modulation cache) is touched
+    if (T <= 0 || T > c.max_t) return set_error("hvx_cfm_solve: T=%d outside (0, max_t=%d]", T, c.max_t), -1;
+    if (n_steps <= 0 || !x || !mu || !spks || !cond || !t_steps || !dt_steps) return set_error("hvx_cfm_solve: bad arguments"), -1;
     EstBufs b;
     if (carve_est(c, (char*)ws, 2, T, b) > ws_bytes) return set_error("hvx_cfm_solve: workspace too small"), -1;
     const size_t plane = (size_t)c.mel * T * 4;
@@ -381,17 +399,16 @@ int hvx_cfm_solve_streaming(hvx_flow* h, hvx_stream stream, void* ws, size_t ws_
         HIP_OK(hipMemcpyAsync(b.x_in, x, plane, hipMemcpyDeviceToDevice, s));
         HIP_OK(hipMemcpyAsync((char*)b.x_in + plane, x, plane, hipMemcpyDeviceToDevice, s));
         bool hit = false;
+        int fill_slot = -1;
         float* ws_mods = b.mods;
         float* ws_fmod = b.fmod;
         if (h->mod_cache) {
             int slot = -1;
             for (size_t e = 0; e < h->mod_t.size(); ++e)
-                if (memcmp(&h->mod_t[e], &t_steps[st], 4) == 0) slot = (int)e;
+                if (memcmp(&h->mod_t[e].t, &t_steps[st], 4) == 0) slot = (int)e;
             hit = slot >= 0;
-            if (!hit && (int)h->mod_t.size() < h->mod_slots) {
-                slot = (int)h->mod_t.size();
-                h->mod_t.push_back(t_steps[st]);
-            }
+            if (hit && h->mod_t[slot].s != s) HIP_OK(hipStreamWaitEvent(s, h->mod_t[slot].ev, 0));     // filled on another stream
+            if (!hit && (int)h->mod_t.size() < h->mod_slots) slot = fill_slot = (int)h->mod_t.size();
             if (slot >= 0) {
                 b.mods = h->mod_cache + (size_t)slot * h->mod_slot_floats();
                 b.fmod = b.mods + (size_t)c.depth * 2 * 6 * c.dim;
@@ -402,6 +419,14 @@ int hvx_cfm_solve_streaming(hvx_flow* h, hvx_stream stream, void* ws, size_t ws_
         b.mods = ws_mods;
         b.fmod = ws_fmod;
         if (rc) return -1;
+        if (fill_slot >= 0) {                      // the slot's contents are enqueued: register it, with the event a reader on another stream waits for
+            hvx_flow::ModSlot m{t_steps[st], s, nullptr};
+            if (hipEventCreateWithFlags(&m.ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(m.ev, s) != hipSuccess) {
+                if (m.ev) hipEventDestroy(m.ev);
+                return set_error("hvx_cfm_solve: event for the modulation cache failed"), -1;
+            }
+            h->mod_t.push_back(m);
+        }
         HVX_CHECK(launch_cfg_euler(x, b.outrow, c.mel, (long long)T * c.mel, dt_steps[st], c.cfg_rate, T, c.mel, s));
     }
     return 0;

@@ -25,10 +25,11 @@ def shard_by_cost(costs: Sequence[float], world: int) -> List[List[int]]:
     return [sorted(s) for s in shards]
 
 
-def gather_waveforms(wavs: List[torch.Tensor], global_ids: List[int], dst: int = 0, group=None):
+def gather_waveforms(wavs: List[torch.Tensor], global_ids: List[int], dst: int = 0, group=None, shortcut_single: bool = True):
     """Every rank passes its finished waveforms (1-D float32 tensors on its device) with their global utterance ids.
-    Rank `dst` returns {global_id: waveform}; the others return {}.  Works on RCCL ("nccl") and gloo."""
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    Rank `dst` returns {global_id: waveform}; the others return {}.  Works on RCCL ("nccl") and gloo.
+    `shortcut_single=False` runs the collectives even in a group of one (the 1-GPU RCCL test)."""
+    if not dist.is_available() or not dist.is_initialized() or (shortcut_single and dist.get_world_size(group) == 1):
         return dict(zip(global_ids, wavs))
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     dev = wavs[0].device if wavs else torch.device('cuda' if dist.get_backend(group) == 'nccl' else 'cpu')

@@ -120,7 +120,7 @@ class HvxFlow:
         self._h = h
         # adaLN modulation cache: one slot per distinct Euler step time (the t-grid is a model constant)
         slot = (c.depth * 2 * 6 * c.dim + 2 * 2 * c.dim) * 4
-        self._mod_cache = torch.empty(16 * slot, dtype=torch.uint8, device=dev)
+        self._mod_cache = torch.zeros(16 * slot, dtype=torch.uint8, device=dev)
         check(self.lib.hvx_flow_set_mod_cache(self._h, ptr(self._mod_cache), self._mod_cache.numel()), 'hvx_flow_set_mod_cache')
         return self
 

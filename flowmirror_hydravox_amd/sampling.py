@@ -55,8 +55,15 @@ class NoiseStream:
         if generator is None and seed is not None:
             generator = torch.Generator()
             generator.manual_seed(int(seed))
-        self.gen = generator            # None -> torch's global CPU generator, exactly what the reference uses
-        self._state0 = torch.get_rng_state() if generator is None else generator.get_state()
+        # seed None / generator None: the reference draws from torch's GLOBAL CPU generator.  The read-ahead below must not disturb it (other
+        # threads may use it, and an abandoned utterance must leave it untouched), so the values come from a private fork of its current
+        # state — the same stream — and `finalize` advances the global generator by exactly the number of values the utterance consumed.
+        self._global = generator is None
+        if self._global:
+            generator = torch.Generator()
+            generator.set_state(torch.get_rng_state())
+        self.gen = generator
+        self._state0 = generator.get_state()
         self._pos0 = 0                  # absolute stream position of _state0
         self.chunk = chunk
         self.buf = np.empty(0, dtype=np.float32)
@@ -76,15 +83,14 @@ class NoiseStream:
 
     def finalize(self, consumed):
         """Leave the generator exactly where the reference would have left it: rewind the read-ahead and draw
-        the `consumed` values the utterance really used."""
-        if self.gen is None:
-            torch.set_rng_state(self._state0)
-        else:
-            self.gen.set_state(self._state0)
+        the `consumed` values the utterance really used (from the global generator too when the stream was forked from it)."""
+        self.gen.set_state(self._state0)
         n = int(consumed) - self._pos0
         if n > 0:
             torch.empty(n, dtype=torch.float32).exponential_(1.0, generator=self.gen)
+            if self._global:
+                torch.empty(n, dtype=torch.float32).exponential_(1.0)
         self.buf = np.empty(0, dtype=np.float32)
         self.base = int(consumed)
-        self._state0 = torch.get_rng_state() if self.gen is None else self.gen.get_state()
+        self._state0 = self.gen.get_state()
         self._pos0 = int(consumed)

@@ -21,6 +21,15 @@ def _env_flag(name, default=False):
     return raw.strip().lower() in {'1', 'true', 'yes', 'on'}
 
 
+def _text_normaliser():
+    """the reference worker's `fmtn` normaliser (server/worker.py:46-52, 72-88); identity when the proprietary wheel is absent"""
+    try:
+        from fmtn import create_default_tn
+        return create_default_tn(verbose=True).process_text
+    except Exception:
+        return lambda s: s
+
+
 def worker_process_tts(num_workers_gpu, task_queue, result_dict, worker_id, frontend_factory=None):
     os.environ['CUDA_VISIBLE_DEVICES'] = str(worker_id % num_workers_gpu)
     from .model_manager import HvxModelManager, text_to_speech, inference_zero_shot
@@ -30,12 +39,7 @@ def worker_process_tts(num_workers_gpu, task_queue, result_dict, worker_id, fron
     args = argparse.Namespace(config=os.getenv('TTS_CONFIG'), model_dir=os.getenv('TTS_MODEL_DIR'), bf16=_env_flag('TTS_BF_16'),
                               fp16=_env_flag('TTS_FP_16'), cpu=_env_flag('TTS_CPU', False))
     model_manager.load_models(args)
-    try:
-        from fmtn import create_default_tn
-        tn = create_default_tn(verbose=True)
-        normalise = tn.process_text
-    except Exception:
-        normalise = lambda s: s                                # noqa: E731
+    normalise = _text_normaliser()
     while True:
         task = task_queue.get()
         if task is None:
@@ -77,6 +81,7 @@ def worker_process_tts_batched(num_workers_gpu, task_queue, result_dict, worker_
     mm = HvxModelManager(frontend_factory=frontend_factory)
     mm.load_models(argparse.Namespace(config=os.getenv('TTS_CONFIG'), model_dir=os.getenv('TTS_MODEL_DIR'), bf16=_env_flag('TTS_BF_16'),
                                       fp16=_env_flag('TTS_FP_16'), cpu=_env_flag('TTS_CPU', False)))
+    normalise = _text_normaliser()                  # the same normaliser as worker_process_tts, in the batched and the one-by-one path
     pending = []
     stop = False
     while not stop:
@@ -90,8 +95,9 @@ def worker_process_tts_batched(num_workers_gpu, task_queue, result_dict, worker_
         if any(t is None for t in pending):
             stop = True
             pending = [t for t in pending if t is not None]
-        batch, rest = group_batchable(pending)
-        pending = []
+        # the leading run of batchable tasks is decoded together; what follows the first task that cannot join (a load_pt, other sampling
+        # parameters) waits for the next round, so arrival order around a hot swap is what the reference's one-by-one loop gives
+        batch, rest, pending = group_batchable(pending)
         if len(batch) > 1:
             try:
                 apply_extra_params(mm, batch[0], ras_sampling)
@@ -99,11 +105,11 @@ def worker_process_tts_batched(num_workers_gpu, task_queue, result_dict, worker_
                 inputs, zs = [], []
                 for t in batch:
                     if t['task_type'] == 'tts':
-                        inputs.append(fe.frontend_sft(fe.text_normalize(t['text'], split=True, text_frontend=True)[0], t['speaker_id']))
+                        inputs.append(fe.frontend_sft(fe.text_normalize(normalise(t['text']), split=True, text_frontend=True)[0], t['speaker_id']))
                         zs.append(False)
                     else:
-                        p_text = fe.text_normalize(t.get('prompt_text', ''), split=False, text_frontend=True)
-                        inputs.append(fe.frontend_zero_shot(fe.text_normalize(t['tts_text'], split=True, text_frontend=True)[0], p_text,
+                        p_text = fe.text_normalize(normalise(t.get('prompt_text', '')), split=False, text_frontend=True)
+                        inputs.append(fe.frontend_zero_shot(fe.text_normalize(normalise(t['tts_text']), split=True, text_frontend=True)[0], p_text,
                                                             (t['prompt_audio'], t['prompt_sample_rate']), mm.configs['sample_rate'], zero_shot_spk_id=''))
                         zs.append(True)
                 speeds = [float(t.get('extra_params', {}).get('speed', 1.0)) for t in batch]
@@ -120,11 +126,11 @@ def worker_process_tts_batched(num_workers_gpu, task_queue, result_dict, worker_
             try:
                 speed = apply_extra_params(mm, t, ras_sampling)
                 if t['task_type'] == 'zero_shot':
-                    out = inference_zero_shot(mm, t['tts_text'], t.get('prompt_text', ''), t['prompt_audio'], t['prompt_sample_rate'], speed=speed)
+                    out = inference_zero_shot(mm, normalise(t['tts_text']), normalise(t.get('prompt_text', '')), t['prompt_audio'], t['prompt_sample_rate'], speed=speed)
                     sr = mm.configs['sample_rate']
                     result = {'output_audio': out, 'sample_rate': sr, 'format': t.get('output_format', 'wav'), 'duration': out.shape[-1] / sr}
                 elif t['task_type'] == 'tts':
-                    result = text_to_speech(mm, t['text'], t['speaker_id'], speed=speed)
+                    result = text_to_speech(mm, normalise(t['text']), t['speaker_id'], speed=speed)
                 elif t['task_type'] == 'load_pt':
                     result = mm.load_pt(t['llm_pt'], t['flow_pt'])
                 else:
@@ -136,19 +142,22 @@ def worker_process_tts_batched(num_workers_gpu, task_queue, result_dict, worker_
 
 
 def group_batchable(tasks):
-    """-> (tasks that can be decoded together, the others in arrival order): synthesis tasks whose sampling parameters equal those of the
-    first synthesis task (llm.sampling / inference_head_num are per-model state, server/worker.py:57-65)"""
+    """-> (batch, singles, later): `batch` = the leading run of synthesis tasks with the same sampling parameters (llm.sampling /
+    inference_head_num are per-model state, server/worker.py:57-65); when the head of the queue cannot be batched (load_pt, unknown type) it
+    is returned alone in `singles`; `later` = everything behind the first task that does not join, in arrival order — FIFO is kept, a
+    load_pt is never overtaken by requests that arrived after it."""
     def key(t):
         ep = t.get('extra_params') or {}
         return tuple(ep.get(k) for k in ('top_p', 'top_k', 'win_size', 'tau_r', 'inference_head_num'))
-    batch, rest, k0 = [], [], None
-    for t in tasks:
-        if t.get('task_type') in ('tts', 'zero_shot') and (k0 is None or key(t) == k0):
-            k0 = key(t)
-            batch.append(t)
-        else:
-            rest.append(t)
-    return batch, rest
+    if not tasks:
+        return [], [], []
+    if tasks[0].get('task_type') not in ('tts', 'zero_shot'):
+        return [], [tasks[0]], list(tasks[1:])
+    k0 = key(tasks[0])
+    n = 1
+    while n < len(tasks) and tasks[n].get('task_type') in ('tts', 'zero_shot') and key(tasks[n]) == k0:
+        n += 1
+    return list(tasks[:n]), [], list(tasks[n:])
 
 
 def apply_extra_params(mm, task, ras_sampling):

@@ -623,3 +623,28 @@ def test_smallest_inputs_vs_oracle(tiny_cfg, flow_setup, hift_setup):
         assert _rel(wav.numpy(), o_wav[0].numpy()) < 1e-3, (T, _rel(wav.numpy(), o_wav[0].numpy()))
         wav2, s2 = hift.inference(speech_feat=mel.to(DEV))
         assert tuple(wav2.shape) == (1, 480 * T) and (s2.cpu() - o_s).abs().max() < 2e-3
+
+
+def test_waveform_gather_over_rccl_one_rank():
+    """the hand-off collective of dp.gather_waveforms on the RCCL ("nccl") backend with a group of one GPU: count all_gather + meta all_gather
+    run on the device (the fan-in send/recv needs more than one GPU and is covered by the gloo world-size-2 test on the CPU)"""
+    import os
+    import socket
+    import torch.distributed as dist
+    from flowmirror_hydravox_amd.dp import gather_waveforms
+    if dist.is_initialized():
+        pytest.skip('a process group already exists in this process')
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        assert dist.get_backend() == 'nccl'
+        wavs = [torch.randn(n, device=DEV) for n in (4800, 0, 960)]
+        got = gather_waveforms(wavs, [7, 3, 5], dst=0, shortcut_single=False)
+        assert sorted(got) == [3, 5, 7]
+        for gid, w in zip([7, 3, 5], wavs):
+            assert got[gid].device.type == 'cuda' and torch.equal(got[gid], w)
+    finally:
+        dist.destroy_process_group()

@@ -239,10 +239,18 @@ def test_batching_worker_groups_tasks_by_sampling_parameters():
              dict(id=3, task_type='zero_shot', tts_text='b', extra_params=dict(ep)),
              dict(id=4, task_type='tts', text='c', speaker_id='s', extra_params=dict(ep, top_k=10)),
              dict(id=5, task_type='tts', text='d', speaker_id='s', extra_params=dict(ep))]
-    batch, rest = group_batchable(tasks)
-    assert [t['id'] for t in batch] == [1, 3, 5] and [t['id'] for t in rest] == [2, 4]
-    batch, rest = group_batchable([dict(id=9, task_type='load_pt')])
-    assert batch == [] and len(rest) == 1
+    # FIFO around a hot swap (reference: one task at a time, server/worker.py:54-102): only the LEADING run of compatible synthesis tasks is
+    # decoded together; the load_pt that arrived second is never overtaken by tasks 3..5
+    batch, singles, later = group_batchable(tasks)
+    assert [t['id'] for t in batch] == [1] and singles == [] and [t['id'] for t in later] == [2, 3, 4, 5]
+    batch, singles, later = group_batchable(later)
+    assert batch == [] and [t['id'] for t in singles] == [2] and [t['id'] for t in later] == [3, 4, 5]
+    batch, singles, later = group_batchable(later)
+    assert [t['id'] for t in batch] == [3] and [t['id'] for t in later] == [4, 5]          # task 4 has another top_k
+    same = [dict(id=i, task_type='tts', text='x', speaker_id='s', extra_params=dict(ep)) for i in range(4)]
+    batch, singles, later = group_batchable(same + [dict(id=9, task_type='load_pt')])
+    assert [t['id'] for t in batch] == [0, 1, 2, 3] and singles == [] and [t['id'] for t in later] == [9]
+    assert group_batchable([]) == ([], [], [])
 
 
 def test_stream_tts_chunk_schedule_matches_the_reference_loop():
