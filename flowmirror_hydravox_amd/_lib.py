@@ -110,6 +110,7 @@ SYMBOLS = {
     'hvx_llm_bind': (c_i32, [c_vp, c_vp, c_sz, c_i32, c_i32, c_vp, c_sz, c_i32, c_i32, c_vp]),
     'hvx_llm_forward': (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp]),
     'hvx_llm_decode_steps': (c_i32, [c_vp, c_vp, C.POINTER(DecodeArgs), c_i32]),
+    'hvx_llm_decode_join': (c_i32, [c_vp, c_vp, C.POINTER(DecodeArgs), c_i32, c_i32, c_i32, c_i32, c_i32]),
     'hvx_llm_use_graph': (c_i32, [c_vp, c_i32]),
     'hvx_llm_last_hidden': (c_i32, [c_vp, c_vp, c_i32, c_vp]),
     'hvx_flow_create': (c_i32, [C.POINTER(FlowConfig), C.POINTER(c_vp), c_i32, C.POINTER(c_vp)]),

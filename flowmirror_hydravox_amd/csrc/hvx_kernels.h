@@ -211,6 +211,7 @@ struct AdvanceArgs {
     int* out_tokens;                        // [n_seq][max_out]
 };
 int launch_decode_advance(const AdvanceArgs& a, hipStream_t s);
+int launch_decode_join(const AdvanceArgs& a, long long* cursor, int slot, int first_tok, int pos, int min_len, int max_len, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------
 // HiFT source / STFT / iSTFT

@@ -305,6 +305,19 @@ int hvx_llm_decode_steps(hvx_llm* h, hvx_stream stream, const hvx_decode_args* a
     return 0;
 }
 
+int hvx_llm_decode_join(hvx_llm* h, hvx_stream stream, const hvx_decode_args* a, int32_t slot, int32_t first_tok, int32_t pos,
+                        int32_t min_len, int32_t max_len) {
+    if (!h || !h->ws || !a) return set_error("hvx_llm_decode_join: handle not bound / null argument"), -1;
+    if (slot < 0 || slot >= a->n_seq || slot >= h->n_slots || pos < 0 || pos + 1 > h->max_ctx || !a->cursor)
+        return set_error("hvx_llm_decode_join: slot %d / position %d outside the bound grid", slot, pos), -1;
+    AdvanceArgs aa;
+    memset(&aa, 0, sizeof(aa));
+    aa.n_seq = a->n_seq; aa.head_k = a->head_k; aa.win_cap = a->win_cap; aa.max_out = a->max_out; aa.speech_tokens = h->c.speech_tokens;
+    aa.ids = a->ids; aa.tok = a->tok; aa.ctrl = a->ctrl; aa.hist = a->hist; aa.hist_len = a->hist_len; aa.min_adj = a->min_adj; aa.active = a->active;
+    aa.seq_state = a->seq_state; aa.out_tokens = a->out_tokens;
+    return launch_decode_join(aa, (long long*)a->cursor, slot, first_tok, pos, min_len, max_len, (hipStream_t)stream);
+}
+
 int hvx_llm_use_graph(hvx_llm* h, int32_t enable) {
     if (!h) return set_error("hvx_llm_use_graph: null handle"), -1;
     h->use_graph = enable != 0;

@@ -326,6 +326,31 @@ __global__ void decode_advance_kernel(AdvanceArgs a) {
     st[2] = done;
 }
 
+// A new sequence takes over slot i of a running decode grid (continuous batching): what the host-side set-up of a batch writes for
+// every sequence, for one slot, ordered on the stream between two steps.  Its prefix but the last row is already in the slot's KV cache.
+__global__ void decode_join_kernel(AdvanceArgs a, long long* cursor, int i, int first_tok, int pos, int min_len, int max_len) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int K = a.head_k;
+    a.tok[i * K] = first_tok;
+    for (int j = 1; j < K; ++j) a.tok[i * K + j] = -1;
+    a.ctrl[0 * a.n_seq + i] = i;
+    a.ctrl[1 * a.n_seq + i] = pos;
+    a.ctrl[2 * a.n_seq + i] = 1;
+    a.ctrl[3 * a.n_seq + i] = pos + 1;
+    a.ctrl[4 * a.n_seq + i] = i * K;
+    a.hist_len[i] = 0;
+    a.min_adj[i] = min_len;
+    a.active[i] = 1;
+    int* st = a.seq_state + i * 8;
+    st[0] = pos; st[1] = 0; st[2] = 0; st[3] = min_len; st[4] = max_len; st[5] = 0; st[6] = 0; st[7] = 0;
+    cursor[i] = 0;
+}
+
+int launch_decode_join(const AdvanceArgs& a, long long* cursor, int slot, int first_tok, int pos, int min_len, int max_len, hipStream_t s) {
+    hipLaunchKernelGGL(decode_join_kernel, dim3(1), dim3(64), 0, s, a, cursor, slot, first_tok, pos, min_len, max_len);
+    return hipGetLastError() == hipSuccess ? 0 : (set_error("decode_join launch failed"), -1);
+}
+
 int launch_decode_advance(const AdvanceArgs& a, hipStream_t s) {
     if (a.n_seq <= 0) return 0;
     hipLaunchKernelGGL(decode_advance_kernel, dim3((a.n_seq + 63) / 64), dim3(64), 0, s, a);

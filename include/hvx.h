@@ -164,6 +164,14 @@ typedef struct {
     const int64_t* noise_limit;   /* [n_seq] absolute positions up to which the noise ring is filled (the caller tops it up while steps run) */
 } hvx_decode_args;
 int hvx_llm_decode_steps(hvx_llm* h, hvx_stream s, const hvx_decode_args* a, int32_t n_steps);
+/* Continuous batching — the batching scheduler SURVEY.md §8(f) N1 asks for in place of the reference's one-request-at-a-time worker loop
+ * (server/worker.py:54-102): between two hvx_llm_decode_steps calls on the same stream a new sequence takes over slot `slot` of the grid
+ * described by `a` (a finished sequence's slot, or one that was never used).  The caller has prefilled all but the last prefix row into
+ * that slot's KV cache (hvx_llm_forward with ctrl = {slot, 0, n, n, n - 1}, head_k = 0) and has put the sequence's noise at position 0 of
+ * the slot's ring; this call writes the slot's decode state: first_tok = the last prefix row, pos = rows already cached, the length
+ * limits, an empty repetition window, cursor 0, active. */
+int hvx_llm_decode_join(hvx_llm* h, hvx_stream s, const hvx_decode_args* a, int32_t slot, int32_t first_tok, int32_t pos,
+                        int32_t min_len, int32_t max_len);
 /* debugging / parity: copy the post-final-norm hidden of the last rows of the previous forward (fp32 [n_seq][H]) */
 int hvx_llm_last_hidden(hvx_llm* h, hvx_stream s, int32_t n_seq, float* out);
 
