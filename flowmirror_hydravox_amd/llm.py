@@ -247,224 +247,42 @@ class HvxLLM:
     # engine
     # ------------------------------------------------------------------------------------------------------------
     def _run(self, reqs, stream_first, sync_every=None):
-        """Generator over the tokens of request 0 (stream_first) that drives all requests to completion.
-        Device work runs on a private stream (hipGraph capture is illegal on the legacy default stream); nothing
-        stays selected as torch's current stream across a yield."""
-        import time
-        c = self.cfg
-        S = len(reqs)
-        K = self.head_k()
-        sp = sampling_params(self.sampling)
-        thr = rep_threshold(sp['win_size'], sp['tau_r'])
-        dev = self.device
-        longest = max(len(r.prefix) for r in reqs)
-        need_ctx = max(len(r.prefix) + r.max_len + K for r in reqs)
-        if need_ctx > self.max_ctx:
-            raise ValueError('context %d exceeds max_ctx=%d' % (need_ctx, self.max_ctx))
-        if getattr(self, '_stream', None) is None:
-            self._stream = torch.cuda.Stream(device=dev, priority=-1)       # decode launches go ahead of a concurrent acoustic stage
-        stream = self._stream
-        stream.wait_stream(torch.cuda.current_stream())
-        t_start = time.time()
-        W = sp['win_size'] if sp['win_size'] > 0 else max(r.max_len for r in reqs)
-        W = max(W, 1)
-        if sync_every is None:
-            sync_every = 4 if stream_first else 8          # steps enqueued per host round trip (tokens surface in bursts of this many steps)
-        d = type('DecodeState', (), {})()
-        with torch.cuda.stream(stream):
-            self._bind(S, max(longest, S * K))
-            # ---- prefill: everything but the last prefix row, one utterance at a time (kn = its length) --------------------
-            for i, r in enumerate(reqs):
-                n = len(r.prefix) - 1
-                if n > 0:
-                    tok = torch.tensor(r.prefix[:n], dtype=torch.int32, device=dev)
-                    ctrl = torch.tensor([i, 0, n, n, n - 1], dtype=torch.int32, device=dev)
-                    self._forward(1, n, tok, ctrl, 0, None)
-                r.pos = n
-                r.next = [r.prefix[-1]]
-            # ---- decode state (fixed device addresses: the step graph is captured once and replayed) ---------------------------
-            # The loop itself lives on the device (hvx_llm_decode_steps): forward, sampling of the K heads and the bookkeeping the
-            # reference does in Python between two steps (accept / append / stop, llm_multi_head_v3.py:890-905) are one graph per
-            # step, `sync_every` steps are enqueued per host round trip and only the per-sequence state words come back.
-            max_trials = 100
-            ncap = self.noise_cap          # a sequence that runs out of noise stalls on the device until the host refills (below)
-            max_out = max(max(r.max_len for r in reqs), 1)
-            o_tok, o_ctrl, o_hist = 0, S * K, S * K + 5 * S
-            o_hlen, o_min, o_act = o_hist + S * W, o_hist + S * W + S, o_hist + S * W + 2 * S
-            o_state, o_ids = o_act + S, o_act + S + 8 * S
-            n_ctl = o_ids + S * K
-            ctl_host = torch.zeros(n_ctl, dtype=torch.int32).pin_memory()
-            ch = ctl_host.numpy()
-            ch[o_tok:o_tok + S * K] = -1
-            for i, r in enumerate(reqs):
-                ch[o_tok + i * K] = r.next[0]
-                ch[o_ctrl + 0 * S + i] = i
-                ch[o_ctrl + 1 * S + i] = r.pos
-                ch[o_ctrl + 2 * S + i] = 1
-                ch[o_ctrl + 3 * S + i] = r.pos + 1
-                ch[o_ctrl + 4 * S + i] = i * K
-                ch[o_min + i] = r.min_len
-                ch[o_act + i] = 1
-                ch[o_state + 8 * i:o_state + 8 * i + 5] = [r.pos, 0, 0, r.min_len, r.max_len]
-            ctl_dev = ctl_host.to(dev, non_blocking=True)
-            out_dev = torch.zeros(S, max_out, dtype=torch.int32, device=dev)
-            logp = torch.empty(S, K, c.vocab, dtype=torch.float32, device=dev)
-            # Exp(1) noise: a ring of `ncap` values per sequence addressed by ABSOLUTE stream position; the host tops it up behind the
-            # device cursor while the steps run (no stop-the-world refill)
-            d.ncap = ncap
-            d.noise_dev = torch.empty(S, d.ncap, dtype=torch.float32, device=dev)
-            d.head = [0] * S                     # absolute position up to which sequence i's ring is filled
-            d.limit_dev = torch.zeros(S, dtype=torch.int64, device=dev)
-            d.cur_dev = torch.zeros(S, dtype=torch.int64, device=dev)
-            d.cur_host = torch.zeros(S, dtype=torch.int64)
-            d.last_fill = [0] * S
+        """Generator over the tokens of request 0 (stream_first) that drives all requests to completion, every request in its own slot."""
+        eng = _DecodeEngine(self, n_slots=len(reqs), max_out=max(max(r.max_len for r in reqs), 1), max_prefix=max(len(r.prefix) for r in reqs),
+                            stream_first=stream_first, sync_every=sync_every)
+        for kind, x in eng.run(iter(reqs)):
+            if kind == 'token':
+                yield x
+        self.last_stats = eng.stats
 
-        def decode_args():
-            a = _lib.DecodeArgs()
-            a.n_seq, a.head_k, a.win_cap, a.max_out = S, K, W, max_out
-            base = ctl_dev.data_ptr()
-            a.tok, a.ctrl, a.hist, a.hist_len = base + 4 * o_tok, base + 4 * o_ctrl, base + 4 * o_hist, base + 4 * o_hlen
-            a.min_adj, a.active, a.seq_state, a.ids = base + 4 * o_min, base + 4 * o_act, base + 4 * o_state, base + 4 * o_ids
-            a.out_tokens, a.logp = out_dev.data_ptr(), logp.data_ptr()
-            a.top_k, a.top_p, a.win_size, a.rep_thresh, a.max_trials = sp['top_k'], sp['top_p'], sp['win_size'], thr, max_trials
-            a.noise, a.noise_seq_stride, a.noise_len, a.cursor = d.noise_dev.data_ptr(), d.ncap, d.ncap, d.cur_dev.data_ptr()
-            a.noise_limit = d.limit_dev.data_ptr()
-            return a
+    @torch.inference_mode()
+    def generate_stream(self, requests, n_slots=None, max_out=None, max_prefix=None):
+        """Continuous batching (replaces the one-request-at-a-time loop of server/worker.py:54-102): `requests` is an
+        iterable of dicts (text, prompt_text, prompt_speech_token, seed, max_token_text_ratio, min_token_text_ratio, tag).  Up to `n_slots`
+        sequences share one decode grid — the weights are streamed once per step for all of them — and the slot of a finished sequence is
+        taken over by the next waiting request between two blocks of steps (prefill into the slot's KV cache + hvx_llm_decode_join).
+        Yields (tag, token list) in completion order.  A request's ids do not depend on what else is in flight (own noise stream)."""
+        n_slots = n_slots or self.max_batch
 
-        def top_up(cursors, force=False):
-            """fill every ring up to cursor + ncap: the slots overwritten hold positions below a cursor the device has already reported,
-            so they are never read again; the new limits are published behind the data on the same stream"""
-            moved = [False] * S
-            for i, r in enumerate(reqs):
-                target = int(cursors[i]) + d.ncap
-                n = target - d.head[i]
-                if n <= 0 or (not force and n < max(d.ncap // 8, 1)):
-                    continue
-                vals = torch.from_numpy(r.noise.window(d.head[i], n).copy()).pin_memory()
-                p0 = d.head[i] % d.ncap
-                first = min(n, d.ncap - p0)
-                d.noise_dev[i, p0:p0 + first].copy_(vals[:first], non_blocking=True)
-                if n > first:
-                    d.noise_dev[i, :n - first].copy_(vals[first:], non_blocking=True)
-                d.head[i] = target
-                moved[i] = True
-            if any(moved):
-                d.limit_dev.copy_(torch.tensor(d.head, dtype=torch.int64).pin_memory(), non_blocking=True)
-            return moved
-
-        def grow_ring(cursors):
-            """one step needs more values than the ring holds (toy capacities only): quadruple it, keeping the unread values"""
-            old, cap0 = d.noise_dev, d.ncap
-            d.ncap *= 4
-            d.noise_dev = torch.empty(S, d.ncap, dtype=torch.float32, device=dev)
-            for i in range(S):
-                j = torch.arange(int(cursors[i]), d.head[i], device=dev)
-                d.noise_dev[i, j % d.ncap] = old[i, j % cap0]
-
-        with torch.cuda.stream(stream):
-            top_up([0] * S, force=True)
-            stream.synchronize()
-        t_setup = time.time() - t_start
-
-        args = [decode_args()]
-        emitted = 0
-        blocks = []                                   # hipEvent brackets around every block of steps (2 events per sync_every steps)
-        pos_start = [r.pos for r in reqs]
-        # The host runs AHEAD of the device: up to NS blocks of steps are enqueued before the oldest is waited for, so neither the wake-up
-        # latency of a wait nor a descheduled driver thread (tens of ms on a busy host) leaves the GPU without work.  Blocks beyond the
-        # second are only enqueued while some sequence is still short of its min_len by that many steps (it cannot stop before), so a
-        # finished batch costs at most one surplus block of inactive steps.
-        NS = 8
-        slots = [dict(state=torch.zeros(S, 8, dtype=torch.int32).pin_memory(), cur=torch.zeros(S, dtype=torch.int64).pin_memory(),
-                      first=torch.zeros(max_out, dtype=torch.int32).pin_memory(), done=torch.cuda.Event()) for _ in range(NS)]
-
-        def launch(slot):
-            with torch.cuda.stream(stream):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(stream)
-                check(self.lib.hvx_llm_decode_steps(self._h, C.c_void_p(stream.cuda_stream), C.byref(args[0]), sync_every), 'hvx_llm_decode_steps')
-                e1.record(stream)
-                blocks.append((e0, e1))
-                slot['state'].copy_(ctl_dev[o_state:o_state + 8 * S].view(S, 8), non_blocking=True)
-                slot['cur'].copy_(d.cur_dev, non_blocking=True)
-                if stream_first:
-                    slot['first'].copy_(out_dev[0], non_blocking=True)
-                slot['done'].record(stream)
-
-        def steps_certainly_needed(st):
-            need = 0
-            for r, row in zip(reqs, st):
-                if not row[2]:
-                    need = max(need, -(-(min(r.min_len, r.max_len) - row[1]) // K))
-            return need
-
-        st = [[r.pos, 0, 0, r.min_len, r.max_len, 0, 0, 0] for r in reqs]
-        launched = processed = 0
-        draining = False                              # True while the queue is being emptied to re-allocate the noise ring
-        while True:
-            if not draining:
-                while launched - processed < NS:
-                    ahead = launched - processed
-                    if ahead >= 2 and (ahead + 1) * sync_every > steps_certainly_needed(st):
-                        break
-                    launch(slots[launched % NS])
-                    launched += 1
-            cur = slots[processed % NS]
-            while not cur['done'].query():            # polled (a blocking wait may wake up late); the sleep releases the GIL
-                time.sleep(0.0002)
-            processed += 1
-            st = cur['state'].tolist()
-            d.cur_host.copy_(cur['cur'])
-            if any(row[6] == 1 for row in st):
-                raise RuntimeError('sampling reaches max_trials {} and still get eos when ignore_eos is True, check your input!'.format(max_trials))
-            if stream_first:
-                n0 = st[0][1]
-                for t in cur['first'][emitted:n0].tolist():
-                    yield t
-                emitted = n0
-            if all(row[2] for row in st):
-                break
-            cursors = d.cur_host.tolist()
-            stall = [row[6] == 2 for row in st]       # waiting for noise: that sequence's steps are void until its ring is topped up
-            if draining:
-                if launched == processed:             # the stream is idle: the ring can be re-allocated
-                    with torch.cuda.stream(stream):
-                        grow_ring(cursors)
-                        top_up(cursors, force=True)
-                        ctl_dev[o_state:o_state + 8 * S].view(S, 8)[:, 6] = 0
-                        args[0] = decode_args()
-                    draining = False
-                    d.last_fill = [launched] * S
-                continue
-            with torch.cuda.stream(stream):
-                moved = top_up(cursors, force=any(stall))
-                for i in range(S):
-                    if moved[i]:
-                        d.last_fill[i] = launched     # blocks enqueued from here on see sequence i's new limit
-                    elif stall[i] and processed - 1 >= d.last_fill[i]:
-                        # stalled in a block that was enqueued AFTER its ring had been filled up to cursor + ncap: one step needs
-                        # more values than the ring holds
-                        draining = True
-        stream.synchronize()                          # a surplus block of inactive steps may still be running: it changes nothing
-        with torch.cuda.stream(stream):
-            out_host = out_dev.cpu()
-        n_llm_tokens = 0
-        for i, r in enumerate(reqs):
-            r.out = out_host[i, :st[i][1]].tolist()
-            r.done = True
-            n_llm_tokens += len(r.out)
-            r.cursor = int(d.cur_host[i])
-            r.noise.finalize(r.cursor)
-        steps = max(row[5] for row in st)
-        torch.cuda.current_stream().wait_stream(stream)
-        dt = time.time() - t_start
-        step_ms = sum(a.elapsed_time(b) for a, b in blocks) / (len(blocks) * sync_every)
-        gaps = sorted(blocks[i][1].elapsed_time(blocks[i + 1][0]) for i in range(len(blocks) - 1))
-        mean_ctx = sum(0.5 * (p0 + row[0]) for p0, row in zip(pos_start, st)) / S
-        self.last_stats = dict(steps=steps, tokens=n_llm_tokens, seconds=dt, tps=n_llm_tokens / dt if dt > 0 else 0.0, head_k=K, batch=S,
-                               prefill_and_setup_seconds=t_setup, device_idle_ms_between_blocks=sum(gaps),
-                               decode_step_us=1e3 * step_ms, decode_steps_timed=len(blocks) * sync_every, mean_ctx=mean_ctx,
-                               decode_step_bytes=self.decode_step_bytes(S, K, mean_ctx))
+        def to_req(d):
+            text = torch.as_tensor(d['text'])
+            pt, ps = d.get('prompt_text'), d.get('prompt_speech_token')
+            n_text = int(text.numel())
+            r = _Request(self._encode_prefix(text, None if pt is None else torch.as_tensor(pt), None if ps is None else torch.as_tensor(ps)), n_text,
+                         int(n_text * d.get('min_token_text_ratio', 2)), int(n_text * d.get('max_token_text_ratio', 20)), NoiseStream(seed=d.get('seed')))
+            r.tag = d.get('tag')
+            return r
+        it = (to_req(d) for d in requests)
+        if max_out is None or max_prefix is None:
+            it = list(it)
+            max_out = max([r.max_len for r in it] + [1])
+            max_prefix = max([len(r.prefix) for r in it] + [1])
+            it = iter(it)
+        eng = _DecodeEngine(self, n_slots=n_slots, max_out=max_out, max_prefix=max_prefix)
+        for kind, r in eng.run(it):
+            if kind == 'done':
+                yield r.tag, r.out
+        self.last_stats = eng.stats
 
     def decode_step_bytes(self, n_seq, head_k, ctx):
         """Algorithmic HBM bytes of one decode step: every weight of the backbone, of the head_k MTP blocks and of
@@ -495,3 +313,336 @@ class HvxLLM:
         check(self.lib.hvx_llm_last_hidden(self._h, stream_ptr(), 1, ptr(y)), 'hvx_llm_last_hidden')
         torch.cuda.synchronize()
         return logp[0], y[0]
+
+
+class _DecodeEngine:
+    """The device-resident decode loop with continuous batching.
+
+    `n_slots` sequences share one decode grid [n_slots][K]; a slot is a KV-cache page, a row of the control block and a noise ring.  The
+    loop itself lives on the device (hvx_llm_decode_steps): forward, sampling of the K heads and the bookkeeping the reference does in
+    Python between two steps (accept / append / stop, llm_multi_head_v3.py:890-905) are one hipGraph per step; `sync_every` steps are
+    enqueued per block and only the per-sequence state words come back.  The host runs AHEAD of the device (up to NS blocks) so that neither
+    the wake-up latency of a wait nor a descheduled driver thread leaves the GPU without work.  When the state of a block shows a finished
+    sequence, its tokens are copied out and the next waiting request takes the slot over: prefill of its prefix into the slot's KV cache,
+    hvx_llm_decode_join, noise at position 0 of the slot's ring — all ordered on the decode stream behind the blocks already enqueued."""
+    NS = 8
+
+    def __init__(self, llm, n_slots, max_out, max_prefix, stream_first=False, sync_every=None):
+        import time
+        self.llm, self.S, self.max_out = llm, int(n_slots), int(max_out)
+        self.K = llm.head_k()
+        self.sp = sampling_params(llm.sampling)
+        self.thr = rep_threshold(self.sp['win_size'], self.sp['tau_r'])
+        self.stream_first = stream_first
+        self.sync_every = sync_every or (4 if stream_first else 8)    # steps enqueued per host round trip (tokens surface in bursts of this many steps)
+        self.max_trials = 100
+        self.stats = {}
+        self.t_start = time.time()
+        dev = llm.device
+        S, K = self.S, self.K
+        if getattr(llm, '_stream', None) is None:
+            llm._stream = torch.cuda.Stream(device=dev, priority=-1)       # decode launches go ahead of a concurrent acoustic stage
+        self.stream = llm._stream
+        self.stream.wait_stream(torch.cuda.current_stream())
+        self.W = max(self.sp['win_size'] if self.sp['win_size'] > 0 else self.max_out, 1)
+        W = self.W
+        with torch.cuda.stream(self.stream):
+            llm._bind(S, max(int(max_prefix), S * K))
+            # ---- decode state (fixed device addresses: the step graph is captured once and replayed); every slot starts empty ------------
+            self.o_tok, self.o_ctrl, self.o_hist = 0, S * K, S * K + 5 * S
+            self.o_hlen, self.o_min, self.o_act = self.o_hist + S * W, self.o_hist + S * W + S, self.o_hist + S * W + 2 * S
+            self.o_state, self.o_ids = self.o_act + S, self.o_act + S + 8 * S
+            n_ctl = self.o_ids + S * K
+            ctl_host = torch.zeros(n_ctl, dtype=torch.int32).pin_memory()
+            ch = ctl_host.numpy()
+            ch[self.o_tok:self.o_tok + S * K] = -1
+            for i in range(S):
+                ch[self.o_ctrl + 0 * S + i] = i
+                ch[self.o_ctrl + 4 * S + i] = -1
+                ch[self.o_state + 8 * i + 2] = 1                     # done: an empty slot is a finished sequence
+            self.ctl_dev = ctl_host.to(dev, non_blocking=True)
+            self.out_dev = torch.zeros(S, self.max_out, dtype=torch.int32, device=dev)
+            self.logp = torch.empty(S, K, llm.cfg.vocab, dtype=torch.float32, device=dev)
+            # Exp(1) noise: a ring of `ncap` values per slot addressed by ABSOLUTE stream position; the host tops it up behind the device
+            # cursor while the steps run; a sequence that outruns its ring stalls on the device (its steps are void) until the refill
+            self.ncap = llm.noise_cap
+            self.noise_dev = torch.empty(S, self.ncap, dtype=torch.float32, device=dev)
+            self.head = [0] * S                  # absolute position up to which slot i's ring is filled
+            self.limit_dev = torch.zeros(S, dtype=torch.int64, device=dev)
+            self.cur_dev = torch.zeros(S, dtype=torch.int64, device=dev)
+        self.slot_req = [None] * S
+        self.join_block = [0] * S                # blocks launched when the slot's request joined: older snapshots describe its predecessor
+        self.last_fill = [0] * S
+        self._keep = []                          # pinned staging tensors of asynchronous copies still in flight
+        self.args = self._decode_args()
+
+    def _decode_args(self):
+        a = _lib.DecodeArgs()
+        a.n_seq, a.head_k, a.win_cap, a.max_out = self.S, self.K, self.W, self.max_out
+        base = self.ctl_dev.data_ptr()
+        a.tok, a.ctrl, a.hist, a.hist_len = base + 4 * self.o_tok, base + 4 * self.o_ctrl, base + 4 * self.o_hist, base + 4 * self.o_hlen
+        a.min_adj, a.active, a.seq_state, a.ids = base + 4 * self.o_min, base + 4 * self.o_act, base + 4 * self.o_state, base + 4 * self.o_ids
+        a.out_tokens, a.logp = self.out_dev.data_ptr(), self.logp.data_ptr()
+        sp = self.sp
+        a.top_k, a.top_p, a.win_size, a.rep_thresh, a.max_trials = sp['top_k'], sp['top_p'], sp['win_size'], self.thr, self.max_trials
+        a.noise, a.noise_seq_stride, a.noise_len, a.cursor = self.noise_dev.data_ptr(), self.ncap, self.ncap, self.cur_dev.data_ptr()
+        a.noise_limit = self.limit_dev.data_ptr()
+        return a
+
+    def _h2d(self, values, dtype):
+        t = torch.tensor(values, dtype=dtype).pin_memory()
+        self._keep.append(t)
+        return t.to(self.llm.device, non_blocking=True)
+
+    def _fill_ring(self, i, target):
+        """ring of slot i up to absolute position `target` (the slots overwritten hold positions below a cursor the device has reported)"""
+        n = target - self.head[i]
+        if n <= 0:
+            return False
+        vals = torch.from_numpy(self.slot_req[i].noise.window(self.head[i], n).copy()).pin_memory()
+        self._keep.append(vals)
+        p0 = self.head[i] % self.ncap
+        first = min(n, self.ncap - p0)
+        self.noise_dev[i, p0:p0 + first].copy_(vals[:first], non_blocking=True)
+        if n > first:
+            self.noise_dev[i, :n - first].copy_(vals[first:], non_blocking=True)
+        self.head[i] = target
+        return True
+
+    def _publish_limits(self):
+        self.limit_dev.copy_(self._h2d(self.head, torch.int64), non_blocking=True)     # behind the data, on the same stream
+
+    def _join(self, i, r, launched):
+        """request r takes slot i (stream-ordered behind every block enqueued so far)"""
+        llm = self.llm
+        n = len(r.prefix) - 1
+        if len(r.prefix) + r.max_len + self.K > llm.max_ctx:
+            raise ValueError('context %d exceeds max_ctx=%d' % (len(r.prefix) + r.max_len + self.K, llm.max_ctx))
+        if r.max_len > self.max_out:
+            raise ValueError('max_len %d exceeds the engine\'s max_out=%d' % (r.max_len, self.max_out))
+        if n > 0:
+            tok = self._h2d(r.prefix[:n], torch.int32)
+            ctrl = self._h2d([i, 0, n, n, n - 1], torch.int32)
+            llm._forward(1, n, tok, ctrl, 0, None)
+        r.pos = n
+        check(llm.lib.hvx_llm_decode_join(llm._h, C.c_void_p(self.stream.cuda_stream), C.byref(self.args), i, int(r.prefix[-1]), n, r.min_len, r.max_len),
+              'hvx_llm_decode_join')
+        self.slot_req[i] = r
+        self.join_block[i] = launched
+        self.head[i] = 0
+        self._fill_ring(i, self.ncap)
+        self.last_fill[i] = launched
+        r.state = [n, 0, 0, r.min_len, r.max_len, 0, 0, 0]
+        r.cursor = 0
+
+    def run(self, requests):
+        """generator: ('token', id) for the first request when stream_first, ('done', request) as requests finish"""
+        import time
+        llm, S, K, NS, sync_every, stream = self.llm, self.S, self.K, self.NS, self.sync_every, self.stream
+        dev = llm.device
+        o_state = self.o_state
+        slots = [dict(state=torch.zeros(S, 8, dtype=torch.int32).pin_memory(), cur=torch.zeros(S, dtype=torch.int64).pin_memory(),
+                      first=torch.zeros(self.max_out, dtype=torch.int32).pin_memory() if self.stream_first else None, done=torch.cuda.Event())
+                 for _ in range(NS)]
+        blocks = []                                   # (event, event, active sequences, cached positions) per block of steps
+        pending_out = []                              # (event, pinned tokens, request) of finished sequences whose ids are on their way
+        waiting = None                                # next request pulled from the iterator (None: not pulled yet / exhausted)
+        exhausted = False
+        emitted = 0
+        launched = processed = 0
+        draining = False                              # True while the queue is being emptied to re-allocate the noise ring
+        n_done = n_tokens = 0
+        finished_clean = False
+        t_setup = 0.0
+        ready = []                                    # ('token', id) / ('done', request) waiting to be handed out
+
+        def pull():
+            nonlocal waiting, exhausted
+            while waiting is None and not exhausted:
+                try:
+                    waiting = next(requests)
+                except StopIteration:
+                    exhausted = True
+                    return
+                if waiting.max_len <= 0:              # `while len(out_tokens) < max_len` never runs (llm_multi_head_v3.py:871)
+                    r, waiting = waiting, None
+                    r.out, r.done = [], True
+                    r.noise.finalize(0)
+                    ready.append(('done', r))
+
+        def launch(slot):
+            with torch.cuda.stream(stream):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                check(llm.lib.hvx_llm_decode_steps(llm._h, C.c_void_p(stream.cuda_stream), C.byref(self.args), sync_every), 'hvx_llm_decode_steps')
+                e1.record(stream)
+                live = [r for r in self.slot_req if r is not None and not r.done]
+                blocks.append((e0, e1, len(live), sum(r.state[0] for r in live)))
+                slot['state'].copy_(self.ctl_dev[o_state:o_state + 8 * S].view(S, 8), non_blocking=True)
+                slot['cur'].copy_(self.cur_dev, non_blocking=True)
+                if self.stream_first:
+                    slot['first'].copy_(self.out_dev[0], non_blocking=True)
+                slot['done'].record(stream)
+
+        def steps_needed(r):
+            return max(0, -(-(min(r.min_len, r.max_len) - r.state[1]) // K))
+
+        def grow_ring():
+            """one step needs more values than the ring holds (toy capacities only): quadruple it, keeping the unread values"""
+            old, cap0 = self.noise_dev, self.ncap
+            self.ncap *= 4
+            self.noise_dev = torch.empty(S, self.ncap, dtype=torch.float32, device=dev)
+            for i, r in enumerate(self.slot_req):
+                if r is None or r.done:
+                    continue
+                j = torch.arange(int(r.cursor), self.head[i], device=dev)
+                self.noise_dev[i, j % self.ncap] = old[i, j % cap0]
+
+        def fill_free_slots():
+            nonlocal waiting
+            joined = False
+            for i in range(S):
+                if self.slot_req[i] is not None and not self.slot_req[i].done:
+                    continue
+                pull()
+                if waiting is None:
+                    break
+                self._join(i, waiting, launched)
+                waiting = None
+                joined = True
+            return joined
+
+        try:
+            with torch.cuda.stream(stream):
+                fill_free_slots()                     # first occupants
+                self._publish_limits()
+            t_setup = time.time() - self.t_start
+            while True:
+                while ready:
+                    yield ready.pop(0)
+                live = [r for r in self.slot_req if r is not None and not r.done]
+                if not live and launched == processed:
+                    with torch.cuda.stream(stream):
+                        if fill_free_slots():         # (every sequence had finished while requests were still arriving)
+                            self._publish_limits()
+                            continue
+                    break
+                if not draining and live:
+                    need_max = max(steps_needed(r) for r in live)
+                    need_min = min(steps_needed(r) for r in live)
+                    pull()
+                    # Blocks beyond the second are only enqueued while no slot can run empty inside them: with requests waiting that is
+                    # "no live sequence can finish before" (its slot would idle until the host notices), otherwise "some sequence certainly
+                    # still needs that many steps" (a finished batch costs at most one surplus block of void steps).
+                    need = need_min if waiting is not None else need_max
+                    while launched - processed < NS:
+                        ahead = launched - processed
+                        if ahead >= 2 and (ahead + 1) * sync_every > need:
+                            break
+                        launch(slots[launched % NS])
+                        launched += 1
+                if launched == processed:
+                    if draining:                      # the stream is idle: the ring can be re-allocated
+                        with torch.cuda.stream(stream):
+                            stream.synchronize()
+                            grow_ring()
+                            for i, r in enumerate(self.slot_req):
+                                if r is not None and not r.done:
+                                    self._fill_ring(i, int(r.cursor) + self.ncap)
+                            self._publish_limits()
+                            self.ctl_dev[o_state:o_state + 8 * S].view(S, 8)[:, 6] = 0
+                            self.args = self._decode_args()
+                        draining = False
+                        self.last_fill = [launched] * S
+                    continue
+                cur = slots[processed % NS]
+                while not cur['done'].query():        # polled (a blocking wait may wake up late); the sleep releases the GIL
+                    time.sleep(0.0002)
+                blk = processed
+                processed += 1
+                st = cur['state'].tolist()
+                cursors = cur['cur'].tolist()
+                stall = [False] * S
+                with torch.cuda.stream(stream):
+                    moved_any = False
+                    for i, r in enumerate(self.slot_req):
+                        if r is None or r.done or blk < self.join_block[i]:
+                            continue                  # empty slot, or a snapshot taken before this request joined
+                        r.state, r.cursor = st[i], cursors[i]
+                        if st[i][6] == 1:
+                            raise RuntimeError('sampling reaches max_trials {} and still get eos when ignore_eos is True, check your input!'.format(self.max_trials))
+                        if st[i][2]:                  # finished: fetch its ids; the slot is free for the next request from here on
+                            out_pin = torch.empty(max(st[i][1], 1), dtype=torch.int32).pin_memory()
+                            out_pin.copy_(self.out_dev[i, :max(st[i][1], 1)], non_blocking=True)
+                            ev = torch.cuda.Event()
+                            ev.record(stream)
+                            pending_out.append((ev, out_pin, r))
+                            r.done = True
+                            continue
+                        stall[i] = st[i][6] == 2      # waiting for noise: that sequence's steps are void until its ring is topped up
+                    if self.stream_first and self.slot_req[0] is not None and blk >= self.join_block[0]:
+                        n0 = self.slot_req[0].state[1]
+                        for t in cur['first'][emitted:n0].tolist():
+                            ready.append(('token', t))
+                        emitted = n0
+                    if not draining:
+                        for i, r in enumerate(self.slot_req):
+                            if r is None or r.done:
+                                continue
+                            target = int(r.cursor) + self.ncap
+                            if target - self.head[i] >= max(self.ncap // 8, 1) or (stall[i] and target > self.head[i]):
+                                self._fill_ring(i, target)
+                                self.last_fill[i] = launched          # blocks enqueued from here on see the slot's new limit
+                                moved_any = True
+                            elif stall[i] and blk >= self.last_fill[i]:
+                                # stalled in a block that was enqueued AFTER its ring had been filled up to cursor + ncap: one step needs
+                                # more values than the ring holds
+                                draining = True
+                        # free slots go to waiting requests
+                        if fill_free_slots():
+                            moved_any = True
+                        if moved_any:
+                            self._publish_limits()
+                # requests whose ids have arrived
+                while pending_out and pending_out[0][0].query():
+                    ev, out_pin, r = pending_out.pop(0)
+                    r.out = out_pin[:r.state[1]].tolist()
+                    r.noise.finalize(r.cursor)
+                    n_done += 1
+                    n_tokens += len(r.out)
+                    ready.append(('done', r))
+                if len(self._keep) > 64:
+                    self._keep = self._keep[-32:]     # their copies were enqueued before blocks that have completed since
+            stream.synchronize()                      # a surplus block of inactive steps may still be running: it changes nothing
+            while pending_out:
+                ev, out_pin, r = pending_out.pop(0)
+                r.out = out_pin[:r.state[1]].tolist()
+                r.noise.finalize(r.cursor)
+                n_done += 1
+                n_tokens += len(r.out)
+                ready.append(('done', r))
+            finished_clean = True
+            while ready:
+                yield ready.pop(0)
+        finally:
+            # an abandoned generator / an error: let the queued blocks drain before the buffers go away, and leave every generator where
+            # the values really consumed put it
+            stream.synchronize()
+            for ev, out_pin, r in pending_out:
+                r.noise.finalize(r.cursor)
+            for r in self.slot_req:
+                if r is not None and not r.done:
+                    r.noise.finalize(getattr(r, 'cursor', 0))
+            torch.cuda.current_stream().wait_stream(stream)
+            dt = time.time() - self.t_start
+            timed = [(a.elapsed_time(b), n, p) for a, b, n, p in blocks]
+            n_blk = len(timed)
+            step_ms = sum(t for t, _, _ in timed) / (n_blk * sync_every) if n_blk else 0.0
+            gaps = [blocks[i][1].elapsed_time(blocks[i + 1][0]) for i in range(n_blk - 1)]
+            seqs = sum(n for _, n, _ in timed) / n_blk if n_blk else 0.0
+            ctx_sum = sum(p for _, _, p in timed) / n_blk if n_blk else 0.0
+            self.stats = dict(steps=n_blk * sync_every, tokens=n_tokens, seconds=dt, tps=n_tokens / dt if dt > 0 else 0.0, head_k=K, batch=S,
+                              requests=n_done, prefill_and_setup_seconds=t_setup,
+                              device_idle_ms_between_blocks=sum(gaps), decode_step_us=1e3 * step_ms, decode_steps_timed=n_blk * sync_every,
+                              mean_active_sequences=seqs, mean_ctx=ctx_sum / seqs if seqs else 0.0,
+                              decode_step_bytes=llm.decode_step_bytes(1, K, ctx_sum), clean=finished_clean)

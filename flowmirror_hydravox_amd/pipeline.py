@@ -203,6 +203,70 @@ class HvxPipeline:
         return wavs, st
 
     @torch.inference_mode()
+    def synthesize_continuous(self, utts, lm_slots=16, max_token_text_ratio=20, min_token_text_ratio=2):
+        """Generator over (index, waveform, tokens) in completion order — continuous batching end to end.
+        The LM decodes up to `lm_slots` utterances in ONE grid (HvxLLM.generate_stream: the weights are streamed once per step for all of
+        them, a finished utterance's slot goes to the next waiting one), driven by a worker thread on the high-priority decode stream; every
+        finished utterance goes straight to the flow decoder and the vocoder, which run here on a second stream beside the decode of the
+        utterances still in flight.  Results equal synthesize(): every utterance carries its own sampler seed.  `self.last_continuous`
+        holds the stage accounting of the run."""
+        import queue
+        import threading
+        utts = list(utts)
+        if getattr(self, '_bg_stream', None) is None:
+            self._bg_stream = torch.cuda.Stream(device=self.device, priority=0)
+            self._bg_streams = [self._bg_stream]
+            self._bg_pools = []
+        flow, hift, stream = self._acoustic_chain(0)
+        q = queue.Queue()
+        lm_info = {}
+        maxr = max_token_text_ratio if isinstance(max_token_text_ratio, (list, tuple)) else [max_token_text_ratio] * len(utts)
+        minr = min_token_text_ratio if isinstance(min_token_text_ratio, (list, tuple)) else [min_token_text_ratio] * len(utts)
+
+        def lm_thread():
+            try:
+                torch.cuda.set_device(stream.device)               # the current device is per thread
+                with torch.inference_mode():
+                    reqs = (dict(text=u.text, prompt_text=u.prompt_text, prompt_speech_token=u.prompt_speech_token, seed=u.seed, tag=i,
+                                 max_token_text_ratio=maxr[i], min_token_text_ratio=minr[i]) for i, u in enumerate(utts))
+                    max_out = max([int(len(u.text) * maxr[i]) for i, u in enumerate(utts)] + [1])
+                    max_prefix = max([2 + len(u.text) + (0 if u.prompt_text is None else len(u.prompt_text)) +
+                                      (0 if u.prompt_speech_token is None else len(u.prompt_speech_token)) for u in utts] + [1])
+                    t0 = time.time()
+                    for tag, toks in self.llm.generate_stream(reqs, n_slots=lm_slots, max_out=max_out, max_prefix=max_prefix):
+                        q.put((tag, toks))
+                    lm_info.update(seconds=time.time() - t0, stats=dict(self.llm.last_stats))
+                q.put(None)
+            except BaseException as e:                              # surfaces in the consuming thread
+                q.put(e)
+
+        th = threading.Thread(target=lm_thread, name='hvx-lm', daemon=True)
+        t_begin = time.time()
+        th.start()
+        acoustic = audio = 0.0
+        tokens = 0
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                i, toks = item
+                t0 = time.time()
+                with torch.cuda.stream(stream):
+                    wav = self._waves(self._mels([utts[i]], [toks], flow), hift)[0]
+                    stream.synchronize()
+                acoustic += time.time() - t0
+                audio += wav.numel() / float(self.cfg.sample_rate)
+                tokens += len(toks)
+                yield i, wav, toks
+        finally:
+            th.join()
+            self.last_continuous = dict(tokens=tokens, audio_seconds=audio, acoustic_seconds=acoustic, total_seconds=time.time() - t_begin,
+                                        llm_seconds=lm_info.get('seconds', 0.0), llm=lm_info.get('stats', {}), lm_slots=lm_slots)
+
+    @torch.inference_mode()
     def synthesize_pipelined(self, batches, max_token_text_ratio=20, min_token_text_ratio=2, lm_chains=3, acoustic_chains=1):
         """Generator over (waveforms, SynthStats) of successive batches, in order, with the stages of neighbouring batches overlapped.
         The multi-head LM decode is a chain of ~160 short dependent launches per step that leaves most of the GPU idle, so (a) the flow

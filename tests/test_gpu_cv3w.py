@@ -312,3 +312,19 @@ def test_hift_stages_vs_reference(cfg):
         wav2, s2 = hift.inference(speech_feat=mel.to(DEV))
         assert tuple(wav2.shape) == (1, 480 * mel.shape[-1])
         assert np.abs(wav2.cpu().numpy() - g[p + 'wav']).max() < 2e-2, (r, 'end to end')       # F0 -> phase accumulation
+
+
+def test_llm_continuous_batching_fp32_vs_reference(cfg, llm_setup):
+    """the 8 utterances of the K = 2 golden set through a 3-slot grid (sequences join as others finish; prefills of 16..478 rows land in
+    slots whose neighbours are mid-decode): ids == the reference's"""
+    g, sd, sampling = llm_setup
+    llm = _make_llm(cfg, sd, sampling, torch.float32, max_batch=3, max_ctx=1024)
+    llm.inference_head_num = 2
+    k2 = [r for r in range(int(g['n_runs'])) if int(g['r%d_K' % r]) == 2]
+    reqs = [dict(text=torch.from_numpy(g['r%d_text' % r]), prompt_text=torch.from_numpy(g['r%d_ptext' % r]),
+                 prompt_speech_token=torch.from_numpy(g['r%d_pspeech' % r]), seed=int(g['r%d_seed' % r]), tag=r,
+                 max_token_text_ratio=float(g['r%d_ratios' % r][0]), min_token_text_ratio=float(g['r%d_ratios' % r][1])) for r in k2]
+    got = dict(llm.generate_stream(iter(reqs), n_slots=3))
+    for r in k2:
+        assert got[r] == g['r%d_tokens' % r].tolist(), r
+    assert llm.last_stats['requests'] == 8

@@ -648,3 +648,59 @@ def test_waveform_gather_over_rccl_one_rank():
             assert got[gid].device.type == 'cuda' and torch.equal(got[gid], w)
     finally:
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# continuous batching: sequences join a running decode grid
+# ------------------------------------------------------------------------------------------------------------------------
+def test_llm_continuous_batching_vs_oracle(tiny_cfg, llm_setup):
+    """11 requests of mixed text / prompt lengths (one of them empty: max_len 0) through a 3-slot decode grid: a finished sequence's slot is
+    taken over by the next waiting request while the others keep decoding.  Every request's ids == the fp32 oracle's for that request
+    alone (same text / prompt / seed), whatever shared the grid with it."""
+    from functools import partial
+    from flowmirror_hydravox_amd.llm import HvxLLM
+    from flowmirror_hydravox_amd.sampling import ras_sampling
+    from oracle import llm_ref, sampler_ref
+    g, sd = llm_setup
+    cfg = tiny_cfg.llm
+    sampling = dict(top_p=0.8, top_k=25, win_size=10, tau_r=0.1)
+    llm = HvxLLM(cfg, sd, dtype=torch.float32, max_batch=3, max_ctx=512, inference_head_num=2, sampling=partial(ras_sampling, **sampling))
+    gen = torch.Generator().manual_seed(2024)
+    reqs = []
+    for i in range(11):
+        n_text = 0 if i == 4 else int(torch.randint(3, 18, (1,), generator=gen))
+        n_ps = int(torch.randint(0, 40, (1,), generator=gen)) if i % 3 else 0
+        reqs.append(dict(text=torch.randint(0, cfg.text_vocab, (n_text,), generator=gen, dtype=torch.int32),
+                         prompt_speech_token=torch.randint(0, cfg.speech_tokens, (n_ps,), generator=gen, dtype=torch.int32), seed=4000 + i, tag=i,
+                         max_token_text_ratio=3 + i % 4, min_token_text_ratio=1 + i % 2))
+    got = dict(llm.generate_stream(iter(reqs), n_slots=3))
+    assert sorted(got) == list(range(11)) and got[4] == []
+    st = llm.last_stats
+    assert st['requests'] == 10 and st['clean'] and 1.0 < st['mean_active_sequences'] <= 3.0
+    for r in reqs:
+        ora = list(llm_ref.llm_inference(sd, cfg, r['text'], sampler_ref.NoiseStream(seed=r['seed']), prompt_speech_token=r['prompt_speech_token'],
+                                         inference_head_num=2, sampling=sampling, max_token_text_ratio=r['max_token_text_ratio'],
+                                         min_token_text_ratio=r['min_token_text_ratio'], use_kv_cache=True))
+        assert ora == got[r['tag']], r['tag']
+    assert len({len(v) for v in got.values()}) > 4              # they really finish at different steps
+    # the same requests through a grid wide enough for all of them at once, and one at a time: the same ids
+    assert dict(llm.generate_stream(iter(reqs), n_slots=11)) == got
+    assert dict(llm.generate_stream(iter(reqs), n_slots=1)) == got
+
+
+def test_continuous_synthesis_equals_serial(tiny_cfg):
+    """llm -> flow -> hift with continuous batching (finished utterances go to the acoustic stage while the others decode) returns, per
+    utterance, the samples of the back-to-back path"""
+    from flowmirror_hydravox_amd.pipeline import HvxPipeline, synthetic_utterance
+    pipe = HvxPipeline(tiny_cfg, llm_dtype=torch.float32, flow_dtype=torch.float32, max_batch=3, max_ctx=512, max_t=1024, seed=7, init='fan_in',
+                       inference_head_num=2)
+    utts = [synthetic_utterance(tiny_cfg, 50 + i, 5 + (3 * i) % 7) for i in range(7)]
+    serial = [pipe.synthesize([u], max_token_text_ratio=5, min_token_text_ratio=3)[0][0] for u in utts]
+    seen = {}
+    for i, wav, toks in pipe.synthesize_continuous(utts, lm_slots=3, max_token_text_ratio=5, min_token_text_ratio=3):
+        seen[i] = wav
+        assert wav.numel() == 960 * len(toks)
+    assert sorted(seen) == list(range(7))
+    for i in range(7):
+        assert seen[i].shape == serial[i].shape and torch.equal(seen[i], serial[i]), i
+    assert pipe.last_continuous['tokens'] > 0 and pipe.last_continuous['llm']['requests'] == 7
