@@ -44,10 +44,14 @@ def parse():
     ap.add_argument('--heads', type=int, default=2, help='inference_head_num')
     ap.add_argument('--tiny', action='store_true', help='toy dimensions (plumbing check only; INVALID as a benchmark)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--acoustic-chains', type=int, default=1, help='batches whose flow + vocoder run concurrently in the pipelined timed region')
-    ap.add_argument('--lm-chains', type=int, default=3, help='batches whose LM decode runs concurrently in the pipelined timed region')
-    ap.add_argument('--serial', action='store_true', help='run the stages of a step back to back instead of overlapping neighbouring steps')
-    ap.add_argument('--prof-period', type=int, default=16)
+    ap.add_argument('--lm-slots', type=int, default=24, help='sequences decoded in one grid (continuous batching): utterances of later steps join as earlier ones finish')
+    ap.add_argument('--mode', choices=['continuous', 'chains', 'serial'], default='continuous',
+                    help='continuous: one decode grid of --lm-slots sequences + acoustic stage of finished utterances beside it (default); '
+                         'chains: the round-1 form, --lm-chains independent decode chains of one step each; serial: stages back to back')
+    ap.add_argument('--acoustic-chains', type=int, default=1, help='(--mode chains) batches whose flow + vocoder run concurrently')
+    ap.add_argument('--lm-chains', type=int, default=3, help='(--mode chains) batches whose LM decode runs concurrently')
+    ap.add_argument('--serial', action='store_true', help='same as --mode serial')
+    ap.add_argument('--prof-period', type=int, default=17, help='every n-th launch of a kernel class is bracketed in the profiling step (prime: no aliasing with the 4-GEMM block period)')
     ap.add_argument('--cpu-baseline-worker', action='store_true', help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -137,6 +141,9 @@ def cpu_baseline(cfg, pipe_seed, chars, heads):
 
 def main():
     args = parse()
+    if args.serial:
+        args.mode = 'serial'
+    args.serial = args.mode == 'serial'
     if args.cpu_baseline_worker:
         from flowmirror_hydravox_amd.config import cv3_config, tiny_config
         print(json.dumps(cpu_baseline(tiny_config() if args.tiny else cv3_config(), 1986, args.chars, args.heads)))
@@ -203,18 +210,39 @@ def main():
     serial = None
     for _ in range(args.warmup):
         serial, got = step()
+    lm_alone = None
+    if args.mode == 'continuous' and args.warmup > 0:
+        # the wide decode grid alone (nothing else on the GPU): --lm-slots utterances through the engine, untimed — `roofline.alone`
+        reqs = [dict(text=utts[i % B].text, seed=10_000 + i, tag=i, max_token_text_ratio=ratio, min_token_text_ratio=ratio) for i in range(args.lm_slots)]
+        for _ in pipe.llm.generate_stream(iter(reqs), n_slots=args.lm_slots):
+            pass
+        lm_alone = dict(pipe.llm.last_stats)
     barrier()
     stats = []
+    cont = None
     t0 = time.time()
-    if args.serial:
+    if args.mode == 'serial':
         for _ in range(args.steps):
             st, got = step()
             stats.append(st)
-    else:
+    elif args.mode == 'chains':
         for wavs, st in pipe.synthesize_pipelined([utts] * args.steps, max_token_text_ratio=ratio, min_token_text_ratio=ratio,
                                                   lm_chains=args.lm_chains, acoustic_chains=args.acoustic_chains):
             got = gather_waveforms(wavs, gids, dst=0)
             stats.append(st)
+    else:
+        # K steps of B utterances each = K * B utterances through the continuous-batching engine; finished waveforms are handed to rank 0
+        # one step's worth (B utterances) at a time, inside the timed region
+        job = [synthetic_utterance(cfg, (k * world + rank) * B + i, chars) for k in range(args.steps) for i in range(B)]
+        ready, n_handed = [], 0
+        for i, wav, toks in pipe.synthesize_continuous(job, lm_slots=args.lm_slots, max_token_text_ratio=ratio, min_token_text_ratio=ratio):
+            ready.append((job[i].seed, wav))
+            if len(ready) == B:
+                got = gather_waveforms([w for _, w in ready], [gid for gid, _ in ready], dst=0)
+                n_handed += len(ready)
+                ready = []
+        assert n_handed == args.steps * B and not ready
+        cont = dict(pipe.last_continuous)
     barrier()
     elapsed = time.time() - t0
     # Per-kernel durations: hipEvent brackets on the launch stream, every `prof_period`-th launch of each kernel class.
@@ -231,13 +259,16 @@ def main():
         lib.hvx_prof_enable(0)
     barrier()
 
-    tokens = sum(s.tokens for s in stats)
-    audio = sum(s.audio_seconds for s in stats)
-    llm_s = sum(s.llm_seconds for s in stats)
-    flow_s = sum(s.flow_seconds for s in stats)
-    hift_s = sum(s.hift_seconds for s in stats)
-    if not args.serial:                          # overlapped: only the sum of the two acoustic stages is a wall time
-        flow_s, hift_s = flow_s + hift_s, 0.0
+    if cont is not None:
+        tokens, audio, llm_s, flow_s, hift_s = cont['tokens'], cont['audio_seconds'], cont['llm_seconds'], cont['acoustic_seconds'], 0.0
+    else:
+        tokens = sum(s.tokens for s in stats)
+        audio = sum(s.audio_seconds for s in stats)
+        llm_s = sum(s.llm_seconds for s in stats)
+        flow_s = sum(s.flow_seconds for s in stats)
+        hift_s = sum(s.hift_seconds for s in stats)
+        if not args.serial:                          # overlapped: only the sum of the two acoustic stages is a wall time
+            flow_s, hift_s = flow_s + hift_s, 0.0
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([elapsed, float(tokens), audio, llm_s, flow_s, hift_s], dtype=torch.float64, device='cuda')
@@ -251,6 +282,7 @@ def main():
     if rank != 0:
         return
     assert world > 1 or len(got) == B
+    in_flight = {'continuous': args.lm_slots + 1, 'chains': B * (max(args.lm_chains, args.acoustic_chains) + 1), 'serial': B}[args.mode]
 
     # The dominant "kernel" is the decode step: one hipGraph replay of forward + sampler + advance (~160 launches of 5-9 us, which a
     # per-launch event bracket would distort), timed over the timed region itself by hipEvents around every block of 8 replays on
@@ -265,8 +297,12 @@ def main():
         ach = by / us / 1e3
         return dict(achieved=round(ach, 1), frac=round(ach / HBM_PEAK_GBS, 4), avg_launch_us=round(us, 1), algorithmic_bytes_per_launch=round(by),
                     launches=n)
-    rl_timed = step_roofline(stats)
-    rl_alone = step_roofline([serial]) if serial is not None else None
+    class _S:                                        # (engine statistics in the shape step_roofline reads)
+        def __init__(self, d):
+            self.llm = d
+    rl_timed = step_roofline(stats if cont is None else [_S(cont['llm'])])
+    rl_alone = step_roofline([_S(lm_alone)] if lm_alone else ([serial] if serial is not None else []))
+    grid_seqs = cont['llm'].get('mean_active_sequences', B) if cont is not None else B
     est = sorted(((p['est_total_ms'], n) for n, p in prof.items() if n not in ('llm_decode_gemm', 'llm_attention', 'ras_sampler')), reverse=True)
     line = {
         'metric': 'speech-tokens/sec + RTF, HydraVox-CV3 head_num=%d, %d-char batch' % (K, chars),
@@ -277,29 +313,44 @@ def main():
                                'each), llm+flow bf16 / hift fp32, llm->flow->hift end to end, seeded N(0,0.02) weights'
                                % (' [TINY DIMS - NOT A BENCHMARK]' if args.tiny else '', K, B, chars, chars, n_spk, 2 * n_spk),
                    'global_batch': B * world, 'parallelism': 'utterance-dp%d' % world,
+                   'schedule': {'continuous': 'continuous batching: one decode grid of %d slots, utterances of later steps join as earlier ones finish; '
+                                              'flow + vocoder of finished utterances run beside it' % args.lm_slots,
+                                'chains': '%d independent decode chains of one step each + %d acoustic chain(s)' % (args.lm_chains, args.acoustic_chains),
+                                'serial': 'stages back to back'}[args.mode],
+                   'utterances_in_flight_per_gpu': in_flight,
                    'sampling': {'top_p': 0.9, 'top_k': 10, 'win_size': 32, 'tau_r': 0.2}},
         'rtf': round(elapsed / audio, 6) if audio else None,
         'llm_tokens_per_s': round(tokens / llm_s, 2) if llm_s else None,
         'stage_seconds_per_step': ({'llm': round(llm_s / args.steps, 4), 'flow': round(flow_s / args.steps, 4), 'hift': round(hift_s / args.steps, 4)} if args.serial else
-                                   {'llm': round(llm_s / args.steps, 4), 'flow+hift': round(flow_s / args.steps, 4), 'overlap': 'flow+hift of step i runs beside the llm of the next %d step(s); llm = mean decode wall time of a step while %d decode at once' % (args.lm_chains, args.lm_chains)}),
+                                   {'llm': round(llm_s / args.steps, 4), 'flow+hift': round(flow_s / args.steps, 4),
+                                    'overlap': ('llm = wall time of the decode engine / steps, flow+hift = busy time of the acoustic stage / steps; they run beside each other'
+                                                if args.mode == 'continuous' else
+                                                'flow+hift of step i runs beside the llm of the next %d step(s); llm = mean decode wall time of a step while %d decode at once' % (args.lm_chains, args.lm_chains))}),
         'stage_seconds_serial': None if serial is None else {'llm': round(serial.llm_seconds, 4), 'flow': round(serial.flow_seconds, 4), 'hift': round(serial.hift_seconds, 4)},
         'audio_seconds_per_step': round(audio / args.steps, 2),
         'setup_seconds': round(t_build, 1),
     }
     if rl_timed:
-        line['roofline'] = dict(kernel='llm_decode_step (hipGraph: %d-layer backbone + %d MTP heads + sampler, one launch = one step of %d sequences)'
-                                       % (cfg.llm.layers, K, B), bound='hbm', achieved=rl_timed['achieved'], peak=HBM_PEAK_GBS, unit='GB/s',
+        line['roofline'] = dict(kernel='llm_decode_step (hipGraph: %d-layer backbone + %d MTP heads + sampler + advance, one launch = one step of a grid of %.1f live sequences x %d heads)'
+                                       % (cfg.llm.layers, K, grid_seqs, K), bound='hbm', achieved=rl_timed['achieved'], peak=HBM_PEAK_GBS, unit='GB/s',
                                 frac=rl_timed['frac'], traffic=pmc_traffic('llm_decode_step'), avg_launch_us=rl_timed['avg_launch_us'],
                                 algorithmic_bytes_per_launch=rl_timed['algorithmic_bytes_per_launch'], launches_per_timed_region=rl_timed['launches'],
                                 measured='hipEvents around every 8 replays on the decode stream, all timed steps' +
-                                         ('' if args.serial else '; the flow decoder + vocoder of an earlier step and the decode chain of %d other step(s) share the GPU meanwhile' % (args.lm_chains - 1)))
-        if not args.serial and args.lm_chains > 1:
+                                         ('' if args.serial else '; the flow decoder + vocoder of finished utterances share the GPU meanwhile' if args.mode == 'continuous' else
+                                          '; the flow decoder + vocoder of an earlier step and the decode chain of %d other step(s) share the GPU meanwhile' % (args.lm_chains - 1)))
+        # what the LM stage moves over the WHOLE timed region (every decode launch of the job) against the HBM peak: the pipeline-wide figure
+        line['roofline']['pipeline_wide'] = dict(achieved=round(rl_timed['algorithmic_bytes_per_launch'] * rl_timed['launches'] / elapsed / 1e9, 1), unit='GB/s',
+                                                 frac=round(rl_timed['algorithmic_bytes_per_launch'] * rl_timed['launches'] / elapsed / 1e9 / HBM_PEAK_GBS, 4),
+                                                 note='algorithmic bytes of all decode launches / wall time of the timed region (the acoustic stage owns most of the GPU time)')
+        if args.mode == 'chains' and args.lm_chains > 1:
             # launches of different steps overlap in time: per launch `achieved` is bytes / its own duration; the chains together move this much
             line['roofline']['concurrent_decode_chains'] = args.lm_chains
             line['roofline']['achieved_all_chains'] = round(rl_timed['achieved'] * args.lm_chains, 1)
         if rl_alone and not args.serial:
             line['roofline']['alone'] = dict(achieved=rl_alone['achieved'], frac=rl_alone['frac'], avg_launch_us=rl_alone['avg_launch_us'],
-                                             measured='same brackets in the warm-up step (stages back to back, nothing else on the GPU)')
+                                             algorithmic_bytes_per_launch=rl_alone['algorithmic_bytes_per_launch'],
+                                             measured='the same grid of %d sequences with nothing else on the GPU (untimed run before the timed region)' % args.lm_slots
+                                                      if lm_alone else 'same brackets in the warm-up step (stages back to back, nothing else on the GPU)')
     if est:
         line['roofline_other'] = [roofline_of(n, prof[n]) for _, n in est if prof[n]['work_per_launch'] > 0]
         line['kernel_time_share_ms'] = {n: round(t, 1) for t, n in est}

@@ -63,6 +63,11 @@ struct EstBufs {
     float *mods, *fmod, *x, *outrow;
     // solver extras
     float *x_in, *mu_in, *spk_in, *cond_in, *t_in;
+    int* kv_in;
+    // adaLN modulation vectors: [depth][mod_rows][6D] + final [mod_rows][2D]; mod_bs = 6D (a row per batch entry) or 0 (one row for all:
+    // the solver, where every batch entry sits at the same step time t)
+    long long mod_bs = -1;
+    int mod_rows = 0;
     // encoder extras
     float *e_h0, *e_out;
     void *e_h0t, *e_c1;
@@ -91,11 +96,13 @@ size_t carve_est(const hvx_flow_config& c, char* base, int B, int T, EstBufs& b)
     b.att = cv.take<void>((size_t)B * T * D * es);
     b.ffh = cv.take<void>((size_t)B * T * c.ff * es);
     b.outrow = cv.take<float>((size_t)B * T * c.mel * 4);
-    b.x_in = cv.take<float>((size_t)2 * c.mel * T * 4);
-    b.mu_in = cv.take<float>((size_t)2 * c.mel * T * 4);
-    b.spk_in = cv.take<float>((size_t)2 * c.mel * 4);
-    b.cond_in = cv.take<float>((size_t)2 * c.mel * T * 4);
+    const int Bs = B < 2 ? 2 : B;
+    b.x_in = cv.take<float>((size_t)Bs * c.mel * T * 4);
+    b.mu_in = cv.take<float>((size_t)Bs * c.mel * T * 4);
+    b.spk_in = cv.take<float>((size_t)Bs * c.mel * 4);
+    b.cond_in = cv.take<float>((size_t)Bs * c.mel * T * 4);
     b.t_in = cv.take<float>(64);
+    b.kv_in = cv.take<int>((size_t)Bs * 4);
     return cv.off;
 }
 
@@ -188,6 +195,9 @@ int estimator_core(const hvx_flow* h, hipStream_t s, EstBufs& b, int B, int T, c
                    const float* t, const float* spks, const float* cond, bool skip_mods = false, int chunk = 0) {
     const hvx_flow_config& c = h->c;
     const int dt = c.dtype, D = c.dim, H = c.heads, Tp = b.t_pad, mel = c.mel;
+    // rows of modulation vectors that are computed (from t[0 .. MB)) and how the batch entries index them
+    const int MB = b.mod_rows > 0 ? b.mod_rows : B;
+    const long long mbs = b.mod_bs >= 0 ? b.mod_bs : 6LL * D, fbs = b.mod_bs >= 0 ? (b.mod_bs ? 2LL * D : 0) : 2LL * D;
     const size_t es = dtype_size(dt);
     const void* const* w = h->w.data();
     if (T > c.max_t) return set_error("estimator: T=%d exceeds max_t=%d", T, c.max_t), -1;
@@ -196,20 +206,20 @@ int estimator_core(const hvx_flow* h, hipStream_t s, EstBufs& b, int B, int T, c
     GemmArgs g;
     const void* const* tw = w + 19 + 10 * c.depth;
     if (!skip_mods) {
-    HVX_CHECK(launch_time_sinus(t, b.tsin, dt, B, c.time_freq_dim, s));
-    g = linear(dt, B, D, c.time_freq_dim, b.tsin, c.time_freq_dim, w[9], (const float*)w[10]);
+    HVX_CHECK(launch_time_sinus(t, b.tsin, dt, MB, c.time_freq_dim, s));
+    g = linear(dt, MB, D, c.time_freq_dim, b.tsin, c.time_freq_dim, w[9], (const float*)w[10]);
     g.act = ACT_SILU; g.out = b.th; g.ldo = D; g.out_cols = D;
     HVX_CHECK(launch_gemm(g, s));
-    g = linear(dt, B, D, D, b.th, D, w[11], (const float*)w[12]);
+    g = linear(dt, MB, D, D, b.th, D, w[11], (const float*)w[12]);
     g.out2 = b.tsilu; g.act2 = ACT_SILU; g.ldo2 = D; g.out2_cols = D;
     HVX_CHECK(launch_gemm(g, s));
     for (int i = 0; i < c.depth; ++i) {
         const void* const* bw = w + 19 + 10 * i;
-        g = linear(dt, B, 6 * D, D, b.tsilu, D, bw[0], (const float*)bw[1]);
-        g.out = b.mods + (size_t)i * B * 6 * D; g.out_f32 = 1; g.ldo = 6 * D; g.out_cols = 6 * D;
+        g = linear(dt, MB, 6 * D, D, b.tsilu, D, bw[0], (const float*)bw[1]);
+        g.out = b.mods + (size_t)i * MB * 6 * D; g.out_f32 = 1; g.ldo = 6 * D; g.out_cols = 6 * D;
         HVX_CHECK(launch_gemm(g, s));
     }
-    g = linear(dt, B, 2 * D, D, b.tsilu, D, tw[0], (const float*)tw[1]);
+    g = linear(dt, MB, 2 * D, D, b.tsilu, D, tw[0], (const float*)tw[1]);
     g.out = b.fmod; g.out_f32 = 1; g.ldo = 2 * D; g.out_cols = 2 * D;
     HVX_CHECK(launch_gemm(g, s));
     }
@@ -241,8 +251,8 @@ int estimator_core(const hvx_flow* h, hipStream_t s, EstBufs& b, int B, int T, c
     HIP_OK(hipMemsetAsync(b.vT, 0, (size_t)B * H * Tp * 64 * es, s));       // padded key columns must be finite
     for (int i = 0; i < c.depth; ++i) {
         const void* const* bw = w + 19 + 10 * i;
-        const float* mod = b.mods + (size_t)i * B * 6 * D;
-        HVX_CHECK(launch_layernorm_mod(b.x, mod, mod + D, 6 * D, 1e-6f, b.n, dt, B, T, D, s));
+        const float* mod = b.mods + (size_t)i * MB * 6 * D;
+        HVX_CHECK(launch_layernorm_mod(b.x, mod, mod + D, mbs, 1e-6f, b.n, dt, B, T, D, s));
         g = linear(dt, T, 3 * D, D, b.n, D, bw[2], (const float*)bw[3]);
         g.batch = B; g.a_bs = (long long)T * D; g.epi = EPI_QKV_DIT;
         g.q = b.q; g.k = b.k; g.vT = b.vT; g.heads = H; g.t_pad = Tp; g.rope_cos = (const float*)w[0]; g.rope_sin = (const float*)w[1];
@@ -258,22 +268,22 @@ int estimator_core(const hvx_flow* h, hipStream_t s, EstBufs& b, int B, int T, c
         HVX_CHECK(launch_attention(at, s));
         g = linear(dt, T, D, D, b.att, D, bw[4], (const float*)bw[5]);
         g.batch = B; g.a_bs = (long long)T * D;
-        g.gate = mod + 2 * D; g.gate_bs = 6 * D; g.res = b.x; g.res_bs = (long long)T * D; g.ldres = D;
+        g.gate = mod + 2 * D; g.gate_bs = mbs; g.res = b.x; g.res_bs = (long long)T * D; g.ldres = D;
         g.out = b.x; g.out_f32 = 1; g.out_bs = (long long)T * D; g.ldo = D; g.out_cols = D;
         HVX_CHECK(launch_gemm(g, s));
-        HVX_CHECK(launch_layernorm_mod(b.x, mod + 3 * D, mod + 4 * D, 6 * D, 1e-6f, b.n, dt, B, T, D, s));
+        HVX_CHECK(launch_layernorm_mod(b.x, mod + 3 * D, mod + 4 * D, mbs, 1e-6f, b.n, dt, B, T, D, s));
         g = linear(dt, T, c.ff, D, b.n, D, bw[6], (const float*)bw[7]);
         g.batch = B; g.a_bs = (long long)T * D; g.act = ACT_GELU_TANH;
         g.out = b.ffh; g.out_f32 = 0; g.out_bs = (long long)T * c.ff; g.ldo = c.ff; g.out_cols = c.ff;
         HVX_CHECK(launch_gemm(g, s));
         g = linear(dt, T, D, c.ff, b.ffh, c.ff, bw[8], (const float*)bw[9]);
         g.batch = B; g.a_bs = (long long)T * c.ff;
-        g.gate = mod + 5 * D; g.gate_bs = 6 * D; g.res = b.x; g.res_bs = (long long)T * D; g.ldres = D;
+        g.gate = mod + 5 * D; g.gate_bs = mbs; g.res = b.x; g.res_bs = (long long)T * D; g.ldres = D;
         g.out = b.x; g.out_f32 = 1; g.out_bs = (long long)T * D; g.ldo = D; g.out_cols = D;
         HVX_CHECK(launch_gemm(g, s));
     }
     // ---- final adaLN (scale first, then shift: modules.py:262) + projection -------------------------------------------
-    HVX_CHECK(launch_layernorm_mod(b.x, b.fmod + D, b.fmod, 2 * D, 1e-6f, b.n, dt, B, T, D, s));
+    HVX_CHECK(launch_layernorm_mod(b.x, b.fmod + D, b.fmod, fbs, 1e-6f, b.n, dt, B, T, D, s));
     g = linear(dt, T, mel, D, b.n, D, tw[2], (const float*)tw[3]);
     g.batch = B; g.a_bs = (long long)T * D;
     g.out = b.outrow; g.out_f32 = 1; g.out_bs = (long long)T * mel; g.ldo = mel; g.out_cols = mel;
@@ -377,27 +387,51 @@ int hvx_flow_set_mod_cache(hvx_flow* h, void* buf, size_t bytes) {
     return 0;
 }
 
-int hvx_cfm_solve_streaming(hvx_flow* h, hvx_stream stream, void* ws, size_t ws_bytes, int32_t T, float* x, const float* mu, const float* spks,
-                            const float* cond, int32_t n_steps, const float* t_steps, const float* dt_steps, int32_t static_chunk_size) {
+// x[u][ch][t] += dt * ((1 + rate) * v[u][t][ch] - rate * v[n + u][t][ch])   (flow_matching.py:116-120), all utterances of a batch
+__global__ void cfg_euler_batch_kernel(float* x, const float* v, int n, int T, int mel, float dt, float rate) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, ch = blockIdx.y, u = blockIdx.z;
+    if (t >= T) return;
+    const float vc = v[((long long)u * T + t) * mel + ch], vu = v[((long long)(n + u) * T + t) * mel + ch];
+    float* px = x + ((long long)u * mel + ch) * T + t;
+    *px = *px + dt * ((1.0f + rate) * vc - rate * vu);
+}
+
+__global__ void kv_len_pair_kernel(const int* t_len, int* kv, int n, int T) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 2 * n) kv[i] = t_len ? t_len[i % n] : T;
+}
+
+int hvx_cfm_solve_batch(hvx_flow* h, hvx_stream stream, void* ws, size_t ws_bytes, int32_t n, int32_t T, const int32_t* t_len, float* x,
+                        const float* mu, const float* spks, const float* cond, int32_t n_steps, const float* t_steps, const float* dt_steps,
+                        int32_t static_chunk_size) {
     hipStream_t s = (hipStream_t)stream;
-    if (static_chunk_size < 0) return set_error("hvx_cfm_solve: negative chunk size"), -1;
+    if (!h) return set_error("hvx_cfm_solve: null handle"), -1;
     const hvx_flow_config& c = h->c;
     // everything that can be refused is refused before any state (workspace, modulation cache) is touched
-    if (T <= 0 || T > c.max_t) return set_error("hvx_cfm_solve: T=%d outside (0, max_t=%d]", T, c.max_t), -1;
+    if (static_chunk_size < 0) return set_error("hvx_cfm_solve: negative chunk size"), -1;
+    if (n < 1 || T <= 0 || T > c.max_t) return set_error("hvx_cfm_solve: %d utterances of T=%d outside (0, max_t=%d]", n, T, c.max_t), -1;
     if (n_steps <= 0 || !x || !mu || !spks || !cond || !t_steps || !dt_steps) return set_error("hvx_cfm_solve: bad arguments"), -1;
     EstBufs b;
-    if (carve_est(c, (char*)ws, 2, T, b) > ws_bytes) return set_error("hvx_cfm_solve: workspace too small"), -1;
+    const int B = 2 * n;
+    if (carve_est(c, (char*)ws, B, T, b) > ws_bytes) return set_error("hvx_cfm_solve: workspace too small"), -1;
+    b.mod_rows = 2;                    // every batch entry sits at the same step time: one modulation row serves all (two are kept: the cache layout)
+    b.mod_bs = 0;
     const size_t plane = (size_t)c.mel * T * 4;
-    // row 0: conditional, row 1: unconditional (zeros)  (flow_matching.py:95-108)
-    HIP_OK(hipMemsetAsync(b.mu_in, 0, 2 * plane, s));
-    HIP_OK(hipMemsetAsync(b.cond_in, 0, 2 * plane, s));
-    HIP_OK(hipMemsetAsync(b.spk_in, 0, (size_t)2 * c.mel * 4, s));
-    HIP_OK(hipMemcpyAsync(b.mu_in, mu, plane, hipMemcpyDeviceToDevice, s));
-    HIP_OK(hipMemcpyAsync(b.cond_in, cond, plane, hipMemcpyDeviceToDevice, s));
-    HIP_OK(hipMemcpyAsync(b.spk_in, spks, (size_t)c.mel * 4, hipMemcpyDeviceToDevice, s));
+    // rows [0, n): conditional, rows [n, 2n): unconditional (zeros)  (flow_matching.py:95-108)
+    HIP_OK(hipMemsetAsync(b.mu_in, 0, B * plane, s));
+    HIP_OK(hipMemsetAsync(b.cond_in, 0, B * plane, s));
+    HIP_OK(hipMemsetAsync(b.spk_in, 0, (size_t)B * c.mel * 4, s));
+    HIP_OK(hipMemcpyAsync(b.mu_in, mu, n * plane, hipMemcpyDeviceToDevice, s));
+    HIP_OK(hipMemcpyAsync(b.cond_in, cond, n * plane, hipMemcpyDeviceToDevice, s));
+    HIP_OK(hipMemcpyAsync(b.spk_in, spks, (size_t)n * c.mel * 4, hipMemcpyDeviceToDevice, s));
+    const int* kv = nullptr;
+    if (t_len) {
+        hipLaunchKernelGGL(kv_len_pair_kernel, dim3((B + 63) / 64), dim3(64), 0, s, t_len, b.kv_in, n, T);
+        kv = b.kv_in;
+    }
     for (int st = 0; st < n_steps; ++st) {
-        HIP_OK(hipMemcpyAsync(b.x_in, x, plane, hipMemcpyDeviceToDevice, s));
-        HIP_OK(hipMemcpyAsync((char*)b.x_in + plane, x, plane, hipMemcpyDeviceToDevice, s));
+        HIP_OK(hipMemcpyAsync(b.x_in, x, n * plane, hipMemcpyDeviceToDevice, s));
+        HIP_OK(hipMemcpyAsync((char*)b.x_in + n * plane, x, n * plane, hipMemcpyDeviceToDevice, s));
         bool hit = false;
         int fill_slot = -1;
         float* ws_mods = b.mods;
@@ -415,7 +449,7 @@ int hvx_cfm_solve_streaming(hvx_flow* h, hvx_stream stream, void* ws, size_t ws_
             }
         }
         if (!hit) hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(64), 0, s, b.t_in, 2, t_steps[st]);
-        const int rc = estimator_core(h, s, b, 2, T, b.x_in, nullptr, b.mu_in, b.t_in, b.spk_in, b.cond_in, hit, static_chunk_size);
+        const int rc = estimator_core(h, s, b, B, T, b.x_in, kv, b.mu_in, b.t_in, b.spk_in, b.cond_in, hit, static_chunk_size);
         b.mods = ws_mods;
         b.fmod = ws_fmod;
         if (rc) return -1;
@@ -427,14 +461,20 @@ int hvx_cfm_solve_streaming(hvx_flow* h, hvx_stream stream, void* ws, size_t ws_
             }
             h->mod_t.push_back(m);
         }
-        HVX_CHECK(launch_cfg_euler(x, b.outrow, c.mel, (long long)T * c.mel, dt_steps[st], c.cfg_rate, T, c.mel, s));
+        hipLaunchKernelGGL(cfg_euler_batch_kernel, dim3((T + 255) / 256, c.mel, n), dim3(256), 0, s, x, b.outrow, n, T, c.mel, dt_steps[st], c.cfg_rate);
+        HIP_OK(hipGetLastError());
     }
     return 0;
 }
 
+int hvx_cfm_solve_streaming(hvx_flow* h, hvx_stream stream, void* ws, size_t ws_bytes, int32_t T, float* x, const float* mu, const float* spks,
+                            const float* cond, int32_t n_steps, const float* t_steps, const float* dt_steps, int32_t static_chunk_size) {
+    return hvx_cfm_solve_batch(h, stream, ws, ws_bytes, 1, T, nullptr, x, mu, spks, cond, n_steps, t_steps, dt_steps, static_chunk_size);
+}
+
 int hvx_cfm_solve(hvx_flow* h, hvx_stream stream, void* ws, size_t ws_bytes, int32_t T, float* x, const float* mu, const float* spks,
                   const float* cond, int32_t n_steps, const float* t_steps, const float* dt_steps) {
-    return hvx_cfm_solve_streaming(h, stream, ws, ws_bytes, T, x, mu, spks, cond, n_steps, t_steps, dt_steps, 0);
+    return hvx_cfm_solve_batch(h, stream, ws, ws_bytes, 1, T, nullptr, x, mu, spks, cond, n_steps, t_steps, dt_steps, 0);
 }
 
 }  // extern "C"

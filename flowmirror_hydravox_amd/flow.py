@@ -213,6 +213,59 @@ class HvxFlow:
                                                self.static_chunk_size if streaming else 0), 'hvx_cfm_solve_streaming')
         return z
 
+    def solve_batch(self, mus, spks, conds, n_timesteps=None, streaming=False):
+        """Padded multi-utterance solve (hvx_cfm_solve_batch): lists of mu (mel, T_i), spk (mel,), cond (mel, T_i) -> list of mel (mel, T_i).
+        The utterances are padded to the longest one; every one draws the same noise prefix the reference gives a single utterance
+        (`rand_noise[:, :, :T_i]`, flow_matching.py:222) and key-padding masks keep the padding out of its attention."""
+        n_utt = len(mus)
+        lens = [int(m.shape[-1]) for m in mus]
+        T = max(lens)
+        mel, dev = self.cfg.mel, self.device
+        n = n_timesteps or self.cfg.n_timesteps
+        x = torch.zeros(n_utt, mel, T, dtype=torch.float32, device=dev)
+        mu = torch.zeros(n_utt, mel, T, dtype=torch.float32, device=dev)
+        cond = torch.zeros(n_utt, mel, T, dtype=torch.float32, device=dev)
+        for i in range(n_utt):
+            x[i, :, :lens[i]] = self.rand_noise[0, :, :lens[i]]
+            mu[i, :, :lens[i]] = mus[i]
+            cond[i, :, :lens[i]] = conds[i]
+        spk = torch.stack([s_.to(dev, torch.float32).view(-1) for s_ in spks]).contiguous()
+        t_len = None if min(lens) == T else torch.tensor(lens, dtype=torch.int32).pin_memory().to(dev, non_blocking=True)
+        ts, dts = euler_schedule(n)
+        ta = (C.c_float * n)(*ts)
+        da = (C.c_float * n)(*dts)
+        ws = self._workspace(2 * n_utt, T)
+        check(self.lib.hvx_cfm_solve_batch(self._h, stream_ptr(), ptr(ws), ws.numel(), n_utt, T, ptr(t_len), ptr(x), ptr(mu), ptr(spk), ptr(cond), n, ta, da,
+                                           self.static_chunk_size if streaming else 0), 'hvx_cfm_solve_batch')
+        return [x[i, :, :lens[i]] for i in range(n_utt)]
+
+    @torch.inference_mode()
+    def inference_batch(self, tokens, embeddings, prompt_tokens=None, prompt_feats=None, streaming=False):
+        """Several utterances through ONE solve (length-bucketed acoustic batches; the reference's `inference` asserts
+        batch 1, flow.py:387).  tokens: list of int tensors (n_i,); embeddings: list of (spk_dim,); prompt_tokens / prompt_feats: lists with
+        None where an utterance has no prompt.  Returns a list of mels (1, mel, 2 n_i), each what `inference` returns for that utterance."""
+        n_utt = len(tokens)
+        mus, spks, conds, cut = [], [], [], []
+        for i in range(n_utt):
+            tok = tokens[i].reshape(-1)
+            pt = None if prompt_tokens is None else prompt_tokens[i]
+            pf = None if prompt_feats is None else prompt_feats[i]
+            if pt is not None:
+                tok = torch.concat([pt.reshape(-1).to(tok.device), tok])
+            mu, spk = self.encode(tok, embeddings[i].reshape(-1), finalize=True)
+            cond = torch.zeros(self.cfg.mel, mu.shape[-1], dtype=torch.float32, device=self.device)
+            n1 = 0
+            if pf is not None:
+                pf = pf.reshape(-1, self.cfg.mel)
+                n1 = pf.shape[0]
+                cond[:, :n1] = pf.to(self.device, torch.float32).t()
+            mus.append(mu)
+            spks.append(spk)
+            conds.append(cond)
+            cut.append(n1)
+        feats = self.solve_batch(mus, spks, conds, streaming=streaming)
+        return [f[:, c:].unsqueeze(0).float() for f, c in zip(feats, cut)]
+
     # ---- reference surface ---------------------------------------------------------------------------------------------------
     @torch.inference_mode()
     def inference(self, token, token_len, embedding, finalize=True, prompt_token=None, prompt_token_len=None, prompt_feat=None,

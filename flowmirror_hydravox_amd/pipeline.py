@@ -109,6 +109,26 @@ class HvxPipeline:
             mels.append(mel)
         return mels
 
+    def _mels_batched(self, utts, toks, flow=None, max_pad=0.15):
+        """the same mels as _mels, solved in length buckets: utterances whose frame counts lie within `max_pad` of the longest of their
+        bucket share one padded solve (hvx_cfm_solve_batch)"""
+        flow = flow or self.flow
+        dev = self.device
+        mels = [None] * len(utts)
+        order = sorted((i for i in range(len(utts)) if toks[i]), key=lambda i: -(len(toks[i]) + (0 if utts[i].prompt_speech_token is None else len(utts[i].prompt_speech_token))))
+        while order:
+            def frames(i):
+                return len(toks[i]) + (0 if utts[i].prompt_speech_token is None else len(utts[i].prompt_speech_token))
+            top = frames(order[0])
+            bucket = [i for i in order if frames(i) >= (1.0 - max_pad) * top]
+            order = [i for i in order if i not in bucket]
+            out = flow.inference_batch([torch.tensor(toks[i], dtype=torch.int32, device=dev) for i in bucket], [utts[i].embedding.to(dev) for i in bucket],
+                                       prompt_tokens=[None if utts[i].prompt_speech_token is None else utts[i].prompt_speech_token.to(dev) for i in bucket],
+                                       prompt_feats=[None if utts[i].prompt_feat is None else utts[i].prompt_feat.to(dev) for i in bucket])
+            for i, m in zip(bucket, out):
+                mels[i] = m
+        return mels
+
     def _waves(self, mels, hift=None):
         wavs = []
         hift = hift or self.hift
@@ -203,7 +223,7 @@ class HvxPipeline:
         return wavs, st
 
     @torch.inference_mode()
-    def synthesize_continuous(self, utts, lm_slots=16, max_token_text_ratio=20, min_token_text_ratio=2):
+    def synthesize_continuous(self, utts, lm_slots=16, max_token_text_ratio=20, min_token_text_ratio=2, acoustic_batch=4):
         """Generator over (index, waveform, tokens) in completion order — continuous batching end to end.
         The LM decodes up to `lm_slots` utterances in ONE grid (HvxLLM.generate_stream: the weights are streamed once per step for all of
         them, a finished utterance's slot goes to the next waiting one), driven by a worker thread on the high-priority decode stream; every
@@ -252,15 +272,27 @@ class HvxPipeline:
                     break
                 if isinstance(item, BaseException):
                     raise item
-                i, toks = item
+                # whatever else has finished meanwhile joins this acoustic batch (up to `acoustic_batch` utterances, solved in length buckets)
+                group = [item]
+                while len(group) < acoustic_batch:
+                    try:
+                        nxt = q.get_nowait()
+                    except queue.Empty:
+                        break
+                    if nxt is None or isinstance(nxt, BaseException):
+                        q.put(nxt)                                 # (the sentinel / error is handled by the outer loop after this batch)
+                        break
+                    group.append(nxt)
+                idx = [i for i, _ in group]
                 t0 = time.time()
                 with torch.cuda.stream(stream):
-                    wav = self._waves(self._mels([utts[i]], [toks], flow), hift)[0]
+                    wavs = self._waves(self._mels_batched([utts[i] for i in idx], [t for _, t in group], flow), hift)
                     stream.synchronize()
                 acoustic += time.time() - t0
-                audio += wav.numel() / float(self.cfg.sample_rate)
-                tokens += len(toks)
-                yield i, wav, toks
+                for (i, toks), wav in zip(group, wavs):
+                    audio += wav.numel() / float(self.cfg.sample_rate)
+                    tokens += len(toks)
+                    yield i, wav, toks
         finally:
             th.join()
             self.last_continuous = dict(tokens=tokens, audio_seconds=audio, acoustic_seconds=acoustic, total_seconds=time.time() - t_begin,

@@ -229,6 +229,15 @@ int hvx_cfm_solve(hvx_flow* h, hvx_stream s, void* ws, size_t ws_bytes, int32_t 
 int hvx_cfm_solve_streaming(hvx_flow* h, hvx_stream s, void* ws, size_t ws_bytes, int32_t t_len, float* x, const float* mu, const float* spks,
                             const float* cond, int32_t n_steps, const float* t_steps, const float* dt_steps, int32_t static_chunk_size);
 
+/* Padded multi-utterance solve (length-bucketed acoustic batches; the reference solves one utterance per call,
+ * cosyvoice/flow/flow.py:387, with the batch-2 CFG layout of flow_matching.py:95-108): n utterances padded to T frames, t_len device
+ * int32 [n] valid frames of each (NULL: all T).  x (n, mel, T) holds the noise on entry and the mels on return; mu, cond (n, mel, T);
+ * spks (n, mel).  The estimator runs on 2n batch entries (n conditional, n unconditional) with key-padding masks from t_len; frames at or
+ * beyond an utterance's t_len hold unspecified values on return.  Workspace: hvx_flow_workspace_bytes(h, 2n, T). */
+int hvx_cfm_solve_batch(hvx_flow* h, hvx_stream s, void* ws, size_t ws_bytes, int32_t n, int32_t t_max, const int32_t* t_len, float* x,
+                        const float* mu, const float* spks, const float* cond, int32_t n_steps, const float* t_steps, const float* dt_steps,
+                        int32_t static_chunk_size);
+
 /* ---------------------------------------------------------------------------------------------------
  * HiFT — replaces CausalHiFTGenerator.inference / decode (cosyvoice/hifigan/generator.py:713-726, 672-711),
  * CausalConvRNNF0Predictor.forward (cosyvoice/hifigan/f0_predictor.py:95-103), SourceModuleHnNSF / SineGen2

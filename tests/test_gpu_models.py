@@ -704,3 +704,42 @@ def test_continuous_synthesis_equals_serial(tiny_cfg):
     for i in range(7):
         assert seen[i].shape == serial[i].shape and torch.equal(seen[i], serial[i]), i
     assert pipe.last_continuous['tokens'] > 0 and pipe.last_continuous['llm']['requests'] == 7
+
+
+def test_flow_mixed_length_batch_vs_per_utterance_oracle(tiny_cfg, flow_setup):
+    """hvx_cfm_solve_batch: four utterances of 41 / 37 / 36 / 12 tokens (one with a prompt) — the first three share one padded solve (key-padding
+    masks from their frame counts), the short one gets its own bucket.  Every mel is within 1e-3 of the fp32 oracle run on that utterance
+    alone and bit-equal to what the batch-1 `inference` returns for it."""
+    from flowmirror_hydravox_amd.flow import HvxFlow
+    from flowmirror_hydravox_amd.pipeline import HvxPipeline, Utterance
+    from oracle import flow_ref
+    g, sd = flow_setup
+    c = tiny_cfg.flow
+    flow = HvxFlow(c, sd, dtype=torch.float32, max_t=512)
+    gen = torch.Generator().manual_seed(77)
+    lens, plens = [41, 37, 30, 12], [0, 0, 6, 0]
+    toks = [torch.randint(0, c.vocab, (n,), generator=gen) for n in lens]
+    ptoks = [torch.randint(0, c.vocab, (n,), generator=gen) if n else None for n in plens]
+    pfeats = [torch.randn(2 * n, 80, generator=gen) if n else None for n in plens]
+    embs = [torch.randn(192, generator=gen) for _ in lens]
+    got = flow.inference_batch([t.to(DEV) for t in toks[:3]], embs[:3], prompt_tokens=ptoks[:3], prompt_feats=pfeats[:3])
+    for i in range(3):
+        ref = flow_ref.flow_inference(toks[i][None], embs[i][None], sd, c, prompt_token=None if ptoks[i] is None else ptoks[i][None],
+                                      prompt_feat=None if pfeats[i] is None else pfeats[i][None])
+        assert tuple(got[i].shape) == (1, 80, 2 * lens[i])
+        assert _rel(got[i].cpu().numpy(), ref.numpy()) < 1e-3, (i, _rel(got[i].cpu().numpy(), ref.numpy()))
+        kw = {}
+        if ptoks[i] is not None:
+            kw = dict(prompt_token=ptoks[i][None].to(DEV), prompt_token_len=torch.tensor([plens[i]]), prompt_feat=pfeats[i][None].to(DEV),
+                      prompt_feat_len=torch.tensor([2 * plens[i]]))
+        one, _ = flow.inference(token=toks[i][None].to(DEV), token_len=torch.tensor([lens[i]], dtype=torch.int32), embedding=embs[i][None].to(DEV), finalize=True, **kw)
+        assert torch.equal(one, got[i]), i
+    # the bucketing of the pipeline: the 12-token utterance is not padded to 82 frames
+    pipe = HvxPipeline.__new__(HvxPipeline)
+    pipe.flow, pipe.device = flow, torch.device(DEV)
+    utts = [Utterance(text=torch.zeros(1, dtype=torch.int32), seed=0, embedding=embs[i], prompt_speech_token=ptoks[i], prompt_feat=pfeats[i]) for i in range(4)]
+    mels = pipe._mels_batched(utts, [t.tolist() for t in toks])
+    for i in range(3):
+        assert torch.equal(mels[i], got[i]), i
+    ref = flow_ref.flow_inference(toks[3][None], embs[3][None], sd, c)
+    assert _rel(mels[3].cpu().numpy(), ref.numpy()) < 1e-3
