@@ -47,7 +47,7 @@ class AttnArgs(C.Structure):
     _fields_ = [('dtype', c_i32), ('batch', c_i32), ('heads', c_i32), ('t', c_i32), ('t_pad', c_i32),
                 ('q', c_vp), ('k', c_vp), ('vT', c_vp), ('out', c_vp), ('kv_len', c_vp),
                 ('causal', c_i32), ('scale', c_f32),
-                ('n_splits', c_i32), ('split_chunk', c_i32), ('part_o', c_vp), ('part_ml', c_vp), ('chunk', c_i32)]
+                ('n_splits', c_i32), ('split_chunk', c_i32), ('part_o', c_vp), ('part_ml', c_vp), ('chunk', c_i32), ('q_log2', c_i32)]
 
 
 class LLMConfig(C.Structure):

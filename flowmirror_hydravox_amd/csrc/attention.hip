@@ -327,7 +327,20 @@ __global__ void attn_combine_kernel(AttnArgs a) {
 // wave from L2.  Same register-resident S^T / P^T orientation as above.  Softmax runs on exp2 with the scale folded into one
 // fma per score, and the key-padding mask is only evaluated on the last tile.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int QR>                        // 16-row query tiles per wave: every K / V^T fragment read from LDS feeds QR MFMAs
+//
+// FAST form (the default): the softmax of a 64-key tile is phase-pure vector work between two phase-pure MFMA blocks, and the two waves
+// that share a SIMD (one from each resident workgroup) run the same phases — the matrix cores idle while both exponentiate.  The fast
+// tile therefore (1) drops the running maximum: every row keeps ONE reference m_ref (its maximum over the first key tile, found in a
+// prologue) and p = exp2(s c - m_ref) may exceed 1 — softmax is shift-invariant, bf16 keeps its relative precision at any magnitude
+// and the sums are fp32 — which removes the max chain, the two cross-lane exchanges and the rescale branch, leaving one basic block of
+// 72 MFMAs and ~130 VALU per wave and tile; (2) software-pipelines that block by 16-row query tile inside the wave:
+//     QK(0) | QK(1) + SM(0) | QK(2) + SM(1) + PV(0) | QK(3) + SM(2) + PV(1) | SM(3) + PV(2) | PV(3)
+// with the MFMA : VALU interleave pinned by sched_group_barrier.  A score that outgrows its reference by more than 2^127 overflows to
+// inf; that is detected at the end (l or O not finite, workgroup-wide vote) and the workgroup then simply runs again with the classical
+// online-softmax loop below (FAST = false path; exercised by tests/test_gpu_ops.py::test_attention_dit_fallback_on_score_spike).
+// PRE: the query operand already carries scale * log2(e) (a.q_log2: written that way by the fused QKV epilogue, one rounding) — the MFMA
+// accumulator then starts at -m_ref and exp2 is the only arithmetic left per score.  Otherwise the scale is applied to the fp32 score.
+template <int QR, bool FAST, bool PRE>   // 16-row query tiles per wave: every K / V^T fragment read from LDS feeds QR MFMAs
 __global__ __launch_bounds__(256, 2) void attn_dit_kernel(AttnArgs a) {
     typedef bf16_t T;
     constexpr int KT = 64;                 // keys per tile
@@ -398,15 +411,16 @@ __global__ __launch_bounds__(256, 2) void attn_dit_kernel(AttnArgs a) {
     };
 
     float m_run[QR];
-    f32x4 o_acc[QR][4], l_acc[QR];
+    f32x4 o_acc[QR][4];
+    float l_acc[QR];
 #pragma unroll
     for (int i = 0; i < QR; ++i) {
         m_run[i] = -INFINITY;
-        l_acc[i] = f32x4{0, 0, 0, 0};
+        l_acc[i] = 0.0f;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o_acc[i][dt] = f32x4{0, 0, 0, 0};
     }
-    const float c = a.scale * 1.4426950408889634f;                      // softmax(s * scale) == exp2(s * c - m * c)
+    const float c = PRE ? 1.0f : a.scale * 1.4426950408889634f;         // softmax(s * scale) == exp2(s * c - m * c); PRE: c sits in q
     const f32x2 c2 = {c, c};
     bf16x8 ones;
 #pragma unroll
@@ -474,9 +488,12 @@ __global__ __launch_bounds__(256, 2) void attn_dit_kernel(AttnArgs a) {
         }
         // O^T += V^T P^T; each V^T fragment is read from LDS once and used for all query tiles.  l += 1^T P^T on the matrix cores.
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int i = 0; i < QR; ++i) mma32(l_acc[i], ones, pf[i][m]);
+        for (int i = 0; i < QR; ++i) {
+            f32x4 lt = {0, 0, 0, 0};                                     // every row of the ones-MFMA holds the column (query) sum
+            mma32(lt, ones, pf[i][0]);
+            mma32(lt, ones, pf[i][1]);
+            l_acc[i] += lt[0];
+        }
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
@@ -487,33 +504,167 @@ __global__ __launch_bounds__(256, 2) void attn_dit_kernel(AttnArgs a) {
             }
     };
 
+    // ---- the fast tile (see the header of this kernel) --------------------------------------------------------------------
+    f32x4 nm_ref[QR];
+    auto mask_tail = [&](f32x4 (&sv)[4], int key0, int i) {
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (key0 + kt * 16 + fg * 4 + r >= lim[i]) sv[kt][r] = -INFINITY;
+    };
+    auto tile_fast = [&](int buf, int key0, auto tail_tag) {
+        constexpr bool TAIL = decltype(tail_tag)::value;
+        bf16x8 kf[4][2], vf[4][2];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            kf[kt][0] = load8(&Ks[buf][(kt * 16 + fr) * LD + fg * 8]);
+            kf[kt][1] = load8(&Ks[buf][(kt * 16 + fr) * LD + 32 + fg * 8]);
+        }
+        auto qk = [&](int i, f32x4 (&sv)[4]) {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                // the accumulator starts at -m_ref (loop-invariant registers): the scores arrive shifted, exp2 is all that is left
+                if constexpr (PRE) sv[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt][0], qf[i][0], nm_ref[i], 0, 0, 0);
+                else sv[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt][0], qf[i][0], f32x4{0, 0, 0, 0}, 0, 0, 0);
+                mma32(sv[kt], kf[kt][1], qf[i][1]);
+            }
+        };
+        auto sm = [&](int i, f32x4 (&sv)[4], bf16x8 (&pf)[2]) {
+            if constexpr (TAIL) mask_tail(sv, key0, i);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        pf[m][4 * hh + r] = f32_to_bf16(__builtin_amdgcn_exp2f(PRE ? sv[2 * m + hh][r] : __builtin_fmaf(sv[2 * m + hh][r], c, nm_ref[i][0])));   // -inf -> 0
+        };
+        auto pv = [&](int i, const bf16x8 (&pf)[2]) {
+            f32x4 lt = {0, 0, 0, 0};
+            mma32(lt, ones, pf[0]);
+            mma32(lt, ones, pf[1]);
+            l_acc[i] += lt[0];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) mma32(o_acc[i][dt], vf[dt][m], pf[m]);
+        };
+        // MFMA : VALU interleave of one pipeline step (masks: 0x8 MFMA, 0x2 VALU; the transcendental ops count as VALU)
+        auto pin = [&](auto NM, auto NV) {
+            constexpr int nm = decltype(NM)::value, nv = decltype(NV)::value;
+#pragma unroll
+            for (int u = 0; u < nm; ++u) {
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x2, nv, 0);
+            }
+        };
+        f32x4 sa[4], sb[4];
+        bf16x8 pa[2], pb[2];
+        static_assert(QR == 4 || QR == 2, "pipeline written for 2 or 4 query tiles per wave");
+        qk(0, sa);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) vf[dt][m] = load8(&Vs[buf][(dt * 16 + fr) * LD + m * 32 + fg * 8]);
+        if constexpr (QR == 4) {
+            qk(1, sb); sm(0, sa, pa);
+            pin(std::integral_constant<int, 8>{}, std::integral_constant<int, PRE ? 3 : 5>{});
+            qk(2, sa); sm(1, sb, pb); pv(0, pa);
+            pin(std::integral_constant<int, PRE ? 12 : 18>{}, std::integral_constant<int, 2>{});
+            qk(3, sb); sm(2, sa, pa); pv(1, pb);
+            pin(std::integral_constant<int, PRE ? 12 : 18>{}, std::integral_constant<int, 2>{});
+            sm(3, sb, pb); pv(2, pa);
+            pin(std::integral_constant<int, 10>{}, std::integral_constant<int, PRE ? 3 : 4>{});
+            pv(3, pb);
+        } else {
+            qk(1, sb); sm(0, sa, pa);
+            pin(std::integral_constant<int, 8>{}, std::integral_constant<int, PRE ? 3 : 5>{});
+            sm(1, sb, pb); pv(0, pa);
+            pin(std::integral_constant<int, 10>{}, std::integral_constant<int, PRE ? 3 : 4>{});
+            pv(1, pb);
+        }
+    };
+
     const int n_tiles = (lim_hi + KT - 1) / KT;
+    const int n_full = lim_lo / KT;                                    // the first loop holds unmasked tiles only
+    auto run = [&](auto&& tf) {
+        for (int it = 0; it < n_full; ++it) {
+            const int buf = it & 1, key0 = it * KT;
+            const bool more = (it + 1) < n_tiles;
+            if (more) gload(key0 + KT);
+            tf(buf, key0, std::false_type{});
+            if (more) stash(buf ^ 1);
+            __syncthreads();
+        }
+        // masked tiles: one (the ragged end) without a chunk mask, the tiles between the first and the last row's chunk end with one
+        for (int it = n_full; it < n_tiles; ++it) {
+            const int buf = it & 1, key0 = it * KT;
+            const bool more = (it + 1) < n_tiles;
+            if (more) gload(key0 + KT);
+            tf(buf, key0, std::true_type{});
+            if (more) stash(buf ^ 1);
+            __syncthreads();
+        }
+    };
     if (n_tiles > 0) {
         gload(0);
         stash(0);
     }
     __syncthreads();
-    const int n_full = lim_lo / KT;                                    // this loop holds unmasked tiles only
-    for (int it = 0; it < n_full; ++it) {
-        const int buf = it & 1, key0 = it * KT;
-        const bool more = (it + 1) < n_tiles;
-        if (more) gload(key0 + KT);
-        tile(buf, key0, std::false_type{});
-        if (more) stash(buf ^ 1);
-        __syncthreads();
+    bool classical = !FAST;
+    if constexpr (FAST) {
+        if (n_tiles > 0) {
+            // reference maximum of every row: its (masked) scores against the first key tile
+#pragma unroll
+            for (int i = 0; i < QR; ++i) {
+                f32x4 sv[4];
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) {
+                    sv[kt] = f32x4{0, 0, 0, 0};
+                    mma32(sv[kt], load8(&Ks[0][(kt * 16 + fr) * LD + fg * 8]), qf[i][0]);
+                    mma32(sv[kt], load8(&Ks[0][(kt * 16 + fr) * LD + 32 + fg * 8]), qf[i][1]);
+                }
+                mask_tail(sv, 0, i);
+                float mx = fmax3(fmax3(sv[0][0], sv[0][1], sv[0][2]), fmax3(sv[0][3], sv[1][0], sv[1][1]), fmax3(sv[1][2], sv[1][3], sv[2][0]));
+                mx = fmax3(mx, fmax3(sv[2][1], sv[2][2], sv[2][3]), fmax3(sv[3][0], sv[3][1], sv[3][2]));
+                mx = fmax2(mx, sv[3][3]);
+                mx = fmax2(mx, __shfl_xor(mx, 16, 64));
+                mx = fmax2(mx, __shfl_xor(mx, 32, 64));
+                mx = -fmax2(mx * c, -1e30f);                                  // a row without a visible key in the tile: finite reference, p = 0
+                nm_ref[i] = f32x4{mx, mx, mx, mx};
+            }
+        }
+        run(tile_fast);
+        // overflow vote: any non-finite row sum / output (exponent bits all ones) sends the whole workgroup to the classical loop
+        unsigned bad = 0;
+#pragma unroll
+        for (int i = 0; i < QR; ++i) {
+            bad |= ((__float_as_uint(l_acc[i]) & 0x7f800000u) == 0x7f800000u);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bad |= ((__float_as_uint(o_acc[i][dt][r]) & 0x7f800000u) == 0x7f800000u);
+        }
+        classical = __syncthreads_or((int)bad) != 0;
+        if (classical) {
+#pragma unroll
+            for (int i = 0; i < QR; ++i) {
+                l_acc[i] = 0.0f;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) o_acc[i][dt] = f32x4{0, 0, 0, 0};
+            }
+            if (n_tiles > 0) {
+                gload(0);
+                stash(0);
+            }
+            __syncthreads();
+        }
     }
-    // masked tiles: one (the ragged end) without a chunk mask, the tiles between the first and the last row's chunk end with one
-    for (int it = n_full; it < n_tiles; ++it) {
-        const int buf = it & 1, key0 = it * KT;
-        const bool more = (it + 1) < n_tiles;
-        if (more) gload(key0 + KT);
-        tile(buf, key0, std::true_type{});
-        if (more) stash(buf ^ 1);
-        __syncthreads();
-    }
+    if (classical) run(tile);
 #pragma unroll
     for (int i = 0; i < QR; ++i) {
-        const float l = l_acc[i][0];                                   // every row of the ones-MFMA holds the column (query) sum
+        const float l = l_acc[i];
         const int r = row0 + i * 16 + fr;
         if (r >= a.n_rows) continue;
         const float inv = l > 0.0f ? 1.0f / l : 0.0f;
@@ -529,7 +680,8 @@ __global__ __launch_bounds__(256, 2) void attn_dit_kernel(AttnArgs a) {
 }
 
 template <class T>
-static int launch_t(const AttnArgs& a, hipStream_t s) {
+static int launch_t(const AttnArgs& a_in, hipStream_t s) {
+    AttnArgs a = a_in;
     if (sizeof(T) == 2 && !a.causal && a.n_splits == 1 && a.kn >= a.n_rows && !a.kv_slot && !a.n_valid_lo && a.n_rows >= 256 &&
         (a.v_ld & 63) == 0) {
         const double fl = 4.0 * a.n_rows * (double)a.kv_len_const * 64.0 * a.heads * a.batch;
@@ -540,11 +692,18 @@ static int launch_t(const AttnArgs& a, hipStream_t s) {
         // the decode step next to it takes 2.6 ms instead of 4.1 ms (tools/contention_probe.py).
         // With a chunk mask the last workgroup of a head does twice the average work: 128-row workgroups (twice as many, three per SIMD)
         // balance better than 256-row ones (T = 5632, chunk 50: 244 vs 288 us; the unmasked pass takes 392 us).
-        if (a.n_rows >= 2048 && a.chunk <= 0) hipLaunchKernelGGL(attn_dit_kernel<4>, dim3((a.n_rows + 255) / 256, a.heads, a.batch), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL(attn_dit_kernel<2>, dim3((a.n_rows + 127) / 128, a.heads, a.batch), dim3(256), 0, s, a);
+        const dim3 g4((a.n_rows + 255) / 256, a.heads, a.batch), g2((a.n_rows + 127) / 128, a.heads, a.batch);
+        if (a.n_rows >= 2048 && a.chunk <= 0) {
+            if (a.q_log2) hipLaunchKernelGGL((attn_dit_kernel<4, true, true>), g4, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((attn_dit_kernel<4, true, false>), g4, dim3(256), 0, s, a);
+        } else {
+            if (a.q_log2) hipLaunchKernelGGL((attn_dit_kernel<2, true, true>), g2, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((attn_dit_kernel<2, true, false>), g2, dim3(256), 0, s, a);
+        }
         prof_end(slot, s);
         return hipGetLastError() == hipSuccess ? 0 : (set_error("attention launch failed"), -1);
     }
+    if (a.q_log2) a.scale = 0.6931471805599453f;                   // generic kernels: softmax(s_log2 * ln 2)
     const bool big = a.n_rows >= 256;
     const int rows_per_wave = big ? 32 : 16;
     const int n_qt = (a.n_rows + rows_per_wave - 1) / rows_per_wave;
@@ -570,6 +729,7 @@ int launch_attention(const AttnArgs& a_in, hipStream_t s) {
     AttnArgs a = a_in;
     if (a.n_rows <= 0 || a.batch <= 0) return 0;
     if (a.n_splits < 1) a.n_splits = 1;
+
     if (a.kn < 1) a.kn = a.n_rows;
     if (a.n_splits == 1 || a.n_rows > 32 || a.sub_chunk * 4 != a.split_chunk || (a.sub_chunk & 31)) a.sub_chunk = 0;
     if ((a.v_ld & 31) || (a.n_splits > 1 && ((a.split_chunk & 31) || !a.part_o || !a.part_ml || a.n_rows_pad < a.n_rows))) {

@@ -402,6 +402,10 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(GemmArgs a) {
                         x[c + 1] = o * cs + e * sn;
                     }
                 }
+                if (which == 0 && a.q_scale != 0.0f) {
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) x[c] *= a.q_scale;
+                }
                 T* dst = reinterpret_cast<T*>(which == 0 ? a.q : a.k) + ((((long long)bz * a.heads + h) * a.t_pad) + row) * 64 + d0;
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {

@@ -141,7 +141,7 @@ int hvx_op_attention(const hvx_attn_args* a, hvx_stream s) {
     k.q = a->q; k.q_bs = (long long)a->heads * a->t_pad * 64; k.q_hs = (long long)a->t_pad * 64; k.q_hi = 0; k.q_lo = 64;
     k.k = a->k; k.k_bs = k.q_bs; k.k_hs = k.q_hs;
     k.vT = a->vT; k.v_bs = k.q_bs; k.v_hs = (long long)64 * a->t_pad; k.v_ld = a->t_pad;
-    k.kv_len = a->kv_len; k.kv_len_const = a->t; k.causal = a->causal; k.chunk = a->chunk > 0 ? a->chunk : 0; k.scale = a->scale;
+    k.kv_len = a->kv_len; k.kv_len_const = a->t; k.causal = a->causal; k.chunk = a->chunk > 0 ? a->chunk : 0; k.scale = a->scale; k.q_log2 = a->q_log2;
     k.out = a->out; k.o_bs = (long long)a->t * D; k.o_hs = 64; k.o_hi = 0; k.o_lo = D;
     k.n_splits = a->n_splits > 1 ? a->n_splits : 1; k.split_chunk = a->split_chunk; k.part_o = a->part_o; k.part_ml = a->part_ml;
     k.n_rows_pad = (a->t + 31) & ~31;

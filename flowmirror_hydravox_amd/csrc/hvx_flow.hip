@@ -256,6 +256,7 @@ int estimator_core(const hvx_flow* h, hipStream_t s, EstBufs& b, int B, int T, c
         g = linear(dt, T, 3 * D, D, b.n, D, bw[2], (const float*)bw[3]);
         g.batch = B; g.a_bs = (long long)T * D; g.epi = EPI_QKV_DIT;
         g.q = b.q; g.k = b.k; g.vT = b.vT; g.heads = H; g.t_pad = Tp; g.rope_cos = (const float*)w[0]; g.rope_sin = (const float*)w[1];
+        g.q_scale = 0.125f * 1.4426950408889634f;              // dim_head^-0.5 (modules.py:391, SDPA default scale) in log2 units, rounded once with q
         HVX_CHECK(launch_gemm(g, s));
         AttnArgs at;
         memset(&at, 0, sizeof(at));
@@ -263,7 +264,7 @@ int estimator_core(const hvx_flow* h, hipStream_t s, EstBufs& b, int B, int T, c
         at.q = b.q; at.q_bs = (long long)H * Tp * 64; at.q_hs = (long long)Tp * 64; at.q_lo = 64;
         at.k = b.k; at.k_bs = at.q_bs; at.k_hs = at.q_hs;
         at.vT = b.vT; at.v_bs = at.q_bs; at.v_hs = (long long)64 * Tp; at.v_ld = Tp;
-        at.kv_len = kv_len; at.kv_len_const = T; at.causal = 0; at.chunk = chunk; at.scale = 0.125f;
+        at.kv_len = kv_len; at.kv_len_const = T; at.causal = 0; at.chunk = chunk; at.scale = 0.125f; at.q_log2 = 1;
         at.out = b.att; at.o_bs = (long long)T * D; at.o_hs = 64; at.o_lo = D; at.n_splits = 1;
         HVX_CHECK(launch_attention(at, s));
         g = linear(dt, T, D, D, b.att, D, bw[4], (const float*)bw[5]);

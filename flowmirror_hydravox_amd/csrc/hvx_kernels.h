@@ -50,6 +50,7 @@ struct GemmArgs {
     // ---- EPI_QKV_DIT: N = 3*heads*64; + bias; interleaved-pair RoPE on channels [0,64) of q and k (head 0);
     //      q,k -> [b][head][t_pad][64], v -> vT [b][head][64][t_pad]   (all `dtype`)
     void* q; void* k; void* vT; int heads; int t_pad; const float* rope_cos; const float* rope_sin;   // [t][32]
+    float q_scale;                // != 0: q is stored multiplied by this (softmax scale * log2 e: the scores then leave the attention MFMAs in log2 units)
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
 
@@ -112,6 +113,7 @@ struct AttnArgs {
     const int* n_valid_lo;        // optional: rows with r_lo >= n_valid_lo[b] are skipped (inactive)
     int chunk;                    // > 0: static chunk mask (cosyvoice/utils/mask.py:128-158): row r also needs j < (r_lo / chunk + 1) * chunk
     float scale;
+    int q_log2;                   // q already multiplied by scale * log2(e) (fused QKV epilogue, GemmArgs.q_scale): scale is ignored
     void* out; long long o_bs, o_hs, o_hi, o_lo;      // dtype
     int n_splits; int split_chunk;                    // keys per split (multiple of 32) when n_splits > 1
     int sub_chunk;                                    // > 0 (needs n_rows <= 32): one workgroup per split, its 4 waves take sub_chunk keys

@@ -48,7 +48,7 @@ def conv1d(x, w_packed, bias, *, n_out, taps, cin_pad, pad_left=0, dil=1, stride
     return out
 
 
-def attention(q, k, vT, t, *, kv_len=None, causal=False, scale=None, n_splits=1, split_chunk=0, chunk=0):
+def attention(q, k, vT, t, *, kv_len=None, causal=False, scale=None, n_splits=1, split_chunk=0, chunk=0, q_log2=False):
     """q, k: [B][H][Tpad][64]; vT: [B][H][64][Tpad]  ->  [B][t][H*64]"""
     lib = _lib.load()
     B, H, Tp, d = q.shape
@@ -59,6 +59,7 @@ def attention(q, k, vT, t, *, kv_len=None, causal=False, scale=None, n_splits=1,
     a.q, a.k, a.vT, a.out, a.kv_len = ptr(q), ptr(k), ptr(vT), ptr(out), ptr(kv_len)
     a.causal, a.scale = int(causal), (1.0 / math.sqrt(64)) if scale is None else scale
     a.chunk = int(chunk)
+    a.q_log2 = int(q_log2)
     keep = []
     if n_splits > 1:
         rp = _pad32(t)

@@ -87,6 +87,7 @@ typedef struct {
     int32_t causal; float scale;
     int32_t n_splits, split_chunk; float* part_o; float* part_ml;   /* optional key splits (workspace) */
     int32_t chunk;                             /* > 0: static chunk mask, row i sees keys j < (i / chunk + 1) * chunk (cosyvoice/utils/mask.py:128-158) */
+    int32_t q_log2;                            /* != 0: q already holds q * scale * log2(e) (the fused QKV epilogue's form); `scale` is ignored */
 } hvx_attn_args;
 /* F.scaled_dot_product_attention (cosyvoice/flow/DiT/modules.py:391) */
 int hvx_op_attention(const hvx_attn_args* a, hvx_stream s);

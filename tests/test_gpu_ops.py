@@ -212,6 +212,53 @@ def test_attention_long_sequence_many_workgroups():
     torch.testing.assert_close(out.float().cpu(), ref, rtol=3e-2, atol=3e-2)
 
 
+@pytest.mark.parametrize('T,chunk', [(300, 0), (2300, 0), (2300, 50), (777, 64)])
+def test_attention_prescaled_query(T, chunk):
+    """q_log2: the fused QKV epilogue stores q * scale * log2(e) (one rounding); the attention kernels then work in log2 units
+    (bf16: the accumulator of the score MFMA starts at minus the row's reference maximum, exp2 is the only per-score arithmetic)."""
+    _lib, ops, packing = _mods()
+    for dtype in (torch.bfloat16, torch.float32):
+        q, k, v, qd, kd, vd = _attn_inputs(2, 3, T, dtype, seed=95)
+        ql = (q.float() * (0.125 * math.log2(math.e))).to(dtype)
+        Tp = qd.shape[2]
+        qp = torch.zeros(2, 3, Tp, 64, dtype=dtype)
+        qp[:, :, :T] = ql
+        kv_len = torch.tensor([T, T - 41], dtype=torch.int32)
+        # reference from the operands the kernel sees: softmax over (q_log2 . k) * ln 2
+        ref = _attn_ref(ql.double() * (8.0 * math.log(2.0)), k.double(), v.double(), kv_len=kv_len, chunk=chunk).float()
+        out = ops.attention(qp.to(DEV), kd, vd, T, kv_len=kv_len.to(DEV), chunk=chunk, q_log2=True).float().cpu()
+        tol = dict(rtol=3e-2, atol=3e-2) if dtype == torch.bfloat16 else dict(rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(out, ref, **tol)
+
+
+@pytest.mark.parametrize('T', [300, 2300])
+@pytest.mark.parametrize('spike', [12.0, 60.0, 3000.0])
+def test_attention_dit_fallback_on_score_spike(T, spike):
+    """The LDS-staged bf16 kernel keeps one softmax reference per row (its maximum over the first 64 keys) instead of a running maximum.
+    Keys far from the first tile whose scores exceed that reference by `spike` nats must still give the exact softmax: moderate growth stays
+    on the fast path (p > 1, fp32 sums), growth beyond 2^127 overflows and sends the workgroup through the classical online-softmax loop.
+    Rows, heads and batch entries without a spike share workgroups with spiked ones."""
+    _lib, ops, packing = _mods()
+    B, H = 2, 2
+    q, k, v, qd, kd, vd = _attn_inputs(B, H, T, torch.bfloat16, seed=90)
+    q, k = q.float(), k.float()
+    # rows 5, 130 and T-1 of (batch 0, head 1) meet keys 100, T-70 and 77 with a score of about +spike nats above everything else
+    for row, key in ((5, 100), (130, T - 70), (T - 1, 77)):
+        d = q[0, 1, row] / q[0, 1, row].norm()
+        k[0, 1, key] = d * (spike * 8.0 / q[0, 1, row].norm())
+    q, k = q.bfloat16(), k.bfloat16()
+    Tp = (T + 63) // 64 * 64
+    qp = torch.zeros(B, H, Tp, 64, dtype=torch.bfloat16)
+    kp = torch.zeros_like(qp)
+    qp[:, :, :T] = q
+    kp[:, :, :T] = k
+    kv_len = torch.tensor([T, T - 9], dtype=torch.int32)
+    ref = _attn_ref(q.double(), k.double(), v.double(), kv_len=kv_len).float()
+    out = ops.attention(qp.to(DEV), kp.to(DEV), vd, T, kv_len=kv_len.to(DEV)).float().cpu()
+    assert torch.isfinite(out).all()
+    torch.testing.assert_close(out, ref, rtol=3e-2, atol=3e-2)
+
+
 @pytest.mark.parametrize('T,n_splits,chunk', [(50, 1, 0), (300, 1, 0), (200, 4, 64), (97, 5, 32)])
 def test_attention_causal_and_splits(T, n_splits, chunk):
     _lib, ops, packing = _mods()
