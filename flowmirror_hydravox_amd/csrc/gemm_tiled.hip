@@ -13,13 +13,12 @@
 
 #include "hvx_device.h"
 #include "hvx_kernels.h"
+#include "gemm_epilogue.h"
 
 namespace hvx {
 
 template <class T> struct LdsPad { static constexpr int value = (sizeof(T) == 2) ? 8 : 4; };
 
-// a 64-byte row of zeros: where the LDS-DMA form needs a padding / out-of-range row it points the lane's source address here
-__device__ __attribute__((aligned(64))) const float g_zero_row[16] = {0};
 
 template <class T, int BM, int BN, int WM, int WN, int EPI, int BK, int NBUF = 1, int GLDS = 0>
 __global__ __launch_bounds__(256) void gemm_tiled_kernel(GemmArgs a) {
@@ -215,240 +214,7 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(GemmArgs a) {
     }
 
     // ---- epilogue ----------------------------------------------------------------------------------
-    // The MFMA C layout gives a lane 4 rows x 1 column per tile: stored directly that is 2-4 byte scatters.  Each wave
-    // therefore transposes its accumulators through a private fp32 LDS tile and every lane finishes 16 CONSECUTIVE columns
-    // of one row: bias / gate / residual come in as 16-byte loads and the result leaves as 32-64 contiguous bytes per lane
-    // (a full 128-256 B row segment per 4 lanes).
-    float* scr = reinterpret_cast<float*>(smem) + wave * ROWS_PASS * SLD;
-    constexpr int MT_PASS = ROWS_PASS / 16;
-    static_assert(MT % MT_PASS == 0, "wave tile must be a whole number of staging passes");
-    auto stage = [&](auto IP) {
-        constexpr int ip = decltype(IP)::value;                // compile-time: a runtime index would push acc[][] to scratch
-#pragma unroll
-        for (int ii = 0; ii < MT_PASS; ++ii)
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) scr[(ii * 16 + fg * 4 + r) * SLD + j * 16 + fr] = acc[ip + ii][j][r];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    };
-    auto unstage = [&]() {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    };
-
-    if constexpr (EPI == EPI_GENERIC) {
-        constexpr int LPR = WN / 16;                     // lanes per staged row
-        const int prow = lane / LPR, pcs = (lane % LPR) * 16;
-        const long long ob = (long long)bz * a.out_bs;
-        const int col0 = n0 + wn0 + pcs;
-        const int gc0 = g * a.N + col0;
-        const bool full = (col0 + 16) <= a.N;
-        // 16-byte vector access is legal when every leading dimension / base keeps 4-float (8-bf16) alignment
-        auto al = [](const void* p, long long ld, int esz) { return p == nullptr || ((((unsigned long long)p) & 15) == 0 && ((ld * esz) & 15) == 0); };
-        const bool vec = al(a.bias, 0, 4) && al(a.act_alpha, 0, 4) && al(a.act2_alpha, 0, 4) && al(a.gate, a.gate_bs, 4) &&
-                         al(a.res, a.ldres, 4) && ((a.res_bs * 4) & 15) == 0 && al(a.res2, a.ldres2, 4) && ((a.res2_bs * 4) & 15) == 0 &&
-                         al(a.out, a.ldo, a.out_f32 ? 4 : (int)sizeof(T)) && ((a.out_bs * (a.out_f32 ? 4 : (int)sizeof(T))) & 15) == 0 &&
-                         al(a.out2, a.ldo2, (int)sizeof(T)) && ((a.out2_bs * (int)sizeof(T)) & 15) == 0 && ((g * a.N) & 7) == 0;
-        auto do_pass = [&](auto IP) {
-            constexpr int ip = decltype(IP)::value;
-            stage(IP);
-            float x[16];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 t = *reinterpret_cast<const f32x4*>(&scr[prow * SLD + pcs + q * 4]);
-                x[q * 4 + 0] = t[0]; x[q * 4 + 1] = t[1]; x[q * 4 + 2] = t[2]; x[q * 4 + 3] = t[3];
-            }
-            unstage();
-            const int row = m0 + wm0 + ip * 16 + prow;
-            if (row >= a.M || (row + a.out_row_off) < 0) return;
-            if (full) {
-                // four self-contained 4-column chunks (keeps the live register set small: the accumulators own most of the file)
-                const float* resp = a.res ? a.res + (long long)bz * a.res_bs + (long long)(row + a.res_row_off) * a.ldres + gc0 : nullptr;
-                const float* res2p = a.res2 ? a.res2 + (long long)bz * a.res2_bs + (long long)row * a.ldres2 + gc0 : nullptr;
-                const long long o1 = ob + (long long)(row + a.out_row_off) * a.ldo + gc0;
-                const long long o2 = (long long)bz * a.out2_bs + (long long)(row + a.out2_row_off) * a.ldo2 + gc0;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int c4 = q * 4;
-                    auto ld4 = [&](const float* p) -> f32x4 {
-                        if (vec) return *reinterpret_cast<const f32x4*>(p);
-                        return f32x4{p[0], p[1], p[2], p[3]};
-                    };
-                    f32x4 v = {x[c4], x[c4 + 1], x[c4 + 2], x[c4 + 3]};
-                    if (a.bias) v += ld4(a.bias + gc0 + c4);
-                    if (a.act != ACT_NONE) {
-                        f32x4 al = {1.0f, 1.0f, 1.0f, 1.0f}, be = {1.0f, 1.0f, 1.0f, 1.0f};
-                        if (a.act_alpha) al = ld4(a.act_alpha + gc0 + c4);
-                        if (a.act == ACT_SNAKEBETA) be = ld4(a.act_alpha + a.groups * a.N + gc0 + c4);   // second half of the table
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = act_apply(a.act, v[e], a.act_param, al[e], be[e]);
-                    }
-                    if (a.gate) v *= ld4(a.gate + (long long)bz * a.gate_bs + gc0 + c4);
-                    if (resp) v += ld4(resp + c4);
-                    if (res2p) v += ld4(res2p + c4);
-                    v *= a.scale;
-                    if (a.div != 0.0f) v = v / a.div;
-                    if (a.out) {
-                        if (a.out_f32) {
-                            float* op = reinterpret_cast<float*>(a.out) + o1 + c4;
-                            if (vec) *reinterpret_cast<f32x4*>(op) = v;
-                            else { op[0] = v[0]; op[1] = v[1]; op[2] = v[2]; op[3] = v[3]; }
-                        } else {
-                            T* op = reinterpret_cast<T*>(a.out) + o1 + c4;
-                            if constexpr (sizeof(T) == 2) {
-                                bf16x4 w4 = {f32_to_bf16(v[0]), f32_to_bf16(v[1]), f32_to_bf16(v[2]), f32_to_bf16(v[3])};
-                                if (vec) *reinterpret_cast<bf16x4*>(op) = w4;
-                                else { op[0] = w4[0]; op[1] = w4[1]; op[2] = w4[2]; op[3] = w4[3]; }
-                            } else {
-                                if (vec) *reinterpret_cast<f32x4*>(op) = v;
-                                else { op[0] = v[0]; op[1] = v[1]; op[2] = v[2]; op[3] = v[3]; }
-                            }
-                        }
-                    }
-                    if (a.out2) {
-                        f32x4 al2 = {1.0f, 1.0f, 1.0f, 1.0f};
-                        if (a.act2_alpha) al2 = ld4(a.act2_alpha + gc0 + c4);
-                        f32x4 u;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) u[e] = act_apply(a.act2, v[e], a.act2_param, al2[e]);
-                        T* op = reinterpret_cast<T*>(a.out2) + o2 + c4;
-                        if constexpr (sizeof(T) == 2) {
-                            bf16x4 w4 = {f32_to_bf16(u[0]), f32_to_bf16(u[1]), f32_to_bf16(u[2]), f32_to_bf16(u[3])};
-                            if (vec) *reinterpret_cast<bf16x4*>(op) = w4;
-                            else { op[0] = w4[0]; op[1] = w4[1]; op[2] = w4[2]; op[3] = w4[3]; }
-                        } else {
-                            if (vec) *reinterpret_cast<f32x4*>(op) = u;
-                            else { op[0] = u[0]; op[1] = u[1]; op[2] = u[2]; op[3] = u[3]; }
-                        }
-                    }
-                }
-            } else {
-                // partial column tile: element-wise with the padding rules (cols [groups*N, out_cols) are zero-filled)
-                for (int c = 0; c < 16; ++c) {
-                    const int col = col0 + c, gc = gc0 + c;
-                    const bool col_ok = col < a.N;
-                    const bool col_pad = (!col_ok) && (g == a.groups - 1) && (gc < a.out_cols);
-                    const bool col_pad2 = (!col_ok) && (g == a.groups - 1) && (gc < a.out2_cols);
-                    if (!col_ok && !col_pad && !col_pad2) continue;
-                    float v = 0.0f;
-                    float al2 = 1.0f;
-                    if (col_ok) {
-                        const float bi = a.bias ? a.bias[gc] : 0.0f;
-                        const float al1 = a.act_alpha ? a.act_alpha[gc] : 1.0f;
-                        al2 = a.act2_alpha ? a.act2_alpha[gc] : 1.0f;
-                        const float gt = a.gate ? a.gate[(long long)bz * a.gate_bs + gc] : 1.0f;
-                        const float be1 = a.act == ACT_SNAKEBETA ? a.act_alpha[a.groups * a.N + gc] : 1.0f;
-                        v = act_apply(a.act, x[c] + bi, a.act_param, al1, be1) * gt;
-                        if (a.res) v += a.res[(long long)bz * a.res_bs + (long long)(row + a.res_row_off) * a.ldres + gc];
-                        if (a.res2) v += a.res2[(long long)bz * a.res2_bs + (long long)row * a.ldres2 + gc];
-                        v *= a.scale;
-                        if (a.div != 0.0f) v = v / a.div;
-                    }
-                    if (a.out && (col_ok || col_pad)) {
-                        const long long o = ob + (long long)(row + a.out_row_off) * a.ldo + gc;
-                        if (a.out_f32) reinterpret_cast<float*>(a.out)[o] = v;
-                        else reinterpret_cast<T*>(a.out)[o] = from_f32<T>(v);
-                    }
-                    if (a.out2 && (col_ok || col_pad2)) {
-                        const long long o2 = (long long)bz * a.out2_bs + (long long)(row + a.out2_row_off) * a.ldo2 + gc;
-                        reinterpret_cast<T*>(a.out2)[o2] = from_f32<T>(col_ok ? act_apply(a.act2, v, a.act2_param, al2) : 0.0f);
-                    }
-                }
-            }
-        };
-        do_pass(std::integral_constant<int, 0>{});
-        if constexpr (MT > 1 * MT_PASS) do_pass(std::integral_constant<int, 1 * MT_PASS>{});
-        if constexpr (MT > 2 * MT_PASS) do_pass(std::integral_constant<int, 2 * MT_PASS>{});
-        if constexpr (MT > 3 * MT_PASS) do_pass(std::integral_constant<int, 3 * MT_PASS>{});
-        if constexpr (MT > 4 * MT_PASS) do_pass(std::integral_constant<int, 4 * MT_PASS>{});
-        if constexpr (MT > 5 * MT_PASS) do_pass(std::integral_constant<int, 5 * MT_PASS>{});
-        if constexpr (MT > 6 * MT_PASS) do_pass(std::integral_constant<int, 6 * MT_PASS>{});
-        if constexpr (MT > 7 * MT_PASS) do_pass(std::integral_constant<int, 7 * MT_PASS>{});
-        static_assert(MT <= 8 * MT_PASS, "epilogue passes are unrolled by hand up to 8");
-    } else {   // EPI_QKV_DIT: a wave's WN columns lie inside one of q / k / v and one head
-        const int D = a.heads * 64;
-        const int cw = n0 + wn0;                          // first column of this wave
-        const bool wave_ok = cw < a.N;
-        const int which = wave_ok ? cw / D : 0;
-        const int cb = cw - which * D;                    // channel inside q / k / v
-        const int h = cb >> 6;
-        constexpr int LPR = WN / 16;
-        auto do_pass = [&](auto IP) {
-            constexpr int ip = decltype(IP)::value;
-            stage(IP);
-            if (which < 2) {
-                // q, k: row-major, 16 consecutive channels per lane; interleaved-pair RoPE on channels [0, 64) of the row
-                const int prow = lane / LPR, pcs = (lane % LPR) * 16;
-                float x[16];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 t = *reinterpret_cast<const f32x4*>(&scr[prow * SLD + pcs + q * 4]);
-                    x[q * 4 + 0] = t[0]; x[q * 4 + 1] = t[1]; x[q * 4 + 2] = t[2]; x[q * 4 + 3] = t[3];
-                }
-                unstage();
-                const int row = m0 + wm0 + ip * 16 + prow;
-                const int c0 = cb + pcs, d0 = c0 & 63;
-                if (!wave_ok || row >= a.M) return;
-#pragma unroll
-                for (int c = 0; c < 16; ++c) x[c] += a.bias ? a.bias[cw + pcs + c] : 0.0f;
-                if (c0 < 64 && a.rope_cos) {                 // (no table: plain multi-head QKV, e.g. the Matcha transformer blocks)
-#pragma unroll
-                    for (int c = 0; c < 16; c += 2) {
-                        const float cs = a.rope_cos[(long long)row * 32 + ((d0 + c) >> 1)], sn = a.rope_sin[(long long)row * 32 + ((d0 + c) >> 1)];
-                        const float e = x[c], o = x[c + 1];
-                        x[c] = e * cs - o * sn;
-                        x[c + 1] = o * cs + e * sn;
-                    }
-                }
-                if (which == 0 && a.q_scale != 0.0f) {
-#pragma unroll
-                    for (int c = 0; c < 16; ++c) x[c] *= a.q_scale;
-                }
-                T* dst = reinterpret_cast<T*>(which == 0 ? a.q : a.k) + ((((long long)bz * a.heads + h) * a.t_pad) + row) * 64 + d0;
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    typename Vec8<T>::type w8;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) w8[e] = from_f32<T>(x[q * 8 + e]);
-                    store8(dst + q * 8, w8);
-                }
-            } else {
-                // v: written transposed (V^T [d][t]): a lane takes one channel and 16 consecutive time steps
-                const int pc = lane % WN, rblk = lane / WN;
-                float x[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) x[r] = scr[(rblk * 16 + r) * SLD + pc];
-                unstage();
-                const int row0 = m0 + wm0 + ip * 16 + rblk * 16;
-                if (!wave_ok || row0 >= a.M) return;
-                const float bi = a.bias ? a.bias[cw + pc] : 0.0f;
-                const int d = (cb + pc) & 63;
-                T* dst = reinterpret_cast<T*>(a.vT) + (((long long)bz * a.heads + h) * 64 + d) * a.t_pad + row0;
-                if (row0 + 16 <= a.M) {
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        typename Vec8<T>::type w8;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) w8[e] = from_f32<T>(x[q * 8 + e] + bi);
-                        store8(dst + q * 8, w8);
-                    }
-                } else {
-                    for (int r = 0; r < 16 && row0 + r < a.M; ++r) dst[r] = from_f32<T>(x[r] + bi);
-                }
-            }
-        };
-        do_pass(std::integral_constant<int, 0>{});
-        if constexpr (MT > 1 * MT_PASS) do_pass(std::integral_constant<int, 1 * MT_PASS>{});
-        if constexpr (MT > 2 * MT_PASS) do_pass(std::integral_constant<int, 2 * MT_PASS>{});
-        if constexpr (MT > 3 * MT_PASS) do_pass(std::integral_constant<int, 3 * MT_PASS>{});
-        if constexpr (MT > 4 * MT_PASS) do_pass(std::integral_constant<int, 4 * MT_PASS>{});
-        if constexpr (MT > 5 * MT_PASS) do_pass(std::integral_constant<int, 5 * MT_PASS>{});
-        if constexpr (MT > 6 * MT_PASS) do_pass(std::integral_constant<int, 6 * MT_PASS>{});
-        if constexpr (MT > 7 * MT_PASS) do_pass(std::integral_constant<int, 7 * MT_PASS>{});
-        static_assert(MT <= 8 * MT_PASS, "epilogue passes are unrolled by hand up to 8");
-    }
+    gemm_epilogue<T, MT, NT, WN, EPI>(a, acc, reinterpret_cast<float*>(smem) + wave * ROWS_PASS * SLD, lane, m0 + wm0, n0 + wn0, bz, g);
 }
 
 template <class T, int BM, int BN, int WM, int WN, int BK, int NBUF = 1, int GLDS = 0>
@@ -500,6 +266,8 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
         set_error("launch_gemm: bad QKV geometry N=%d heads=%d t_pad=%d", a.N, a.heads, a.t_pad);
         return -1;
     }
+    const int big = launch_gemm_big(a, s);                 // the 256 x 256 tile form takes the large bf16 Linears (gemm_big.hip)
+    if (big) return big < 0 ? -1 : 0;
     return a.dtype == DT_BF16 ? launch_t<bf16_t>(a, s) : launch_t<float>(a, s);
 }
 

@@ -53,6 +53,7 @@ struct GemmArgs {
     float q_scale;                // != 0: q is stored multiplied by this (softmax scale * log2 e: the scores then leave the attention MFMAs in log2 units)
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
+int launch_gemm_big(const GemmArgs& a, hipStream_t s);   // 1 = launched, 0 = not eligible (launch_gemm falls through), -1 = error
 
 // ------------------------------------------------------------------------------------------------
 // Skinny weight-streaming GEMM for the AR decode step:  out[m, n] = sum_k A[m, k] * W[n, k], M <= 128 per launch chunk.

@@ -56,6 +56,26 @@ def _rows(x_bct, dtype, cpad=None):
     return o.to(dtype)
 
 
+@pytest.mark.parametrize('M,N,K,B', [(6144, 4096, 128, 1), (3000, 1024, 192, 8), (6181, 4096 + 64, 64, 1), (2049, 2048, 1024, 6)])
+def test_linear_256_tile_form(M, N, K, B):
+    """gemm_big.hip (256 x 256 x 64 tiles, 8 waves, LDS-DMA with source-side swizzle, XCD-ordered tiles) takes bf16 Linears with at least
+    384 tiles: ragged last row tile, a partial column tile, batch > 1, one and many K-tiles; bias + GELU + gate + fp32 residual + both outputs."""
+    _lib, ops, packing = _mods()
+    x = _rand(B, M, K, seed=70).bfloat16()
+    w = (_rand(N, K, seed=71) / math.sqrt(K)).bfloat16()
+    b = _rand(N, seed=72)
+    gate = _rand(B, N, seed=73)
+    res = _rand(B, M, N, seed=74)
+    acc = x.float() @ w.float().t() + b
+    ref = torch.nn.functional.gelu(acc, approximate='tanh') * gate[:, None, :] + res
+    out = torch.zeros(B, M, N, dtype=torch.float32, device=DEV)
+    out2 = torch.zeros(B, M, N, dtype=torch.bfloat16, device=DEV)
+    ops.conv1d(x.to(DEV), w.to(DEV), b.to(DEV), n_out=N, taps=1, cin_pad=K, act=_lib.ACT_GELU_TANH, gate=gate.to(DEV), res=res.to(DEV), out=out,
+               out2=out2)
+    torch.testing.assert_close(out.cpu(), ref, rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(out2.float().cpu(), ref, rtol=3e-2, atol=3e-2)
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('cin,cout,k,dil,T', [(80, 64, 5, 1, 50), (64, 64, 11, 5, 333), (32, 48, 3, 3, 130), (18, 32, 1, 1, 77), (512, 256, 7, 1, 90)])
 def test_causal_conv_left_and_right(dtype, cin, cout, k, dil, T):

@@ -31,7 +31,8 @@ def timeit(fn, iters=20, warm=3):
 
 def bench_gemm():
     for dtype in (torch.bfloat16, torch.float32):
-        shapes = [(11264, 1024, 1024), (11264, 3072, 1024), (11264, 2048, 1024), (11264, 1024, 2048), (2816, 1024, 1024)] if dtype == torch.bfloat16 else \
+        shapes = [(11264, 1024, 1024), (11264, 3072, 1024), (11264, 2048, 1024), (11264, 1024, 2048), (2816, 1024, 1024),
+                  (45056, 1024, 1024), (45056, 3072, 1024), (45056, 2048, 1024), (45056, 1024, 2048)] if dtype == torch.bfloat16 else \
                  [(45056, 256, 512 * 16), (225280, 128, 128 * 7), (675841, 64, 64 * 11), (675841, 64, 64 * 3)]
         for M, N, K in shapes:
             x = torch.randn(1, M, K if dtype == torch.bfloat16 else min(K, 512), device=DEV).to(dtype)
