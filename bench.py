@@ -48,6 +48,8 @@ def parse():
     ap.add_argument('--mode', choices=['continuous', 'chains', 'serial'], default='continuous',
                     help='continuous: one decode grid of --lm-slots sequences + acoustic stage of finished utterances beside it (default); '
                          'chains: the round-1 form, --lm-chains independent decode chains of one step each; serial: stages back to back')
+    ap.add_argument('--acoustic-batch', type=int, default=4, help='utterances per padded CFM solve (x CFG 2 rows per estimator call)')
+    ap.add_argument('--acoustic-min-batch', type=int, default=4, help='(--mode continuous) the acoustic stage waits for this many finished utterances (throughput over latency)')
     ap.add_argument('--acoustic-chains', type=int, default=1, help='(--mode chains) batches whose flow + vocoder run concurrently')
     ap.add_argument('--lm-chains', type=int, default=3, help='(--mode chains) batches whose LM decode runs concurrently')
     ap.add_argument('--serial', action='store_true', help='same as --mode serial')
@@ -188,6 +190,7 @@ def main():
     t_build = time.time()
     pipe = HvxPipeline(cfg, llm_dtype=torch.bfloat16, flow_dtype=torch.bfloat16, max_batch=B, max_ctx=max_ctx, max_t=2 * n_spk + 64,
                        seed=1986, init='normal02', sampling=sampling, inference_head_num=K)
+    pipe.acoustic_batch = max(1, args.acoustic_batch)
     t_build = time.time() - t_build
     utts = [synthetic_utterance(cfg, rank * B + i, chars) for i in range(B)]
     gids = [rank * B + i for i in range(B)]
@@ -235,7 +238,8 @@ def main():
         # one step's worth (B utterances) at a time, inside the timed region
         job = [synthetic_utterance(cfg, (k * world + rank) * B + i, chars) for k in range(args.steps) for i in range(B)]
         ready, n_handed = [], 0
-        for i, wav, toks in pipe.synthesize_continuous(job, lm_slots=args.lm_slots, max_token_text_ratio=ratio, min_token_text_ratio=ratio):
+        for i, wav, toks in pipe.synthesize_continuous(job, lm_slots=args.lm_slots, max_token_text_ratio=ratio, min_token_text_ratio=ratio,
+                                                       acoustic_batch=args.acoustic_batch, acoustic_min_batch=args.acoustic_min_batch):
             ready.append((job[i].seed, wav))
             if len(ready) == B:
                 got = gather_waveforms([w for _, w in ready], [gid for gid, _ in ready], dst=0)

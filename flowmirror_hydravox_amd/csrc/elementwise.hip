@@ -300,9 +300,100 @@ __global__ __launch_bounds__(256) void layernorm_mod_kernel(const float* x, cons
     const float inv = rsqrtf(wave_sum(s2) / (float)D + eps);
     for (int c = lane; c < D; c += 64) yr[c] = from_f32<T>((xr[c] - mean) * inv * (1.0f + sc[c]) + sh[c]);
 }
+// D == 1024 (the DiT width): a wave owns TWO rows, 8 consecutive channels per lane and step, every load of both rows in flight before the
+// first reduction (a row is 4 KB: one row per wave leaves the memory pipe idle during the two dependent wave reductions), 16-byte stores.
+template <class T>
+__global__ __launch_bounds__(256) void layernorm_mod1024_kernel(const float* __restrict__ x, const float* __restrict__ shift,
+                                                                const float* __restrict__ scale, long long mod_bs, float eps, T* __restrict__ y, int T_) {
+    constexpr int D = 1024;
+    const int lane = threadIdx.x & 63;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
+    const int b = blockIdx.y;
+    if (row0 >= T_) return;
+    const bool two = row0 + 1 < T_;
+    const float* xr = x + ((long long)b * T_ + row0) * D;
+    f32x4 v[2][4];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float* p = xr + (r && two ? D : 0) + q * 512 + lane * 8;
+            v[r][2 * q] = *reinterpret_cast<const f32x4*>(p);
+            v[r][2 * q + 1] = *reinterpret_cast<const f32x4*>(p + 4);
+        }
+    const float* sh = shift + (long long)b * mod_bs;
+    const float* sc = scale + (long long)b * mod_bs;
+    f32x4 s4[4], h4[4];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        s4[2 * q] = *reinterpret_cast<const f32x4*>(sc + q * 512 + lane * 8);
+        s4[2 * q + 1] = *reinterpret_cast<const f32x4*>(sc + q * 512 + lane * 8 + 4);
+        h4[2 * q] = *reinterpret_cast<const f32x4*>(sh + q * 512 + lane * 8);
+        h4[2 * q + 1] = *reinterpret_cast<const f32x4*>(sh + q * 512 + lane * 8 + 4);
+    }
+    float mean[2], inv[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        float s1 = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s1 += (v[r][q][0] + v[r][q][1]) + (v[r][q][2] + v[r][q][3]);
+        mean[r] = s1;
+    }
+    // the two rows' reductions interleave (independent shuffle chains)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mean[0] += __shfl_xor(mean[0], o, 64);
+        mean[1] += __shfl_xor(mean[1], o, 64);
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        mean[r] *= (1.0f / D);
+        float s2 = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[r][q][e] - mean[r];
+                s2 += d * d;
+            }
+        inv[r] = s2;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        inv[0] += __shfl_xor(inv[0], o, 64);
+        inv[1] += __shfl_xor(inv[1], o, 64);
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        if (r && !two) break;
+        const float iv = rsqrtf(inv[r] * (1.0f / D) + eps);
+        T* yr = y + ((long long)b * T_ + row0 + r) * D;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[e] = (v[r][2 * q][e] - mean[r]) * iv * (1.0f + s4[2 * q][e]) + h4[2 * q][e];
+                o[4 + e] = (v[r][2 * q + 1][e] - mean[r]) * iv * (1.0f + s4[2 * q + 1][e]) + h4[2 * q + 1][e];
+            }
+            typename Vec8<T>::type w8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) w8[e] = from_f32<T>(o[e]);
+            store8(yr + q * 512 + lane * 8, w8);
+        }
+    }
+}
 int launch_layernorm_mod(const float* x, const float* shift, const float* scale, long long mod_bs, float eps, void* y, int dtype, int B, int T_,
                          int D, hipStream_t s) {
     if (B <= 0 || T_ <= 0) return 0;
+    if (D == 1024 && ((mod_bs & 3) == 0) && ((((unsigned long long)shift | (unsigned long long)scale | (unsigned long long)x | (unsigned long long)y)) & 15) == 0) {
+        dim3 grid((T_ + 7) / 8, B);
+        if (dtype == DT_BF16)
+            hipLaunchKernelGGL(layernorm_mod1024_kernel<bf16_t>, grid, dim3(256), 0, s, x, shift, scale, mod_bs, eps, reinterpret_cast<bf16_t*>(y), T_);
+        else
+            hipLaunchKernelGGL(layernorm_mod1024_kernel<float>, grid, dim3(256), 0, s, x, shift, scale, mod_bs, eps, reinterpret_cast<float*>(y), T_);
+        return hipGetLastError() == hipSuccess ? 0 : (set_error("layernorm_mod launch failed"), -1);
+    }
     dim3 grid((T_ + 3) / 4, B);
     if (dtype == DT_BF16)
         hipLaunchKernelGGL(layernorm_mod_kernel<bf16_t>, grid, dim3(256), 0, s, x, shift, scale, mod_bs, eps, reinterpret_cast<bf16_t*>(y), T_, D);

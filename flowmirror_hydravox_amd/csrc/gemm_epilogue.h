@@ -90,8 +90,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT]
                 for (int q = 0; q < 4; ++q) {
                     v[q] += bi[q];
                     if (a.act != ACT_NONE) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[q][e] = act_apply(a.act, v[q][e], a.act_param, 1.0f, 1.0f);
+                        v[q] = act_apply4(a.act, v[q], a.act_param, f32x4{1, 1, 1, 1}, f32x4{1, 1, 1, 1});
                     }
                     v[q] *= gt[q];
                     if (resb) v[q] += rs[q];
@@ -124,8 +123,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT]
                         if (a.act2 != ACT_NONE) {
 #pragma unroll
                             for (int q = 0; q < 4; ++q)
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) v[q][e] = act_apply(a.act2, v[q][e], a.act2_param, 1.0f);
+                                v[q] = act_apply4(a.act2, v[q], a.act2_param, f32x4{1, 1, 1, 1}, f32x4{1, 1, 1, 1});
                         }
                         if constexpr (sizeof(T) == 2) {
 #pragma unroll
@@ -187,8 +185,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT]
                         f32x4 al = {1.0f, 1.0f, 1.0f, 1.0f}, be = {1.0f, 1.0f, 1.0f, 1.0f};
                         if (a.act_alpha) al = ld4(a.act_alpha + gc0 + c4);
                         if (a.act == ACT_SNAKEBETA) be = ld4(a.act_alpha + a.groups * a.N + gc0 + c4);   // second half of the table
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = act_apply(a.act, v[e], a.act_param, al[e], be[e]);
+                        v = act_apply4(a.act, v, a.act_param, al, be);
                     }
                     if (a.gate) v *= ld4(a.gate + (long long)bz * a.gate_bs + gc0 + c4);
                     if (resp) v += ld4(resp + c4);
@@ -216,8 +213,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT]
                         f32x4 al2 = {1.0f, 1.0f, 1.0f, 1.0f};
                         if (a.act2_alpha) al2 = ld4(a.act2_alpha + gc0 + c4);
                         f32x4 u;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) u[e] = act_apply(a.act2, v[e], a.act2_param, al2[e]);
+                        u = act_apply4(a.act2, v, a.act2_param, al2, f32x4{1, 1, 1, 1});
                         T* op = reinterpret_cast<T*>(a.out2) + o2 + c4;
                         if constexpr (sizeof(T) == 2) {
                             bf16x4 w4 = {f32_to_bf16(u[0]), f32_to_bf16(u[1]), f32_to_bf16(u[2]), f32_to_bf16(u[3])};

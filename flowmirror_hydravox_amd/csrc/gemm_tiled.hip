@@ -266,6 +266,8 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
         set_error("launch_gemm: bad QKV geometry N=%d heads=%d t_pad=%d", a.N, a.heads, a.t_pad);
         return -1;
     }
+    const int x3 = launch_gemm_x3(a, s);                   // fp32 operands split into bf16 pairs (gemm_x3.hip), where the caller allows it
+    if (x3) return x3 < 0 ? -1 : 0;
     const int big = launch_gemm_big(a, s);                 // the 256 x 256 tile form takes the large bf16 Linears (gemm_big.hip)
     if (big) return big < 0 ? -1 : 0;
     return a.dtype == DT_BF16 ? launch_t<bf16_t>(a, s) : launch_t<float>(a, s);

@@ -15,6 +15,8 @@
 
 #include "hvx.h"
 #include "hvx_device.h"
+#include <stdlib.h>
+
 #include "hvx_kernels.h"
 
 using namespace hvx;
@@ -82,6 +84,15 @@ GemmArgs conv(int M, int N, int taps, int cin_pad, const float* A, int lda, int 
     return g;
 }
 
+// decode-path convolutions: fp32 operands as bf16 pairs on the bf16 matrix cores (gemm_x3.hip, ~1e-6 relative; HVX_HIFT_FP32_MFMA=1 keeps the
+// exact fp32 MFMA form).  The F0 predictor (hvx_hift_f0) always stays exact: its output is integrated into the harmonic phase.
+GemmArgs conv3(int M, int N, int taps, int cin_pad, const float* A, int lda, int rows_in, const float* W, const float* bias) {
+    static const int allow = getenv("HVX_HIFT_FP32_MFMA") ? 0 : 1;
+    GemmArgs g = conv(M, N, taps, cin_pad, A, lda, rows_in, W, bias);
+    g.x3 = allow;
+    return g;
+}
+
 struct WCursor {
     const void* const* w;
     int n, i = 0;
@@ -100,12 +111,12 @@ int resblock(hipStream_t s, WCursor& wc, int L, int C, int k, const int* dils, c
     float* raw_bufs[2] = {curA, curB};
     float* act_bufs[2] = {actA, actB};
     for (int d = 0; d < 3; ++d) {
-        GemmArgs g = conv(L, C, k, Cp, cur_act, Cp, L, w1[d], b1[d]);
+        GemmArgs g = conv3(L, C, k, Cp, cur_act, Cp, L, w1[d], b1[d]);
         g.conv_dil = dils[d]; g.pad_left = (k - 1) * dils[d];
         g.act = ACT_SNAKE; g.act_alpha = a2[d];
         g.out = t1; g.out_f32 = 1; g.ldo = Cp; g.out_cols = Cp;
         HVX_CHECK(launch_gemm(g, s));
-        g = conv(L, C, k, Cp, t1, Cp, L, w2[d], b2[d]);
+        g = conv3(L, C, k, Cp, t1, Cp, L, w2[d], b2[d]);
         g.pad_left = k - 1;
         g.res = cur; g.ldres = Cp;
         if (d < 2) {
@@ -224,7 +235,7 @@ static int decode_impl(hvx_hift* h, hvx_stream stream, void* ws, size_t ws_bytes
         const float* W = wc.next();
         const float* bias = wc.next();
         const int C0 = c.base_channels;
-        GemmArgs g = conv(T, C0, c.conv_pre_kernel, melp, b.melT, melp, T_in, W, bias);
+        GemmArgs g = conv3(T, C0, c.conv_pre_kernel, melp, b.melT, melp, T_in, W, bias);
         g.act = ACT_LRELU; g.act_param = c.lrelu_slope;
         g.out = xin; g.out_f32 = 1; g.ldo = pad32(C0); g.out_cols = pad32(C0);
         HVX_CHECK(launch_gemm(g, s));
@@ -256,9 +267,9 @@ static int decode_impl(hvx_hift* h, hvx_stream stream, void* ws, size_t ws_bytes
             const int d = down[i];
             GemmArgs g;
             if (d == 1) {
-                g = conv((int)L, C, 1, 32, b.spec, 32, frames, sdW, sdB);
+                g = conv3((int)L, C, 1, 32, b.spec, 32, frames, sdW, sdB);
             } else {
-                g = conv((int)L, C, 2 * d, 32, b.spec, 32, frames, sdW, sdB);
+                g = conv3((int)L, C, 2 * d, 32, b.spec, 32, frames, sdW, sdB);
                 g.conv_stride = d; g.pad_left = d - 1;
             }
             g.out = sd_raw; g.out_f32 = 1; g.ldo = Cp; g.out_cols = Cp;
@@ -272,7 +283,7 @@ static int decode_impl(hvx_hift* h, hvx_stream stream, void* ws, size_t ws_bytes
         float* x_raw = P[2];
         {
             const int Cpp = pad32(Cprev);
-            GemmArgs g = conv((int)Lup, C, ku, Cpp, xin, Cpp, (int)Lprev, upW, upB);
+            GemmArgs g = conv3((int)Lup, C, ku, Cpp, xin, Cpp, (int)Lprev, upW, upB);
             g.up = u; g.pad_left = ku - 1;
             g.res = si; g.ldres = Cp;
             g.out = x_raw; g.out_f32 = 1; g.ldo = Cp; g.out_cols = Cp;
@@ -306,7 +317,7 @@ static int decode_impl(hvx_hift* h, hvx_stream stream, void* ws, size_t ws_bytes
         const float* W = wc.next();
         const float* bias = wc.next();
         const int Cpp = pad32(Cprev);
-        GemmArgs g = conv((int)Lprev, c.n_fft + 2, c.conv_post_kernel, Cpp, xin, Cpp, (int)Lprev, W, bias);
+        GemmArgs g = conv3((int)Lprev, c.n_fft + 2, c.conv_post_kernel, Cpp, xin, Cpp, (int)Lprev, W, bias);
         g.pad_left = c.conv_post_kernel - 1;
         g.out = b.post; g.out_f32 = 1; g.ldo = 32; g.out_cols = 32;
         HVX_CHECK(launch_gemm(g, s));

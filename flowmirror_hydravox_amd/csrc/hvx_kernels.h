@@ -50,9 +50,11 @@ struct GemmArgs {
     // ---- EPI_QKV_DIT: N = 3*heads*64; + bias; interleaved-pair RoPE on channels [0,64) of q and k (head 0);
     //      q,k -> [b][head][t_pad][64], v -> vT [b][head][64][t_pad]   (all `dtype`)
     void* q; void* k; void* vT; int heads; int t_pad; const float* rope_cos; const float* rope_sin;   // [t][32]
+    int x3;                       // fp32 operands may be split into bf16 pairs and multiplied on the bf16 matrix cores (gemm_x3.hip; ~1e-6 relative)
     float q_scale;                // != 0: q is stored multiplied by this (softmax scale * log2 e: the scores then leave the attention MFMAs in log2 units)
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
+int launch_gemm_x3(const GemmArgs& a, hipStream_t s);    // same convention; fp32 operands on the bf16 matrix cores (GemmArgs.x3)
 int launch_gemm_big(const GemmArgs& a, hipStream_t s);   // 1 = launched, 0 = not eligible (launch_gemm falls through), -1 = error
 
 // ------------------------------------------------------------------------------------------------

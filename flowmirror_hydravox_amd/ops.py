@@ -15,7 +15,7 @@ def _pad32(n):
 
 def conv1d(x, w_packed, bias, *, n_out, taps, cin_pad, pad_left=0, dil=1, stride=1, up=1, m_out=None, groups=1,
            act=_lib.ACT_NONE, act_param=0.0, act_alpha=None, gate=None, res=None, res_row_off=0, scale=1.0,
-           out=None, out_dtype=None, out_row_off=0, out2=None, act2=_lib.ACT_NONE, act2_param=0.0, act2_alpha=None, out2_row_off=0):
+           out=None, out_dtype=None, out_row_off=0, out2=None, act2=_lib.ACT_NONE, act2_param=0.0, act2_alpha=None, out2_row_off=0, x3=False):
     """Implicit-GEMM Conv1d / Linear on time-major rows.  x: [B][rows_in][lda] (f32 or bf16), w_packed: [groups][n_out][taps*cin_pad]."""
     lib = _lib.load()
     B, rows_in, lda = x.shape
@@ -34,6 +34,7 @@ def conv1d(x, w_packed, bias, *, n_out, taps, cin_pad, pad_left=0, dil=1, stride
     if res is not None:
         a.res, a.res_bs, a.ldres, a.res_row_off = ptr(res), res.shape[1] * res.shape[2], res.shape[2], res_row_off
     a.scale = scale
+    a.x3 = int(x3)
     if out is None and out2 is None:
         od = out_dtype or torch.float32
         out = torch.zeros(B, M + max(out_row_off, 0), _pad32(total) if od != torch.float32 else total, dtype=od, device=x.device)

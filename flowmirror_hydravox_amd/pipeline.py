@@ -81,6 +81,9 @@ class HvxPipeline:
         self._hift_kw = dict(device=device, tables=hift_tables)
         self.hift = HvxHift(cfg.hift, hift_sd, **self._hift_kw)
         self._acoustic = [(self.flow, self.hift)]
+        # utterances of similar length that share one padded CFM solve (hvx_cfm_solve_batch): the DiT GEMMs and the attention reach their
+        # large-grid rates from about 4 utterances (x CFG 2) per launch
+        self.acoustic_batch = 4
         self.device = torch.device(device)
 
     # ---- stages -----------------------------------------------------------------------------------------------------------------
@@ -109,9 +112,9 @@ class HvxPipeline:
             mels.append(mel)
         return mels
 
-    def _mels_batched(self, utts, toks, flow=None, max_pad=0.15):
+    def _mels_batched(self, utts, toks, flow=None, max_pad=0.15, max_batch=None):
         """the same mels as _mels, solved in length buckets: utterances whose frame counts lie within `max_pad` of the longest of their
-        bucket share one padded solve (hvx_cfm_solve_batch)"""
+        bucket (at most `max_batch` of them) share one padded solve (hvx_cfm_solve_batch)"""
         flow = flow or self.flow
         dev = self.device
         mels = [None] * len(utts)
@@ -120,7 +123,7 @@ class HvxPipeline:
             def frames(i):
                 return len(toks[i]) + (0 if utts[i].prompt_speech_token is None else len(utts[i].prompt_speech_token))
             top = frames(order[0])
-            bucket = [i for i in order if frames(i) >= (1.0 - max_pad) * top]
+            bucket = [i for i in order if frames(i) >= (1.0 - max_pad) * top][:max_batch]
             order = [i for i in order if i not in bucket]
             out = flow.inference_batch([torch.tensor(toks[i], dtype=torch.int32, device=dev) for i in bucket], [utts[i].embedding.to(dev) for i in bucket],
                                        prompt_tokens=[None if utts[i].prompt_speech_token is None else utts[i].prompt_speech_token.to(dev) for i in bucket],
@@ -153,7 +156,7 @@ class HvxPipeline:
         st.llm = dict(self.llm.last_stats)
         st.per_utt_tokens = [len(t) for t in toks]
         st.tokens = sum(st.per_utt_tokens)
-        mels = self._mels(utts, toks)
+        mels = self._mels_batched(utts, toks, max_batch=self.acoustic_batch) if self.acoustic_batch > 1 else self._mels(utts, toks)
         torch.cuda.synchronize()
         t2 = time.time()
         st.flow_seconds = t2 - t1
@@ -223,13 +226,16 @@ class HvxPipeline:
         return wavs, st
 
     @torch.inference_mode()
-    def synthesize_continuous(self, utts, lm_slots=16, max_token_text_ratio=20, min_token_text_ratio=2, acoustic_batch=4):
+    def synthesize_continuous(self, utts, lm_slots=16, max_token_text_ratio=20, min_token_text_ratio=2, acoustic_batch=None, acoustic_min_batch=1):
         """Generator over (index, waveform, tokens) in completion order — continuous batching end to end.
         The LM decodes up to `lm_slots` utterances in ONE grid (HvxLLM.generate_stream: the weights are streamed once per step for all of
         them, a finished utterance's slot goes to the next waiting one), driven by a worker thread on the high-priority decode stream; every
         finished utterance goes straight to the flow decoder and the vocoder, which run here on a second stream beside the decode of the
         utterances still in flight.  Results equal synthesize(): every utterance carries its own sampler seed.  `self.last_continuous`
-        holds the stage accounting of the run."""
+        holds the stage accounting of the run.  `acoustic_min_batch` > 1 trades latency for throughput: the acoustic stage then waits until
+        that many finished utterances are queued (or the LM is done) before it starts a padded solve."""
+        acoustic_batch = acoustic_batch or self.acoustic_batch
+        acoustic_min_batch = max(1, min(int(acoustic_min_batch), acoustic_batch))
         import queue
         import threading
         utts = list(utts)
@@ -276,7 +282,7 @@ class HvxPipeline:
                 group = [item]
                 while len(group) < acoustic_batch:
                     try:
-                        nxt = q.get_nowait()
+                        nxt = q.get() if len(group) < acoustic_min_batch else q.get_nowait()
                     except queue.Empty:
                         break
                     if nxt is None or isinstance(nxt, BaseException):
@@ -286,7 +292,7 @@ class HvxPipeline:
                 idx = [i for i, _ in group]
                 t0 = time.time()
                 with torch.cuda.stream(stream):
-                    wavs = self._waves(self._mels_batched([utts[i] for i in idx], [t for _, t in group], flow), hift)
+                    wavs = self._waves(self._mels_batched([utts[i] for i in idx], [t for _, t in group], flow, max_batch=acoustic_batch), hift)
                     stream.synchronize()
                 acoustic += time.time() - t0
                 for (i, toks), wav in zip(group, wavs):

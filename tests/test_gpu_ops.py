@@ -56,6 +56,29 @@ def _rows(x_bct, dtype, cpad=None):
     return o.to(dtype)
 
 
+@pytest.mark.parametrize('cin,cout,k,dil,T', [(512, 512, 3, 5, 40000), (128, 64, 7, 1, 9000), (256, 256, 11, 3, 33000)])
+def test_conv_split_bf16_form_matches_fp64(cin, cout, k, dil, T):
+    """gemm_x3.hip: an fp32 convolution computed on the bf16 matrix cores from (hi, lo) bf16 pairs of both operands, three MFMAs per
+    step.  Bound against an fp64 convolution: 2e-5 of the output scale (the exact fp32 MFMA form sits at ~1e-6; the vocoder contract
+    is 1e-3).  Shapes of the HiFT resblocks (dilated, left-padded), Snake epilogue and residual included."""
+    _lib, ops, packing = _mods()
+    x = _rand(1, cin, T, seed=41)
+    w = _rand(cout, cin, k, seed=42) / math.sqrt(cin * k)
+    b = _rand(cout, seed=43)
+    alpha = _rand(cout, seed=44).abs() + 0.1
+    res = _rand(1, T, cout, seed=45)
+    lin = F.conv1d(F.pad(x.double(), ((k - 1) * dil, 0)), w.double(), b.double(), dilation=dil).transpose(1, 2)
+    ref = lin + torch.sin(lin * alpha.double()) ** 2 / (alpha.double() + 1e-9) + res.double()
+    outs = {}
+    for x3 in (False, True):
+        outs[x3] = ops.conv1d(_rows(x, torch.float32).to(DEV), _pack_conv(w, torch.float32).to(DEV), b.to(DEV), n_out=cout, taps=k, cin_pad=(cin + 31) // 32 * 32,
+                              pad_left=(k - 1) * dil, dil=dil, act=_lib.ACT_SNAKE, act_alpha=alpha.to(DEV), res=res.to(DEV), x3=x3).cpu().double()
+    scale = ref.abs().max().item()
+    e_exact, e_split = ((outs[f][..., :cout] - ref).abs().max().item() / scale for f in (False, True))
+    print('fp32 MFMA %.2e, split bf16 %.2e of the output scale' % (e_exact, e_split))
+    assert e_exact < 5e-6 and e_split < 2e-5, (e_exact, e_split)
+
+
 @pytest.mark.parametrize('M,N,K,B', [(6144, 4096, 128, 1), (3000, 1024, 192, 8), (6181, 4096 + 64, 64, 1), (2049, 2048, 1024, 6)])
 def test_linear_256_tile_form(M, N, K, B):
     """gemm_big.hip (256 x 256 x 64 tiles, 8 waves, LDS-DMA with source-side swizzle, XCD-ordered tiles) takes bf16 Linears with at least

@@ -46,6 +46,25 @@ def bench_gemm():
             print('gemm %-8s M=%6d N=%5d K=%5d taps=%2d  %8.1f us  %7.1f TF/s' % (str(dtype)[6:], M, N, K, taps, t * 1e6, 2.0 * M * N * K / t / 1e12))
 
 
+def bench_dit_linears():
+    """the three generic-epilogue Linears of a DiT block at the acoustic-batch shape (4 utterances x CFG 2 x 5632 frames), real epilogues"""
+    B, T, D, FF = 8, 5632, 1024, 2048
+    x = torch.randn(B, T, D, device=DEV)
+    n = torch.randn(B, T, D, device=DEV).bfloat16()
+    h = torch.randn(B, T, FF, device=DEV).bfloat16()
+    gate = torch.randn(B, D, device=DEV)
+    cases = [('out_proj  K=1024 N=1024 gate + fp32 residual in place', n, D, D, dict(gate=gate, res=x, out=x)),
+             ('ff1       K=1024 N=2048 GELU(tanh) -> bf16', n, FF, D, dict(act=_lib.ACT_GELU_TANH, out=h)),
+             ('ff2       K=2048 N=1024 gate + fp32 residual in place', h, D, FF, dict(gate=gate, res=x, out=x)),
+             ('plain     K=1024 N=1024 bias -> bf16', n, D, D, dict(out=torch.empty(B, T, D, device=DEV, dtype=torch.bfloat16))),
+             ('plain     K=1024 N=1024 bias -> fp32', n, D, D, dict(out=torch.empty(B, T, D, device=DEV)))]
+    for name, a, N, K, kw in cases:
+        w = (torch.randn(N, K, device=DEV) / math.sqrt(K)).bfloat16()
+        b = torch.randn(N, device=DEV)
+        t = timeit(lambda: ops.conv1d(a, w, b, n_out=N, taps=1, cin_pad=K, **kw), iters=10)
+        print('%-58s %8.1f us  %7.1f TF/s' % (name, t * 1e6, 2.0 * B * T * N * K / t / 1e12))
+
+
 def bench_attn():
     for T in (1408, 5632):
         B, H = 2, 16
@@ -127,4 +146,4 @@ if __name__ == '__main__':
     _lib.require_gpu()
     which = sys.argv[1:] or ['gemm', 'attn', 'skinny', 'sampler']
     for w in which:
-        {'gemm': bench_gemm, 'attn': bench_attn, 'skinny': bench_skinny, 'sampler': bench_sampler, 'matcha': bench_matcha}[w]()
+        {'gemm': bench_gemm, 'dit': bench_dit_linears, 'attn': bench_attn, 'skinny': bench_skinny, 'sampler': bench_sampler, 'matcha': bench_matcha}[w]()
