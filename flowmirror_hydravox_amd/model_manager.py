@@ -6,9 +6,10 @@ Mirrors server/model_utils/infer_speech_model.py:
     sets .models = {'llm','flow','hift'}, .configs['sample_rate'], .frontend, .device, .is_loaded, .zero_shot_speakers
   * ModelManager.load_pt(llm_pt, flow_pt) -> {"status": "success"|"error", "message": str}, never raises  (:169-184)
   * inference_zero_shot / inference_tts / text_to_speech  (:523-606, :612-690, :743-820)
-Model hyper-parameters: the reference builds its modules from `<model_dir>/hydravox.yaml` through HyperPyYAML, which is not
-part of this build; dimensions come from `<model_dir>/hvx_config.json` when present, else the
-[ASSUMED-CV3] preset.  The text / audio frontend (ONNX tokenizers, text normalisation) is out of scope: `frontend` is any
+Model hyper-parameters: the reference builds its modules from `<model_dir>/hydravox.yaml` through HyperPyYAML (:59-62), which is
+not part of this build; yaml_config.py reads the plain numbers of that file (constructor arguments of the `!new:` nodes, `!ref`s
+resolved, Qwen2 sizes from `CosyVoice-BlankEN/config.json`).  `<model_dir>/hvx_config.json`, when present, takes precedence;
+with neither file the [ASSUMED-CV3] preset applies.  The text / audio frontend (ONNX tokenizers, text normalisation) is out of scope: `frontend` is any
 object with the reference's `text_normalize`, `frontend_sft`, `frontend_zero_shot` methods (e.g. the reference's own
 CosyVoiceFrontEnd), injected by the caller.
 """
@@ -30,13 +31,19 @@ logger = logging.getLogger('hvx')
 
 
 def _load_config(model_dir):
+    """-> (HvxConfig, extras): extras = the yaml's non-dimension settings (sampling defaults, inference_head_num), {} otherwise"""
     p = os.path.join(model_dir or '', 'hvx_config.json')
     if model_dir and os.path.exists(p):
         with open(p) as f:
             d = json.load(f)
         return HvxConfig(llm=LLMConfig(**d.get('llm', {})), flow=FlowConfig(**d.get('flow', {})), hift=HiftConfig(**d.get('hift', {})),
-                         sample_rate=d.get('sample_rate', 24000))
-    return cv3_config()
+                         sample_rate=d.get('sample_rate', 24000)), {}
+    if model_dir:
+        from .yaml_config import config_from_model_dir
+        got = config_from_model_dir(model_dir)                 # <model_dir>/hydravox.yaml, as the reference (:59-62)
+        if got is not None:
+            return got
+    return cv3_config(), {}
 
 
 def _load_pt(path):
@@ -64,12 +71,18 @@ class HvxModelManager:
             return
         if getattr(args, 'cpu', False) or not torch.cuda.is_available():
             raise ValueError('HvxModelManager runs on MI355X only: there is no CPU path (TTS_CPU is not supported)')
-        cfg = _load_config(args.model_dir)
+        cfg, extras = _load_config(args.model_dir)
         self.hvx_config = cfg
         self.device = 'cuda'
         # precision policy of the reference (:101-118): llm bf16 / flow half / hift fp32.  fp16 requests run in bf16 as well:
         # libhvx computes in bf16 (or fp32), with fp32 accumulation and an fp32 residual stream.
         llm = HvxLLM(cfg.llm, None, dtype=torch.bfloat16)
+        if extras.get('sampling'):                           # the yaml's `sampling: !name:...ras_sampling` keyword defaults
+            from functools import partial
+            from .sampling import ras_sampling
+            llm.sampling = partial(ras_sampling, **extras['sampling'])
+        if extras.get('inference_head_num'):
+            llm.inference_head_num = int(extras['inference_head_num'])
         flow = HvxFlow(cfg.flow, None, dtype=torch.bfloat16)
         hift = HvxHift(cfg.hift, None)
         # optional packed-weight cache: args.packed_cache or $HVX_PACKED_CACHE names a directory that holds the
@@ -215,10 +228,104 @@ def inference_tts(model_manager, text, spk_id, speed=1.0):
         raise ValueError('TTS inference failed: %s' % e)
 
 
-def text_to_speech(model_manager, text, speaker_id, speed=1.0):
-    """-> {"output_audio": Tensor(1, L) cpu, "sample_rate", "format": "wav", "duration", "speaker_id", "segments_info"} (:743-820)"""
-    audio = inference_tts(model_manager, text, speaker_id, speed=speed)
+_SEGMENT_MARKS = frozenset('。！？；，、.!?;,')
+
+
+def split_text_by_punctuation(text, max_length=50, min_length=10):
+    """Long-text segmentation of the reference (:263-315): texts up to `max_length` stay whole; otherwise cut after every punctuation
+    mark once the running piece has `min_length` characters, glue a short tail to its predecessor, and fall back to fixed
+    `max_length` slices when no mark produced a cut."""
+    if len(text) <= max_length:
+        return [text]
+    pieces, start = [], 0
+    for pos, ch in enumerate(text):
+        if ch in _SEGMENT_MARKS and pos + 1 - start >= min_length:
+            pieces.append(text[start:pos + 1])
+            start = pos + 1
+    tail = text[start:]
+    if tail:
+        if len(tail) < min_length and pieces:
+            pieces[-1] += tail
+        else:
+            pieces.append(tail)
+    if len(pieces) == 1 and len(pieces[0]) > max_length:
+        pieces = [text[i:i + max_length] for i in range(0, len(text), max_length)]
+    return pieces or [text]
+
+
+def merge_short_segments(segments, min_length=5):
+    """(:318-354) a piece shorter than `min_length` absorbs its successors until it is long enough; a short last piece joins the one
+    before it"""
+    out, cur = [], None
+    for seg in segments:
+        if cur is None:
+            cur = seg
+        elif len(cur) < min_length:
+            cur += seg
+        else:
+            out.append(cur)
+            cur = seg
+    if cur:
+        if len(cur) < min_length and out:
+            out[-1] += cur
+        else:
+            out.append(cur)
+    return out
+
+
+def inference_tts_with_segmentation(model_manager, text, spk_id, max_length=30, min_length=10, last_prompt=True, speed=1.0):
+    """(:357-452) piece-wise synthesis of a long text: the first piece (every piece when `last_prompt` is False) is plain speaker TTS,
+    each later piece is zero-shot with the previous piece's text and audio as its prompt; pieces are joined with 50-150 ms of silence
+    drawn from Python's `random` like the reference's."""
+    import random
+    segments = merge_short_segments(split_text_by_punctuation(text, max_length, min_length), min_length)
+    if len(segments) == 1:
+        return inference_tts(model_manager, text, spk_id, speed=speed)
     sr = model_manager.configs['sample_rate']
-    dur = audio.shape[-1] / sr
-    return {'output_audio': audio, 'sample_rate': sr, 'format': 'wav', 'duration': dur, 'speaker_id': speaker_id,
-            'segments_info': [{'index': 0, 'text': text, 'duration': dur}]}
+    parts, prev_text, prev_audio = [], None, None
+    for i, seg in enumerate(segments):
+        try:
+            if i == 0 or not last_prompt:
+                audio = inference_tts(model_manager, seg, spk_id, speed=speed)
+            else:
+                audio = inference_zero_shot(model_manager, seg, prev_text, prev_audio, 24000, speed=speed)
+        except Exception as e:
+            raise ValueError('segment %d failed: %s' % (i + 1, e))
+        prev_text, prev_audio = seg, audio
+        if parts:
+            gap = list(audio.shape)
+            gap[-1] = int(random.uniform(50, 150) * sr / 1000)
+            parts.append(torch.zeros(gap, dtype=audio.dtype, device=audio.device))
+        parts.append(audio)
+    return torch.cat(parts, dim=-1)
+
+
+def text_to_speech(model_manager, text, speaker_id, speed=1.0):
+    """-> {"output_audio": Tensor(1, L) cpu, "sample_rate", "format": "wav", "duration", "speaker_id", "segments_info"} (:743-820).
+    Texts over 5000 characters take the segmented path (max 30 / min 10 characters per piece, speaker TTS for every piece, :782-800);
+    `segments_info` is then {"total_segments", "segments"} and None otherwise, as in the reference."""
+    try:
+        if not model_manager.is_loaded:
+            raise ValueError('models are not loaded')
+        if not text or not text.strip():
+            raise ValueError('text is empty')
+        speakers = [str(s['speaker_id'] if isinstance(s, dict) else s) for s in model_manager.get_available_speakers()]
+        if speaker_id:
+            if speakers and speaker_id not in speakers:
+                raise ValueError('invalid speaker_id %s; available: %s' % (speaker_id, speakers))
+        elif speakers:
+            speaker_id = speakers[0]                             # (:771-777) default: the first available speaker
+        else:
+            raise ValueError('no speaker available')
+        segments_info = None
+        if len(text) > 5000:
+            audio = inference_tts_with_segmentation(model_manager, text, speaker_id, max_length=30, min_length=10, last_prompt=False, speed=speed)
+            segs = merge_short_segments(split_text_by_punctuation(text, 30, 10), 10)
+            segments_info = {'total_segments': len(segs), 'segments': segs}
+        else:
+            audio = inference_tts(model_manager, text, speaker_id, speed=speed)
+        sr = model_manager.configs['sample_rate']
+        return {'output_audio': audio, 'sample_rate': sr, 'format': 'wav', 'duration': audio.shape[-1] / sr, 'speaker_id': speaker_id,
+                'segments_info': segments_info}
+    except Exception as e:
+        raise ValueError('TTS failed: %s' % e)

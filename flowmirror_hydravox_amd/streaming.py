@@ -13,39 +13,52 @@ import torch
 
 
 class StreamSession:
-    """Per-utterance state of `token2wav` (cli/model.py:405-430): `hift_cache_dict[uuid] = {'mel', 'speech_offset'}`."""
+    """One utterance being synthesised chunk by chunk.  What the reference keeps in `hift_cache_dict[uuid] = {'mel', 'speech_offset'}`
+    (cli/model.py:405-430) lives here as two facts about the session: the mel frames produced so far and how many samples have already
+    been handed to the caller.  Every push = flow over the token prefix -> keep only the frames past the prefix already covered ->
+    vocode ALL frames so far -> return the samples not yet handed out."""
 
     def __init__(self, flow, hift, prompt_token, prompt_feat, embedding, device=None):
         self.flow, self.hift = flow, hift
         self.device = device if device is not None else getattr(flow, 'device', 'cpu')
-        self.prompt_token = prompt_token.to(self.device)
-        self.prompt_feat = prompt_feat.to(self.device)
         self.embedding = embedding.to(self.device)
-        self.mel = None
-        self.speech_offset = 0
+        prompt_token, prompt_feat = prompt_token.to(self.device), prompt_feat.to(self.device)
+        # the prompt never changes during an utterance: its flow arguments are fixed here
+        self._prompt = {}
+        if prompt_token.shape[1] > 0:
+            self._prompt = dict(prompt_token=prompt_token, prompt_token_len=torch.tensor([prompt_token.shape[1]], dtype=torch.int32),
+                                prompt_feat=prompt_feat, prompt_feat_len=torch.tensor([prompt_feat.shape[1]], dtype=torch.int32))
+        self._frames = None            # (1, mel, n) every mel frame of the utterance so far
+        self._handed = 0               # samples already returned
 
-    def token2wav(self, token, token_offset, stream=False, finalize=False, speed=1.0):
-        """token (1, n) = all speech tokens generated so far (plus look-ahead when not final) -> new samples (1, L)."""
-        has_p = self.prompt_token.shape[1] > 0
-        tts_mel, _ = self.flow.inference(
-            token=token.to(self.device, dtype=torch.int32), token_len=torch.tensor([token.shape[1]], dtype=torch.int32),
-            prompt_token=self.prompt_token if has_p else None,
-            prompt_token_len=torch.tensor([self.prompt_token.shape[1]], dtype=torch.int32) if has_p else None,
-            prompt_feat=self.prompt_feat if has_p else None,
-            prompt_feat_len=torch.tensor([self.prompt_feat.shape[1]], dtype=torch.int32) if has_p else None,
-            embedding=self.embedding, streaming=stream, finalize=finalize)
-        tts_mel = tts_mel[:, :, token_offset * self.flow.token_mel_ratio:]
-        if self.mel is not None:                                           # cli/model.py:418-423
-            tts_mel = torch.concat([self.mel, tts_mel], dim=2)
-        self.mel = tts_mel
+    def _fresh_frames(self, token, covered, stream, finalize):
+        """mel frames of the tokens past the first `covered` ones (the flow re-runs over the whole prefix, as the reference does)"""
+        mel, _ = self.flow.inference(token=token.to(self.device, dtype=torch.int32), token_len=torch.tensor([token.shape[1]], dtype=torch.int32),
+                                     embedding=self.embedding, streaming=stream, finalize=finalize, **self._prompt)
+        return mel[:, :, covered * self.flow.token_mel_ratio:]
+
+    def _unheard(self, wav):
+        out = wav[:, self._handed:]
+        self._handed += out.shape[1]
+        return out
+
+    def push(self, token, covered, stream=False, finalize=False, speed=1.0):
+        """token (1, n): all speech tokens generated so far (plus the look-ahead when not final); `covered`: how many of them earlier
+        pushes already turned into frames -> the new samples (1, L)."""
+        fresh = self._fresh_frames(token, covered, stream, finalize)
+        self._frames = fresh if self._frames is None else torch.concat([self._frames, fresh], dim=2)
+        mel = self._frames
         if speed != 1.0:
-            assert token_offset == 0 and finalize is True, 'speed change only support non-stream inference mode'
-            from .ops import resample_linear                            # F.interpolate(mode='linear') in libhvx
-            tts_mel = resample_linear(tts_mel, int(tts_mel.shape[2] / speed))
-        tts_speech, _ = self.hift.inference(speech_feat=tts_mel, finalize=finalize)
-        tts_speech = tts_speech[:, self.speech_offset:]
-        self.speech_offset += tts_speech.shape[1]
-        return tts_speech
+            if covered != 0 or not finalize:
+                raise AssertionError('speed change only support non-stream inference mode')      # cli/model.py:425
+            from .ops import resample_linear                                                      # F.interpolate(mode='linear') in libhvx
+            mel = resample_linear(mel, int(mel.shape[2] / speed))
+        wav, _ = self.hift.inference(speech_feat=mel, finalize=finalize)
+        return self._unheard(wav)
+
+    # the reference's name and argument order (cli/model.py:405)
+    def token2wav(self, token, token_offset, stream=False, finalize=False, speed=1.0):
+        return self.push(token, token_offset, stream=stream, finalize=finalize, speed=speed)
 
 
 def stream_tts(token_source, flow, hift, prompt_token, prompt_feat, embedding, token_hop_len=25, stream=True, speed=1.0):

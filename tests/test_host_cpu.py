@@ -372,3 +372,218 @@ def test_packed_weight_cache_roundtrip_and_validation(tmp_path):
     assert ck.load_or_pack(m3, str(pt), str(tmp_path / 'cache'), loader) == 'packed' and float(m3._weights[0].sum()) == 0.0
     with pytest.raises(ValueError):
         ck.save_packed(Model(Cfg()), str(tmp_path / 'x.hvxpack'))
+
+
+# ---- long-text segmentation (infer_speech_model.py:263-452, 782-800) ------------------------------------------------------
+def test_text_segmentation_equals_the_reference_functions():
+    """split_text_by_punctuation / merge_short_segments against outputs of the reference's own functions (tests/golden/segmentation.json,
+    minted by tests/golden/make_golden_text.py): empty and punctuation-only texts, Han and Latin runs, no punctuation at all, 10..5200 chars."""
+    import json
+    from flowmirror_hydravox_amd.model_manager import merge_short_segments, split_text_by_punctuation
+    g = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'segmentation.json'), encoding='utf-8'))
+    assert len(g['cases']) >= 80
+    for c in g['cases']:
+        seg = split_text_by_punctuation(c['text'], c['max_length'], c['min_length'])
+        assert seg == c['split'], (c['text'][:40], c['max_length'], c['min_length'])
+        assert merge_short_segments(seg, c['min_length']) == c['merged']
+        assert ''.join(seg) == c['text'] or c['text'] == ''
+
+
+class _SegFrontend:
+    spk2info = {'spk_a': {}, 'spk_b': {}}
+
+    def text_normalize(self, text, split=True, text_frontend=True):
+        return [text] if split else text
+
+
+def test_text_to_speech_takes_the_segmented_path_above_5000_chars(monkeypatch):
+    """> 5000 characters: pieces of <= ~30 characters, every piece plain speaker TTS (last_prompt=False), 50-150 ms of silence between
+    pieces, segments_info = {total_segments, segments}; shorter texts: one inference_tts call and segments_info None (:782-800)."""
+    from flowmirror_hydravox_amd import model_manager as mm
+    calls = []
+
+    def fake_tts(manager, text, spk, speed=1.0):
+        calls.append((text, spk, speed))
+        return torch.full((1, 240 * len(text)), float(len(calls)))
+    monkeypatch.setattr(mm, 'inference_tts', fake_tts)
+    man = mm.HvxModelManager()
+    man.is_loaded, man.frontend, man.configs = True, _SegFrontend(), {'sample_rate': 24000}
+    short = mm.text_to_speech(man, 'hello, world.', 'spk_b', speed=1.25)
+    assert short['segments_info'] is None and calls == [('hello, world.', 'spk_b', 1.25)] and short['speaker_id'] == 'spk_b'
+    calls.clear()
+    text = ('一二三四五六七八九十，' * 3 + 'abcdefghij klmnopqrst. ') * 110
+    assert len(text) > 5000
+    out = mm.text_to_speech(man, text, '', speed=1.0)                    # no speaker id: the first available one
+    segs = mm.merge_short_segments(mm.split_text_by_punctuation(text, 30, 10), 10)
+    assert out['speaker_id'] == 'spk_a' and out['segments_info'] == {'total_segments': len(segs), 'segments': segs}
+    assert [c[0] for c in calls] == segs and len(segs) > 100
+    spoken = sum(240 * len(s) for s in segs)
+    gaps = out['output_audio'].shape[-1] - spoken
+    assert (len(segs) - 1) * 1200 <= gaps <= (len(segs) - 1) * 3600      # 50..150 ms at 24 kHz per joint
+    assert out['duration'] == out['output_audio'].shape[-1] / 24000
+    with pytest.raises(ValueError):
+        mm.text_to_speech(man, 'x', 'nobody')
+    with pytest.raises(ValueError):
+        mm.text_to_speech(man, '   ', 'spk_a')
+
+
+# ---- hydravox.yaml (infer_speech_model.py:59-62) ---------------------------------------------------------------------------
+_YAML = """
+# fixed params
+sample_rate: 24000
+llm_input_size: 128
+llm_output_size: 128
+spk_embed_dim: 192
+qwen_pretrain_path: ''
+token_frame_rate: 25
+token_mel_ratio: 2
+chunk_size: 25
+base: 96
+
+llm: !new:cosyvoice.llm.llm_multi_head_v3.CosyVoice3LM
+    llm_input_size: !ref <llm_input_size>
+    llm_output_size: !ref <llm_output_size>
+    speech_token_size: 6561
+    length_normalized_loss: True
+    lsm_weight: 0
+    mix_ratio: [5, 15]
+    head_num: 3
+    inference_head_num: 2
+    mtp_head_num: 2
+    llm: !new:cosyvoice.llm.llm_multi_head_v3.Qwen2Encoder
+        pretrain_path: !ref <qwen_pretrain_path>
+    sampling: !name:cosyvoice.utils.common.ras_sampling
+        top_p: 0.8
+        top_k: 25
+        win_size: 10
+        tau_r: 0.1
+
+flow: !new:cosyvoice.flow.flow.CausalMaskedDiffWithDiT
+    input_size: 80
+    output_size: 80
+    spk_embed_dim: !ref <spk_embed_dim>
+    output_type: 'mel'
+    vocab_size: 6561
+    input_frame_rate: !ref <token_frame_rate>
+    only_mask_loss: True
+    token_mel_ratio: !ref <token_mel_ratio>
+    pre_lookahead_len: 3
+    pre_lookahead_layer: !new:cosyvoice.transformer.upsample_encoder.PreLookaheadLayer
+        in_channels: 80
+        channels: 256
+        pre_lookahead_len: 3
+    decoder: !new:cosyvoice.flow.flow_matching.CausalConditionalCFM
+        in_channels: 240
+        n_spks: 1
+        spk_emb_dim: 80
+        cfm_params: !new:omegaconf.DictConfig
+            content:
+                sigma_min: 1e-06
+                solver: 'euler'
+                t_scheduler: 'cosine'
+                training_cfg_rate: 0.2
+                inference_cfg_rate: 0.5
+                reg_loss_type: 'l1'
+        estimator: !new:cosyvoice.flow.DiT.dit.DiT
+            dim: 512
+            depth: 4
+            heads: 8
+            dim_head: 64
+            ff_mult: 2
+            mel_dim: 80
+            mu_dim: 80
+            spk_dim: 80
+            out_channels: 80
+            static_chunk_size: !ref <chunk_size> * <token_mel_ratio>
+            num_decoding_left_chunks: -1
+
+hift: !new:cosyvoice.hifigan.generator.CausalHiFTGenerator
+    in_channels: 80
+    base_channels: !ref <base>
+    nb_harmonics: 8
+    sampling_rate: !ref <sample_rate>
+    nsf_alpha: 0.1
+    nsf_sigma: 0.003
+    nsf_voiced_threshold: 10
+    upsample_rates: [8, 5, 3]
+    upsample_kernel_sizes: [16, 11, 7]
+    istft_params:
+        n_fft: 16
+        hop_len: 4
+    resblock_kernel_sizes: [3, 7]
+    resblock_dilation_sizes: [[1, 3, 5], [1, 3, 5]]
+    source_resblock_kernel_sizes: [7, 7, 11]
+    source_resblock_dilation_sizes: [[1, 3, 5], [1, 3, 5], [1, 3, 5]]
+    lrelu_slope: 0.1
+    audio_limit: 0.99
+    conv_pre_look_right: 4
+    f0_predictor: !new:cosyvoice.hifigan.f0_predictor.CausalConvRNNF0Predictor
+        num_class: 1
+        in_channels: 80
+        cond_channels: 64
+"""
+
+
+def test_hydravox_yaml_dimensions(tmp_path):
+    """yaml_config reads the plain numbers of a HyperPyYAML model description: tagged nodes, `!ref <key>` and `!ref <a> * <b>`,
+    the DictConfig wrapper of cfm_params, Qwen2 sizes from CosyVoice-BlankEN/config.json; load_models' config lookup picks it up."""
+    import json
+    from flowmirror_hydravox_amd.model_manager import _load_config
+    from flowmirror_hydravox_amd.yaml_config import config_from_model_dir, load_hyperpyyaml_plain
+    d = tmp_path / 'model'
+    (d / 'CosyVoice-BlankEN').mkdir(parents=True)
+    (d / 'hydravox.yaml').write_text(_YAML)
+    (d / 'CosyVoice-BlankEN' / 'config.json').write_text(json.dumps(dict(hidden_size=128, num_hidden_layers=3, num_attention_heads=2, num_key_value_heads=1,
+                                                                         intermediate_size=320, rope_theta=1000000.0, rms_norm_eps=1e-6, vocab_size=151936)))
+    doc = load_hyperpyyaml_plain(_YAML)
+    assert doc['flow']['decoder']['estimator']['static_chunk_size'] == 50 and doc['hift']['base_channels'] == 96
+    assert doc['llm']['__tag__'].endswith('CosyVoice3LM')
+    cfg, extras = config_from_model_dir(str(d))
+    assert (cfg.llm.hidden, cfg.llm.layers, cfg.llm.q_heads, cfg.llm.kv_heads, cfg.llm.inter) == (128, 3, 2, 1, 320)
+    assert (cfg.llm.head_num, cfg.llm.mtp_heads, cfg.llm.speech_tokens) == (3, 2, 6561)
+    assert extras == {'sampling': {'top_p': 0.8, 'top_k': 25, 'win_size': 10, 'tau_r': 0.1}, 'inference_head_num': 2}
+    f = cfg.flow
+    assert (f.dim, f.depth, f.heads, f.ff_mult, f.static_chunk_size, f.cfg_rate, f.pre_lookahead_channels, f.vocab) == (512, 4, 8, 2, 50, 0.5, 256, 6561)
+    h = cfg.hift
+    assert (h.base_channels, h.f0_channels, h.resblock_kernel_sizes, h.upsample_rates, h.n_fft, h.hop, h.sampling_rate) == (96, 64, [3, 7], [8, 5, 3], 16, 4, 24000)
+    assert h.upsample_total == 480 and cfg.sample_rate == 24000
+    got, ex2 = _load_config(str(d))
+    assert got == cfg and ex2 == extras
+    # an explicit hvx_config.json still wins; an unsupported head size is refused by name
+    (d / 'hydravox.yaml').write_text(_YAML.replace('dim_head: 64', 'dim_head: 32'))
+    with pytest.raises(ValueError, match='dim_head'):
+        config_from_model_dir(str(d))
+    # no yaml: None (the caller falls back to the preset)
+    assert config_from_model_dir(str(tmp_path)) is None
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference'), reason='reference tree not present (GPU box)')
+def test_yaml_fixture_uses_only_real_constructor_arguments():
+    """every key the test yaml gives a `!new:` node is an argument of that reference class's __init__ (checked on the sources' AST:
+    the modules themselves need packages that are absent here)"""
+    import ast
+    from flowmirror_hydravox_amd.yaml_config import load_hyperpyyaml_plain
+    base = '/root/reference/server/model_utils/'
+    doc = load_hyperpyyaml_plain(_YAML)
+
+    def init_args(tag):
+        mod, cls = tag.split(':', 1)[1].rsplit('.', 1)
+        path = base + mod.replace('.', '/') + '.py'
+        tree = ast.parse(open(path, encoding='utf-8').read())
+        c = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == cls)
+        f = next(n for n in c.body if isinstance(n, ast.FunctionDef) and n.name == '__init__')
+        return {a.arg for a in f.args.args + f.args.kwonlyargs} - {'self'}
+
+    def walk(node, seen):
+        if isinstance(node, dict):
+            tag = node.get('__tag__', '')
+            if tag.startswith('!new:cosyvoice.'):
+                args = init_args(tag)
+                for k in node:
+                    assert k == '__tag__' or k in args, (tag, k)
+                seen.append(tag)
+            for v in node.values():
+                walk(v, seen)
+    seen = []
+    walk(doc, seen)
+    assert len(seen) >= 7
