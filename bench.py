@@ -99,46 +99,73 @@ def roofline_of(name, p):
 
 
 def cpu_baseline(cfg, pipe_seed, chars, heads):
-    """Reference algorithm on the host cores (oracle/ = the fp32 CPU restatement, including the reference's full-prefix
-    recompute per AR step), on a bounded sample of the same workload."""
+    """Reference algorithm on the host cores (oracle/ = the fp32 CPU restatement), BASELINE.md §2: the LM with the reference's
+    no-KV-cache full-prefix recompute per AR step over a wall-clock budget at the true context offsets (up to 128 tokens), the same LM
+    KV-cached ("fair CPU"), the flow decoder at T = 704 and T = 1408 frames extrapolated to the bench length with a*T + b*T^2, HiFT at
+    T = 704 scaled linearly.  Bounded: about 80 s of host work."""
     from oracle import llm_ref, flow_ref, hift_ref, sampler_ref
     from flowmirror_hydravox_amd import weights as W
     from flowmirror_hydravox_amd.pipeline import synthetic_utterance
     # 256 OpenMP threads on a 2-socket host make these small fp32 GEMMs slower, not faster: use at most 32 and say so
     cores = min(os.cpu_count() or 1, int(os.environ.get('HVX_CPU_BASELINE_THREADS', '32')))
     torch.set_num_threads(cores)
+    budget = float(os.environ.get('HVX_CPU_BASELINE_LLM_SECONDS', '25'))
     u = synthetic_utterance(cfg, 0, chars)
     sampling = dict(top_p=0.9, top_k=10, win_size=32, tau_r=0.2)
-    # ---- LLM: first 4 AR steps (2*heads... tokens) of one utterance at the true context offset, no KV cache (reference behaviour)
     sd = W.make_llm_state(cfg.llm, seed=pipe_seed, init='normal02')
-    n_steps = 3
-    t0 = time.time()
-    toks = list(llm_ref.llm_inference(sd, cfg.llm, u.text, sampler_ref.NoiseStream(seed=0), inference_head_num=heads, sampling=sampling,
-                                      max_token_text_ratio=5.5, min_token_text_ratio=5.5, use_kv_cache=False, max_steps=n_steps))
-    t_llm = (time.time() - t0) / max(len(toks), 1)
-    n_llm = len(toks)
+    ratio = 5.5
+
+    def run_llm(use_kv, seconds, max_tokens):
+        n, t0 = 0, time.time()
+        for _ in llm_ref.llm_inference(sd, cfg.llm, u.text, sampler_ref.NoiseStream(seed=0), inference_head_num=heads, sampling=sampling,
+                                       max_token_text_ratio=ratio, min_token_text_ratio=ratio, use_kv_cache=use_kv):
+            n += 1
+            if n >= max_tokens or time.time() - t0 > seconds:
+                break
+        return n, time.time() - t0
+    n_nc, t_nc = run_llm(False, budget, 128)                 # reference behaviour
+    n_kv, t_kv = run_llm(True, 10.0, 128)                    # "fair CPU": same arithmetic, keys / values kept (includes the prefill of the prefix)
     del sd
-    # ---- flow + HiFT on a 64-token (128-frame) utterance; per-token cost (attention share grows with T: this favours the CPU)
-    n_tok = 64
-    g = torch.Generator().manual_seed(1)
-    token = torch.randint(0, cfg.flow.vocab, (1, n_tok), generator=g)
+    t_llm = t_nc / max(n_nc, 1)
+    # ---- flow: 10 Euler steps x CFG 2 at two lengths -> a*T + b*T^2 (linear layers / attention), extrapolated to the bench length
     sdf = W.make_flow_state(cfg.flow, seed=pipe_seed + 1, init='normal02')
-    t0 = time.time()
-    mel = flow_ref.flow_inference(token, u.embedding[None], sdf, cfg.flow)
-    t_flow = (time.time() - t0) / n_tok
+    g = torch.Generator().manual_seed(1)
+    n_spk = int(chars * ratio)
+    T_full = n_spk * cfg.flow.token_mel_ratio
+    t_flow, mel = {}, None
+    for n_tok in (352, 704):
+        token = torch.randint(0, cfg.flow.vocab, (1, n_tok), generator=g)
+        t0 = time.time()
+        m = flow_ref.flow_inference(token, u.embedding[None], sdf, cfg.flow)
+        t_flow[n_tok * cfg.flow.token_mel_ratio] = time.time() - t0
+        if mel is None:
+            mel = m
     del sdf
+    (T1, f1), (T2, f2) = sorted(t_flow.items())
+    qb = max((f2 / T2 - f1 / T1) / (T2 - T1), 0.0)
+    qa = f1 / T1 - qb * T1
+    flow_full = qa * T_full + qb * T_full * T_full
     sdh = W.make_hift_state(cfg.hift, seed=pipe_seed + 2, init='normal02')
     tables = hift_ref.make_tables(cfg.hift, seed=0, n_samples=mel.shape[-1] * cfg.hift.upsample_total)
     t0 = time.time()
     hift_ref.hift_inference(mel, sdh, cfg.hift, tables)
-    t_hift = (time.time() - t0) / n_tok
-    per_tok = t_llm + t_flow + t_hift
-    return dict(value=round(1.0 / per_tok, 3), unit='speech-tokens/s', cores=cores, kind='port',
-                sample='oracle/ (fp32 CPU restatement of the reference algorithm, torch CPU, %d threads): LLM = first %d tokens of one %d-char '
-                       'utterance with the reference\'s no-KV-cache full-prefix recompute (%.2f s/token); flow (10 Euler steps, CFG) + HiFT on a '
-                       '%d-token / %d-frame utterance (%.3f + %.3f s/token); value = 1 / sum of per-token costs'
-                       % (cores, n_llm, chars, t_llm, n_tok, 2 * n_tok, t_flow, t_hift),
-                llm_tokens_per_s=round(1.0 / t_llm, 3))
+    t_hift = time.time() - t0
+    hift_full = t_hift * T_full / mel.shape[-1]
+    total = n_spk * t_llm + flow_full + hift_full            # one bench utterance on the host cores
+    return dict(value=round(n_spk / total, 3), unit='speech-tokens/s', cores=cores, kind='port',
+                sample='oracle/ (fp32 CPU restatement of the reference algorithm, torch CPU, %d threads) on one %d-char utterance of the bench workload: '
+                       'LM = first %d speech tokens in %.1f s with the reference\'s no-KV-cache full-prefix recompute at the true context offsets '
+                       '(context %d..%d; the utterance mean is ~%d, so this favours the CPU); flow (10 Euler steps x CFG 2) measured at T = %d / %d frames '
+                       '(%.1f / %.1f s) and extrapolated to T = %d with a*T + b*T^2 (%.0f s); HiFT measured at T = %d (%.1f s), scaled linearly (%.0f s); '
+                       'value = %d tokens / (%d * LM seconds per token + flow + HiFT)'
+                       % (cores, chars, n_nc, t_nc, chars + 2, chars + 2 + n_nc, chars + 2 + n_spk // 2, T1, T2, f1, f2, T_full, flow_full, mel.shape[-1], t_hift,
+                          hift_full, n_spk, n_spk),
+                llm_tokens_per_s=round(n_nc / t_nc, 3),
+                fair_cpu_kv_cached={'llm_tokens_per_s': round(n_kv / t_kv, 3), 'tokens': n_kv, 'seconds': round(t_kv, 2),
+                                    'value': round(n_spk / (n_spk * t_kv / max(n_kv, 1) + flow_full + hift_full), 3),
+                                    'note': 'the same LM arithmetic with a KV cache (prefix prefill included in the seconds); flow / HiFT as above'},
+                flow_seconds={'T%d' % T1: round(f1, 2), 'T%d' % T2: round(f2, 2), 'T%d_extrapolated' % T_full: round(flow_full, 1)},
+                hift_seconds={'T%d' % mel.shape[-1]: round(t_hift, 2), 'T%d_scaled' % T_full: round(hift_full, 1)})
 
 
 def main():

@@ -50,6 +50,11 @@ class AttnArgs(C.Structure):
                 ('n_splits', c_i32), ('split_chunk', c_i32), ('part_o', c_vp), ('part_ml', c_vp), ('chunk', c_i32), ('q_log2', c_i32)]
 
 
+class FeatureConfig(C.Structure):
+    _fields_ = [('frame_len', c_i32), ('hop', c_i32), ('reflect_pad', c_i32), ('n_frames', c_i32), ('bins', c_i32), ('power', c_i32), ('mag_eps', c_f32),
+                ('n_mels', c_i32), ('log_floor', c_f32), ('log_scale', c_f32), ('post', c_i32), ('time_major', c_i32)]
+
+
 class LLMConfig(C.Structure):
     _fields_ = [('dtype', c_i32), ('hidden', c_i32), ('layers', c_i32), ('q_heads', c_i32), ('kv_heads', c_i32), ('inter', c_i32),
                 ('vocab', c_i32), ('vocab_pad', c_i32), ('speech_tokens', c_i32), ('text_vocab', c_i32),
@@ -136,6 +141,8 @@ SYMBOLS = {
     'hvx_hifigan_workspace_bytes': (c_sz, [c_vp, c_i32]),
     'hvx_hifigan_forward': (c_i32, [c_vp, c_vp, c_vp, c_sz, c_vp, c_i32, c_vp]),
     'hvx_denoise_workspace_bytes': (c_sz, [c_i32, c_i32, c_i32]),
+    'hvx_frame_features_workspace_bytes': (c_sz, [c_i32, c_vp]),
+    'hvx_frame_features': (c_i32, [c_vp, c_vp, c_sz, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp]),
     'hvx_mel_workspace_bytes': (c_sz, [c_i32, c_i32, c_i32, c_i32]),
     'hvx_mel_spectrogram': (c_i32, [c_vp, c_vp, c_sz, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp]),
     'hvx_stft_magnitude': (c_i32, [c_vp, c_vp, c_sz, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),

@@ -711,9 +711,44 @@ __global__ void spectral_magnitude_kernel(const float* spec, int ld, int bins, f
     float v = 0.0f;
     if (k < bins) {
         const float re = spec[(long long)f * ld + k], im = spec[(long long)f * ld + bins + k];
-        v = sqrtf(re * re + im * im + eps);
+        v = eps < 0.0f ? re * re + im * im : sqrtf(re * re + im * im + eps);     // eps < 0: the power spectrum
     }
     mag[(long long)f * ld_mag + k] = v;
+}
+// ---- feature post-processing of the speech frontends (cosyvoice/cli/frontend.py:92-115) --------------------------------------------
+// whisper.log_mel_spectrogram: x = (max(x, max_all(x) - 8) + 4) / 4 over a [rows][cols] block with row stride ld
+__global__ __launch_bounds__(1024) void whisper_range_kernel(float* x, int ld, int rows, int cols) {
+    __shared__ float red[16];
+    float m = -INFINITY;
+    const long long n = (long long)rows * cols;
+    for (long long i = threadIdx.x; i < n; i += 1024) m = fmaxf(m, x[(i / cols) * ld + (i % cols)]);
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = red[0];
+    for (int w = 1; w < 16; ++w) m = fmaxf(m, red[w]);
+    for (long long i = threadIdx.x; i < n; i += 1024) {
+        float* p = x + (i / cols) * ld + (i % cols);
+        *p = (fmaxf(*p, m - 8.0f) + 4.0f) * 0.25f;
+    }
+}
+// cepstral mean normalisation of the CAM++ features: x[r][c] -= mean_r x[r][c]   (frontend.py:108), one workgroup per column
+__global__ __launch_bounds__(256) void column_mean_sub_kernel(float* x, int ld, int rows) {
+    __shared__ double red[4];
+    const int c = blockIdx.x;
+    double s = 0.0;
+    for (int r = threadIdx.x; r < rows; r += 256) s += (double)x[(long long)r * ld + c];
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float mean = (float)((red[0] + red[1] + red[2] + red[3]) / (double)rows);
+    for (int r = threadIdx.x; r < rows; r += 256) x[(long long)r * ld + c] -= mean;
+}
+int launch_feature_post(float* x, int ld, int rows, int cols, int post, hipStream_t s) {
+    if (rows <= 0 || cols <= 0 || post == 0) return 0;
+    if (post == 1) hipLaunchKernelGGL(whisper_range_kernel, dim3(1), dim3(1024), 0, s, x, ld, rows, cols);
+    else hipLaunchKernelGGL(column_mean_sub_kernel, dim3(cols), dim3(256), 0, s, x, ld, rows);
+    return hipGetLastError() == hipSuccess ? 0 : (set_error("feature post-processing launch failed"), -1);
 }
 int launch_spectral_magnitude(const float* spec, int ld, int frames, int bins, float* mag, int ld_mag, float eps, hipStream_t s) {
     if (frames <= 0) return 0;

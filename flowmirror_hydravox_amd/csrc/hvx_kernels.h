@@ -182,6 +182,7 @@ int launch_euler_rows(float* x, const float* v, int ldv, float dt, int B, int T,
 int launch_reflect_pad(const float* x, float* y, int L, int pad, int total, hipStream_t s);
 int launch_spectral_magnitude(const float* spec, int ld, int frames, int bins, float* mag, int ld_mag, float eps, hipStream_t s);
 int launch_spectral_subtract(float* spec, int ld, int frames, int bins, const float* bias, float strength, hipStream_t s);
+int launch_feature_post(float* x, int ld, int rows, int cols, int post, hipStream_t s);   // 1: whisper dynamic range + affine, 2: subtract column means
 int launch_overlap_add(const float* frames_buf, int ld, int frames, int n_fft, int hop, const float* wsq, float* y, int out_len, hipStream_t s);
 int launch_resample_linear(const float* x, int rows, int t_in, float* y, int t_out, hipStream_t s);   // F.interpolate(mode='linear') along the last axis
 int launch_transpose_f32(const float* src, float* dst, int rows, int cols, int ld_src, int ld_dst, hipStream_t s);   // dst[c][r] = src[r][c]

@@ -554,36 +554,70 @@ int hvx_stft_magnitude(hvx_stream stream, void* ws, size_t ws_bytes, const float
 /* mel_spectrogram (matcha/utils/audio.py:45-82; the prompt-feature extractor of cosyvoice/cli/frontend.py:119): reflect pad by
  * (n_fft - hop) / 2, STFT(center=False, hann), sqrt(re^2 + im^2 + 1e-9), mel filterbank, log(clamp(., 1e-5)).
  * mel_basis f32 [n_mels][pad32(n_fft/2 + 1)] (zero padded); out f32 (n_mels, frames), frames = (L + (n_fft - hop)/2*2 - n_fft) / hop + 1. */
+size_t hvx_frame_features_workspace_bytes(int32_t L, const hvx_feature_config* c) {
+    if (!c || c->hop <= 0) return 0;
+    const size_t padded = (size_t)L + 2 * (size_t)c->reflect_pad + c->frame_len + 64, frames = (size_t)c->n_frames;
+    return align_up(padded * 4) + align_up(frames * pad32(2 * c->bins) * 4) + align_up(frames * pad32(c->bins) * 4) + align_up(frames * pad32(c->n_mels) * 4);
+}
+int hvx_frame_features(hvx_stream stream, void* ws, size_t ws_bytes, const float* audio, int32_t L, const hvx_feature_config* c, const float* basis,
+                       const float* mel_basis, float* out) {
+    if (!ws || !audio || !c || !basis || !mel_basis || !out) return set_error("hvx_frame_features: null argument"), -1;
+    if (c->frame_len % 32 || c->hop % 32 || c->hop <= 0 || c->frame_len <= 0 || c->reflect_pad < 0 || c->reflect_pad >= L || c->n_frames < 1 ||
+        c->bins < 1 || c->n_mels < 1)
+        return set_error("hvx_frame_features: frame_len=%d hop=%d reflect_pad=%d frames=%d L=%d", c->frame_len, c->hop, c->reflect_pad, c->n_frames, L), -1;
+    const long long padded = (long long)L + 2 * c->reflect_pad;
+    // every frame must start inside the (padded) signal; samples past its end are zero (the caller's basis gives them zero weight anyway)
+    if ((long long)(c->n_frames - 1) * c->hop >= padded) return set_error("hvx_frame_features: %d frames do not fit %lld samples", c->n_frames, padded), -1;
+    if (hvx_frame_features_workspace_bytes(L, c) > ws_bytes) return set_error("hvx_frame_features: workspace too small"), -1;
+    hipStream_t s = (hipStream_t)stream;
+    const int frames = c->n_frames, bins = c->bins, ldspec = pad32(2 * bins), ldmag = pad32(bins), ldm = pad32(c->n_mels);
+    const long long total = (long long)(frames - 1) * c->hop + c->frame_len;         // samples the framing GEMM touches
+    Carve cv((char*)ws);
+    float* xp = cv.take((size_t)padded + c->frame_len + 64);
+    float* spec = cv.take((size_t)frames * ldspec);
+    float* mag = cv.take((size_t)frames * ldmag);
+    float* mel = cv.take((size_t)frames * ldm);
+    const long long fill = ((total > padded ? total : padded) + 31) / 32 * 32;
+    HVX_CHECK(launch_reflect_pad(audio, xp, L, c->reflect_pad, (int)padded, s));
+    if (fill > padded) HIP_OK(hipMemsetAsync(xp + padded, 0, (size_t)(fill - padded) * 4, s));
+    GemmArgs g = conv(frames, 2 * bins, c->frame_len / 32, 32, xp, 32, (int)(fill / 32), basis, nullptr);
+    g.conv_stride = c->hop / 32;
+    g.out = spec; g.ldo = ldspec; g.out_cols = ldspec;
+    HVX_CHECK(launch_gemm(g, s));
+    HVX_CHECK(launch_spectral_magnitude(spec, ldspec, frames, bins, mag, ldmag, c->power ? -1.0f : c->mag_eps, s));
+    g = conv(frames, c->n_mels, 1, ldmag, mag, ldmag, frames, mel_basis, nullptr);
+    g.act = ACT_LOG_CLAMP; g.act_param = c->log_floor; g.scale = c->log_scale;
+    g.out = mel; g.ldo = ldm; g.out_cols = ldm;
+    HVX_CHECK(launch_gemm(g, s));
+    HVX_CHECK(launch_feature_post(mel, ldm, frames, c->n_mels, c->post, s));
+    if (c->time_major) {
+        HIP_OK(hipMemcpy2DAsync(out, (size_t)c->n_mels * 4, mel, (size_t)ldm * 4, (size_t)c->n_mels * 4, frames, hipMemcpyDeviceToDevice, s));
+        return 0;
+    }
+    return launch_transpose_f32(mel, out, frames, c->n_mels, ldm, frames, s);
+}
+
 size_t hvx_mel_workspace_bytes(int32_t L, int32_t n_fft, int32_t hop, int32_t n_mels) {
-    const size_t padded = (size_t)L + n_fft, frames = padded / hop + 1, ldspec = (size_t)pad32(n_fft + 2), ldmag = (size_t)pad32(n_fft / 2 + 1);
-    return align_up((padded + 64) * 4) + align_up(frames * ldspec * 4) + align_up(frames * ldmag * 4) + align_up(frames * pad32(n_mels) * 4);
+    if (hop <= 0 || n_fft < hop) return 0;
+    const int pad = (n_fft - hop) / 2;
+    hvx_feature_config c;
+    memset(&c, 0, sizeof(c));
+    c.frame_len = n_fft; c.hop = hop; c.reflect_pad = pad; c.n_frames = (L + 2 * pad - n_fft) / hop + 1; c.bins = n_fft / 2 + 1; c.n_mels = n_mels;
+    return c.n_frames < 1 ? 0 : hvx_frame_features_workspace_bytes(L, &c);
 }
 int hvx_mel_spectrogram(hvx_stream stream, void* ws, size_t ws_bytes, const float* audio, int32_t L, int32_t n_fft, int32_t hop,
                         const float* stft_basis, const float* mel_basis, int32_t n_mels, float* out) {
     if (!ws || !audio || !stft_basis || !mel_basis || !out) return set_error("hvx_mel_spectrogram: null argument"), -1;
     const int pad = (n_fft - hop) / 2;
     if (n_fft % 32 || hop % 32 || hop > n_fft || L <= pad) return set_error("hvx_mel_spectrogram: n_fft=%d hop=%d L=%d", n_fft, hop, L), -1;
-    if (hvx_mel_workspace_bytes(L, n_fft, hop, n_mels) > ws_bytes) return set_error("hvx_mel_spectrogram: workspace too small"), -1;
-    hipStream_t s = (hipStream_t)stream;
-    const int padded = L + 2 * pad, frames = (padded - n_fft) / hop + 1;
-    const int bins = n_fft / 2 + 1, ldspec = pad32(2 * bins), ldmag = pad32(bins), ldm = pad32(n_mels);
+    const int frames = (L + 2 * pad - n_fft) / hop + 1;
     if (frames < 1) return set_error("hvx_mel_spectrogram: signal shorter than one frame"), -1;
-    Carve cv((char*)ws);
-    float* xp = cv.take((size_t)L + n_fft + 64);
-    float* spec = cv.take((size_t)frames * ldspec);
-    float* mag = cv.take((size_t)frames * ldmag);
-    float* mel = cv.take((size_t)frames * ldm);
-    HVX_CHECK(launch_reflect_pad(audio, xp, L, pad, padded + 32, s));
-    GemmArgs g = conv(frames, 2 * bins, n_fft / 32, 32, xp, 32, (padded + 31) / 32, stft_basis, nullptr);
-    g.conv_stride = hop / 32;
-    g.out = spec; g.ldo = ldspec; g.out_cols = ldspec;
-    HVX_CHECK(launch_gemm(g, s));
-    HVX_CHECK(launch_spectral_magnitude(spec, ldspec, frames, bins, mag, ldmag, 1e-9f, s));
-    g = conv(frames, n_mels, 1, ldmag, mag, ldmag, frames, mel_basis, nullptr);
-    g.act = ACT_LOG_CLAMP; g.act_param = 1e-5f;
-    g.out = mel; g.ldo = ldm; g.out_cols = ldm;
-    HVX_CHECK(launch_gemm(g, s));
-    return launch_transpose_f32(mel, out, frames, n_mels, ldm, frames, s);
+    // matcha/utils/audio.py:45-82: reflect pad (n_fft - hop) / 2, hann STFT, sqrt(|X|^2 + 1e-9), mel, log(clamp(., 1e-5))
+    hvx_feature_config c;
+    memset(&c, 0, sizeof(c));
+    c.frame_len = n_fft; c.hop = hop; c.reflect_pad = pad; c.n_frames = frames; c.bins = n_fft / 2 + 1; c.power = 0; c.mag_eps = 1e-9f;
+    c.n_mels = n_mels; c.log_floor = 1e-5f; c.log_scale = 1.0f; c.post = 0; c.time_major = 0;
+    return hvx_frame_features(stream, ws, ws_bytes, audio, L, &c, stft_basis, mel_basis, out);
 }
 
 int hvx_denoise(hvx_stream stream, void* ws, size_t ws_bytes, const float* audio, int32_t L, int32_t n_fft, int32_t hop, const float* stft_basis,

@@ -1,5 +1,10 @@
-"""Prompt-feature extraction on the device: the log-mel spectrogram the zero-shot frontend computes for the prompt
-audio — `feat_extractor` = matcha.utils.audio.mel_spectrogram (matcha/utils/audio.py:45-82, called at cosyvoice/cli/frontend.py:119;
+"""Prompt-feature extraction on the device: the three spectral features the zero-shot frontend computes from the prompt
+audio (cosyvoice/cli/frontend.py:92-122) — HvxMelSpectrogram (prompt log-mel for the flow, below), HvxWhisperLogMel (128-bin input of the
+speech tokenizer, :95) and HvxKaldiFbank (80-bin input of the CAM++ speaker encoder with its mean subtraction, :104-108).  The ONNX
+graphs those last two feed are assets of the weights repository and stay outside this build; what runs on the host in the reference —
+the feature extraction — runs here as two GEMMs (framing x folded DFT basis, power x mel filterbank) in libhvx: hvx_frame_features.
+
+The log-mel spectrogram the zero-shot frontend computes for the prompt audio — `feat_extractor` = matcha.utils.audio.mel_spectrogram (matcha/utils/audio.py:45-82, called at cosyvoice/cli/frontend.py:119;
 CosyVoice3 settings n_fft 1920, hop 480, win 1920, 80 mels, 24 kHz, fmin 0, fmax 8000).  Same call signature as the reference's partial:
     HvxMelSpectrogram(n_fft=1920, num_mels=80, sampling_rate=24000, hop_size=480, win_size=1920, fmin=0, fmax=8000)(y)  ->  (B, num_mels, frames)
 STFT and mel projection are fp32-MFMA GEMMs against bases built at construction (libhvx: hvx_mel_spectrogram); no CPU fallback."""
@@ -7,7 +12,9 @@ import torch
 
 from . import _lib
 from ._lib import check, ptr, stream_ptr
-from .packing import mel_filterbank, stft_bases
+import ctypes as C
+
+from .packing import kaldi_fbank_bases, mel_filterbank, stft_bases, whisper_bases
 
 
 class HvxMelSpectrogram:
@@ -42,3 +49,73 @@ class HvxMelSpectrogram:
             check(self.lib.hvx_mel_spectrogram(stream_ptr(), ptr(self._ws), self._ws.numel(), ptr(y[b]), L, self.n_fft, self.hop, ptr(self._ana),
                                                ptr(self._mel), self.num_mels, ptr(out[b])), 'hvx_mel_spectrogram')
         return out
+
+
+class _FramedFeatures:
+    """shared driver of hvx_frame_features: bases on the device, a growing workspace, one launch chain per waveform"""
+
+    def __init__(self, basis, mel, device):
+        _lib.require_gpu()
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        self._basis, self._mel = basis.to(self.device).contiguous(), mel.to(self.device).contiguous()
+        self._ws = None
+
+    def _run(self, y, cfg, out):
+        need = self.lib.hvx_frame_features_workspace_bytes(y.numel(), C.byref(cfg))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        check(self.lib.hvx_frame_features(stream_ptr(), ptr(self._ws), self._ws.numel(), ptr(y), y.numel(), C.byref(cfg), ptr(self._basis), ptr(self._mel),
+                                          ptr(out)), 'hvx_frame_features')
+        return out
+
+
+class HvxWhisperLogMel(_FramedFeatures):
+    """`whisper.log_mel_spectrogram(audio, n_mels=128)` (frontend.py:95; whisper/audio.py:110-157) for 16 kHz audio:
+    (L,) or (B, L) -> (n_mels, L // 160) or (B, n_mels, L // 160)"""
+
+    def __init__(self, n_mels=128, device='cuda'):
+        basis, mel = whisper_bases(n_mels)
+        super().__init__(basis, mel, device)
+        self.n_mels = n_mels
+
+    @torch.inference_mode()
+    def __call__(self, audio):
+        a = audio.to(self.device, torch.float32)
+        single = a.dim() == 1
+        a = a.reshape(-1, a.shape[-1]).contiguous()
+        B, L = a.shape
+        if L <= 200:
+            raise ValueError('whisper log-mel: the audio must be longer than the 200-sample reflection pad')
+        frames = L // 160                                    # 1 + L // 160 STFT frames, the last one dropped (audio.py:149)
+        if frames < 1:
+            raise ValueError('whisper log-mel: audio shorter than one hop')
+        cfg = _lib.FeatureConfig(frame_len=416, hop=160, reflect_pad=200, n_frames=frames, bins=201, power=1, mag_eps=0.0, n_mels=self.n_mels,
+                                 log_floor=1e-10, log_scale=0.4342944819032518, post=1, time_major=0)
+        out = torch.empty(B, self.n_mels, frames, dtype=torch.float32, device=self.device)
+        for b in range(B):                                   # the dynamic-range floor is per call (log_spec.max()): one waveform at a time
+            self._run(a[b], cfg, out[b])
+        return out[0] if single else out
+
+
+class HvxKaldiFbank(_FramedFeatures):
+    """`kaldi.fbank(speech, num_mel_bins=80, dither=0, sample_frequency=16000)` and the frontend's mean subtraction (frontend.py:104-108):
+    (1, L) or (L,) -> (1 + (L - 400) // 160, num_mel_bins)"""
+
+    def __init__(self, num_mel_bins=80, sample_frequency=16000, subtract_mean=True, device='cuda'):
+        if int(sample_frequency) != 16000:
+            raise NotImplementedError('the reference frontend extracts speaker features at 16 kHz')
+        basis, mel = kaldi_fbank_bases(num_mel_bins, float(sample_frequency))
+        super().__init__(basis, mel, device)
+        self.num_mel_bins, self.subtract_mean = num_mel_bins, subtract_mean
+
+    @torch.inference_mode()
+    def __call__(self, waveform):
+        a = waveform.to(self.device, torch.float32).reshape(-1).contiguous()
+        L = a.numel()
+        if L < 400:
+            return torch.empty(0, self.num_mel_bins, device=self.device)
+        frames = 1 + (L - 400) // 160
+        cfg = _lib.FeatureConfig(frame_len=416, hop=160, reflect_pad=0, n_frames=frames, bins=257, power=1, mag_eps=0.0, n_mels=self.num_mel_bins,
+                                 log_floor=1.1920928955078125e-07, log_scale=1.0, post=2 if self.subtract_mean else 0, time_major=1)
+        return self._run(a, cfg, torch.empty(frames, self.num_mel_bins, dtype=torch.float32, device=self.device))

@@ -127,6 +127,57 @@ def stft_bases(n_fft, win_length=None):
     return ana.float().contiguous(), syn_p.float().contiguous(), (win * win).float().contiguous()
 
 
+def whisper_bases(n_mels=128):
+    """GEMM operands of whisper.log_mel_spectrogram (whisper/audio.py:110-157: N_FFT 400, HOP 160, periodic Hann, 201 bins, librosa Slaney
+    mel filters for sr 16000) -> (basis f32 [2*201][416], mel f32 [n_mels][pad32(201)]); the 400-sample frame is given as 416 samples
+    (13 rows of 32) whose last 16 basis columns are zero."""
+    import math
+    N, bins, FL = 400, 201, 416
+    win = torch.hann_window(N, dtype=torch.float64)
+    n = torch.arange(N, dtype=torch.float64)
+    k = torch.arange(bins, dtype=torch.float64)
+    ang = 2.0 * math.pi * k[:, None] * n[None, :] / N
+    ana = torch.zeros(2 * bins, FL, dtype=torch.float64)
+    ana[:bins, :N] = torch.cos(ang) * win[None, :]
+    ana[bins:, :N] = -torch.sin(ang) * win[None, :]
+    mel = torch.zeros(n_mels, (bins + 31) // 32 * 32)
+    mel[:, :bins] = mel_filterbank(16000, N, n_mels, 0.0, 8000.0)
+    return ana.float().contiguous(), mel.contiguous()
+
+
+def kaldi_fbank_bases(num_mel_bins=80, sample_frequency=16000.0, low_freq=20.0, preemphasis=0.97):
+    """GEMM operands of torchaudio.compliance.kaldi.fbank at its defaults (25 ms / 10 ms frames, DC removal, pre-emphasis, Povey window,
+    FFT zero-padded to 512, power spectrum, mel(f) = 1127 ln(1 + f / 700) triangles from `low_freq` to Nyquist).  Everything up to the
+    FFT is linear in the frame x:  X = F_512 . pad . diag(povey) . P . (I - 1 1^T / N) x,  so it is folded into ONE basis matrix in
+    float64 -> (basis f32 [2*257][416], mel f32 [num_mel_bins][pad32(257)])."""
+    import math
+    N, padded, FL = int(sample_frequency * 0.025), 512, 416
+    bins = padded // 2 + 1
+    assert N == 400
+    eye = torch.eye(N, dtype=torch.float64)
+    dc = eye - torch.full((N, N), 1.0 / N, dtype=torch.float64)
+    pre = eye.clone()
+    pre[0, 0] -= preemphasis                                  # the first sample is its own predecessor (replicate padding)
+    pre[torch.arange(1, N), torch.arange(0, N - 1)] -= preemphasis
+    win = torch.hann_window(N, periodic=False, dtype=torch.float64).pow(0.85)
+    lin = win[:, None] * (pre @ dc)                           # frame -> windowed frame
+    n = torch.arange(N, dtype=torch.float64)
+    k = torch.arange(bins, dtype=torch.float64)
+    ang = 2.0 * math.pi * k[:, None] * n[None, :] / padded
+    ana = torch.zeros(2 * bins, FL, dtype=torch.float64)
+    ana[:bins, :N] = torch.cos(ang) @ lin
+    ana[bins:, :N] = -torch.sin(ang) @ lin
+    nyq = 0.5 * sample_frequency
+    ml, mh = 1127.0 * math.log(1.0 + low_freq / 700.0), 1127.0 * math.log(1.0 + nyq / 700.0)
+    delta = (mh - ml) / (num_mel_bins + 1)
+    b = torch.arange(num_mel_bins, dtype=torch.float64)[:, None]
+    mk = (1127.0 * torch.log(1.0 + (sample_frequency / padded) * torch.arange(padded // 2, dtype=torch.float64) / 700.0))[None, :]
+    up, down = (mk - (ml + b * delta)) / delta, ((ml + (b + 2.0) * delta) - mk) / delta
+    mel = torch.zeros(num_mel_bins, (bins + 31) // 32 * 32)
+    mel[:, :padded // 2] = torch.clamp(torch.minimum(up, down), min=0.0).float()
+    return ana.float().contiguous(), mel.contiguous()
+
+
 def mel_filterbank(sr, n_fft, n_mels, fmin=0.0, fmax=None):
     """librosa.filters.mel(sr, n_fft, n_mels, fmin, fmax) with its defaults htk=False, norm='slaney' (librosa is what
     matcha/utils/audio.py:53 calls; it is not installed here, this is its published algorithm): triangular filters on the Slaney mel

@@ -328,6 +328,25 @@ int hvx_hifigan_forward(hvx_hifigan* h, hvx_stream s, void* ws, size_t ws_bytes,
 size_t hvx_mel_workspace_bytes(int32_t L, int32_t n_fft, int32_t hop, int32_t n_mels);
 int hvx_mel_spectrogram(hvx_stream s, void* ws, size_t ws_bytes, const float* audio, int32_t L, int32_t n_fft, int32_t hop,
                         const float* stft_basis, const float* mel_basis, int32_t n_mels, float* out);
+/* Framed spectral features of the speech frontends — one description for matcha's mel_spectrogram, whisper's
+ * log_mel_spectrogram (speech-tokenizer input, cosyvoice/cli/frontend.py:95) and kaldi's fbank (CAM++ input, frontend.py:104-108):
+ * [reflect-pad ->] frames of `frame_len` samples every `hop` -> GEMM with `basis` [2*bins][frame_len] (window and whatever else is
+ * linear in the frame folded in by the caller: DC removal, pre-emphasis, zero padding of the FFT) -> |X| or |X|^2 -> GEMM with
+ * `mel_basis` [n_mels][pad32(bins)] -> ln(max(., log_floor)) * log_scale -> post-processing.  frame_len and hop are multiples of 32
+ * (a 400-sample frame is given as 416 with 16 zero basis columns). */
+typedef struct {
+    int32_t frame_len, hop;
+    int32_t reflect_pad;        /* samples mirrored onto both ends before framing (torch.stft center=True: n_fft/2); 0: frames start at sample 0 */
+    int32_t n_frames;
+    int32_t bins;
+    int32_t power; float mag_eps;               /* power != 0: |X|^2; else sqrt(|X|^2 + mag_eps) */
+    int32_t n_mels; float log_floor, log_scale;
+    int32_t post;               /* 0 none; 1 whisper: (max(x, max(x) - 8) + 4) / 4; 2 subtract every mel bin's mean over the frames */
+    int32_t time_major;         /* output (n_frames, n_mels) instead of (n_mels, n_frames) */
+} hvx_feature_config;
+size_t hvx_frame_features_workspace_bytes(int32_t L, const hvx_feature_config* c);
+int hvx_frame_features(hvx_stream s, void* ws, size_t ws_bytes, const float* audio, int32_t L, const hvx_feature_config* c, const float* basis,
+                       const float* mel_basis, float* out);
 size_t hvx_denoise_workspace_bytes(int32_t L, int32_t n_fft, int32_t hop);
 /* |torch.stft(audio, n_fft, hop, window=hann, center=True)|: mag f32 [1 + L/hop][n_fft/2 + 1] */
 int hvx_stft_magnitude(hvx_stream s, void* ws, size_t ws_bytes, const float* audio, int32_t L, int32_t n_fft, int32_t hop, const float* stft_basis,

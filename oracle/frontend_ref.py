@@ -1,0 +1,74 @@
+"""oracle/frontend_ref.py — CPU restatement of the two third-party feature extractors of the zero-shot frontend
+(server/model_utils/cosyvoice/cli/frontend.py:92-110).  TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+PARITY UNPINNED: both algorithms live in third-party packages that are neither under /root/reference nor installed in this image
+(requirements.txt: openai-whisper==20231117, torchaudio==2.3.1), and the reference holds no test vectors for them.  They are restated
+from the published sources of those versions and anchored on the reference's call sites only:
+
+  * `whisper.log_mel_spectrogram(speech, n_mels=128)`  (frontend.py:95)  — whisper/audio.py:110-157: 16 kHz, N_FFT 400, HOP 160,
+    periodic Hann window, torch.stft(center=True, reflect), the last frame dropped, |X|^2, the librosa Slaney mel filterbank
+    (assets/mel_filters.npz = librosa.filters.mel(sr=16000, n_fft=400, n_mels=128)), log10(clamp(., 1e-10)),
+    max(., global max - 8), (. + 4) / 4.
+  * `torchaudio.compliance.kaldi.fbank(speech, num_mel_bins=80, dither=0, sample_frequency=16000)` followed by
+    `feat - feat.mean(dim=0, keepdim=True)`  (frontend.py:104-108) — kaldi.py defaults: 25 ms frames every 10 ms, snip_edges, per-frame
+    DC removal, pre-emphasis 0.97 with the first sample replicated, Povey window (symmetric Hann ^ 0.85), zero-padding to 512, power
+    spectrum, 80 triangular filters equally spaced on mel(f) = 1127 ln(1 + f / 700) between 20 Hz and Nyquist evaluated at the first 256
+    FFT bin centres, log(max(., float32 eps)).
+
+Both are written with torch.stft / torch.fft directly — deliberately NOT in the folded-basis GEMM form the HIP path uses — so that a
+test of one against the other checks the framing, the folding and the filterbanks independently.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def whisper_log_mel(audio, mel_filters):
+    """audio (L,) or (B, L) float at 16 kHz; mel_filters (n_mels, 201) -> (n_mels, frames) or (B, n_mels, frames), frames = L // 160"""
+    window = torch.hann_window(400)
+    stft = torch.stft(audio, 400, 160, window=window, return_complex=True)           # center=True, pad_mode='reflect'
+    magnitudes = stft[..., :-1].abs() ** 2
+    mel_spec = mel_filters @ magnitudes
+    log_spec = torch.clamp(mel_spec, min=1e-10).log10()
+    log_spec = torch.maximum(log_spec, log_spec.max() - 8.0)
+    return (log_spec + 4.0) / 4.0
+
+
+def kaldi_mel_banks(num_bins=80, padded=512, sample_freq=16000.0, low_freq=20.0, high_freq=0.0):
+    """torchaudio.compliance.kaldi.get_mel_banks without VTLN -> (num_bins, padded // 2)"""
+    nyquist = 0.5 * sample_freq
+    if high_freq <= 0.0:
+        high_freq += nyquist
+    n_fft_bins = padded // 2
+    bin_width = sample_freq / padded
+
+    def mel(f):
+        return 1127.0 * math.log(1.0 + f / 700.0)
+    mel_low, mel_high = mel(low_freq), mel(high_freq)
+    delta = (mel_high - mel_low) / (num_bins + 1)
+    b = torch.arange(num_bins, dtype=torch.float64).unsqueeze(1)
+    left, center, right = mel_low + b * delta, mel_low + (b + 1.0) * delta, mel_low + (b + 2.0) * delta
+    m = (1127.0 * torch.log(1.0 + bin_width * torch.arange(n_fft_bins, dtype=torch.float64) / 700.0)).unsqueeze(0)
+    up, down = (m - left) / (center - left), (right - m) / (right - center)
+    return torch.clamp(torch.minimum(up, down), min=0.0).float()
+
+
+def kaldi_fbank(waveform, num_mel_bins=80, sample_frequency=16000.0, subtract_mean=True):
+    """waveform (1, L) or (L,) float -> (frames, num_mel_bins), frames = 1 + (L - 400) // 160; `subtract_mean` applies the
+    frontend's `feat - feat.mean(dim=0)` (cepstral mean normalisation of the CAM++ input)."""
+    x = waveform.reshape(-1).to(torch.float32)
+    win, shift, padded = int(sample_frequency * 0.025), int(sample_frequency * 0.010), 512
+    if x.numel() < win:
+        return torch.empty(0, num_mel_bins)
+    m = 1 + (x.numel() - win) // shift
+    frames = x.as_strided((m, win), (shift, 1)).clone()
+    frames = frames - frames.mean(dim=1, keepdim=True)                                # remove_dc_offset
+    prev = F.pad(frames.unsqueeze(0), (1, 0), mode='replicate').squeeze(0)[:, :-1]
+    frames = frames - 0.97 * prev                                                     # preemphasis_coefficient
+    frames = frames * torch.hann_window(win, periodic=False).pow(0.85).unsqueeze(0)   # povey
+    frames = F.pad(frames, (0, padded - win))
+    power = torch.fft.rfft(frames).abs().pow(2.0)                                     # (m, 257)
+    banks = F.pad(kaldi_mel_banks(num_mel_bins, padded, sample_frequency), (0, 1))    # zero weight on the Nyquist bin
+    feat = torch.clamp(power @ banks.t(), min=torch.finfo(torch.float32).eps).log()
+    return feat - feat.mean(dim=0, keepdim=True) if subtract_mean else feat

@@ -132,3 +132,50 @@ def test_prompt_mel_spectrogram_vs_reference(golden):
         assert out.shape == ref.shape
         # log domain: absolute tolerance (values span about [-11.5, 3]); 1e-3 abs is 0.1 % in the linear domain
         assert np.abs(out - ref).max() < 2e-3
+
+
+def _speechlike(n, seed, sr=16000):
+    """a few seconds of a harmonic source with vibrato, an amplitude envelope, a silent gap and noise: exercises the dynamic range
+    (whisper's max - 8 floor, kaldi's epsilon floor) better than white noise"""
+    g = torch.Generator().manual_seed(seed)
+    t = torch.arange(n, dtype=torch.float64) / sr
+    f0 = 140.0 + 30.0 * torch.sin(2 * np.pi * 0.7 * t)
+    ph = 2 * np.pi * torch.cumsum(f0, 0) / sr
+    y = sum(torch.sin(k * ph) / k for k in range(1, 12)) * (0.5 + 0.5 * torch.sin(2 * np.pi * 1.3 * t)) * 0.2
+    y[n // 3: n // 3 + sr // 4] = 0.0
+    return (y + 0.003 * torch.randn(n, generator=g, dtype=torch.float64)).float()
+
+
+@pytest.mark.parametrize('n', [16000 * 3 + 77, 160 * 5, 401, 16000 * 12])
+def test_whisper_log_mel_vs_oracle(n):
+    """whisper.log_mel_spectrogram(speech, n_mels=128) (frontend.py:95) on the device against the torch.stft
+    restatement in oracle/frontend_ref.py (third-party algorithm, parity unpinned: see the oracle's header).  Log10 domain scaled by 1/4:
+    2e-3 abs is about 2 % in the linear domain at the floor and far less above it."""
+    from flowmirror_hydravox_amd.frontend import HvxWhisperLogMel
+    from flowmirror_hydravox_amd.packing import mel_filterbank
+    from oracle import frontend_ref
+    y = _speechlike(n, seed=n)
+    ref = frontend_ref.whisper_log_mel(y, mel_filterbank(16000, 400, 128, 0.0, 8000.0))
+    fe = HvxWhisperLogMel(128)
+    out = fe(y).cpu()
+    assert out.shape == ref.shape == (128, n // 160)
+    assert (out - ref).abs().max().item() < 2e-3
+    both = fe(torch.stack([y, y.flip(0)])).cpu()                                   # batched call: per-waveform dynamic range
+    assert torch.equal(both[0], out)
+    assert (both[1] - frontend_ref.whisper_log_mel(y.flip(0), mel_filterbank(16000, 400, 128, 0.0, 8000.0))).abs().max().item() < 2e-3
+
+
+@pytest.mark.parametrize('n', [16000 * 3 + 77, 400, 560, 16000 * 9])
+def test_kaldi_fbank_vs_oracle(n):
+    """kaldi.fbank(num_mel_bins=80, dither=0, 16 kHz) + mean subtraction (frontend.py:104-108): the device path folds DC removal,
+    pre-emphasis, the Povey window and the FFT zero-padding into one GEMM basis; the oracle applies them one by one with torch.fft.
+    Natural-log domain: 5e-3 abs (power-spectrum cancellation in near-silent bins carries the fp32 GEMM's rounding)."""
+    from flowmirror_hydravox_amd.frontend import HvxKaldiFbank
+    from oracle import frontend_ref
+    y = _speechlike(n, seed=n + 1)
+    for sub in (True, False):
+        ref = frontend_ref.kaldi_fbank(y[None], subtract_mean=sub)
+        out = HvxKaldiFbank(80, subtract_mean=sub)(y[None]).cpu()
+        assert out.shape == ref.shape == (1 + (n - 400) // 160, 80)
+        assert (out - ref).abs().max().item() < 5e-3, (sub, (out - ref).abs().max().item())
+    assert HvxKaldiFbank(80)(y[:399]).shape == (0, 80)

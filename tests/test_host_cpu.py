@@ -587,3 +587,31 @@ def test_yaml_fixture_uses_only_real_constructor_arguments():
     seen = []
     walk(doc, seen)
     assert len(seen) >= 7
+
+
+def test_frontend_gemm_bases_reproduce_the_oracle_features():
+    """the folded GEMM operands the device path uses (packing.whisper_bases / kaldi_fbank_bases: window, DC removal, pre-emphasis and FFT
+    zero-padding inside ONE basis matrix; 400-sample frames as 13 rows of 32) evaluated in float64 on the host == the step-by-step
+    torch.stft / torch.fft restatement of oracle/frontend_ref.py"""
+    import torch.nn.functional as F
+    from flowmirror_hydravox_amd.packing import kaldi_fbank_bases, mel_filterbank, whisper_bases
+    from oracle import frontend_ref as R
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(16000 * 2, generator=g) * 0.1 + 0.05
+
+    def framed(sig, n):
+        sig = F.pad(sig, (0, 416))
+        return torch.stack([sig[i * 160: i * 160 + 416] for i in range(n)]).double()
+    ana, mel = whisper_bases(128)
+    xp = F.pad(x[None, None], (200, 200), mode='reflect')[0, 0]
+    spec = framed(xp, len(x) // 160) @ ana.double().t()
+    m = torch.clamp((spec[:, :201] ** 2 + spec[:, 201:] ** 2) @ mel[:, :201].double().t(), min=1e-10).log10()
+    m = (torch.maximum(m, m.max() - 8.0) + 4.0) / 4.0
+    assert (m.t().float() - R.whisper_log_mel(x, mel_filterbank(16000, 400, 128, 0.0, 8000.0))).abs().max().item() < 1e-4
+    ana, mel = kaldi_fbank_bases(80)
+    spec = framed(x, 1 + (len(x) - 400) // 160) @ ana.double().t()
+    f = torch.clamp((spec[:, :257] ** 2 + spec[:, 257:] ** 2) @ mel[:, :257].double().t(), min=1.1920929e-07).log()
+    assert ((f - f.mean(0, keepdim=True)).float() - R.kaldi_fbank(x[None])).abs().max().item() < 5e-4
+    # the kaldi mel banks: 80 triangles, unit peak, zero outside [20 Hz, Nyquist)
+    banks = R.kaldi_mel_banks()
+    assert banks.shape == (80, 256) and float(banks.max()) <= 1.0 and float(banks[:, 0].max()) == 0.0 and (banks.sum(1) > 0).all()
