@@ -42,9 +42,13 @@ def parse():
     ap.add_argument('--batch', type=int, default=8, help='utterances per GPU per step')
     ap.add_argument('--chars', type=int, default=512, help='text tokens per utterance')
     ap.add_argument('--heads', type=int, default=2, help='inference_head_num')
+    ap.add_argument('--config', choices=['tts', 'stress', 'zero_shot', 'acoustic'], default='tts',
+                    help='tts: BASELINE configs[1] (the headline, default); stress: configs[2] (4 heads, batch 32); zero_shot: configs[3] (mixed lengths U{64..512} with a 3 s '
+                         'prompt: 75 speech tokens + 150 mel frames + 20 prompt-text tokens, 8 per GPU and step); acoustic: configs[4] (flow + vocoder only on pre-tokenised streams)')
+    ap.add_argument('--streams', type=int, default=64, help='(--config acoustic) pre-tokenised speech-token streams per GPU, lengths U{352..2816}')
     ap.add_argument('--tiny', action='store_true', help='toy dimensions (plumbing check only; INVALID as a benchmark)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--lm-slots', type=int, default=24, help='sequences decoded in one grid (continuous batching): utterances of later steps join as earlier ones finish')
+    ap.add_argument('--lm-slots', type=int, default=64, help='sequences decoded in one grid (continuous batching): utterances of later steps join as earlier ones finish')
     ap.add_argument('--mode', choices=['continuous', 'chains', 'serial'], default='continuous',
                     help='continuous: one decode grid of --lm-slots sequences + acoustic stage of finished utterances beside it (default); '
                          'chains: the round-1 form, --lm-chains independent decode chains of one step each; serial: stages back to back')
@@ -168,6 +172,89 @@ def cpu_baseline(cfg, pipe_seed, chars, heads):
                 hift_seconds={'T%d' % mel.shape[-1]: round(t_hift, 2), 'T%d_scaled' % T_full: round(hift_full, 1)})
 
 
+def run_acoustic(args, cfg, world, rank, lib):
+    """BASELINE configs[4] on this rank's share: pre-tokenised speech-token streams (lengths U{352..2816}, seeded by the global stream index)
+    through the flow decoder (10 Euler steps x CFG 2, padded solves of --acoustic-batch streams of similar length) and the vocoder.
+    value = mel frames per second of the whole job; the roofline object is the DiT matrix work against the bf16 MFMA peak."""
+    from flowmirror_hydravox_amd import weights as W
+    from flowmirror_hydravox_amd.flow import HvxFlow
+    from flowmirror_hydravox_amd.hift import HvxHift
+    from flowmirror_hydravox_amd.dp import gather_waveforms
+    flow = HvxFlow(cfg.flow, W.make_flow_state(cfg.flow, seed=1987, init='normal02'), dtype=torch.bfloat16, max_t=2 * 2816 + 64)
+    hift = HvxHift(cfg.hift, W.make_hift_state(cfg.hift, seed=1988, init='normal02'))
+    n = args.streams
+    ids = [rank * n + i for i in range(n)]
+    lens = [int(torch.randint(352, 2817, (1,), generator=torch.Generator().manual_seed(9_000_011 + i))) for i in ids]
+    toks = [torch.randint(0, cfg.flow.vocab, (m,), generator=torch.Generator().manual_seed(i), dtype=torch.int32).cuda() for i, m in zip(ids, lens)]
+    embs = [torch.randn(cfg.flow.spk_embed_dim, generator=torch.Generator().manual_seed(i)).cuda() for i in ids]
+    order = sorted(range(n), key=lambda i: -lens[i])
+    groups = [order[i:i + max(1, args.acoustic_batch)] for i in range(0, n, max(1, args.acoustic_batch))]      # length buckets: neighbours in the sorted order
+
+    def run_all():
+        wavs = [None] * n
+        t_flow = t_hift = 0.0
+        for g in groups:
+            torch.cuda.synchronize()
+            t0 = time.time()
+            mels = flow.inference_batch([toks[i] for i in g], [embs[i] for i in g])
+            torch.cuda.synchronize()
+            t1 = time.time()
+            for i, m in zip(g, mels):
+                wavs[i] = hift.inference(speech_feat=m)[0][0]
+            torch.cuda.synchronize()
+            t_flow += t1 - t0
+            t_hift += time.time() - t1
+        return wavs, t_flow, t_hift
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        run_all()
+    barrier()
+    t0 = time.time()
+    t_flow = t_hift = 0.0
+    for _ in range(args.steps):
+        wavs, a, b = run_all()
+        got = gather_waveforms(wavs, ids, dst=0)
+        t_flow, t_hift = t_flow + a, t_hift + b
+    barrier()
+    elapsed = time.time() - t0
+    frames = float(sum(2 * m for m in lens)) * args.steps
+    dit_flops = sum(7.56e9 * 2 * m + 1.80e6 * (2 * m) ** 2 for m in lens) * args.steps
+    hift_flops = 672e6 * frames
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed, t_flow, t_hift], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, t_flow, t_hift = (float(v) for v in t)
+        t = torch.tensor([frames, dit_flops, hift_flops], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        frames, dit_flops, hift_flops = (float(v) for v in t)
+    if rank != 0:
+        return
+    ach = dit_flops / t_flow / 1e12 / world                     # per GPU, while the flow stage runs
+    print(json.dumps({
+        'metric': 'mel frames/sec, flow-matching (10 Euler steps x CFG 2) + HiFT vocoder only, pre-tokenised streams', 'value': round(frames / elapsed, 1),
+        'unit': 'mel-frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 2),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+        'config': {'workload': 'BASELINE configs[4] slice: %d speech-token streams per GPU and step, lengths U{352..2816} (mean %.0f), flow bf16 (DiT 22 x 1024) in padded '
+                               'solves of up to %d streams of neighbouring length, HiFT fp32 contract (decode convolutions as split-bf16 MFMA), seeded N(0,0.02) weights'
+                               % (n, sum(lens) / len(lens), args.acoustic_batch), 'streams_per_gpu': n, 'parallelism': 'stream-dp%d' % world},
+        'utterances_per_s': round(n * world * args.steps / elapsed, 2), 'audio_seconds_per_s': round(frames / 50.0 / elapsed, 1),
+        'stage_seconds_per_step': {'flow': round(t_flow / args.steps, 4), 'hift': round(t_hift / args.steps, 4)},
+        'roofline': {'kernel': 'DiT estimator (all bf16 GEMMs + attention of the flow stage)', 'bound': 'mfma', 'achieved': round(ach, 1), 'peak': MFMA_BF16_PEAK_TF,
+                     'unit': 'TFLOP/s', 'frac': round(ach / MFMA_BF16_PEAK_TF, 4), 'traffic': None,
+                     'algorithmic_flops': 'SURVEY.md §8(d): 7.56 GF*T + 1.80 MF*T^2 per stream of T frames, summed over the streams / wall time of the flow stage'},
+        'roofline_other': [{'kernel': 'HiFT vocoder', 'bound': 'mfma', 'achieved': round(hift_flops / t_hift / 1e12 / world, 1), 'peak': MFMA_F32_PEAK_TF, 'unit': 'TFLOP/s',
+                            'frac': round(hift_flops / t_hift / 1e12 / world / MFMA_F32_PEAK_TF, 4),
+                            'note': '672 MF of fp32 convolution per mel frame against the fp32 matrix peak; the decode convolutions run as 3 bf16 MFMAs per step (gemm_x3.hip), '
+                                    'so fractions above what fp32 MFMA could reach are possible'}]}))
+
+
 def main():
     args = parse()
     if args.serial:
@@ -209,17 +296,29 @@ def main():
     lib = _lib.load()
 
     cfg = tiny_config() if args.tiny else cv3_config()
+    if args.config == 'acoustic':
+        return run_acoustic(args, cfg, world, rank, lib)
+    if args.config == 'stress' and '--heads' not in sys.argv and '--batch' not in sys.argv:
+        args.heads, args.batch = 4, 32                        # BASELINE configs[2]: multi-head accept-rate stress (win_size 32, tau_r 0.2 are the defaults here)
+    zero_shot = args.config == 'zero_shot'
     chars, B, K = args.chars, args.batch, args.heads
     ratio = 5.5
     n_spk = int(chars * ratio)
-    max_ctx = 2 + chars + n_spk + K + 32
+    P_SPK, P_TXT = (75, 20) if zero_shot else (0, 0)           # configs[3]: 3 s prompt = 75 speech tokens / 150 mel frames, 20 prompt-text tokens
+
+    def make_utt(index):
+        if not zero_shot:
+            return synthetic_utterance(cfg, index, chars)
+        n_text = int(torch.randint(64, 513, (1,), generator=torch.Generator().manual_seed(7_000_003 + index)))
+        return synthetic_utterance(cfg, index, n_text, n_prompt_speech=P_SPK, n_prompt_text=P_TXT)
+    max_ctx = 2 + chars + P_TXT + P_SPK + n_spk + K + 32
     sampling = partial(ras_sampling, top_p=0.9, top_k=10, win_size=32, tau_r=0.2)
     t_build = time.time()
-    pipe = HvxPipeline(cfg, llm_dtype=torch.bfloat16, flow_dtype=torch.bfloat16, max_batch=B, max_ctx=max_ctx, max_t=2 * n_spk + 64,
+    pipe = HvxPipeline(cfg, llm_dtype=torch.bfloat16, flow_dtype=torch.bfloat16, max_batch=B, max_ctx=max_ctx, max_t=2 * (n_spk + P_SPK) + 64,
                        seed=1986, init='normal02', sampling=sampling, inference_head_num=K)
     pipe.acoustic_batch = max(1, args.acoustic_batch)
     t_build = time.time() - t_build
-    utts = [synthetic_utterance(cfg, rank * B + i, chars) for i in range(B)]
+    utts = [make_utt(rank * B + i) for i in range(B)]
     gids = [rank * B + i for i in range(B)]
 
     def barrier():
@@ -263,7 +362,7 @@ def main():
     else:
         # K steps of B utterances each = K * B utterances through the continuous-batching engine; finished waveforms are handed to rank 0
         # one step's worth (B utterances) at a time, inside the timed region
-        job = [synthetic_utterance(cfg, (k * world + rank) * B + i, chars) for k in range(args.steps) for i in range(B)]
+        job = [make_utt((k * world + rank) * B + i) for k in range(args.steps) for i in range(B)]
         ready, n_handed = [], 0
         for i, wav, toks in pipe.synthesize_continuous(job, lm_slots=args.lm_slots, max_token_text_ratio=ratio, min_token_text_ratio=ratio,
                                                        acoustic_batch=args.acoustic_batch, acoustic_min_batch=args.acoustic_min_batch):
@@ -313,7 +412,7 @@ def main():
     if rank != 0:
         return
     assert world > 1 or len(got) == B
-    in_flight = {'continuous': args.lm_slots + 1, 'chains': B * (max(args.lm_chains, args.acoustic_chains) + 1), 'serial': B}[args.mode]
+    in_flight = {'continuous': args.lm_slots + args.acoustic_batch, 'chains': B * (max(args.lm_chains, args.acoustic_chains) + 1), 'serial': B}[args.mode]
 
     # The dominant "kernel" is the decode step: one hipGraph replay of forward + sampler + advance (~160 launches of 5-9 us, which a
     # per-launch event bracket would distort), timed over the timed region itself by hipEvents around every block of 8 replays on
@@ -336,13 +435,15 @@ def main():
     grid_seqs = cont['llm'].get('mean_active_sequences', B) if cont is not None else B
     est = sorted(((p['est_total_ms'], n) for n, p in prof.items() if n not in ('llm_decode_gemm', 'llm_attention', 'ras_sampler')), reverse=True)
     line = {
-        'metric': 'speech-tokens/sec + RTF, HydraVox-CV3 head_num=%d, %d-char batch' % (K, chars),
+        'metric': 'speech-tokens/sec + RTF, HydraVox-CV3 head_num=%d, %s' % (K, '%d-char batch' % chars if not zero_shot else 'zero-shot mixed-length batch'),
         'value': round(tokens / elapsed, 2), 'unit': 'speech-tokens/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 2),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
         'config': {'workload': 'HydraVox-CV3%s inference_head_num=%d, batch=%dx%d-char utterances per GPU (%d text -> %d speech tokens -> %d mel frames '
                                'each), llm+flow bf16 / hift fp32, llm->flow->hift end to end, seeded N(0,0.02) weights'
                                % (' [TINY DIMS - NOT A BENCHMARK]' if args.tiny else '', K, B, chars, chars, n_spk, 2 * n_spk),
+                   'baseline_config': {'tts': 'configs[1]', 'stress': 'configs[2]', 'zero_shot': 'configs[3]: text lengths U{64..512} per utterance (the chars figure above is the maximum), '
+                                       'prompt = 75 speech tokens + 150 mel frames + 20 prompt-text tokens'}[args.config],
                    'global_batch': B * world, 'parallelism': 'utterance-dp%d' % world,
                    'schedule': {'continuous': 'continuous batching: one decode grid of %d slots, utterances of later steps join as earlier ones finish; '
                                               'flow + vocoder of finished utterances run beside it' % args.lm_slots,

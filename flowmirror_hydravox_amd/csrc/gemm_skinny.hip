@@ -36,6 +36,108 @@ __device__ __forceinline__ RowCtl load_rowctl(const SkinnyArgs& a, int row, int 
     return c;
 }
 
+// ---- epilogues of the decode GEMMs, shared by the skinny (M <= 32 per chunk) and the mid (33..128 rows) kernels ------------------------
+// acc: MT x NT accumulator tiles in the MFMA C layout, first row m0, first 16-column tile ntile0; HOIST: e_res / e_rc were fetched
+// before the weight stream (single-tile decode geometry), otherwise they are loaded here.
+template <class T, int MT, int NT, int EPI, bool HOIST>
+__device__ __forceinline__ void skinny_finish(const SkinnyArgs& a, f32x4 (&acc)[MT][NT], int m0, int ntile0, int z, int ks, int lane,
+                                              const float (&e_bias)[NT], const float (&e_res)[MT][NT][4], const RowCtl (&e_rc)[MT][4],
+                                              int q_which, int q_hh, int q_d, int q_f) {
+    const int fr = lane & 15, fg = lane >> 4;
+    // ---- epilogues ---------------------------------------------------------------------------------
+    if constexpr (EPI == SK_PARTIAL) {
+        float* part = a.part + (long long)z * a.part_zs + (long long)ks * a.M * a.N;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int col = (ntile0 + j) * 16 + fr;
+            if (col >= a.N) continue;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = m0 + i * 16 + fg * 4 + r;
+                    if (row < a.M) part[(long long)row * a.N + col] = acc[i][j][r];
+                }
+        }
+    } else if constexpr (EPI == SK_RESID) {
+        // residual stream update in place: x[row][col] += acc (+ bias).  split_k == 1, so every element has exactly one writer.
+        float* xo = reinterpret_cast<float*>(a.out) + (long long)z * a.out_zs;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int col = (ntile0 + j) * 16 + fr;
+            if (col >= a.N) continue;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = m0 + i * 16 + fg * 4 + r;
+                    if (row >= a.M) continue;
+                    float* px = xo + (long long)row * a.ldo + col;
+                    const float x0 = HOIST ? e_res[i][j][r] : *px;
+                    const float x1 = x0 + (acc[i][j][r] + e_bias[j]);
+                    *px = x1;
+                    if (a.out2) reinterpret_cast<T*>(a.out2)[(long long)z * a.out_zs + (long long)row * a.ldo2 + col] = from_f32<T>(x1);
+                }
+        }
+    } else if constexpr (EPI == SK_STORE) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int col = (ntile0 + j) * 16 + fr;
+            if (col >= (a.n_valid ? a.n_valid : a.N)) continue;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = m0 + i * 16 + fg * 4 + r;
+                    if (row >= a.M) continue;
+                    const float v = acc[i][j][r] + e_bias[j];
+                    const long long o = (long long)z * a.out_zs + (long long)row * a.ldo + col;
+                    if (a.out_f32) reinterpret_cast<float*>(a.out)[o] = v;
+                    else reinterpret_cast<T*>(a.out)[o] = from_f32<T>(v);
+                }
+        }
+    } else if constexpr (EPI == SK_SWIGLU) {
+        // tiles come in (gate, up) pairs: tile 2p holds gate columns 16p..16p+15, tile 2p+1 the matching up columns
+        static_assert(EPI != SK_SWIGLU || NT % 2 == 0, "SwiGLU needs tile pairs");
+#pragma unroll
+        for (int j = 0; j + 1 < NT; j += 2) {
+            const int col = ((ntile0 + j) >> 1) * 16 + fr;
+            if (col * 2 >= a.N) continue;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = m0 + i * 16 + fg * 4 + r;
+                    if (row >= a.M) continue;
+                    const float gte = acc[i][j][r], up = acc[i][j + 1][r];
+                    const float v = gte * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * gte)) * up;   // silu(gate) * up
+                    reinterpret_cast<T*>(a.out)[(long long)z * a.out_zs + (long long)row * a.ldo + col] = from_f32<T>(v);
+                }
+        }
+    } else {   // SK_QKV_ROPE
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + i * 16 + fg * 4 + r;
+                float x = acc[i][0][r] + e_bias[0];
+                const float partner = __shfl_xor(x, 8, 64);         // same row (same fg), the other half of the head
+                const RowCtl c = HOIST ? e_rc[i][r] : load_rowctl(a, row, q_f, q_which);
+                if (!c.ok) continue;
+                if (q_which < 2)                                    // rotate-half RoPE (HF Qwen2): d pairs with d +- 32
+                    x = (fr < 8) ? (x * c.cs - partner * c.sn) : (x * c.cs + partner * c.sn);
+                if (q_which == 0) {
+                    reinterpret_cast<T*>(a.qbuf)[((long long)row * a.q_heads + q_hh) * 64 + q_d] = from_f32<T>(x);
+                } else if (q_which == 1) {
+                    reinterpret_cast<T*>(a.kcache)[(((long long)c.slot * a.kv_heads + q_hh) * a.max_ctx + c.pos) * 64 + q_d] = from_f32<T>(x);
+                } else {
+                    reinterpret_cast<T*>(a.vTcache)[(((long long)c.slot * a.kv_heads + q_hh) * 64 + q_d) * a.max_ctx + c.pos] = from_f32<T>(x);
+                }
+            }
+        }
+    }
+}
+
 // ANORM == 1: A is the residual stream x (in the operand type: the producing epilogue keeps a T copy beside the fp32 stream) and the
 // GEMM computes RMSNorm(x) @ W^T without a norm kernel in front of it.  RMSNorm is a per-row scale:
 // norm(x)[k] = gain[k] * x[k] * rsqrt(mean(x^2) + eps).  The gain is folded into the weight columns when the checkpoint is packed
@@ -206,98 +308,210 @@ __global__ __launch_bounds__(64 * KW) void gemm_skinny_kernel(SkinnyArgs a) {
             }
     }
 
-    // ---- epilogues ---------------------------------------------------------------------------------
-    if constexpr (EPI == SK_PARTIAL) {
-        float* part = a.part + (long long)z * a.part_zs + (long long)ks * a.M * a.N;
+    skinny_finish<T, MT, NT, EPI, HOIST>(a, acc, m0, ntile0, z, ks, lane, e_bias, e_res, e_rc, q_which, q_hh, q_d, q_f);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Mid form: 33..128 rows — the decode grid of continuous batching (17..64 sequences x 2 heads).  The skinny kernel above serves such a
+// grid in 64-row chunks whose waves fetch their activation fragments straight from L2 (16 rows x 64 B per load instruction) and re-read the
+// weights per chunk: at 128 rows SwiGLU takes 24 us and down_proj 19 + 5 us for 3.8 GF and 30 MB of weights per layer.  Here a workgroup
+// of 4 waves owns ALL rows (8 row tiles) of 4 x NT column tiles: the activation K-tiles (128 rows x 64) go through LDS once per workgroup
+// (full 128-byte rows, double-buffered, padded against bank conflicts) and are shared by the four waves, each wave streams the
+// fragment-packed weights of its own NT tiles straight into registers one K-tile ahead, and every weight fragment feeds 8 MFMAs.  No
+// in-block K split, so no LDS reduction; split-K across workgroups (fp32 partials) remains for the long-K down projection.
+template <class T, int NT, int EPI, int ANORM>
+__global__ __launch_bounds__(256) void gemm_mid_kernel(SkinnyArgs a) {
+    typedef typename Vec8<T>::type V8;
+    constexpr int MT = 8, BK = 64, KS = BK / 32, ROWS = MT * 16;
+    constexpr int LDK = BK + (sizeof(T) == 2 ? 8 : 4);
+    __shared__ __attribute__((aligned(16))) T xs[2][ROWS * LDK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int z = blockIdx.z, ks = blockIdx.y;
+    const int ntile0 = (blockIdx.x * 4 + wave) * NT;
+    const int KT = a.K >> 5;                                   // 32-wide k-steps of the packed weights
+    const int nkt = a.K / BK;                                  // K-tiles
+    const int per = (nkt + a.split_k - 1) / a.split_k;
+    const int kc0 = ks * per, kc1 = min(nkt, kc0 + per);
+    const int nk = kc1 - kc0;
+
+    const T* __restrict__ W = reinterpret_cast<const T*>(a.W) + (long long)z * a.w_zs;
+    const T* wtile[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        int nt = ntile0 + j;
+        nt = (nt * 16 < a.N) ? nt : (a.N / 16 - 1);
+        wtile[j] = W + ((long long)nt * KT) * 512 + lane * 8;
+    }
+    // activation tile loader: thread t moves 4 x 8 elements: rows t/8 + 32 i, chunk t % 8
+    const T* __restrict__ Ab = reinterpret_cast<const T*>(a.A) + (long long)z * a.a_zs;
+    const int lrow = tid >> 3, lchunk = (tid & 7) * 8;
+    const T* arow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int r = lrow + 32 * i;
+        r = r < a.M ? r : a.M - 1;
+        arow[i] = Ab + (long long)r * a.lda + lchunk;
+    }
+    // Both operand streams run PF K-tiles ahead in registers (static ring, the loop is unrolled by PF): a workgroup is alone on its CU
+    // (14..76 workgroups per launch), so nothing else hides the ~2 us of an HBM round trip — with one tile of look-ahead every K-tile
+    // cost that round trip (28 us for the 14 K-tiles of the QKV projection).
+    constexpr int PF = 4;
+    V8 xr[PF][4], wr[PF][NT][KS];
+    auto load_x = [&](int kc, V8 (&dst)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dst[i] = load8(arow[i] + (long long)kc * BK);
+    };
+    auto stash_x = [&](int buf, const V8 (&src)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) store8(&xs[buf][(lrow + 32 * i) * LDK + lchunk], src[i]);
+    };
+    auto load_w = [&](int kc, V8 (&dst)[NT][KS]) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) dst[j][kk] = load8_nt(wtile[j] + (long long)(kc * KS + kk) * 512);
+    };
+
+    f32x4 acc[MT][NT];
+    float ssq[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        ssq[i] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+    }
+    // epilogue operands (bias, the residual rows this lane will update, per-row position / cache slot / rotary factors): requested before
+    // the operand streams so that their latency — 32 rows per lane, dependent loads for the QKV controls — hides under the K loop
+    float e_bias[NT];
+    float e_res[MT][NT][4];
+    RowCtl e_rc[MT][4];
+    int q_which = 0, q_hh = 0, q_d = 0, q_f = 0;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) e_bias[j] = 0.0f;
+    if constexpr (EPI == SK_QKV_ROPE) {
+        static_assert(EPI != SK_QKV_ROPE || NT == 1, "QKV epilogue works on single permuted tiles");
+        const int head = ntile0 >> 2, tq = ntile0 & 3;
+        q_which = head < a.q_heads ? 0 : (head < a.q_heads + a.kv_heads ? 1 : 2);
+        q_hh = q_which == 0 ? head : (q_which == 1 ? head - a.q_heads : head - a.q_heads - a.kv_heads);
+        q_d = (fr < 8) ? (8 * tq + fr) : (32 + 8 * tq + (fr - 8));
+        q_f = 8 * tq + (fr & 7);
+        if (ntile0 * 16 < a.N) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) e_rc[i][r] = load_rowctl(a, i * 16 + fg * 4 + r, q_f, q_which);
+        }
+    }
+    if constexpr (EPI == SK_RESID || EPI == SK_STORE || EPI == SK_QKV_ROPE) {
+        const float* bias = a.bias ? a.bias + (long long)z * a.bias_zs : nullptr;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int col = (ntile0 + j) * 16 + fr;
-            if (col >= a.N) continue;
+            e_bias[j] = (bias && col < a.N) ? bias[col] : 0.0f;
+        }
+    }
+    if constexpr (EPI == SK_RESID) {
+        const float* xo = reinterpret_cast<const float*>(a.out) + (long long)z * a.out_zs;
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int row = m0 + i * 16 + fg * 4 + r;
-                    if (row < a.M) part[(long long)row * a.N + col] = acc[i][j][r];
+                    const int row = i * 16 + fg * 4 + r, col = (ntile0 + j) * 16 + fr;
+                    e_res[i][j][r] = (row < a.M && col < a.N) ? xo[(long long)row * a.ldo + col] : 0.0f;
                 }
-        }
-    } else if constexpr (EPI == SK_RESID) {
-        // residual stream update in place: x[row][col] += acc (+ bias).  split_k == 1, so every element has exactly one writer.
-        float* xo = reinterpret_cast<float*>(a.out) + (long long)z * a.out_zs;
+    }
+    // Every load below is unconditional (tile indices are clamped to the last tile of the range instead): with a load under a runtime
+    // condition hipcc cannot count the outstanding requests and waits for ALL of them before each use — which put the HBM round trip
+    // back into every K-tile.  The surplus loads at the end of the range re-read a tile that is already in L2.
+    const int klast = kc1 - 1;
+    auto step = [&](int t, auto P, bool refill) __attribute__((always_inline)) {
+        constexpr int p = decltype(P)::value;
+        __syncthreads();                                       // tile t is visible; buffer (t + 1) & 1 is free
+        stash_x((t + 1) & 1, xr[(p + 1) % PF]);                // tile u travels in ring slot u % PF (past the end: a duplicate nobody reads)
+        if (refill) load_x(min(kc0 + t + 1 + PF, klast), xr[(p + 1) % PF]);
+        const T* xb = xs[t & 1];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int col = (ntile0 + j) * 16 + fr;
-            if (col >= a.N) continue;
+        for (int kk = 0; kk < KS; ++kk) {
+            V8 af[MT];
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
+            for (int i = 0; i < MT; ++i) af[i] = load8(&xb[(i * 16 + fr) * LDK + kk * 32 + fg * 8]);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = m0 + i * 16 + fg * 4 + r;
-                    if (row >= a.M) continue;
-                    float* px = xo + (long long)row * a.ldo + col;
-                    const float x0 = HOIST ? e_res[i][j][r] : *px;
-                    const float x1 = x0 + (acc[i][j][r] + e_bias[j]);
-                    *px = x1;
-                    if (a.out2) reinterpret_cast<T*>(a.out2)[(long long)z * a.out_zs + (long long)row * a.ldo2 + col] = from_f32<T>(x1);
+            for (int i = 0; i < MT; ++i) {
+                if constexpr (ANORM) {
+                    float x[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x[e] = to_f32(af[i][e]);
+                    ssq[i] += ((x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3])) + ((x[4] * x[4] + x[5] * x[5]) + (x[6] * x[6] + x[7] * x[7]));
                 }
+#pragma unroll
+                for (int j = 0; j < NT; ++j) mma32(acc[i][j], af[i], wr[p][j][kk]);
+            }
         }
-    } else if constexpr (EPI == SK_STORE) {
+        if (refill) load_w(min(kc0 + t + PF, klast), wr[p]);
+    };
+    if (nk > 0) {
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int col = (ntile0 + j) * 16 + fr;
-            if (col >= (a.n_valid ? a.n_valid : a.N)) continue;
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = m0 + i * 16 + fg * 4 + r;
-                    if (row >= a.M) continue;
-                    const float v = acc[i][j][r] + e_bias[j];
-                    const long long o = (long long)z * a.out_zs + (long long)row * a.ldo + col;
-                    if (a.out_f32) reinterpret_cast<float*>(a.out)[o] = v;
-                    else reinterpret_cast<T*>(a.out)[o] = from_f32<T>(v);
-                }
+        for (int p = 0; p < PF; ++p) {
+            load_w(min(kc0 + p, klast), wr[p]);
+            load_x(min(kc0 + p, klast), xr[p]);
         }
-    } else if constexpr (EPI == SK_SWIGLU) {
-        // tiles come in (gate, up) pairs: tile 2p holds gate columns 16p..16p+15, tile 2p+1 the matching up columns
-        static_assert(EPI != SK_SWIGLU || NT % 2 == 0, "SwiGLU needs tile pairs");
-#pragma unroll
-        for (int j = 0; j + 1 < NT; j += 2) {
-            const int col = ((ntile0 + j) >> 1) * 16 + fr;
-            if (col * 2 >= a.N) continue;
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = m0 + i * 16 + fg * 4 + r;
-                    if (row >= a.M) continue;
-                    const float gte = acc[i][j][r], up = acc[i][j + 1][r];
-                    const float v = (gte / (1.0f + expf(-gte))) * up;
-                    reinterpret_cast<T*>(a.out)[(long long)z * a.out_zs + (long long)row * a.ldo + col] = from_f32<T>(v);
-                }
+        stash_x(0, xr[0]);
+        load_x(min(kc0 + PF, klast), xr[0]);
+        const int nfull = nk / PF * PF;
+        for (int t0 = 0; t0 < nfull; t0 += PF) {
+            step(t0 + 0, std::integral_constant<int, 0>{}, true);
+            step(t0 + 1, std::integral_constant<int, 1>{}, true);
+            step(t0 + 2, std::integral_constant<int, 2>{}, true);
+            step(t0 + 3, std::integral_constant<int, 3>{}, true);
         }
-    } else {   // SK_QKV_ROPE
+        static_assert(PF == 4, "the step sequence is written out for a ring of 4");
+        const int rem = nk - nfull;                            // the last 0..3 tiles are already in the ring
+        if (rem > 0) step(nfull + 0, std::integral_constant<int, 0>{}, false);
+        if (rem > 1) step(nfull + 1, std::integral_constant<int, 1>{}, false);
+        if (rem > 2) step(nfull + 2, std::integral_constant<int, 2>{}, false);
+    }
+    if (ntile0 * 16 >= a.N) return;                            // (a wave past the last column tile only helped with the staging)
+    if constexpr (ANORM) {
+        // every wave has seen the whole K of its rows: lane (fr, fg) holds a quarter of row 16 i + fr's sum of squares
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
+            float v = ssq[i];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = m0 + i * 16 + fg * 4 + r;
-                float x = acc[i][0][r] + e_bias[0];
-                const float partner = __shfl_xor(x, 8, 64);         // same row (same fg), the other half of the head
-                const RowCtl c = HOIST ? e_rc[i][r] : load_rowctl(a, row, q_f, q_which);
-                if (!c.ok) continue;
-                if (q_which < 2)                                    // rotate-half RoPE (HF Qwen2): d pairs with d +- 32
-                    x = (fr < 8) ? (x * c.cs - partner * c.sn) : (x * c.cs + partner * c.sn);
-                if (q_which == 0) {
-                    reinterpret_cast<T*>(a.qbuf)[((long long)row * a.q_heads + q_hh) * 64 + q_d] = from_f32<T>(x);
-                } else if (q_which == 1) {
-                    reinterpret_cast<T*>(a.kcache)[(((long long)c.slot * a.kv_heads + q_hh) * a.max_ctx + c.pos) * 64 + q_d] = from_f32<T>(x);
-                } else {
-                    reinterpret_cast<T*>(a.vTcache)[(((long long)c.slot * a.kv_heads + q_hh) * 64 + q_d) * a.max_ctx + c.pos] = from_f32<T>(x);
-                }
+                const float inv = rsqrtf(__shfl(v, fg * 4 + r, 64) / (float)a.K + a.norm_eps);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j][r] *= inv;
             }
         }
     }
+    skinny_finish<T, MT, NT, EPI, true>(a, acc, 0, ntile0, z, ks, lane, e_bias, e_res, e_rc, q_which, q_hh, q_d, q_f);
+}
+
+template <class T, int NT, int EPI, int ANORM>
+static int launch_mid_one(const SkinnyArgs& a, hipStream_t s) {
+    const int ntiles = a.N / 16;
+    dim3 grid((ntiles + 4 * NT - 1) / (4 * NT), a.split_k, a.nz);
+    const double bytes = (double)a.nz * ((double)a.N * a.K * sizeof(T) + (double)a.M * a.K * sizeof(T) +
+                                         (double)a.M * a.N * (EPI == SK_PARTIAL ? 4.0 * a.split_k : (double)sizeof(T)));
+    const int slot = prof_begin(PK_SKINNY, bytes, s);
+    hipLaunchKernelGGL((gemm_mid_kernel<T, NT, EPI, ANORM>), grid, dim3(256), 0, s, a);
+    prof_end(slot, s);
+    return hipGetLastError() == hipSuccess ? 0 : (set_error("mid gemm launch failed"), -1);
+}
+
+// 33..128 rows of one matrix (nz == 1), K a multiple of 64.  Measured at 128 rows (64 sequences x 2 heads, tools/bench_decode.py, us per
+// launch, mid form vs the 64-row-chunk skinny form): split-K partials of down_proj 11.2 vs 18.6; QKV + RoPE 22 vs 15, SwiGLU 32-36 vs 24,
+// o_proj 15 vs 9.8 (4-column form) — with one workgroup per CU and 14..76 workgroups per launch the short-K GEMMs are bound by their
+// per-K-tile barrier / LDS round trip and by the 32-rows-per-lane epilogues, not by the operand streams.  Only the long-K partial form
+// is dispatched here; the other epilogues stay on the skinny kernel.
+template <class T>
+static int launch_mid(const SkinnyArgs& a, hipStream_t s) {
+    return launch_mid_one<T, 1, SK_PARTIAL, 0>(a, s);
 }
 
 template <class T, int MT, int NT, int EPI, int KW = 4, int ANORM = 0, int U_ = 0>
@@ -451,6 +665,7 @@ static int launch_t(const SkinnyArgs& a, hipStream_t s) {
     // rows per launch chunk: one A fragment set per 16 rows; larger M is covered by blockIdx.z chunks
     if (a.M <= 16) return launch_mt<T, 1>(a, s);
     if (a.M <= 32) return launch_mt<T, 2>(a, s);
+    if (a.M <= 128 && a.nz == 1 && (a.K & 63) == 0 && a.epi == SK_PARTIAL && a.split_k > 1) return launch_mid<T>(a, s);
     return launch_mt<T, 4>(a, s);
 }
 

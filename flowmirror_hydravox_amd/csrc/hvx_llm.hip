@@ -194,6 +194,7 @@ static int resid_wide(hvx_llm* h, SkinnyArgs g, const void* w_frag, void* xcopy,
     int split = (512 + groups - 1) / groups;
     const int kt = g.K / 32;
     if (split > kt / 8) split = kt / 8;
+    if (g.M <= 128 && (g.K & 63) == 0 && g.K / 64 / 12 > 1) split = g.K / 64 / 12;       // mid form (gemm_mid_kernel): a workgroup per 64 columns, ~12 K-tiles of 64 each
     if (split > MAX_SPLIT) split = MAX_SPLIT;
     g.W = w_frag; g.w_narrow = 0;
     if (split <= 1) return launch_skinny(g, s);                      // SK_RESID, one writer per element

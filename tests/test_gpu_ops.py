@@ -312,7 +312,8 @@ def test_attention_causal_and_splits(T, n_splits, chunk):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize('M,N,K,split', [(16, 896, 896, 1), (16, 896, 4864, 8), (3, 304, 128, 2), (40, 6768, 896, 1), (130, 128, 256, 4)])
+@pytest.mark.parametrize('M,N,K,split', [(16, 896, 896, 1), (16, 896, 4864, 8), (3, 304, 128, 2), (40, 6768, 896, 1), (130, 128, 256, 4),
+                                         (128, 896, 4864, 6), (100, 1152, 896, 1), (64, 896, 896, 1), (33, 304, 128, 2)])
 def test_skinny_gemm(dtype, M, N, K, split):
     _lib, ops, packing = _mods()
     x = _rand(M, K, seed=50).to(dtype)
