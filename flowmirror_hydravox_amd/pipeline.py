@@ -244,6 +244,7 @@ class HvxPipeline:
             self._bg_streams = [self._bg_stream]
             self._bg_pools = []
         flow, hift, stream = self._acoustic_chain(0)
+        torch.cuda.synchronize(self.device)               # (everything the handles were built from is complete before other streams use it)
         q = queue.Queue()
         lm_info = {}
         maxr = max_token_text_ratio if isinstance(max_token_text_ratio, (list, tuple)) else [max_token_text_ratio] * len(utts)
@@ -333,6 +334,9 @@ class HvxPipeline:
         self._lm_pools = pools
         for k in range(lm_chains):
             self._lm_chain(k)                             # build the handles on this thread, before the clock of the first job
+        # the handles' tables and workspaces were produced by torch ops on THIS thread's stream; the worker threads use them on other
+        # streams: without this barrier a worker can read a noise / rotary table that is still being written (seen as a rare wrong waveform)
+        torch.cuda.synchronize(self.device)
         window = deque()
         for idx, utts in enumerate(batches):
             k = idx % lm_chains
