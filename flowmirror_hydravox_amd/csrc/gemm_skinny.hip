@@ -508,7 +508,9 @@ static int launch_mid_one(const SkinnyArgs& a, hipStream_t s) {
 // launch, mid form vs the 64-row-chunk skinny form): split-K partials of down_proj 11.2 vs 18.6; QKV + RoPE 22 vs 15, SwiGLU 32-36 vs 24,
 // o_proj 15 vs 9.8 (4-column form) — with one workgroup per CU and 14..76 workgroups per launch the short-K GEMMs are bound by their
 // per-K-tile barrier / LDS round trip and by the 32-rows-per-lane epilogues, not by the operand streams.  Only the long-K partial form
-// is dispatched here; the other epilogues stay on the skinny kernel.
+// is dispatched here; the other epilogues stay on the skinny kernel.  (Also measured: the skinny kernel itself with all 128 rows per
+// workgroup, MT = 8: SwiGLU 33 us with one (gate, up) pair per workgroup, 22 us with two; QKV 26 us — the finishing wave's epilogue over
+// 32 rows per lane and the longer dependent chains cost more than the halved weight re-reads save.)
 template <class T>
 static int launch_mid(const SkinnyArgs& a, hipStream_t s) {
     return launch_mid_one<T, 1, SK_PARTIAL, 0>(a, s);
