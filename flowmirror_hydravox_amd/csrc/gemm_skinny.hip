@@ -207,7 +207,8 @@ __global__ __launch_bounds__(64 * KW) void gemm_skinny_kernel(SkinnyArgs a) {
         q_d = (fr < 8) ? (8 * t + fr) : (32 + 8 * t + (fr - 8));
         q_f = 8 * t + (fr & 7);                             // rotary frequency index (d mod 32)
     }
-    if (wave == 0) {
+    constexpr bool SPREAD = (MT == KW) && MT > 1;     // every wave finishes one of the MT row tiles (see the reduction below)
+    if (wave == 0 || SPREAD) {
         if constexpr (EPI == SK_RESID || EPI == SK_STORE || EPI == SK_QKV_ROPE) {
             const float* bias = a.bias ? a.bias + (long long)z * a.bias_zs : nullptr;
 #pragma unroll
@@ -268,9 +269,49 @@ __global__ __launch_bounds__(64 * KW) void gemm_skinny_kernel(SkinnyArgs a) {
     }
 
     // in-block reduction in fixed wave order (deterministic): waves 1.. park their tiles (and row sums of squares) in LDS,
-    // wave 0 adds them and finishes
-    __shared__ f32x4 red[KW > 1 ? KW - 1 : 1][MT][NT][64];
+    // wave 0 adds them and finishes.  SPREAD (as many row tiles as waves: 64-row chunks of a wide decode grid): every wave parks its
+    // partials and wave w adds — in the same fixed order 0, 1, .. — and finishes row tile w, so the epilogue (16 elements per lane of
+    // scattered loads / stores, the RoPE controls) runs on all waves at once instead of on wave 0 for all 64 rows.
+    __shared__ f32x4 red[SPREAD ? KW : (KW > 1 ? KW - 1 : 1)][MT][NT][64];
     __shared__ float s_ss[ANORM ? KW : 1][MT * 16];
+    if constexpr (SPREAD) {
+        if constexpr (ANORM) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                float v = ssq[i];
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                if (fg == 0) s_ss[wave][i * 16 + fr] = v;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) red[wave][i][j][lane] = acc[i][j];
+        __syncthreads();
+        f32x4 fin[1][NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            fin[0][j] = red[0][wave][j][lane];
+#pragma unroll
+            for (int w = 1; w < KW; ++w) fin[0][j] += red[w][wave][j][lane];
+        }
+        if constexpr (ANORM) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float ss = 0.0f;
+#pragma unroll
+                for (int w = 0; w < KW; ++w) ss += s_ss[w][wave * 16 + fg * 4 + r];
+                const float inv = rsqrtf(ss / (float)a.K + a.norm_eps);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) fin[0][j][r] *= inv;
+            }
+        }
+        float d_res[1][NT][4];
+        RowCtl d_rc[1][4];
+        skinny_finish<T, 1, NT, EPI, false>(a, fin, m0 + wave * 16, ntile0, z, ks, lane, e_bias, d_res, d_rc, q_which, q_hh, q_d, q_f);
+        return;
+    }
     if constexpr (ANORM) {
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
