@@ -695,6 +695,7 @@ static int launch_mt(const SkinnyArgs& a, hipStream_t s) {
             // (decode step at 128 rows 2.08 -> 1.97 ms; four pairs: 2.01 ms; k-steps in flight 1, 2, 4: 1.96 / 1.97 / 2.03 ms)
             if constexpr (MT == 4 && sizeof(T) == 2) {
                 if (a.a_norm && (a.N & 63) == 0) return launch_one<T, 4, 4, SK_SWIGLU, 4, 1, 2>(a, s);
+                if (!a.a_norm && (a.N & 63) == 0) return launch_one<T, 4, 4, SK_SWIGLU, 4, 0, 2>(a, s);      // (the MTP heads of a wide grid)
             }
             return a.a_norm ? launch_one<T, MT, 2, SK_SWIGLU, 4, 1>(a, s) : launch_one<T, MT, 2, SK_SWIGLU>(a, s);
         case SK_QKV_ROPE: return a.a_norm ? launch_one<T, MT, 1, SK_QKV_ROPE, 4, 1>(a, s) : launch_one<T, MT, 1, SK_QKV_ROPE>(a, s);
@@ -715,7 +716,7 @@ static int launch_t(const SkinnyArgs& a, hipStream_t s) {
     // rows per launch chunk: one A fragment set per 16 rows; larger M is covered by blockIdx.z chunks
     if (a.M <= 16) return launch_mt<T, 1>(a, s);
     if (a.M <= 32) return launch_mt<T, 2>(a, s);
-    if (a.M <= 128 && a.nz == 1 && (a.K & 63) == 0 && a.epi == SK_PARTIAL && a.split_k > 1) return launch_mid<T>(a, s);
+    if (a.M <= 128 && (a.K & 63) == 0 && a.epi == SK_PARTIAL && a.split_k > 1) return launch_mid<T>(a, s);      // (backbone down_proj and the stacked MTP heads)
     return launch_mt<T, 4>(a, s);
 }
 
