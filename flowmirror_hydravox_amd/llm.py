@@ -269,7 +269,7 @@ class HvxLLM:
             pt, ps = d.get('prompt_text'), d.get('prompt_speech_token')
             n_text = int(text.numel())
             r = _Request(self._encode_prefix(text, None if pt is None else torch.as_tensor(pt), None if ps is None else torch.as_tensor(ps)), n_text,
-                         int(n_text * d.get('min_token_text_ratio', 2)), int(n_text * d.get('max_token_text_ratio', 20)), NoiseStream(seed=d.get('seed')))
+                         int(n_text * d.get('min_token_text_ratio', 2)), int(n_text * d.get('max_token_text_ratio', 20)), NoiseStream(seed=d.get('seed'), chunk=8192))
             r.tag = d.get('tag')
             return r
         it = (to_req(d) for d in requests)
@@ -367,13 +367,17 @@ class _DecodeEngine:
             # cursor while the steps run; a sequence that outruns its ring stalls on the device (its steps are void) until the refill
             self.ncap = llm.noise_cap
             self.noise_dev = torch.empty(S, self.ncap, dtype=torch.float32, device=dev)
+            # pinned mirror of the ring (same indexing): the staging area of every refill.  A region is rewritten only after the device
+            # has consumed it, i.e. long after the copy that carried its previous contents — no per-refill pin_memory() (0.7 ms each)
+            self.noise_pin = torch.empty(S, self.ncap, dtype=torch.float32).pin_memory()
             self.head = [0] * S                  # absolute position up to which slot i's ring is filled
             self.limit_dev = torch.zeros(S, dtype=torch.int64, device=dev)
             self.cur_dev = torch.zeros(S, dtype=torch.int64, device=dev)
         self.slot_req = [None] * S
         self.join_block = [0] * S                # blocks launched when the slot's request joined: older snapshots describe its predecessor
         self.last_fill = [0] * S
-        self._keep = []                          # pinned staging tensors of asynchronous copies still in flight
+        self._keep = []                          # pinned arena chunks of the small asynchronous copies (see _h2d)
+        self._arena_off = 0
         self.args = self._decode_args()
 
     def _decode_args(self):
@@ -390,22 +394,31 @@ class _DecodeEngine:
         return a
 
     def _h2d(self, values, dtype):
-        t = torch.tensor(values, dtype=dtype).pin_memory()
-        self._keep.append(t)
-        return t.to(self.llm.device, non_blocking=True)
+        """small host list -> device tensor through a pinned arena (bump-allocated 256 KiB chunks, kept until the engine is dropped:
+        a pin_memory() per call costs ~0.7 ms of host time, and a join makes three such copies)"""
+        src = torch.tensor(values, dtype=dtype)
+        nbytes = (src.numel() * src.element_size() + 15) // 16 * 16
+        if not self._keep or self._arena_off + nbytes > self._keep[-1].numel():
+            self._keep.append(torch.empty(max(1 << 18, nbytes), dtype=torch.uint8).pin_memory())
+            self._arena_off = 0
+        dst = self._keep[-1][self._arena_off:self._arena_off + src.numel() * src.element_size()].view(dtype)
+        self._arena_off += nbytes
+        dst.copy_(src)
+        return dst.to(self.llm.device, non_blocking=True)
 
     def _fill_ring(self, i, target):
         """ring of slot i up to absolute position `target` (the slots overwritten hold positions below a cursor the device has reported)"""
         n = target - self.head[i]
         if n <= 0:
             return False
-        vals = torch.from_numpy(self.slot_req[i].noise.window(self.head[i], n).copy()).pin_memory()
-        self._keep.append(vals)
+        vals = torch.from_numpy(self.slot_req[i].noise.window(self.head[i], n))
         p0 = self.head[i] % self.ncap
         first = min(n, self.ncap - p0)
-        self.noise_dev[i, p0:p0 + first].copy_(vals[:first], non_blocking=True)
+        self.noise_pin[i, p0:p0 + first].copy_(vals[:first])
+        self.noise_dev[i, p0:p0 + first].copy_(self.noise_pin[i, p0:p0 + first], non_blocking=True)
         if n > first:
-            self.noise_dev[i, :n - first].copy_(vals[first:], non_blocking=True)
+            self.noise_pin[i, :n - first].copy_(vals[first:])
+            self.noise_dev[i, :n - first].copy_(self.noise_pin[i, :n - first], non_blocking=True)
         self.head[i] = target
         return True
 
@@ -430,7 +443,9 @@ class _DecodeEngine:
         self.slot_req[i] = r
         self.join_block[i] = launched
         self.head[i] = 0
-        self._fill_ring(i, self.ncap)
+        # a first slice only: the rest of the ring is topped up by the polling loop while the first blocks run (generating a full ring of
+        # Exp(1) values costs ~2.4 ms of host time per request, which used to sit in front of the first launch for every slot)
+        self._fill_ring(i, min(self.ncap, 8192))
         self.last_fill[i] = launched
         r.state = [n, 0, 0, r.min_len, r.max_len, 0, 0, 0]
         r.cursor = 0
@@ -492,6 +507,7 @@ class _DecodeEngine:
             old, cap0 = self.noise_dev, self.ncap
             self.ncap *= 4
             self.noise_dev = torch.empty(S, self.ncap, dtype=torch.float32, device=dev)
+            self.noise_pin = torch.empty(S, self.ncap, dtype=torch.float32).pin_memory()
             for i, r in enumerate(self.slot_req):
                 if r is None or r.done:
                     continue
