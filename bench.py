@@ -462,6 +462,9 @@ def main():
         'audio_seconds_per_step': round(audio / args.steps, 2),
         'setup_seconds': round(t_build, 1),
     }
+    if cont is not None:
+        line['llm_engine'] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in cont['llm'].items()
+                              if k in ('steps', 'requests', 'prefill_and_setup_seconds', 'device_idle_ms_between_blocks', 'mean_active_sequences', 'mean_ctx', 'seconds')}
     if rl_timed:
         line['roofline'] = dict(kernel='llm_decode_step (hipGraph: %d-layer backbone + %d MTP heads + sampler + advance, one launch = one step of a grid of %.1f live sequences x %d heads)'
                                        % (cfg.llm.layers, K, grid_seqs, K), bound='hbm', achieved=rl_timed['achieved'], peak=HBM_PEAK_GBS, unit='GB/s',
