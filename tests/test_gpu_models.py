@@ -743,3 +743,41 @@ def test_flow_mixed_length_batch_vs_per_utterance_oracle(tiny_cfg, flow_setup):
         assert torch.equal(mels[i], got[i]), i
     ref = flow_ref.flow_inference(toks[3][None], embs[3][None], sd, c)
     assert _rel(mels[3].cpu().numpy(), ref.numpy()) < 1e-3
+
+
+def test_zero_shot_mixed_length_batch_vs_oracle(tiny_cfg):
+    """BASELINE configs[3] in miniature: zero-shot utterances of mixed text length, each with a prompt (prompt text + prompt speech tokens +
+    prompt mel), through continuous batching with padded acoustic batches.  Ids == the CPU oracle's for every utterance; every waveform ==
+    the one-by-one path's; one waveform is also held against the oracle's flow + vocoder."""
+    from flowmirror_hydravox_amd import weights as W
+    from flowmirror_hydravox_amd.pipeline import HvxPipeline, synthetic_utterance
+    from flowmirror_hydravox_amd.sampling import ras_sampling
+    from functools import partial
+    from oracle import flow_ref, hift_ref, llm_ref, sampler_ref
+    cfg = tiny_cfg
+    llm_sd = W.make_llm_state(cfg.llm, seed=7, init='fan_in')
+    flow_sd = W.make_flow_state(cfg.flow, seed=11, init='fan_in')
+    hift_sd = W.make_hift_state(cfg.hift, seed=3, init='fan_in')
+    tables = hift_ref.make_tables(cfg.hift, seed=9)
+    sampling = dict(top_p=0.9, top_k=10, win_size=24, tau_r=0.2)
+    pipe = HvxPipeline(cfg, llm_sd, flow_sd, hift_sd, llm_dtype=torch.float32, flow_dtype=torch.float32, max_batch=4, max_ctx=512, max_t=1024,
+                       hift_tables=tables, sampling=partial(ras_sampling, **sampling), inference_head_num=2)
+    lens = [4, 9, 13, 7, 13, 12]
+    utts = [synthetic_utterance(cfg, 300 + i, n, n_prompt_speech=6 + i % 3, n_prompt_text=3) for i, n in enumerate(lens)]
+    got = {}
+    for i, wav, toks in pipe.synthesize_continuous(utts, lm_slots=4, max_token_text_ratio=4, min_token_text_ratio=3, acoustic_batch=4, acoustic_min_batch=2):
+        got[i] = (wav, toks)
+    assert sorted(got) == list(range(len(utts)))
+    for i, u in enumerate(utts):
+        ora = list(llm_ref.llm_inference(llm_sd, cfg.llm, u.text, sampler_ref.NoiseStream(seed=u.seed), prompt_text=u.prompt_text,
+                                         prompt_speech_token=u.prompt_speech_token, inference_head_num=2, sampling=sampling,
+                                         max_token_text_ratio=4, min_token_text_ratio=3, use_kv_cache=True))
+        assert ora == got[i][1], i
+        one = pipe.synthesize([u], max_token_text_ratio=4, min_token_text_ratio=3)[0][0]
+        assert one.shape == got[i][0].shape and (one - got[i][0]).abs().max().item() < 1e-4, i       # padded batch vs alone (fp32)
+    u, (wav, toks) = utts[2], got[2]
+    mel = flow_ref.flow_inference(torch.tensor(toks)[None], u.embedding[None], flow_sd, cfg.flow, prompt_token=u.prompt_speech_token[None],
+                                  prompt_feat=u.prompt_feat[None])
+    ref_wav, _ = hift_ref.hift_inference(mel, hift_sd, cfg.hift, tables)
+    assert wav.numel() == ref_wav.numel() == 960 * len(toks)
+    assert (wav.cpu() - ref_wav[0]).abs().max().item() < 5e-2
