@@ -23,6 +23,11 @@ __device__ __forceinline__ void wave_lds_order() {
 
 // acc: the wave's MT x NT accumulator tiles whose first row / column are mw0 / nw0; scr: this wave's private fp32 LDS staging tile of
 // ((64 / WN) * 16) rows x (WN + 4) floats (the caller has passed the barrier that frees it).
+template <bool RT, int ACT, int RES, int OF32, int O2> struct LeanMode {
+    static constexpr bool rt = RT;
+    static constexpr int act = ACT, res = RES, of32 = OF32, o2 = O2;
+};
+
 // LEAN: compile the streamlined pass for whole, aligned column tiles (costs ~50 VGPRs: only the one-workgroup-per-CU 256-tile form takes it)
 template <class T, int MT, int NT, int WN, int EPI, bool LEAN = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT][NT], float* scr, int lane, int mw0, int nw0, int bz, int g) {
@@ -84,10 +89,20 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT]
             };
             f32x4 rs[4];
             if (resb) res_load(mw0 + prow, rs);
-            auto lean_pass = [&](auto IP) __attribute__((always_inline)) {
+            // MODE: compile-time copies of the launch's epilogue switches (activation, residual, output types) for the combinations the DiT
+            // uses, so that a pass is ONE basic block.  With the switches tested at run time inside the pass every arm starts with a
+            // conservative s_waitcnt vmcnt(0) — i.e. each 16-row pass waited for the previous pass's stores to be acknowledged (FF1: +20 us
+            // per 256 x 256 tile).  MODE::rt keeps the run-time form for everything else.
+            auto lean_pass = [&](auto IP, auto MODE) __attribute__((always_inline)) {
                 constexpr int ip = decltype(IP)::value;
+                typedef decltype(MODE) MD;
+                const int act = MD::rt ? a.act : MD::act;
+                const bool has_res = MD::rt ? (resb != nullptr) : (bool)MD::res;
+                const bool out_f32 = MD::rt ? (a.out_f32 != 0) : (bool)MD::of32;
+                const bool has_out = MD::rt ? (a.out != nullptr) : true;
+                const bool has_out2 = MD::rt ? (a.out2 != nullptr) : (bool)MD::o2;
                 f32x4 rn[4];
-                if (resb && ip + MT_PASS < MT) res_load(mw0 + (ip + MT_PASS) * 16 + prow, rn);
+                if (has_res && ip + MT_PASS < MT) res_load(mw0 + (ip + MT_PASS) * 16 + prow, rn);
                 stage(IP);
                 f32x4 v[4];
 #pragma unroll
@@ -97,17 +112,22 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT]
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     v[q] += bi[q];
-                    if (a.act != ACT_NONE) {
-                        v[q] = act_apply4(a.act, v[q], a.act_param, f32x4{1, 1, 1, 1}, f32x4{1, 1, 1, 1});
+                    if (act != ACT_NONE) {
+                        if constexpr (!MD::rt && MD::act == ACT_GELU_TANH) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[q][e] = act_apply(ACT_GELU_TANH, v[q][e], 0.0f, 1.0f, 1.0f);
+                        } else {
+                            v[q] = act_apply4(act, v[q], a.act_param, f32x4{1, 1, 1, 1}, f32x4{1, 1, 1, 1});
+                        }
                     }
                     v[q] *= gt[q];
-                    if (resb) v[q] += rs[q];
+                    if (has_res) v[q] += rs[q];
                     v[q] *= a.scale;
                 }
                 if (row < a.M) {
-                    if (a.out) {
+                    if (has_out) {
                         const long long o1 = ob + (long long)(row + a.out_row_off) * a.ldo + gc0;
-                        if (a.out_f32) {
+                        if (out_f32) {
                             float* op = reinterpret_cast<float*>(a.out) + o1;
 #pragma unroll
                             for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(op + q * 4) = v[q];
@@ -126,7 +146,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT]
                             for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(op + q * 4) = v[q];
                         }
                     }
-                    if (a.out2) {
+                    if (has_out2) {
                         T* op = reinterpret_cast<T*>(a.out2) + (long long)bz * a.out2_bs + (long long)(row + a.out2_row_off) * a.ldo2 + gc0;
                         if (a.act2 != ACT_NONE) {
 #pragma unroll
@@ -147,19 +167,26 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT]
                         }
                     }
                 }
-                if (resb && ip + MT_PASS < MT) {
+                if (has_res && ip + MT_PASS < MT) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) rs[q] = rn[q];
                 }
             };
-            lean_pass(std::integral_constant<int, 0>{});
-            if constexpr (MT > 1 * MT_PASS) lean_pass(std::integral_constant<int, 1 * MT_PASS>{});
-            if constexpr (MT > 2 * MT_PASS) lean_pass(std::integral_constant<int, 2 * MT_PASS>{});
-            if constexpr (MT > 3 * MT_PASS) lean_pass(std::integral_constant<int, 3 * MT_PASS>{});
-            if constexpr (MT > 4 * MT_PASS) lean_pass(std::integral_constant<int, 4 * MT_PASS>{});
-            if constexpr (MT > 5 * MT_PASS) lean_pass(std::integral_constant<int, 5 * MT_PASS>{});
-            if constexpr (MT > 6 * MT_PASS) lean_pass(std::integral_constant<int, 6 * MT_PASS>{});
-            if constexpr (MT > 7 * MT_PASS) lean_pass(std::integral_constant<int, 7 * MT_PASS>{});
+            auto lean_all = [&](auto MODE) __attribute__((always_inline)) {
+                lean_pass(std::integral_constant<int, 0>{}, MODE);
+                if constexpr (MT > 1 * MT_PASS) lean_pass(std::integral_constant<int, 1 * MT_PASS>{}, MODE);
+                if constexpr (MT > 2 * MT_PASS) lean_pass(std::integral_constant<int, 2 * MT_PASS>{}, MODE);
+                if constexpr (MT > 3 * MT_PASS) lean_pass(std::integral_constant<int, 3 * MT_PASS>{}, MODE);
+                if constexpr (MT > 4 * MT_PASS) lean_pass(std::integral_constant<int, 4 * MT_PASS>{}, MODE);
+                if constexpr (MT > 5 * MT_PASS) lean_pass(std::integral_constant<int, 5 * MT_PASS>{}, MODE);
+                if constexpr (MT > 6 * MT_PASS) lean_pass(std::integral_constant<int, 6 * MT_PASS>{}, MODE);
+                if constexpr (MT > 7 * MT_PASS) lean_pass(std::integral_constant<int, 7 * MT_PASS>{}, MODE);
+            };
+            const bool simple = a.out && !a.out2 && a.scale == 1.0f;
+            if (simple && a.act == ACT_NONE && resb && a.out_f32) lean_all(LeanMode<false, ACT_NONE, 1, 1, 0>{});              // out_proj, FF2: x += gate * (.)
+            else if (simple && a.act == ACT_GELU_TANH && !resb && !a.out_f32) lean_all(LeanMode<false, ACT_GELU_TANH, 0, 0, 0>{});   // FF1
+            else if (simple && a.act == ACT_NONE && !resb && !a.out_f32) lean_all(LeanMode<false, ACT_NONE, 0, 0, 0>{});           // plain store
+            else lean_all(LeanMode<true, 0, 0, 0, 0>{});
             return;
         }
         auto do_pass = [&](auto IP) __attribute__((always_inline)) {
