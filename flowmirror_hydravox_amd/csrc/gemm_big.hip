@@ -112,7 +112,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmArgs a, int tiles_
     __syncthreads();                                     // the epilogue reuses the tile memory as staging
 
     constexpr int SCR_FLOATS = 32 * (WN + 4);            // 32 staging rows per wave (the lean V^T epilogue transposes two row tiles at a time)
-    gemm_epilogue<T, MT, NT, WN, EPI, true>(a, acc, reinterpret_cast<float*>(smem) + wave * SCR_FLOATS, lane, m0 + wm0, n0 + wn0, bz, 0);
+    gemm_epilogue<T, MT, NT, WN, EPI, 1>(a, acc, reinterpret_cast<float*>(smem) + wave * SCR_FLOATS, lane, m0 + wm0, n0 + wn0, bz, 0);
 }
 
 }  // namespace

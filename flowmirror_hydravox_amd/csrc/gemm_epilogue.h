@@ -23,13 +23,13 @@ __device__ __forceinline__ void wave_lds_order() {
 
 // acc: the wave's MT x NT accumulator tiles whose first row / column are mw0 / nw0; scr: this wave's private fp32 LDS staging tile of
 // ((64 / WN) * 16) rows x (WN + 4) floats (the caller has passed the barrier that frees it).
-template <bool RT, int ACT, int RES, int OF32, int O2> struct LeanMode {
+template <bool RT, int ACT, int RES, int OF32, int O2, int ACT2 = 0> struct LeanMode {
     static constexpr bool rt = RT;
-    static constexpr int act = ACT, res = RES, of32 = OF32, o2 = O2;
+    static constexpr int act = ACT, res = RES, of32 = OF32, o2 = O2, act2 = ACT2;
 };
 
 // LEAN: compile the streamlined pass for whole, aligned column tiles (costs ~50 VGPRs: only the one-workgroup-per-CU 256-tile form takes it)
-template <class T, int MT, int NT, int WN, int EPI, bool LEAN = false>
+template <class T, int MT, int NT, int WN, int EPI, int LEAN = 0>       // LEAN 1: DiT Linears (no per-column activation tables); 2: + Snake tables (vocoder)
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT][NT], float* scr, int lane, int mw0, int nw0, int bz, int g) {
     constexpr int SLD = WN + 4;                      // staging row stride (floats)
     constexpr int ROWS_PASS = (64 / WN) * 16;        // rows a wave stages per pass: 64 lanes x 16 columns each
@@ -71,10 +71,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT]
         // ---- streamlined form: whole column tiles, 16-byte alignment everywhere, no per-column activation tables, one residual --------
         // (every DiT Linear).  The column operands (bias, gate) do not depend on the pass and are loaded once; the residual rows of pass
         // p + 1 are requested before pass p is finished, so no pass waits on a cold global load; bf16 results leave as 16-byte stores.
-        const bool lean = LEAN && vec && (nw0 + WN) <= a.N && !a.act_alpha && !a.act2_alpha && !a.res2 && a.div == 0.0f && a.out_row_off >= 0 &&
-                          a.out2_row_off >= 0 && a.res_row_off >= 0;
-        if constexpr (LEAN) if (lean) {
-            f32x4 bi[4], gt[4];
+        constexpr bool ALPHA = LEAN == 2;
+        const bool lean = LEAN && vec && (nw0 + WN) <= a.N && (ALPHA || (!a.act_alpha && !a.act2_alpha)) && a.act != ACT_SNAKEBETA && !a.res2 &&
+                          a.div == 0.0f && a.out_row_off >= 0 && a.out2_row_off >= 0 && a.res_row_off >= 0;
+        if constexpr (LEAN != 0) if (lean) {
+            f32x4 bi[4], gt[4], al[ALPHA ? 4 : 1], al2[ALPHA ? 4 : 1];
+            if constexpr (ALPHA) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    al[q] = a.act_alpha ? *reinterpret_cast<const f32x4*>(a.act_alpha + gc0 + q * 4) : f32x4{1, 1, 1, 1};
+                    al2[q] = a.act2_alpha ? *reinterpret_cast<const f32x4*>(a.act2_alpha + gc0 + q * 4) : f32x4{1, 1, 1, 1};
+                }
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 bi[q] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + gc0 + q * 4) : f32x4{0, 0, 0, 0};
@@ -113,11 +121,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT]
                 for (int q = 0; q < 4; ++q) {
                     v[q] += bi[q];
                     if (act != ACT_NONE) {
-                        if constexpr (!MD::rt && MD::act == ACT_GELU_TANH) {
+                        const f32x4 alq = ALPHA ? al[ALPHA ? q : 0] : f32x4{1, 1, 1, 1};
+                        if constexpr (!MD::rt && (MD::act == ACT_GELU_TANH || MD::act == ACT_SNAKE)) {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[q][e] = act_apply(ACT_GELU_TANH, v[q][e], 0.0f, 1.0f, 1.0f);
+                            for (int e = 0; e < 4; ++e) v[q][e] = act_apply(MD::act, v[q][e], 0.0f, alq[e], 1.0f);
                         } else {
-                            v[q] = act_apply4(act, v[q], a.act_param, f32x4{1, 1, 1, 1}, f32x4{1, 1, 1, 1});
+                            v[q] = act_apply4(act, v[q], a.act_param, alq, f32x4{1, 1, 1, 1});
                         }
                     }
                     v[q] *= gt[q];
@@ -148,10 +157,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT]
                     }
                     if (has_out2) {
                         T* op = reinterpret_cast<T*>(a.out2) + (long long)bz * a.out2_bs + (long long)(row + a.out2_row_off) * a.ldo2 + gc0;
-                        if (a.act2 != ACT_NONE) {
+                        const int act2 = MD::rt ? a.act2 : MD::act2;
+                        if (act2 != ACT_NONE) {
 #pragma unroll
-                            for (int q = 0; q < 4; ++q)
-                                v[q] = act_apply4(a.act2, v[q], a.act2_param, f32x4{1, 1, 1, 1}, f32x4{1, 1, 1, 1});
+                            for (int q = 0; q < 4; ++q) {
+                                const f32x4 alq = ALPHA ? al2[ALPHA ? q : 0] : f32x4{1, 1, 1, 1};
+                                if constexpr (!MD::rt && MD::act2 == ACT_SNAKE) {
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) v[q][e] = act_apply(ACT_SNAKE, v[q][e], 0.0f, alq[e], 1.0f);
+                                } else {
+                                    v[q] = act_apply4(act2, v[q], a.act2_param, alq, f32x4{1, 1, 1, 1});
+                                }
+                            }
                         }
                         if constexpr (sizeof(T) == 2) {
 #pragma unroll
@@ -186,6 +203,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT]
             if (simple && a.act == ACT_NONE && resb && a.out_f32) lean_all(LeanMode<false, ACT_NONE, 1, 1, 0>{});              // out_proj, FF2: x += gate * (.)
             else if (simple && a.act == ACT_GELU_TANH && !resb && !a.out_f32) lean_all(LeanMode<false, ACT_GELU_TANH, 0, 0, 0>{});   // FF1
             else if (simple && a.act == ACT_NONE && !resb && !a.out_f32) lean_all(LeanMode<false, ACT_NONE, 0, 0, 0>{});           // plain store
+            else if (ALPHA && a.out && !a.out2 && a.scale == 1.0f && a.act == ACT_SNAKE && !resb && a.out_f32 && !a.gate) lean_all(LeanMode<false, ACT_SNAKE, 0, 1, 0>{});   // ResBlock convs1
+            else if (ALPHA && a.out && a.out2 && a.scale == 1.0f && a.act == ACT_NONE && resb && a.out_f32 && a.act2 == ACT_SNAKE && !a.gate)
+                lean_all(LeanMode<false, ACT_NONE, 1, 1, 1, ACT_SNAKE>{});                                                                                                 // ResBlock convs2 + next Snake
             else lean_all(LeanMode<true, 0, 0, 0, 0>{});
             return;
         }

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(GemmArgs a) {
             __syncthreads();
         }
     }
-    gemm_epilogue<float, MT, NT, WN, EPI_GENERIC>(a, acc, reinterpret_cast<float*>(smem) + wave * ROWS_PASS * SLD, lane, m0 + wm0, n0 + wn0, bz, g);
+    gemm_epilogue<float, MT, NT, WN, EPI_GENERIC, 2>(a, acc, reinterpret_cast<float*>(smem) + wave * ROWS_PASS * SLD, lane, m0 + wm0, n0 + wn0, bz, g);
 }
 
 template <int BM, int BN, int WM, int WN>
