@@ -337,14 +337,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT]
             if (wave_ok && which < 2) {
                 const int prow = lane / LPR, pcs = (lane % LPR) * 16;
                 const int c0 = cb + pcs, d0 = c0 & 63;
-                const bool rope = c0 < 64 && a.rope_cos;
+                const bool rope_rt = cb < 64 && a.rope_cos;            // wave-uniform (cb is a multiple of 64): channels [0, 64) of q and k = head 0
                 const float qs = (which == 0 && a.q_scale != 0.0f) ? a.q_scale : 1.0f;
                 f32x4 bi[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) bi[q] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + cw + pcs + q * 4) : f32x4{0, 0, 0, 0};
                 T* const dbase = reinterpret_cast<T*>(which == 0 ? a.q : a.k) + (((long long)bz * a.heads + h) * a.t_pad) * 64 + d0;
-                auto qk_pass = [&](auto IP) __attribute__((always_inline)) {
+                auto qk_pass = [&](auto IP, auto ROPE) __attribute__((always_inline)) {
                     constexpr int ip = decltype(IP)::value;
+                    constexpr bool rope = decltype(ROPE)::value;       // compile-time: the pass stays one basic block (see LeanMode)
                     const int row = mw0 + ip * 16 + prow;
                     f32x4 cs[2], sn[2];
                     if (rope) {
@@ -381,14 +382,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT]
                         }
                     }
                 };
-                qk_pass(std::integral_constant<int, 0>{});
-                if constexpr (MT > 1) qk_pass(std::integral_constant<int, 1>{});
-                if constexpr (MT > 2) qk_pass(std::integral_constant<int, 2>{});
-                if constexpr (MT > 3) qk_pass(std::integral_constant<int, 3>{});
-                if constexpr (MT > 4) qk_pass(std::integral_constant<int, 4>{});
-                if constexpr (MT > 5) qk_pass(std::integral_constant<int, 5>{});
-                if constexpr (MT > 6) qk_pass(std::integral_constant<int, 6>{});
-                if constexpr (MT > 7) qk_pass(std::integral_constant<int, 7>{});
+                auto qk_all = [&](auto ROPE) __attribute__((always_inline)) {
+                    qk_pass(std::integral_constant<int, 0>{}, ROPE);
+                    if constexpr (MT > 1) qk_pass(std::integral_constant<int, 1>{}, ROPE);
+                    if constexpr (MT > 2) qk_pass(std::integral_constant<int, 2>{}, ROPE);
+                    if constexpr (MT > 3) qk_pass(std::integral_constant<int, 3>{}, ROPE);
+                    if constexpr (MT > 4) qk_pass(std::integral_constant<int, 4>{}, ROPE);
+                    if constexpr (MT > 5) qk_pass(std::integral_constant<int, 5>{}, ROPE);
+                    if constexpr (MT > 6) qk_pass(std::integral_constant<int, 6>{}, ROPE);
+                    if constexpr (MT > 7) qk_pass(std::integral_constant<int, 7>{}, ROPE);
+                };
+                if (rope_rt) qk_all(std::true_type{});
+                else qk_all(std::false_type{});
                 static_assert(MT <= 8 && MT % 2 == 0, "lean QKV epilogue: up to 8 row tiles per wave, in pairs");
                 return;
             }
