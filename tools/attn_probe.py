@@ -17,5 +17,6 @@ for B in [int(x) for x in sys.argv[1:]] or [2, 4, 8, 16]:
     q = torch.randn(B, H, Tp, 64, device='cuda').to(torch.bfloat16)
     k = torch.randn(B, H, Tp, 64, device='cuda').to(torch.bfloat16)
     vT = torch.randn(B, H, 64, Tp, device='cuda').to(torch.bfloat16)
-    t = timeit(lambda: ops.attention(q, k, vT, T), iters=iters)
+    pre = bool(int(os.environ.get('QLOG2', '1')))           # the production form: q already carries scale * log2(e)
+    t = timeit(lambda: ops.attention(q, k, vT, T, q_log2=pre), iters=iters)
     print('attn bf16 T=%5d B=%2d  %8.1f us  %7.1f TF/s' % (T, B, t * 1e6, 4.0 * T * T * 64 * H * B / t / 1e12), flush=True)
