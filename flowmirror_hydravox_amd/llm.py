@@ -443,9 +443,9 @@ class _DecodeEngine:
         self.slot_req[i] = r
         self.join_block[i] = launched
         self.head[i] = 0
-        # a first slice only: the rest of the ring is topped up by the polling loop while the first blocks run (generating a full ring of
-        # Exp(1) values costs ~2.4 ms of host time per request, which used to sit in front of the first launch for every slot)
-        self._fill_ring(i, min(self.ncap, 8192))
+        # the whole ring at once (~2.5 ms of host time per request): filling a first slice only and topping the rest up behind the first
+        # blocks was measured WORSE — 64 large refills issued against a busy launch queue kept it empty for 0.3-0.5 s (one gap after block 7)
+        self._fill_ring(i, self.ncap)
         self.last_fill[i] = launched
         r.state = [n, 0, 0, r.min_len, r.max_len, 0, 0, 0]
         r.cursor = 0
@@ -516,17 +516,23 @@ class _DecodeEngine:
 
         def fill_free_slots():
             nonlocal waiting
-            joined = False
-            for i in range(S):
-                if self.slot_req[i] is not None and not self.slot_req[i].done:
-                    continue
+            free = [i for i in range(S) if self.slot_req[i] is None or self.slot_req[i].done]
+            batch = []
+            for i in free:
                 pull()
                 if waiting is None:
                     break
-                self._join(i, waiting, launched)
+                batch.append((i, waiting))
                 waiting = None
-                joined = True
-            return joined
+            if len(batch) > 2:
+                # many joins at once (the first occupants of a wide grid): their Exp(1) rings — 65 536 values, ~2.5 ms of host time each — are
+                # generated side by side (torch releases the GIL inside exponential_) instead of one after the other in front of the first launch
+                from concurrent.futures import ThreadPoolExecutor
+                with ThreadPoolExecutor(max_workers=min(8, len(batch))) as pool:
+                    list(pool.map(lambda ir: ir[1].noise.window(0, self.ncap), batch))
+            for i, r in batch:
+                self._join(i, r, launched)
+            return bool(batch)
 
         try:
             with torch.cuda.stream(stream):
@@ -659,6 +665,6 @@ class _DecodeEngine:
             ctx_sum = sum(p for _, _, p in timed) / n_blk if n_blk else 0.0
             self.stats = dict(steps=n_blk * sync_every, tokens=n_tokens, seconds=dt, tps=n_tokens / dt if dt > 0 else 0.0, head_k=K, batch=S,
                               requests=n_done, prefill_and_setup_seconds=t_setup,
-                              device_idle_ms_between_blocks=sum(gaps), decode_step_us=1e3 * step_ms, decode_steps_timed=n_blk * sync_every,
+                              device_idle_ms_between_blocks=sum(gaps), idle_gaps_over_1ms=[(i, round(g, 1)) for i, g in enumerate(gaps) if g > 1.0][:24], decode_step_us=1e3 * step_ms, decode_steps_timed=n_blk * sync_every,
                               mean_active_sequences=seqs, mean_ctx=ctx_sum / seqs if seqs else 0.0,
                               decode_step_bytes=llm.decode_step_bytes(1, K, ctx_sum), clean=finished_clean)

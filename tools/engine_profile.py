@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Host-side profile of the decode engine at the bench shape: 64 requests x 512 text tokens -> 2816 speech tokens, 64 slots."""
+import cProfile
+import os
+import pstats
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from flowmirror_hydravox_amd import cv3_config  # noqa: E402
+from flowmirror_hydravox_amd.llm import HvxLLM  # noqa: E402
+from flowmirror_hydravox_amd.pipeline import synthetic_utterance  # noqa: E402
+from flowmirror_hydravox_amd.sampling import ras_sampling  # noqa: E402
+from flowmirror_hydravox_amd.weights import make_llm_state  # noqa: E402
+from functools import partial  # noqa: E402
+
+cfg = cv3_config()
+llm = HvxLLM(cfg.llm, make_llm_state(cfg.llm, seed=1986, init='normal02'), dtype=torch.bfloat16, inference_head_num=2, max_batch=8, max_ctx=3400,
+             sampling=partial(ras_sampling, top_p=0.9, top_k=10, win_size=32, tau_r=0.2))
+utts = [synthetic_utterance(cfg, i, 512) for i in range(64)]
+reqs = [dict(text=u.text, seed=u.seed, tag=i, max_token_text_ratio=5.5, min_token_text_ratio=5.5) for i, u in enumerate(utts)]
+for rep in range(2):
+    pr = cProfile.Profile()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    if rep:
+        pr.enable()
+    n = sum(len(t) for _, t in llm.generate_stream(iter(reqs), n_slots=64))
+    if rep:
+        pr.disable()
+    torch.cuda.synchronize()
+    st = llm.last_stats
+    print('%d tokens in %.2f s; device idle between blocks %.0f ms; decode step %.0f us; noise cursor total ?' % (n, time.time() - t0, st.get('device_idle_ms_between_blocks', -1), st.get('decode_step_us', -1)))
+    print('gaps over 1 ms:', st.get('idle_gaps_over_1ms'))
+    if rep:
+        pstats.Stats(pr).sort_stats('tottime').print_stats(14)
