@@ -37,6 +37,7 @@ class SynthStats:
     hift_seconds: float = 0.0
     total_seconds: float = 0.0
     per_utt_tokens: List[int] = field(default_factory=list)
+    token_ids: List[List[int]] = field(default_factory=list)   # the speech-token ids of every utterance of the batch
     llm: dict = field(default_factory=dict)               # HvxLLM.last_stats of this batch (decode-step timing)
 
     @property
@@ -155,6 +156,7 @@ class HvxPipeline:
         st.llm_seconds = t1 - t0
         st.llm = dict(self.llm.last_stats)
         st.per_utt_tokens = [len(t) for t in toks]
+        st.token_ids = [list(t) for t in toks]
         st.tokens = sum(st.per_utt_tokens)
         mels = self._mels_batched(utts, toks, max_batch=self.acoustic_batch) if self.acoustic_batch > 1 else self._mels(utts, toks)
         torch.cuda.synchronize()
@@ -216,6 +218,7 @@ class HvxPipeline:
             st.llm_seconds = time.time() - t0
             st.llm = dict(llm.last_stats)
             st.per_utt_tokens = [len(t) for t in toks]
+            st.token_ids = [list(t) for t in toks]
             st.tokens = sum(st.per_utt_tokens)
             return toks, st, t0
 

@@ -519,11 +519,17 @@ def test_pipelined_batches_equal_serial(tiny_cfg):
     for kw in ({}, dict(lm_chains=1), dict(lm_chains=2, acoustic_chains=2)):
         piped = list(pipe.synthesize_pipelined(batches, max_token_text_ratio=5, min_token_text_ratio=5, **kw))
         assert len(piped) == len(serial)
-        for (w0, s0), (w1, s1) in zip(serial, piped):
+        for bi, ((w0, s0), (w1, s1)) in enumerate(zip(serial, piped)):
             assert s0.per_utt_tokens == s1.per_utt_tokens and s1.tokens > 0
+            assert s0.token_ids == s1.token_ids, ('speech-token ids differ', kw, bi)
             assert s1.audio_seconds == s0.audio_seconds and s1.total_seconds > 0
-            for a, b in zip(w0, w1):
-                assert a.shape == b.shape and torch.equal(a, b)
+            for ui, (a, b) in enumerate(zip(w0, w1)):
+                assert a.shape == b.shape
+                if not torch.equal(a, b):
+                    d = (a - b).abs()
+                    again = pipe.synthesize(batches[bi], max_token_text_ratio=5, min_token_text_ratio=5)[0][ui]
+                    raise AssertionError('config %r batch %d utterance %d: max |diff| %.3e at sample %d of %d (first differing %d); serial again == serial: %s, == piped: %s'
+                                         % (kw, bi, ui, d.max().item(), int(d.argmax()), a.numel(), int((d > 0).nonzero()[0]), torch.equal(again, a), torch.equal(again, b)))
     assert len(pipe._llms) == 3 and pipe._llms[1]._weights[0].data_ptr() == pipe.llm._weights[0].data_ptr()      # chains share the weights
 
 
