@@ -75,53 +75,57 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT]
         const bool lean = LEAN && vec && (nw0 + WN) <= a.N && (ALPHA || (!a.act_alpha && !a.act2_alpha)) && a.act != ACT_SNAKEBETA && !a.res2 &&
                           a.div == 0.0f && a.out_row_off >= 0 && a.out2_row_off >= 0 && a.res_row_off >= 0;
         if constexpr (LEAN != 0) if (lean) {
-            f32x4 bi[4], gt[4], al[ALPHA ? 4 : 1], al2[ALPHA ? 4 : 1];
-            if constexpr (ALPHA) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    al[q] = a.act_alpha ? *reinterpret_cast<const f32x4*>(a.act_alpha + gc0 + q * 4) : f32x4{1, 1, 1, 1};
-                    al2[q] = a.act2_alpha ? *reinterpret_cast<const f32x4*>(a.act2_alpha + gc0 + q * 4) : f32x4{1, 1, 1, 1};
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                bi[q] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + gc0 + q * 4) : f32x4{0, 0, 0, 0};
-                gt[q] = a.gate ? *reinterpret_cast<const f32x4*>(a.gate + (long long)bz * a.gate_bs + gc0 + q * 4) : f32x4{1, 1, 1, 1};
-            }
-            const float* const resb = a.res ? a.res + (long long)bz * a.res_bs + gc0 : nullptr;
-            auto res_load = [&](int row, f32x4 (&r4)[4]) __attribute__((always_inline)) {
-                const int rr = (row < a.M ? row : a.M - 1) + a.res_row_off;           // rows past the end are never stored: any valid row serves
-                const float* p = resb + (long long)rr * a.ldres;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) r4[q] = *reinterpret_cast<const f32x4*>(p + q * 4);
-            };
-            f32x4 rs[4];
-            if (resb) res_load(mw0 + prow, rs);
-            // MODE: compile-time copies of the launch's epilogue switches (activation, residual, output types) for the combinations the DiT
-            // uses, so that a pass is ONE basic block.  With the switches tested at run time inside the pass every arm starts with a
-            // conservative s_waitcnt vmcnt(0) — i.e. each 16-row pass waited for the previous pass's stores to be acknowledged (FF1: +20 us
-            // per 256 x 256 tile).  MODE::rt keeps the run-time form for everything else.
-            auto lean_pass = [&](auto IP, auto MODE) __attribute__((always_inline)) {
+            // Lane -> (row, column) maps of a pass (PERM), chosen per mode so that every global instruction of the wave covers WHOLE contiguous
+            // row segments: with "16 consecutive columns per lane" (PERM 0) a 16-byte access of the wave is a comb — 16 B used of every 64 B
+            // (fp32) or 32 B (bf16) — and every 128-byte line of the tile is touched by 2-4 instructions.
+            //   PERM 1 (fp32 in / out, 4 lanes per row): instruction q covers columns [16 q, 16 q + 16) of 16 rows = 64 contiguous bytes per row
+            //   PERM 2 (bf16 out, 8 lanes per row):      store u covers all 64 columns of rows [8 u, 8 u + 8) = 128 contiguous bytes per row
+            const int gcw = g * a.N + nw0;
+            const float* const resw = a.res ? a.res + (long long)bz * a.res_bs + gcw : nullptr;
+            auto lean_pass = [&](auto IP, auto MODE, auto PERMC, f32x4 (&bi)[4], f32x4 (&gt)[4], f32x4 (&al)[4], f32x4 (&al2)[4], f32x4 (&rs)[4])
+                                 __attribute__((always_inline)) {
                 constexpr int ip = decltype(IP)::value;
+                constexpr int PERM = decltype(PERMC)::value;
                 typedef decltype(MODE) MD;
+                auto rsel = [&](int q) { return PERM == 2 ? (lane >> 3) + 8 * (q >> 1) : prow; };
+                auto cof = [&](int q) { return PERM == 2 ? (lane & 7) * 8 + (q & 1) * 4 : PERM == 1 ? q * 16 + (lane & 3) * 4 : pcs + q * 4; };
                 const int act = MD::rt ? a.act : MD::act;
-                const bool has_res = MD::rt ? (resb != nullptr) : (bool)MD::res;
+                const bool has_res = MD::rt ? (resw != nullptr) : (bool)MD::res;
                 const bool out_f32 = MD::rt ? (a.out_f32 != 0) : (bool)MD::of32;
                 const bool has_out = MD::rt ? (a.out != nullptr) : true;
                 const bool has_out2 = MD::rt ? (a.out2 != nullptr) : (bool)MD::o2;
+                auto res_load = [&](int row0, f32x4 (&r4)[4]) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int row = row0 + rsel(q);
+                        const int rr = (row < a.M ? row : a.M - 1) + a.res_row_off;       // rows past the end are never stored: any valid row serves
+                        r4[q] = *reinterpret_cast<const f32x4*>(resw + (long long)rr * a.ldres + cof(q));
+                    }
+                };
+                if constexpr (ip == 0) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if constexpr (ALPHA) {
+                            al[q] = a.act_alpha ? *reinterpret_cast<const f32x4*>(a.act_alpha + gcw + cof(q)) : f32x4{1, 1, 1, 1};
+                            al2[q] = a.act2_alpha ? *reinterpret_cast<const f32x4*>(a.act2_alpha + gcw + cof(q)) : f32x4{1, 1, 1, 1};
+                        }
+                        bi[q] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + gcw + cof(q)) : f32x4{0, 0, 0, 0};
+                        gt[q] = a.gate ? *reinterpret_cast<const f32x4*>(a.gate + (long long)bz * a.gate_bs + gcw + cof(q)) : f32x4{1, 1, 1, 1};
+                    }
+                    if (has_res) res_load(mw0, rs);
+                }
                 f32x4 rn[4];
-                if (has_res && ip + MT_PASS < MT) res_load(mw0 + (ip + MT_PASS) * 16 + prow, rn);
+                if (has_res && ip + MT_PASS < MT) res_load(mw0 + (ip + MT_PASS) * 16, rn);
                 stage(IP);
                 f32x4 v[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const f32x4*>(&scr[prow * SLD + pcs + q * 4]);
+                for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const f32x4*>(&scr[rsel(q) * SLD + cof(q)]);
                 unstage();
-                const int row = mw0 + ip * 16 + prow;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     v[q] += bi[q];
                     if (act != ACT_NONE) {
-                        const f32x4 alq = ALPHA ? al[ALPHA ? q : 0] : f32x4{1, 1, 1, 1};
+                        const f32x4 alq = ALPHA ? al[q] : f32x4{1, 1, 1, 1};
                         if constexpr (!MD::rt && (MD::act == ACT_GELU_TANH || MD::act == ACT_SNAKE)) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[q][e] = act_apply(MD::act, v[q][e], 0.0f, alq[e], 1.0f);
@@ -133,55 +137,54 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT]
                     if (has_res) v[q] += rs[q];
                     v[q] *= a.scale;
                 }
-                if (row < a.M) {
-                    if (has_out) {
-                        const long long o1 = ob + (long long)(row + a.out_row_off) * a.ldo + gc0;
-                        if (out_f32) {
-                            float* op = reinterpret_cast<float*>(a.out) + o1;
+                const int row0 = mw0 + ip * 16;
+                if (has_out) {
+                    if (out_f32 || sizeof(T) != 2) {
+                        float* const ob32 = reinterpret_cast<float*>(a.out) + ob + gcw;
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(op + q * 4) = v[q];
-                        } else if constexpr (sizeof(T) == 2) {
-                            T* op = reinterpret_cast<T*>(a.out) + o1;
+                        for (int q = 0; q < 4; ++q)
+                            if (row0 + rsel(q) < a.M) *reinterpret_cast<f32x4*>(ob32 + (long long)(row0 + rsel(q) + a.out_row_off) * a.ldo + cof(q)) = v[q];
+                    } else if constexpr (sizeof(T) == 2) {
+                        static_assert(MD::rt || MD::of32 || PERM != 1, "PERM 1 has no 8-column bf16 runs");
+                        T* const ob16 = reinterpret_cast<T*>(a.out) + ob + gcw;
 #pragma unroll
-                            for (int q = 0; q < 2; ++q) {
-                                bf16x8 w8;
+                        for (int u = 0; u < 2; ++u) {
+                            bf16x8 w8;
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) { w8[e] = f32_to_bf16(v[2 * q][e]); w8[4 + e] = f32_to_bf16(v[2 * q + 1][e]); }
-                                store8(op + q * 8, w8);
-                            }
-                        } else {
-                            float* op = reinterpret_cast<float*>(a.out) + o1;
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(op + q * 4) = v[q];
+                            for (int e = 0; e < 4; ++e) { w8[e] = f32_to_bf16(v[2 * u][e]); w8[4 + e] = f32_to_bf16(v[2 * u + 1][e]); }
+                            if (row0 + rsel(2 * u) < a.M) store8(ob16 + (long long)(row0 + rsel(2 * u) + a.out_row_off) * a.ldo + cof(2 * u), w8);
                         }
                     }
-                    if (has_out2) {
-                        T* op = reinterpret_cast<T*>(a.out2) + (long long)bz * a.out2_bs + (long long)(row + a.out2_row_off) * a.ldo2 + gc0;
-                        const int act2 = MD::rt ? a.act2 : MD::act2;
-                        if (act2 != ACT_NONE) {
+                }
+                if (has_out2) {
+                    static_assert(!MD::o2 || PERM != 1, "PERM 1 has no 8-column bf16 runs");
+                    T* const ob2 = reinterpret_cast<T*>(a.out2) + (long long)bz * a.out2_bs + gcw;
+                    const int act2 = MD::rt ? a.act2 : MD::act2;
+                    if (act2 != ACT_NONE) {
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const f32x4 alq = ALPHA ? al2[ALPHA ? q : 0] : f32x4{1, 1, 1, 1};
-                                if constexpr (!MD::rt && MD::act2 == ACT_SNAKE) {
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x4 alq = ALPHA ? al2[q] : f32x4{1, 1, 1, 1};
+                            if constexpr (!MD::rt && MD::act2 == ACT_SNAKE) {
 #pragma unroll
-                                    for (int e = 0; e < 4; ++e) v[q][e] = act_apply(ACT_SNAKE, v[q][e], 0.0f, alq[e], 1.0f);
-                                } else {
-                                    v[q] = act_apply4(act2, v[q], a.act2_param, alq, f32x4{1, 1, 1, 1});
-                                }
+                                for (int e = 0; e < 4; ++e) v[q][e] = act_apply(ACT_SNAKE, v[q][e], 0.0f, alq[e], 1.0f);
+                            } else {
+                                v[q] = act_apply4(act2, v[q], a.act2_param, alq, f32x4{1, 1, 1, 1});
                             }
                         }
-                        if constexpr (sizeof(T) == 2) {
+                    }
+                    if constexpr (sizeof(T) == 2) {
 #pragma unroll
-                            for (int q = 0; q < 2; ++q) {
-                                bf16x8 w8;
+                        for (int u = 0; u < 2; ++u) {
+                            bf16x8 w8;
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) { w8[e] = f32_to_bf16(v[2 * q][e]); w8[4 + e] = f32_to_bf16(v[2 * q + 1][e]); }
-                                store8(op + q * 8, w8);
-                            }
-                        } else {
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(op) + q * 4) = v[q];
+                            for (int e = 0; e < 4; ++e) { w8[e] = f32_to_bf16(v[2 * u][e]); w8[4 + e] = f32_to_bf16(v[2 * u + 1][e]); }
+                            if (row0 + rsel(2 * u) < a.M) store8(ob2 + (long long)(row0 + rsel(2 * u) + a.out2_row_off) * a.ldo2 + cof(2 * u), w8);
                         }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (row0 + rsel(q) < a.M)
+                                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(ob2) + (long long)(row0 + rsel(q) + a.out2_row_off) * a.ldo2 + cof(q)) = v[q];
                     }
                 }
                 if (has_res && ip + MT_PASS < MT) {
@@ -190,21 +193,26 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT]
                 }
             };
             auto lean_all = [&](auto MODE) __attribute__((always_inline)) {
-                lean_pass(std::integral_constant<int, 0>{}, MODE);
-                if constexpr (MT > 1 * MT_PASS) lean_pass(std::integral_constant<int, 1 * MT_PASS>{}, MODE);
-                if constexpr (MT > 2 * MT_PASS) lean_pass(std::integral_constant<int, 2 * MT_PASS>{}, MODE);
-                if constexpr (MT > 3 * MT_PASS) lean_pass(std::integral_constant<int, 3 * MT_PASS>{}, MODE);
-                if constexpr (MT > 4 * MT_PASS) lean_pass(std::integral_constant<int, 4 * MT_PASS>{}, MODE);
-                if constexpr (MT > 5 * MT_PASS) lean_pass(std::integral_constant<int, 5 * MT_PASS>{}, MODE);
-                if constexpr (MT > 6 * MT_PASS) lean_pass(std::integral_constant<int, 6 * MT_PASS>{}, MODE);
-                if constexpr (MT > 7 * MT_PASS) lean_pass(std::integral_constant<int, 7 * MT_PASS>{}, MODE);
+                typedef decltype(MODE) MD;
+                // the permuted maps assume 4 lanes per 64-column row and one 16-row tile per pass (the 256-tile form and the vocoder form)
+                constexpr int PERM = (MD::rt || MD::o2 || WN != 64 || MT_PASS != 1) ? 0 : (MD::of32 || sizeof(T) != 2) ? 1 : 2;
+                std::integral_constant<int, PERM> pc;
+                f32x4 bi[4], gt[4], al[4], al2[4], rs[4];
+                lean_pass(std::integral_constant<int, 0>{}, MODE, pc, bi, gt, al, al2, rs);
+                if constexpr (MT > 1 * MT_PASS) lean_pass(std::integral_constant<int, 1 * MT_PASS>{}, MODE, pc, bi, gt, al, al2, rs);
+                if constexpr (MT > 2 * MT_PASS) lean_pass(std::integral_constant<int, 2 * MT_PASS>{}, MODE, pc, bi, gt, al, al2, rs);
+                if constexpr (MT > 3 * MT_PASS) lean_pass(std::integral_constant<int, 3 * MT_PASS>{}, MODE, pc, bi, gt, al, al2, rs);
+                if constexpr (MT > 4 * MT_PASS) lean_pass(std::integral_constant<int, 4 * MT_PASS>{}, MODE, pc, bi, gt, al, al2, rs);
+                if constexpr (MT > 5 * MT_PASS) lean_pass(std::integral_constant<int, 5 * MT_PASS>{}, MODE, pc, bi, gt, al, al2, rs);
+                if constexpr (MT > 6 * MT_PASS) lean_pass(std::integral_constant<int, 6 * MT_PASS>{}, MODE, pc, bi, gt, al, al2, rs);
+                if constexpr (MT > 7 * MT_PASS) lean_pass(std::integral_constant<int, 7 * MT_PASS>{}, MODE, pc, bi, gt, al, al2, rs);
             };
             const bool simple = a.out && !a.out2 && a.scale == 1.0f;
-            if (simple && a.act == ACT_NONE && resb && a.out_f32) lean_all(LeanMode<false, ACT_NONE, 1, 1, 0>{});              // out_proj, FF2: x += gate * (.)
-            else if (simple && a.act == ACT_GELU_TANH && !resb && !a.out_f32) lean_all(LeanMode<false, ACT_GELU_TANH, 0, 0, 0>{});   // FF1
-            else if (simple && a.act == ACT_NONE && !resb && !a.out_f32) lean_all(LeanMode<false, ACT_NONE, 0, 0, 0>{});           // plain store
-            else if (ALPHA && a.out && !a.out2 && a.scale == 1.0f && a.act == ACT_SNAKE && !resb && a.out_f32 && !a.gate) lean_all(LeanMode<false, ACT_SNAKE, 0, 1, 0>{});   // ResBlock convs1
-            else if (ALPHA && a.out && a.out2 && a.scale == 1.0f && a.act == ACT_NONE && resb && a.out_f32 && a.act2 == ACT_SNAKE && !a.gate)
+            if (simple && a.act == ACT_NONE && resw && a.out_f32) lean_all(LeanMode<false, ACT_NONE, 1, 1, 0>{});              // out_proj, FF2: x += gate * (.)
+            else if (simple && a.act == ACT_GELU_TANH && !resw && !a.out_f32) lean_all(LeanMode<false, ACT_GELU_TANH, 0, 0, 0>{});   // FF1
+            else if (simple && a.act == ACT_NONE && !resw && !a.out_f32) lean_all(LeanMode<false, ACT_NONE, 0, 0, 0>{});           // plain store
+            else if (ALPHA && a.out && !a.out2 && a.scale == 1.0f && a.act == ACT_SNAKE && !resw && a.out_f32 && !a.gate) lean_all(LeanMode<false, ACT_SNAKE, 0, 1, 0>{});   // ResBlock convs1
+            else if (ALPHA && a.out && a.out2 && a.scale == 1.0f && a.act == ACT_NONE && resw && a.out_f32 && a.act2 == ACT_SNAKE && !a.gate)
                 lean_all(LeanMode<false, ACT_NONE, 1, 1, 1, ACT_SNAKE>{});                                                                                                 // ResBlock convs2 + next Snake
             else lean_all(LeanMode<true, 0, 0, 0, 0>{});
             return;
@@ -335,31 +343,32 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT]
             // streamlined form (the caller's staging tile holds 32 rows): the bias is loaded once, q / k leave as before (a 128-byte head row
             // per 4 lanes), V^T is transposed 32 time steps at a time so that a lane writes 64 contiguous bytes of its channel's row
             if (wave_ok && which < 2) {
-                const int prow = lane / LPR, pcs = (lane % LPR) * 16;
-                const int c0 = cb + pcs, d0 = c0 & 63;
+                // 8 lanes per row: store u of a pass writes rows [8 u, 8 u + 8) of the head's [t][64] block = 1 KB of contiguous memory
+                const int row8 = lane >> 3, c8 = (lane & 7) * 8;
                 const bool rope_rt = cb < 64 && a.rope_cos;            // wave-uniform (cb is a multiple of 64): channels [0, 64) of q and k = head 0
                 const float qs = (which == 0 && a.q_scale != 0.0f) ? a.q_scale : 1.0f;
-                f32x4 bi[4];
+                f32x4 bi[2];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) bi[q] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + cw + pcs + q * 4) : f32x4{0, 0, 0, 0};
-                T* const dbase = reinterpret_cast<T*>(which == 0 ? a.q : a.k) + (((long long)bz * a.heads + h) * a.t_pad) * 64 + d0;
+                for (int hh = 0; hh < 2; ++hh) bi[hh] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + cw + c8 + hh * 4) : f32x4{0, 0, 0, 0};
+                T* const dbase = reinterpret_cast<T*>(which == 0 ? a.q : a.k) + (((long long)bz * a.heads + h) * a.t_pad) * 64 + c8;
                 auto qk_pass = [&](auto IP, auto ROPE) __attribute__((always_inline)) {
                     constexpr int ip = decltype(IP)::value;
                     constexpr bool rope = decltype(ROPE)::value;       // compile-time: the pass stays one basic block (see LeanMode)
-                    const int row = mw0 + ip * 16 + prow;
+                    const int row0 = mw0 + ip * 16 + row8;
                     f32x4 cs[2], sn[2];
                     if (rope) {
-                        const long long ro = (long long)(row < a.M ? row : a.M - 1) * 32 + (d0 >> 1);
 #pragma unroll
-                        for (int q = 0; q < 2; ++q) {
-                            cs[q] = *reinterpret_cast<const f32x4*>(a.rope_cos + ro + q * 4);
-                            sn[q] = *reinterpret_cast<const f32x4*>(a.rope_sin + ro + q * 4);
+                        for (int u = 0; u < 2; ++u) {
+                            const int row = row0 + 8 * u;
+                            const long long ro = (long long)(row < a.M ? row : a.M - 1) * 32 + (c8 >> 1);
+                            cs[u] = *reinterpret_cast<const f32x4*>(a.rope_cos + ro);
+                            sn[u] = *reinterpret_cast<const f32x4*>(a.rope_sin + ro);
                         }
                     }
                     stage(IP);
                     f32x4 v[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const f32x4*>(&scr[prow * SLD + pcs + q * 4]) + bi[q];
+                    for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const f32x4*>(&scr[(row8 + 8 * (q >> 1)) * SLD + c8 + (q & 1) * 4]) + bi[q & 1];
                     unstage();
                     if (rope) {
 #pragma unroll
@@ -372,14 +381,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT]
                                 v[q][e + 1] = od * c_ + ev * s_;
                             }
                     }
-                    if (row < a.M) {
 #pragma unroll
-                        for (int q = 0; q < 2; ++q) {
-                            typename Vec8<T>::type w8;
+                    for (int u = 0; u < 2; ++u) {
+                        typename Vec8<T>::type w8;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) { w8[e] = from_f32<T>(v[2 * q][e] * qs); w8[4 + e] = from_f32<T>(v[2 * q + 1][e] * qs); }
-                            store8(dbase + (long long)row * 64 + q * 8, w8);
-                        }
+                        for (int e = 0; e < 4; ++e) { w8[e] = from_f32<T>(v[2 * u][e] * qs); w8[4 + e] = from_f32<T>(v[2 * u + 1][e] * qs); }
+                        if (row0 + 8 * u < a.M) store8(dbase + (long long)(row0 + 8 * u) * 64, w8);
                     }
                 };
                 auto qk_all = [&](auto ROPE) __attribute__((always_inline)) {
@@ -398,8 +405,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT]
                 return;
             }
             if (wave_ok) {
-                const float bi = a.bias ? a.bias[cw + lane] : 0.0f;
-                T* const dbase = reinterpret_cast<T*>(a.vT) + (((long long)bz * a.heads + h) * 64 + ((cb + lane) & 63)) * a.t_pad;
+                // V^T [d][t]: 4 lanes per channel, each 8 of the 32 staged time steps: a store covers 16 channels x 64 contiguous bytes (one
+                // channel per lane would scatter 64 separate 16-byte pieces per instruction).  The staging rows are 65 floats apart here so
+                // that the transposed ds_read_b32 of the four time groups fall into different banks.
+                constexpr int SLV = WN + 1;
+                const int ch4 = lane >> 2, tq = lane & 3;
+                float bi[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bi[i] = a.bias ? a.bias[cw + i * 16 + ch4] : 0.0f;
+                T* const dbase = reinterpret_cast<T*>(a.vT) + (((long long)bz * a.heads + h) * 64 + ((cb + ch4) & 63)) * a.t_pad + tq * 8;
                 auto v_pass = [&](auto IP) __attribute__((always_inline)) {
                     constexpr int ip = decltype(IP)::value;
 #pragma unroll
@@ -407,27 +421,31 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT]
 #pragma unroll
                         for (int j = 0; j < NT; ++j)
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) scr[(ii * 16 + fg * 4 + r) * SLD + j * 16 + fr] = acc[ip + ii][j][r];
+                            for (int r = 0; r < 4; ++r) scr[(ii * 16 + fg * 4 + r) * SLV + j * 16 + fr] = acc[ip + ii][j][r];
                     wave_lds_order();
-                    float x[32];
+                    float x[4][8];
 #pragma unroll
-                    for (int r = 0; r < 32; ++r) x[r] = scr[r * SLD + lane] + bi;
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) x[i][e] = scr[(tq * 8 + e) * SLV + i * 16 + ch4] + bi[i];
                     unstage();
                     const int row0 = mw0 + ip * 16;
                     if (row0 >= a.M) return;
                     T* dst = dbase + row0;
                     if (row0 + 32 <= a.M) {
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
+                        for (int i = 0; i < 4; ++i) {
                             typename Vec8<T>::type w8;
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) w8[e] = from_f32<T>(x[q * 8 + e]);
-                            store8(dst + q * 8, w8);
+                            for (int e = 0; e < 8; ++e) w8[e] = from_f32<T>(x[i][e]);
+                            store8(dst + (long long)i * 16 * a.t_pad, w8);
                         }
                     } else {
 #pragma unroll
-                        for (int r = 0; r < 32; ++r)
-                            if (row0 + r < a.M) dst[r] = from_f32<T>(x[r]);
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int e = 0; e < 8; ++e)
+                                if (row0 + tq * 8 + e < a.M) dst[(long long)i * 16 * a.t_pad + e] = from_f32<T>(x[i][e]);
                     }
                 };
                 v_pass(std::integral_constant<int, 0>{});
