@@ -80,6 +80,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT]
             // (fp32) or 32 B (bf16) — and every 128-byte line of the tile is touched by 2-4 instructions.
             //   PERM 1 (fp32 in / out, 4 lanes per row): instruction q covers columns [16 q, 16 q + 16) of 16 rows = 64 contiguous bytes per row
             //   PERM 2 (bf16 out, 8 lanes per row):      store u covers all 64 columns of rows [8 u, 8 u + 8) = 128 contiguous bytes per row
+            //   PERM 3 (fp32 in / out, 8 lanes per row): instruction q covers columns [32 (q & 1), + 32) of rows [8 (q >> 1), + 8) = 128 contiguous
+            //           bytes per row; a second bf16 output leaves as 8-byte stores (64 contiguous bytes per row and instruction)
             const int gcw = g * a.N + nw0;
             const float* const resw = a.res ? a.res + (long long)bz * a.res_bs + gcw : nullptr;
             auto lean_pass = [&](auto IP, auto MODE, auto PERMC, f32x4 (&bi)[4], f32x4 (&gt)[4], f32x4 (&al)[4], f32x4 (&al2)[4], f32x4 (&rs)[4])
@@ -87,8 +89,28 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT]
                 constexpr int ip = decltype(IP)::value;
                 constexpr int PERM = decltype(PERMC)::value;
                 typedef decltype(MODE) MD;
-                auto rsel = [&](int q) { return PERM == 2 ? (lane >> 3) + 8 * (q >> 1) : prow; };
-                auto cof = [&](int q) { return PERM == 2 ? (lane & 7) * 8 + (q & 1) * 4 : PERM == 1 ? q * 16 + (lane & 3) * 4 : pcs + q * 4; };
+                auto rsel = [&](int q) { return PERM >= 2 ? (lane >> 3) + 8 * (q >> 1) : prow; };
+                auto cof = [&](int q) {
+                    return PERM == 3 ? (q & 1) * 32 + (lane & 7) * 4 : PERM == 2 ? (lane & 7) * 8 + (q & 1) * 4 : PERM == 1 ? q * 16 + (lane & 3) * 4 : pcs + q * 4;
+                };
+                // bf16 results: 16-byte stores of two adjacent column groups (PERM 0 / 2) or one 8-byte store per group (PERM 1 / 3)
+                auto store_bf16 = [&](auto* base, long long ld, int row_off, const f32x4 (&v)[4]) __attribute__((always_inline)) {
+                    if constexpr (PERM == 0 || PERM == 2) {
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            bf16x8 w8;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { w8[e] = f32_to_bf16(v[2 * u][e]); w8[4 + e] = f32_to_bf16(v[2 * u + 1][e]); }
+                            if (mw0 + ip * 16 + rsel(2 * u) < a.M) store8(base + (long long)(mw0 + ip * 16 + rsel(2 * u) + row_off) * ld + cof(2 * u), w8);
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const bf16x4 w4 = {f32_to_bf16(v[q][0]), f32_to_bf16(v[q][1]), f32_to_bf16(v[q][2]), f32_to_bf16(v[q][3])};
+                            if (mw0 + ip * 16 + rsel(q) < a.M) *reinterpret_cast<bf16x4*>(base + (long long)(mw0 + ip * 16 + rsel(q) + row_off) * ld + cof(q)) = w4;
+                        }
+                    }
+                };
                 const int act = MD::rt ? a.act : MD::act;
                 const bool has_res = MD::rt ? (resw != nullptr) : (bool)MD::res;
                 const bool out_f32 = MD::rt ? (a.out_f32 != 0) : (bool)MD::of32;
@@ -145,19 +167,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT]
                         for (int q = 0; q < 4; ++q)
                             if (row0 + rsel(q) < a.M) *reinterpret_cast<f32x4*>(ob32 + (long long)(row0 + rsel(q) + a.out_row_off) * a.ldo + cof(q)) = v[q];
                     } else if constexpr (sizeof(T) == 2) {
-                        static_assert(MD::rt || MD::of32 || PERM != 1, "PERM 1 has no 8-column bf16 runs");
-                        T* const ob16 = reinterpret_cast<T*>(a.out) + ob + gcw;
-#pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            bf16x8 w8;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) { w8[e] = f32_to_bf16(v[2 * u][e]); w8[4 + e] = f32_to_bf16(v[2 * u + 1][e]); }
-                            if (row0 + rsel(2 * u) < a.M) store8(ob16 + (long long)(row0 + rsel(2 * u) + a.out_row_off) * a.ldo + cof(2 * u), w8);
-                        }
+                        store_bf16(reinterpret_cast<T*>(a.out) + ob + gcw, a.ldo, a.out_row_off, v);
                     }
                 }
                 if (has_out2) {
-                    static_assert(!MD::o2 || PERM != 1, "PERM 1 has no 8-column bf16 runs");
                     T* const ob2 = reinterpret_cast<T*>(a.out2) + (long long)bz * a.out2_bs + gcw;
                     const int act2 = MD::rt ? a.act2 : MD::act2;
                     if (act2 != ACT_NONE) {
@@ -173,13 +186,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT]
                         }
                     }
                     if constexpr (sizeof(T) == 2) {
-#pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            bf16x8 w8;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) { w8[e] = f32_to_bf16(v[2 * u][e]); w8[4 + e] = f32_to_bf16(v[2 * u + 1][e]); }
-                            if (row0 + rsel(2 * u) < a.M) store8(ob2 + (long long)(row0 + rsel(2 * u) + a.out2_row_off) * a.ldo2 + cof(2 * u), w8);
-                        }
+                        store_bf16(ob2, a.ldo2, a.out2_row_off, v);
                     } else {
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
@@ -195,7 +202,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT]
             auto lean_all = [&](auto MODE) __attribute__((always_inline)) {
                 typedef decltype(MODE) MD;
                 // the permuted maps assume 4 lanes per 64-column row and one 16-row tile per pass (the 256-tile form and the vocoder form)
-                constexpr int PERM = (MD::rt || MD::o2 || WN != 64 || MT_PASS != 1) ? 0 : (MD::of32 || sizeof(T) != 2) ? 1 : 2;
+                constexpr int PERM = (MD::rt || WN != 64 || MT_PASS != 1) ? 0 : MD::o2 ? 3 : (MD::of32 || sizeof(T) != 2) ? 1 : 2;   // (PERM 3 for the plain fp32 modes measured 2-3 % slower than PERM 1)
                 std::integral_constant<int, PERM> pc;
                 f32x4 bi[4], gt[4], al[4], al2[4], rs[4];
                 lean_pass(std::integral_constant<int, 0>{}, MODE, pc, bi, gt, al, al2, rs);
