@@ -692,6 +692,9 @@ static int launch_t(const AttnArgs& a_in, hipStream_t s) {
         // the decode step next to it takes 2.6 ms instead of 4.1 ms (tools/contention_probe.py).
         // With a chunk mask the last workgroup of a head does twice the average work: 128-row workgroups (twice as many, three per SIMD)
         // balance better than 256-row ones (T = 5632, chunk 50: 244 vs 288 us; the unmasked pass takes 392 us).
+        // (Measured and dropped: giving the rows of the last, partial round of 256-row workgroups to a second launch of 128-row workgroups —
+        // T = 5632, 704 workgroups: 364 vs 337 us; 2816 workgroups: flow solve 441 vs 431 ms.  The rounds are not uniform enough for the
+        // tail to be worth a kernel boundary.)
         const dim3 g4((a.n_rows + 255) / 256, a.heads, a.batch), g2((a.n_rows + 127) / 128, a.heads, a.batch);
         if (a.n_rows >= 2048 && a.chunk <= 0) {
             if (a.q_log2) hipLaunchKernelGGL((attn_dit_kernel<4, true, true>), g4, dim3(256), 0, s, a);

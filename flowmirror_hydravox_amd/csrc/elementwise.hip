@@ -36,7 +36,12 @@ __global__ __launch_bounds__(256) void reduce_rmsnorm_kernel(ReduceNormArgs a) {
     const float* bias = a.bias ? a.bias + (long long)z * a.bias_zs : nullptr;
     const float* gain = a.gain ? a.gain + (long long)z * a.gain_zs : nullptr;
     float ss = 0.0f;
+    bool y_done = false;
     if (part && (H & 3) == 0 && (a.part_stride & 3) == 0 && (a.ldx & 3) == 0) {
+        // plain copy (no statistics needed): y leaves from the registers that hold the new x — no barrier, no re-read of x through memory
+        const bool y_inline = a.y && !a.do_norm && (a.ldy & 3) == 0;
+        T* const yr = reinterpret_cast<T*>(a.y) + (long long)m * a.ldy;
+        y_done = y_inline;
         // 16-byte columns, all split partials of a column in flight at once (the loads are independent; only the adds are ordered)
         for (int c = threadIdx.x * 4; c < H; c += 1024) {
             f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
@@ -53,8 +58,13 @@ __global__ __launch_bounds__(256) void reduce_rmsnorm_kernel(ReduceNormArgs a) {
             v += acc;
             if (bias) v += *reinterpret_cast<const f32x4*>(bias + c);
             *reinterpret_cast<f32x4*>(xr + c) = v;
+            if (y_inline) {
+                if constexpr (sizeof(T) == 2) *reinterpret_cast<bf16x4*>(yr + c) = bf16x4{f32_to_bf16(v[0]), f32_to_bf16(v[1]), f32_to_bf16(v[2]), f32_to_bf16(v[3])};
+                else *reinterpret_cast<f32x4*>(yr + c) = v;
+            }
             ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
         }
+        if (y_done) return;
     } else {
         for (int c = threadIdx.x; c < H; c += 256) {
             float v = xr[c];

@@ -28,7 +28,9 @@ constexpr int BM = 256, WM = 128, WN = 64, MT = WM / 16, NT = WN / 16;
 //   <BN 128, BK 32, 4 waves>: TWO independent workgroups per CU (48 KiB each), 2 x 2 waves — the same 128 x 64 wave tile and two waves per
 //       SIMD, but the two waves of a SIMD belong to different workgroups: one's epilogue and barrier waits run under the other's K-loop.
 //       K-tile rows are 64 B: a DMA instruction deposits 16 rows, swizzle chunk ^ ((row >> 1) & 3) (conflict-free ds_read_b128, checked by
-//       enumeration of the lane groups).
+//       enumeration of the lane groups).  Correct (GPU tests pass with it) but SLOWER than the first form — 1.5x the L2 -> LDS bytes per
+//       flop and twice the barriers cost more than the overlap returns (out_proj 154 vs 149 us, FF1 276 vs 258, FF2 279 vs 254 at
+//       M = 45056) — so it is not instantiated.
 template <int EPI, int BN, int BK, int NWAVE>
 __global__ __launch_bounds__(NWAVE * 64, 2) void gemm_big_kernel(GemmArgs a, int tiles_m, int tiles_n) {
     typedef bf16_t T;
@@ -155,8 +157,7 @@ int launch_gemm_big(const GemmArgs& a, hipStream_t s) {
     // below half a round of the 256 CUs the 128 x 128 form (2-3 workgroups per CU, four times as many tiles) balances better (measured: M = 11264,
     // N = 1024: 176 tiles tie; M = 2816: 44 tiles lose 177 vs 267 TF/s)
     static const long long min_tiles = [] { const char* e = getenv("HVX_GEMM_BIG_MIN_TILES"); return e ? atoll(e) : 128LL; }();   // (tuning knob)
-    static const int form = [] { const char* e = getenv("HVX_GEMM_BIG_FORM"); return e ? atoi(e) : 1; }();                        // (tuning knob)
-    if (form == 2) return launch_form<128, 32, 4>(a, s, 2 * min_tiles);
+    // (launch_form<128, 32, 4> — two workgroups per CU — measured 3-10 % slower on every DiT Linear at M = 45056: flow solve 450 vs 433 ms)
     return launch_form<256, 64, 8>(a, s, min_tiles);
 }
 
