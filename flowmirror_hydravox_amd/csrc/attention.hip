@@ -567,6 +567,9 @@ __global__ __launch_bounds__(256, 2) void attn_dit_kernel(AttnArgs a) {
         for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
             for (int m = 0; m < 2; ++m) vf[dt][m] = load8(&Vs[buf][(dt * 16 + fr) * LD + m * 32 + fg * 8]);
+        // (Measured and dropped: __builtin_amdgcn_sched_barrier(0) between the pipeline steps.  The disassembly then shows the pinned
+        // "MFMA, exp x 3" interleave with hardly any s_nop left, but 30 more scratch instructions (spills inside the loop) and the kernel is
+        // SLOWER: T = 5632 generic form 369 vs 337 us, flow solve (pre-scaled form) 564 vs 431 ms.)
         if constexpr (QR == 4) {
             qk(1, sb); sm(0, sa, pa);
             pin(std::integral_constant<int, 8>{}, std::integral_constant<int, PRE ? 3 : 5>{});
