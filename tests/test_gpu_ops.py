@@ -79,6 +79,34 @@ def test_conv_split_bf16_form_matches_fp64(cin, cout, k, dil, T):
     assert e_exact < 5e-6 and e_split < 2e-5, (e_exact, e_split)
 
 
+@pytest.mark.parametrize('cin,cout,k,dil,T', [(512, 512, 3, 3, 40003), (64, 64, 7, 1, 70001)])
+def test_conv_split_bf16_resblock_modes(cin, cout, k, dil, T):
+    """The two compile-time epilogue modes the HiFT ResBlocks launch on gemm_x3.hip (gemm_epilogue.h, LEAN 2): convs1 = Snake(conv + b) -> fp32,
+    convs2 = conv + b + residual -> fp32 plus Snake of that as the second output (the next block's input); both vocoder tile forms, ragged last
+    row tile, against fp64."""
+    _lib, ops, packing = _mods()
+    x = _rand(1, cin, T, seed=51)
+    w = _rand(cout, cin, k, seed=52) / math.sqrt(cin * k)
+    b = _rand(cout, seed=53)
+    a1 = _rand(cout, seed=54).abs() + 0.1
+    a2 = _rand(cout, seed=55).abs() + 0.1
+    res = _rand(1, T, cout, seed=56)
+    lin = F.conv1d(F.pad(x.double(), ((k - 1) * dil, 0)), w.double(), b.double(), dilation=dil).transpose(1, 2)
+    snake = lambda v, al: v + torch.sin(v * al.double()) ** 2 / (al.double() + 1e-9)
+    kw = dict(n_out=cout, taps=k, cin_pad=(cin + 31) // 32 * 32, pad_left=(k - 1) * dil, dil=dil, x3=True)
+    xr, wp = _rows(x, torch.float32).to(DEV), _pack_conv(w, torch.float32).to(DEV)
+    o1 = ops.conv1d(xr, wp, b.to(DEV), act=_lib.ACT_SNAKE, act_alpha=a1.to(DEV), **kw).cpu().double()[..., :cout]
+    ref1 = snake(lin, a1)
+    assert (o1 - ref1).abs().max().item() / ref1.abs().max().item() < 2e-5
+    out = torch.zeros(1, T, cout, device=DEV)
+    out2 = torch.zeros(1, T, cout, device=DEV)
+    ops.conv1d(xr, wp, b.to(DEV), res=res.to(DEV), out=out, out2=out2, act2=_lib.ACT_SNAKE, act2_alpha=a2.to(DEV), **kw)
+    ref = lin + res.double()
+    assert (out.cpu().double() - ref).abs().max().item() / ref.abs().max().item() < 2e-5
+    ref2 = snake(ref, a2)
+    assert (out2.cpu().double() - ref2).abs().max().item() / ref2.abs().max().item() < 2e-5
+
+
 @pytest.mark.parametrize('M,N,K,B', [(6144, 4096, 128, 1), (3000, 1024, 192, 8), (6181, 4096 + 64, 64, 1), (2049, 2048, 1024, 6)])
 def test_linear_256_tile_form(M, N, K, B):
     """gemm_big.hip (256 x 256 x 64 tiles, 8 waves, LDS-DMA with source-side swizzle, XCD-ordered tiles) takes bf16 Linears with at least
@@ -97,6 +125,39 @@ def test_linear_256_tile_form(M, N, K, B):
                out2=out2)
     torch.testing.assert_close(out.cpu(), ref, rtol=2e-2, atol=2e-2)
     torch.testing.assert_close(out2.float().cpu(), ref, rtol=3e-2, atol=3e-2)
+
+
+@pytest.mark.parametrize('mode', ['gated_residual_in_place', 'gelu_bf16', 'plain_bf16', 'plain_f32'])
+@pytest.mark.parametrize('M,N,K,B', [(8205, 1024, 1024, 1), (4211, 1024, 2048, 2), (4100, 2048, 1024, 1)])
+def test_linear_256_tile_form_dit_epilogue_modes(mode, M, N, K, B):
+    """The compile-time epilogue modes of gemm_big.hip exactly as the DiT launches them (gemm_epilogue.h: LeanMode + the per-mode lane maps):
+    x += gate * (a W^T + b) in place on the fp32 residual stream (out_proj, FF2), GELU(tanh) -> bf16 (FF1), bias -> bf16, and the run-time
+    form (bias -> fp32); ragged last row tile, per-batch gate.  The model tests reach these modes only through QKV / FF1 (their out_proj /
+    FF2 have fewer than 128 tiles at test sizes and take the 128-tile kernel)."""
+    _lib, ops, packing = _mods()
+    a = _rand(B, M, K, seed=80).bfloat16()
+    w = (_rand(N, K, seed=81) / math.sqrt(K)).bfloat16()
+    b = _rand(N, seed=82)
+    lin = a.float() @ w.float().t() + b
+    ad, wd, bd = a.to(DEV), w.to(DEV), b.to(DEV)
+    if mode == 'gated_residual_in_place':
+        gate = _rand(B, N, seed=83)
+        x = _rand(B, M, N, seed=84)
+        xd = x.to(DEV)
+        ops.conv1d(ad, wd, bd, n_out=N, taps=1, cin_pad=K, gate=gate.to(DEV), res=xd, out=xd)
+        torch.testing.assert_close(xd.cpu(), x + gate[:, None, :] * lin, rtol=2e-3, atol=2e-3)
+    elif mode == 'gelu_bf16':
+        out = torch.zeros(B, M, N, dtype=torch.bfloat16, device=DEV)
+        ops.conv1d(ad, wd, bd, n_out=N, taps=1, cin_pad=K, act=_lib.ACT_GELU_TANH, out=out)
+        torch.testing.assert_close(out.float().cpu(), F.gelu(lin, approximate='tanh'), rtol=1e-2, atol=1e-2)
+    elif mode == 'plain_bf16':
+        out = torch.zeros(B, M, N, dtype=torch.bfloat16, device=DEV)
+        ops.conv1d(ad, wd, bd, n_out=N, taps=1, cin_pad=K, out=out)
+        torch.testing.assert_close(out.float().cpu(), lin, rtol=1e-2, atol=1e-2)
+    else:
+        out = torch.zeros(B, M, N, dtype=torch.float32, device=DEV)
+        ops.conv1d(ad, wd, bd, n_out=N, taps=1, cin_pad=K, out=out)
+        torch.testing.assert_close(out.cpu(), lin, rtol=2e-3, atol=2e-3)
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
