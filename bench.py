@@ -54,7 +54,7 @@ def parse():
                          'chains: the round-1 form, --lm-chains independent decode chains of one step each; serial: stages back to back')
     ap.add_argument('--acoustic-batch', type=int, default=4, help='utterances per padded CFM solve (x CFG 2 rows per estimator call)')
     ap.add_argument('--acoustic-min-batch', type=int, default=4, help='(--mode continuous) the acoustic stage waits for this many finished utterances (throughput over latency)')
-    ap.add_argument('--acoustic-chains', type=int, default=1, help='(--mode chains) batches whose flow + vocoder run concurrently')
+    ap.add_argument('--acoustic-chains', type=int, default=1, help='(--mode chains) kept for compatibility: more than one concurrent acoustic chain is not supported (clamped to 1)')
     ap.add_argument('--lm-chains', type=int, default=3, help='(--mode chains) batches whose LM decode runs concurrently')
     ap.add_argument('--serial', action='store_true', help='same as --mode serial')
     ap.add_argument('--prof-period', type=int, default=17, help='every n-th launch of a kernel class is bracketed in the profiling step (prime: no aliasing with the 4-GEMM block period)')

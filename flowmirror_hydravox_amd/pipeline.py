@@ -316,7 +316,10 @@ class HvxPipeline:
         batches decode, and (b) `lm_chains` batches decode at the same time, each on its own native handle (KV cache, workspace, stream,
         graphs) over the same weight tensors and driven by its own host thread: two chains fill each other's launch gaps and together
         emit 1.63x the tokens of one (tools/two_chain_probe.py); with three the acoustic stage is the bottleneck of the bench workload.
-        `acoustic_chains` > 1 runs the flow + vocoder of several batches at once as well (measured: slower, they are throughput-bound).
+        `acoustic_chains` > 1 (flow + vocoder of several batches at once) is NOT supported and is clamped to 1: two concurrent acoustic chains
+        measured slower (both are throughput-bound) and, in about one run in five of tests/test_gpu_models.py::test_pipelined_batches_equal_serial,
+        returned a waveform that differed from the serial result (token ids equal; never with one chain in 40+ runs; not seen with the caching
+        allocator off, i.e. with every free synchronising the device) — an unexplained cross-stream hazard is not something to ship.
         At most max(lm_chains, acoustic_chains) + 1 batches are in flight.  Results are identical
         to synthesize(): every utterance carries its own sampler seed and no stage depends on another batch.  In the stats llm_seconds
         is the decode wall time of the batch and flow_seconds + hift_seconds the wall time of its acoustic stages, all while overlapped."""
@@ -326,7 +329,10 @@ class HvxPipeline:
             self._bg_stream = torch.cuda.Stream(device=self.device, priority=0)
             self._bg_streams = [self._bg_stream]
             self._bg_pools = []
-        lm_chains, acoustic_chains = max(1, int(lm_chains)), max(1, int(acoustic_chains))
+        if int(acoustic_chains) > 1:
+            import warnings
+            warnings.warn('HvxPipeline.synthesize_pipelined: acoustic_chains > 1 is not supported (see the docstring); using 1')
+        lm_chains, acoustic_chains = max(1, int(lm_chains)), 1
         while len(self._bg_pools) < acoustic_chains:
             self._bg_pools.append(ThreadPoolExecutor(max_workers=1, thread_name_prefix='hvx-acoustic%d' % len(self._bg_pools)))
         for k in range(acoustic_chains):

@@ -515,7 +515,8 @@ def test_pipelined_batches_equal_serial(tiny_cfg):
                        inference_head_num=2)
     batches = [[synthetic_utterance(tiny_cfg, 10 * b + i, 6 + i) for i in range(3)] for b in range(5)]
     serial = [pipe.synthesize(b, max_token_text_ratio=5, min_token_text_ratio=5) for b in batches]
-    # default (three concurrent LM decode chains + one acoustic chain), the plain two-stage overlap, and two acoustic chains
+    # default (three concurrent LM decode chains + one acoustic chain), the plain two-stage overlap, two LM chains (a request for two acoustic
+    # chains is clamped to one: see HvxPipeline.synthesize_pipelined)
     for kw in ({}, dict(lm_chains=1), dict(lm_chains=2, acoustic_chains=2)):
         piped = list(pipe.synthesize_pipelined(batches, max_token_text_ratio=5, min_token_text_ratio=5, **kw))
         assert len(piped) == len(serial)
