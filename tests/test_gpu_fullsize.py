@@ -111,3 +111,67 @@ def test_hift_of_a_512_char_utterance_split_bf16_convs_vs_exact_fp32_convs(tmp_p
     print('HiFT 5632 frames: split-bf16 vs exact fp32 convolutions, relative waveform difference %.2e, max |diff| %.2e' % (rel, float((a - b).abs().max())))
     # measured 2.2e-4 (the harmonic source integrates a phase over 2.7 M samples; the small-size bound per convolution is 2e-5)
     assert rel < 1e-3, rel
+
+
+@pytest.mark.parametrize('S', [32, 64])
+def test_llm_decode_grid_at_full_depth_vs_teacher_forced_prefill(S):
+    """The 24-layer CV3 LM, S sequences x 2 heads = the 64- / 128-row decode grid forms of the bench (skinny GEMMs in 64-row chunks, mid-M
+    split-K, GQA-packed split attention + combine) at contexts 1150..1970: the log-probs of ONE decode step over KV caches filled by prefill must be the
+    log-probs of a teacher-forced prefill of prefix + the step's tokens —
+      * bf16 decode step vs bf16 prefill: the same arithmetic through different kernels (tiled prefill forms) -> bf16 rounding-order noise;
+      * bf16 decode step vs the exact-fp32 prefill forms (what the small-size tests pin to the oracle / the reference): the bf16 contract."""
+    from flowmirror_hydravox_amd import cv3_config
+    from flowmirror_hydravox_amd import weights as W
+    from flowmirror_hydravox_amd.llm import HvxLLM
+    c = cv3_config().llm
+    sd = W.make_llm_state(c, seed=1986, init='fan_in')
+    K = 2
+    g = torch.Generator().manual_seed(9)
+    prefixes, steps = [], []
+    for s in range(S):
+        n_text, n_sp = 150 + 4 * s, 1000 + 9 * s                                    # contexts 1152 .. 1971 rows
+        text = torch.randint(0, c.text_vocab, (n_text,), generator=g, dtype=torch.int32)
+        sp = torch.randint(0, c.speech_tokens, (n_sp + K,), generator=g, dtype=torch.int32)
+        prefixes.append((text, sp[:n_sp]))
+        steps.append(sp[n_sp:])
+    probe = [0, 7, 19, S - 1]                                                         # sequences teacher-forced for the comparison
+    ref = {}
+    for dt in (torch.float32, torch.bfloat16):
+        llm = HvxLLM(c, sd, dtype=dt, max_batch=S, max_ctx=2048, inference_head_num=K)
+        for s in probe:
+            text, sp = prefixes[s]
+            logp, y = llm.prefill_logp(llm._encode_prefix(text, None, torch.cat([sp, steps[s]])), head_k=K)
+            ref[(dt, s)] = (logp.cpu(), y.cpu())
+        if dt == torch.bfloat16:
+            dev = llm.device
+            llm._bind(S, 2048)
+            lens = []
+            for s in range(S):                                                       # prefill every prefix into its own KV slot
+                text, sp = prefixes[s]
+                enc = llm._encode_prefix(text, None, sp)
+                n = len(enc)
+                lens.append(n)
+                tok = torch.tensor(enc, dtype=torch.int32, device=dev)
+                ctrl = torch.tensor([s, 0, n, n, n - 1], dtype=torch.int32, device=dev)
+                llm._forward(1, n, tok, ctrl, K, torch.empty(1, K, c.vocab, dtype=torch.float32, device=dev))
+            tok = torch.cat(steps).to(dev)
+            ctrl = torch.tensor([list(range(S)), lens, [K] * S, [n + K for n in lens], [i * K + K - 1 for i in range(S)]], dtype=torch.int32).reshape(-1).to(dev)
+            logp = torch.empty(S, K, c.vocab, dtype=torch.float32, device=dev)
+            llm._forward(S, K, tok, ctrl, K, logp)
+            torch.cuda.synchronize()
+            dec = logp.cpu()
+        del llm
+        torch.cuda.empty_cache()
+    worst = [0.0, 0.0, 0.0]
+    for s in probe:
+        lb, lf = ref[(torch.bfloat16, s)][0], ref[(torch.float32, s)][0]
+        top = lf.topk(25, dim=-1).indices                                            # the tokens the sampler can pick (top_k 25 of the reference)
+        d_same = (dec[s].gather(-1, top) - lb.gather(-1, top)).abs().max().item()
+        d_fp32 = (dec[s].gather(-1, top) - lf.gather(-1, top)).abs().max().item()
+        agree = (dec[s].argmax(-1) == lf.argmax(-1)).all().item()
+        worst = [max(worst[0], d_same), max(worst[1], d_fp32), worst[2] + (0 if agree else 1)]
+    print('24 layers, %d-row decode grid: |dlogp| over the top-25 tokens vs the bf16 prefill forms %.3f, vs the fp32 forms %.3f; argmax flips %d of %d'
+          % (S * K, worst[0], worst[1], worst[2], len(probe)))
+    assert torch.isfinite(dec).all()
+    # measured 0.034 / 0.064 at 64 rows (log-probs of the 25 most likely of 6761 tokens, 24 layers + the 22016-wide MTP heads in bf16)
+    assert worst[0] < 0.1 and worst[1] < 0.2, worst
