@@ -5,6 +5,8 @@ below the text frontend: speech tokens from the multi-head LM, mel from the flow
 with the reference's own timing definitions (TPS = tokens / LLM wall, RTF = total wall / audio seconds, :563-565, :594-604).
 The LLM decodes all utterances of the batch in lock-step; flow and HiFT run one utterance per call (each saturates the GPU).
 """
+import os
+import threading
 import time
 from dataclasses import dataclass, field
 from typing import List, Optional
@@ -62,6 +64,9 @@ def synthetic_utterance(cfg: HvxConfig, index: int, n_text: int, n_prompt_speech
         u.prompt_feat = torch.randn(2 * n_prompt_speech, cfg.flow.mel, generator=g)
         u.prompt_text = torch.randint(0, hi, (n_prompt_text,), generator=g, dtype=torch.int32)
     return u
+
+
+_DEBUG_LOCK = threading.Lock()
 
 
 class HvxPipeline:
@@ -187,11 +192,22 @@ class HvxPipeline:
         """flow + vocoder of one batch on a background stream (runs in a worker thread; returns when the waveforms are complete)"""
         flow, hift, stream = self._acoustic_chain(k)
         torch.cuda.set_device(stream.device)                       # the current device is per thread
+        dbg = os.environ.get('HVX_DEBUG_SERIALIZE', '')            # (reproducer switch: run one stage of concurrent chains under a lock)
         with torch.inference_mode(), torch.cuda.stream(stream):
             t0 = time.time()
-            mels = self._mels(utts, toks, flow)
+            if dbg in ('flow', 'both'):
+                with _DEBUG_LOCK:
+                    mels = self._mels(utts, toks, flow)
+                    stream.synchronize()
+            else:
+                mels = self._mels(utts, toks, flow)
             t1 = time.time()                       # enqueue time only: the stream is not drained between the stages
-            wavs = self._waves(mels, hift)
+            if dbg in ('hift', 'both'):
+                with _DEBUG_LOCK:
+                    wavs = self._waves(mels, hift)
+                    stream.synchronize()
+            else:
+                wavs = self._waves(mels, hift)
             stream.synchronize()
             t2 = time.time()
         st.flow_seconds, st.hift_seconds = t1 - t0, t2 - t1
@@ -329,10 +345,14 @@ class HvxPipeline:
             self._bg_stream = torch.cuda.Stream(device=self.device, priority=0)
             self._bg_streams = [self._bg_stream]
             self._bg_pools = []
-        if int(acoustic_chains) > 1:
+        if int(acoustic_chains) > 1 and os.environ.get('HVX_EXPERIMENTAL_ACOUSTIC_CHAINS'):     # (reproducer switch: tools/_flake_loop.sh)
+            lm_chains, acoustic_chains = max(1, int(lm_chains)), int(acoustic_chains)
+        elif int(acoustic_chains) > 1:
             import warnings
             warnings.warn('HvxPipeline.synthesize_pipelined: acoustic_chains > 1 is not supported (see the docstring); using 1')
-        lm_chains, acoustic_chains = max(1, int(lm_chains)), 1
+            lm_chains, acoustic_chains = max(1, int(lm_chains)), 1
+        else:
+            lm_chains, acoustic_chains = max(1, int(lm_chains)), 1
         while len(self._bg_pools) < acoustic_chains:
             self._bg_pools.append(ThreadPoolExecutor(max_workers=1, thread_name_prefix='hvx-acoustic%d' % len(self._bg_pools)))
         for k in range(acoustic_chains):
