@@ -16,10 +16,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--lm', type=int, default=2)
 ap.add_argument('--acoustic', type=int, default=2)
 ap.add_argument('--reps', type=int, default=10)
+ap.add_argument('--flow-bf16', action='store_true', help='bf16 flow decoder (other GEMM / attention kernels than the fp32 forms)')
 ap.add_argument('--same-pipe', action='store_true', help='serial and pipelined runs on the same pipeline object (as the test does)')
 a = ap.parse_args()
 cfg = tiny_config()
-kw = dict(llm_dtype=torch.float32, flow_dtype=torch.float32, max_batch=3, max_ctx=512, max_t=1024, seed=7, init='fan_in', inference_head_num=2)
+kw = dict(llm_dtype=torch.float32, flow_dtype=torch.bfloat16 if a.flow_bf16 else torch.float32, max_batch=3, max_ctx=512, max_t=1024, seed=7, init='fan_in', inference_head_num=2)
 ref = HvxPipeline(cfg, **kw)
 pipe = ref if a.same_pipe else HvxPipeline(cfg, **kw)
 batches = [[synthetic_utterance(cfg, 10 * b + i, 6 + i) for i in range(3)] for b in range(5)]
@@ -34,4 +35,4 @@ for rep in range(a.reps):
                 bad += 1
                 d = (x - y).abs()
                 print('rep %d batch %d (chain %d) utterance %d: max |diff| %.3e, first differing sample %d of %d' % (rep, bi, bi % max(a.acoustic, 1), ui, d.max().item(), int((d > 0).nonzero()[0]), x.numel()))
-print('lm %d acoustic %d same_pipe %s: %d differing utterances in %d runs of %d' % (a.lm, a.acoustic, a.same_pipe, bad, a.reps, 15))
+print('lm %d acoustic %d same_pipe %s flow_bf16 %s: %d differing utterances in %d runs of %d' % (a.lm, a.acoustic, a.same_pipe, a.flow_bf16, bad, a.reps, 15))
