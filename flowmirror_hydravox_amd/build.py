@@ -15,8 +15,15 @@ CSRC = os.path.join(HERE, 'csrc')
 INCLUDE = os.path.join(os.path.dirname(HERE), 'include')
 OUT = os.path.join(HERE, 'libhvx.so')
 ARCH = 'gfx950'
+# No packed fp32 VALU instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) anywhere in libhvx.  Measured on MI355X (tools/mfma_interference.py,
+# DESIGN.md §8): a wave executing v_pk_*_f32 returns wrong low halves in lanes 48-63 now and then while ANOTHER wave on its SIMD streams bf16
+# MFMAs — e.g. hift_stft_kernel beside the split-bf16 vocoder convolutions of a second stream: 1941 of 3000 launches differ with the packed
+# forms, 0 of 3000 without.  hipcc's SLP vectoriser forms them from any two adjacent fp32 operations, so the feature is switched off for the
+# device pass (the host pass does not know the feature and says so; harmless).  Beside MFMAs the packed forms are slower than two scalar ops
+# anyway (MI355X_MICROARCH.md, "price of one filler beside MFMAs").
+NO_PACKED_F32 = ['-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops']
 FLAGS = ['-O3', '-std=c++17', '-fPIC', '--offload-arch=' + ARCH, '-Wall', '-Wno-unused-function', '-Wno-unused-variable', '-Wno-pass-failed',
-         '-I', CSRC, '-I', INCLUDE]
+         '-I', CSRC, '-I', INCLUDE] + NO_PACKED_F32
 
 
 # per-file additions: the attention softmax takes maxima of values that are never NaN (scores, -inf masks)

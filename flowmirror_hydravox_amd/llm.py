@@ -30,6 +30,12 @@ def _rope_tables(max_pos, head_dim, theta):
     return fr.cos().contiguous(), fr.sin().contiguous()
 
 
+
+def _fresh_seed():
+    """a sampler seed for a request that came without one, drawn from (and advancing) torch's global CPU generator"""
+    return int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+
+
 class _Request:
     def __init__(self, prefix_tok, n_text, min_len, max_len, noise):
         self.prefix = prefix_tok          # encoded int list (speech ids >= 0, text ids as -2-id)
@@ -230,6 +236,10 @@ class HvxLLM:
         def per_utt(v):
             return list(v) if isinstance(v, (list, tuple)) else [v] * len(texts)
         maxr, minr = per_utt(max_token_text_ratio), per_utt(min_token_text_ratio)
+        if seeds is None and len(texts) > 1:
+            # several unseeded utterances at once have no reference order of draws (the reference decodes one at a time): each gets its own
+            # stream, seeded from the global generator — never the same fork of its state for all of them
+            seeds = [_fresh_seed() for _ in texts]
         reqs = []
         for i, text in enumerate(texts):
             text = torch.as_tensor(text)
@@ -269,7 +279,7 @@ class HvxLLM:
             pt, ps = d.get('prompt_text'), d.get('prompt_speech_token')
             n_text = int(text.numel())
             r = _Request(self._encode_prefix(text, None if pt is None else torch.as_tensor(pt), None if ps is None else torch.as_tensor(ps)), n_text,
-                         int(n_text * d.get('min_token_text_ratio', 2)), int(n_text * d.get('max_token_text_ratio', 20)), NoiseStream(seed=d.get('seed'), chunk=8192))
+                         int(n_text * d.get('min_token_text_ratio', 2)), int(n_text * d.get('max_token_text_ratio', 20)), NoiseStream(seed=d['seed'] if d.get('seed') is not None else _fresh_seed(), chunk=8192))
             r.tag = d.get('tag')
             return r
         it = (to_req(d) for d in requests)

@@ -5,7 +5,6 @@ below the text frontend: speech tokens from the multi-head LM, mel from the flow
 with the reference's own timing definitions (TPS = tokens / LLM wall, RTF = total wall / audio seconds, :563-565, :594-604).
 The LLM decodes all utterances of the batch in lock-step; flow and HiFT run one utterance per call (each saturates the GPU).
 """
-import os
 import threading
 import time
 from dataclasses import dataclass, field
@@ -64,9 +63,6 @@ def synthetic_utterance(cfg: HvxConfig, index: int, n_text: int, n_prompt_speech
         u.prompt_feat = torch.randn(2 * n_prompt_speech, cfg.flow.mel, generator=g)
         u.prompt_text = torch.randint(0, hi, (n_prompt_text,), generator=g, dtype=torch.int32)
     return u
-
-
-_DEBUG_LOCK = threading.Lock()
 
 
 class HvxPipeline:
@@ -192,22 +188,11 @@ class HvxPipeline:
         """flow + vocoder of one batch on a background stream (runs in a worker thread; returns when the waveforms are complete)"""
         flow, hift, stream = self._acoustic_chain(k)
         torch.cuda.set_device(stream.device)                       # the current device is per thread
-        dbg = os.environ.get('HVX_DEBUG_SERIALIZE', '')            # (reproducer switch: run one stage of concurrent chains under a lock)
         with torch.inference_mode(), torch.cuda.stream(stream):
             t0 = time.time()
-            if dbg in ('flow', 'both'):
-                with _DEBUG_LOCK:
-                    mels = self._mels(utts, toks, flow)
-                    stream.synchronize()
-            else:
-                mels = self._mels(utts, toks, flow)
+            mels = self._mels(utts, toks, flow)
             t1 = time.time()                       # enqueue time only: the stream is not drained between the stages
-            if dbg in ('hift', 'both'):
-                with _DEBUG_LOCK:
-                    wavs = self._waves(mels, hift)
-                    stream.synchronize()
-            else:
-                wavs = self._waves(mels, hift)
+            wavs = self._waves(mels, hift)
             stream.synchronize()
             t2 = time.time()
         st.flow_seconds, st.hift_seconds = t1 - t0, t2 - t1
@@ -332,10 +317,9 @@ class HvxPipeline:
         batches decode, and (b) `lm_chains` batches decode at the same time, each on its own native handle (KV cache, workspace, stream,
         graphs) over the same weight tensors and driven by its own host thread: two chains fill each other's launch gaps and together
         emit 1.63x the tokens of one (tools/two_chain_probe.py); with three the acoustic stage is the bottleneck of the bench workload.
-        `acoustic_chains` > 1 (flow + vocoder of several batches at once) is NOT supported and is clamped to 1: two concurrent acoustic chains
-        measured slower (both are throughput-bound) and, in about one run in five of tests/test_gpu_models.py::test_pipelined_batches_equal_serial,
-        returned a waveform that differed from the serial result (token ids equal; never with one chain in 40+ runs; not seen with the caching
-        allocator off, i.e. with every free synchronising the device) — an unexplained cross-stream hazard is not something to ship.
+        `acoustic_chains` > 1 runs flow + vocoder of several batches at once, each chain with its own handles, workspaces and stream (both
+        stages are throughput-bound, so this buys little; it is supported and bit-identical to the serial path — the wrong waveforms it
+        returned now and then in round 2 were packed-fp32 VALU instructions disturbed by another queue's MFMA stream, see build.py).
         At most max(lm_chains, acoustic_chains) + 1 batches are in flight.  Results are identical
         to synthesize(): every utterance carries its own sampler seed and no stage depends on another batch.  In the stats llm_seconds
         is the decode wall time of the batch and flow_seconds + hift_seconds the wall time of its acoustic stages, all while overlapped."""
@@ -345,14 +329,7 @@ class HvxPipeline:
             self._bg_stream = torch.cuda.Stream(device=self.device, priority=0)
             self._bg_streams = [self._bg_stream]
             self._bg_pools = []
-        if int(acoustic_chains) > 1 and os.environ.get('HVX_EXPERIMENTAL_ACOUSTIC_CHAINS'):     # (reproducer switch: tools/_flake_loop.sh)
-            lm_chains, acoustic_chains = max(1, int(lm_chains)), int(acoustic_chains)
-        elif int(acoustic_chains) > 1:
-            import warnings
-            warnings.warn('HvxPipeline.synthesize_pipelined: acoustic_chains > 1 is not supported (see the docstring); using 1')
-            lm_chains, acoustic_chains = max(1, int(lm_chains)), 1
-        else:
-            lm_chains, acoustic_chains = max(1, int(lm_chains)), 1
+        lm_chains, acoustic_chains = max(1, int(lm_chains)), max(1, int(acoustic_chains))
         while len(self._bg_pools) < acoustic_chains:
             self._bg_pools.append(ThreadPoolExecutor(max_workers=1, thread_name_prefix='hvx-acoustic%d' % len(self._bg_pools)))
         for k in range(acoustic_chains):

@@ -84,10 +84,10 @@ def worker_process_tts_batched(num_workers_gpu, task_queue, result_dict, worker_
     normalise = _text_normaliser()                  # the same normaliser as worker_process_tts, in the batched and the one-by-one path
     pending = []
     stop = False
-    while not stop:
+    while not stop or pending:                      # tasks deferred behind a load_pt / other sampling parameters are served before the exit
         if not pending:
             pending.append(task_queue.get())
-        while len(pending) < max_batch:
+        while not stop and len(pending) < max_batch:
             try:
                 pending.append(task_queue.get_nowait())
             except _queue.Empty:

@@ -35,6 +35,28 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert _lib.load().hvx_abi_version() == 1
 
 
+def test_libhvx_holds_no_packed_fp32_instruction(tmp_path):
+    """DESIGN.md §8 / build.py: on MI355X a wave's v_pk_{fma,mul,add}_f32 return wrong values in lanes 48-63 now and then while a wave of
+    another queue streams MFMAs on the same SIMD (tools/mfma_interference.py), so the device code of the shipped library must not contain one."""
+    import shutil
+    from flowmirror_hydravox_amd import build as hvx_build
+    objdump = '/opt/rocm/lib/llvm/bin/llvm-objdump'
+    if not os.path.exists(objdump):
+        pytest.skip('llvm-objdump not present')
+    so = hvx_build.build(force=False)
+    shutil.copy(so, tmp_path / 'libhvx.so')
+    subprocess.run([objdump, '--offloading', 'libhvx.so'], cwd=tmp_path, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    objs = sorted(f for f in os.listdir(tmp_path) if 'amdgcn' in f)
+    assert objs, 'no gfx950 code object found in libhvx.so'
+    n_mfma = 0
+    for f in objs:
+        asm = subprocess.run([objdump, '-d', f], cwd=tmp_path, check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True).stdout
+        hits = sorted(set(re.findall(r'v_pk_(?:fma|mul|add)_f32', asm)))
+        assert not hits, (f, hits)
+        n_mfma += asm.count('v_mfma_')
+    assert n_mfma > 1000                   # (the scan did see the kernels)
+
+
 def test_ctypes_struct_sizes_match_the_c_header(tmp_path):
     """sizeof() of every argument struct as seen by a C compiler == the ctypes mirror (catches field drift)."""
     from flowmirror_hydravox_amd import _lib
