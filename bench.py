@@ -29,6 +29,9 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_BF16_PEAK_TF = 2500.0       # dense bf16
 MFMA_F32_PEAK_TF = 157.3         # f32-input MFMA == fp32 vector rate
+# The vocoder convolutions compute in fp32-equivalent arithmetic as THREE bf16 MFMAs per step (gemm_x3.hip): the rate their instruction mix
+# allows is a third of the bf16 matrix peak, and that is what their fraction is quoted against (never the 157 TF/s of the fp32 MFMA they replace)
+MFMA_X3_PEAK_TF = MFMA_BF16_PEAK_TF / 3.0
 
 KINDS = {0: ('llm_decode_gemm', 'hbm'), 1: ('dit_gemm_bf16', 'mfma'), 2: ('dit_attention_bf16', 'mfma'), 3: ('ras_sampler', 'hbm'),
          4: ('hift_conv_gemm_f32', 'mfma'), 5: ('llm_attention', 'hbm')}
@@ -48,6 +51,7 @@ def parse():
     ap.add_argument('--streams', type=int, default=64, help='(--config acoustic) pre-tokenised speech-token streams per GPU, lengths U{352..2816}')
     ap.add_argument('--tiny', action='store_true', help='toy dimensions (plumbing check only; INVALID as a benchmark)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-fp32-mode', action='store_true', help='skip the extra, untimed step in the parity-exact fp32 mode (the `fp32_mode` object of the line)')
     ap.add_argument('--lm-slots', type=int, default=64, help='sequences decoded in one grid (continuous batching): utterances of later steps join as earlier ones finish')
     ap.add_argument('--mode', choices=['continuous', 'chains', 'serial'], default='continuous',
                     help='continuous: one decode grid of --lm-slots sequences + acoustic stage of finished utterances beside it (default); '
@@ -74,16 +78,29 @@ def read_prof(lib):
     return out
 
 
+_LIB_BYTES = None
+
+
 def pmc_traffic(name):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r*_pmc_traffic.json; FETCH_SIZE / WRITE_SIZE in
-    separate passes with the gfx950 x2 FETCH correction).  PMC collection cannot run inside the timed bench."""
+    separate passes with the gfx950 x2 FETCH correction).  PMC collection cannot run inside the timed bench.  An entry is used only if
+    every kernel it was counted on (its "kernels" list of mangled names) is still a kernel of the libhvx.so being benchmarked — counters
+    of kernels that no longer exist are stale evidence and are refused (null)."""
     import glob
+    global _LIB_BYTES
     for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')), reverse=True):
         try:
             with open(path) as f:
                 d = json.load(f)
-            if name in d:
-                return int(d[name]['hbm_bytes_per_launch'])
+            if name not in d:
+                continue
+            if _LIB_BYTES is None:
+                with open(os.path.join(ROOT, 'flowmirror_hydravox_amd', 'libhvx.so'), 'rb') as f:
+                    _LIB_BYTES = f.read()
+            kernels = d[name].get('kernels')
+            if not kernels or any(k.encode() not in _LIB_BYTES for k in kernels):
+                return None
+            return int(d[name]['hbm_bytes_per_launch'])
         except Exception:
             pass
     return None
@@ -95,11 +112,14 @@ def roofline_of(name, p):
         return dict(kernel=name, bound='hbm', achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(ach / HBM_PEAK_GBS, 4),
                     traffic=pmc_traffic(name), avg_launch_us=round(p['avg_us'], 2), algorithmic_bytes_per_launch=round(p['work_per_launch']),
                     launches_per_timed_region=p['launches'], sampled_launches=p['sampled'])
-    peak = MFMA_F32_PEAK_TF if name.endswith('f32') else MFMA_BF16_PEAK_TF
+    peak = MFMA_X3_PEAK_TF if name.endswith('f32') else MFMA_BF16_PEAK_TF
     ach = p['rate'] / 1e12
-    return dict(kernel=name, bound='mfma', achieved=round(ach, 2), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4), traffic=None,
-                avg_launch_us=round(p['avg_us'], 2), algorithmic_flops_per_launch=round(p['work_per_launch']),
-                launches_per_timed_region=p['launches'], sampled_launches=p['sampled'])
+    d = dict(kernel=name, bound='mfma', achieved=round(ach, 2), peak=round(peak, 1), unit='TFLOP/s', frac=round(ach / peak, 4), traffic=pmc_traffic(name),
+             avg_launch_us=round(p['avg_us'], 2), algorithmic_flops_per_launch=round(p['work_per_launch']),
+             launches_per_timed_region=p['launches'], sampled_launches=p['sampled'])
+    if name.endswith('f32'):
+        d['peak_note'] = 'fp32-equivalent flops of the convolution; every step is 3 bf16 MFMAs on (hi, lo) operand pairs, so the peak is the dense bf16 peak / 3'
+    return d
 
 
 def cpu_baseline(cfg, pipe_seed, chars, heads):
@@ -249,10 +269,10 @@ def run_acoustic(args, cfg, world, rank, lib):
         'roofline': {'kernel': 'DiT estimator (all bf16 GEMMs + attention of the flow stage)', 'bound': 'mfma', 'achieved': round(ach, 1), 'peak': MFMA_BF16_PEAK_TF,
                      'unit': 'TFLOP/s', 'frac': round(ach / MFMA_BF16_PEAK_TF, 4), 'traffic': None,
                      'algorithmic_flops': 'SURVEY.md §8(d): 7.56 GF*T + 1.80 MF*T^2 per stream of T frames, summed over the streams / wall time of the flow stage'},
-        'roofline_other': [{'kernel': 'HiFT vocoder', 'bound': 'mfma', 'achieved': round(hift_flops / t_hift / 1e12 / world, 1), 'peak': MFMA_F32_PEAK_TF, 'unit': 'TFLOP/s',
-                            'frac': round(hift_flops / t_hift / 1e12 / world / MFMA_F32_PEAK_TF, 4),
-                            'note': '672 MF of fp32 convolution per mel frame against the fp32 matrix peak; the decode convolutions run as 3 bf16 MFMAs per step (gemm_x3.hip), '
-                                    'so fractions above what fp32 MFMA could reach are possible'}]}))
+        'roofline_other': [{'kernel': 'HiFT vocoder', 'bound': 'mfma', 'achieved': round(hift_flops / t_hift / 1e12 / world, 1), 'peak': round(MFMA_X3_PEAK_TF, 1), 'unit': 'TFLOP/s',
+                            'frac': round(hift_flops / t_hift / 1e12 / world / MFMA_X3_PEAK_TF, 4),
+                            'note': '672 MF of fp32-equivalent convolution per mel frame over the wall time of the whole vocoder stage; the decode convolutions run as 3 bf16 '
+                                    'MFMAs per step (gemm_x3.hip): peak = dense bf16 peak / 3'}]}))
 
 
 def main():
@@ -289,7 +309,7 @@ def main():
         torch.cuda.set_device(0)
     from flowmirror_hydravox_amd import _lib, cv3_config, tiny_config
     from flowmirror_hydravox_amd.pipeline import HvxPipeline, synthetic_utterance
-    from flowmirror_hydravox_amd.dp import gather_waveforms
+    from flowmirror_hydravox_amd.dp import gather_waveforms, shard_by_cost, Handoff
     from flowmirror_hydravox_amd.sampling import ras_sampling
     from functools import partial
     _lib.require_gpu()
@@ -306,11 +326,13 @@ def main():
     n_spk = int(chars * ratio)
     P_SPK, P_TXT = (75, 20) if zero_shot else (0, 0)           # configs[3]: 3 s prompt = 75 speech tokens / 150 mel frames, 20 prompt-text tokens
 
+    def n_text_of(index):
+        return chars if not zero_shot else int(torch.randint(64, 513, (1,), generator=torch.Generator().manual_seed(7_000_003 + index)))
+
     def make_utt(index):
         if not zero_shot:
             return synthetic_utterance(cfg, index, chars)
-        n_text = int(torch.randint(64, 513, (1,), generator=torch.Generator().manual_seed(7_000_003 + index)))
-        return synthetic_utterance(cfg, index, n_text, n_prompt_speech=P_SPK, n_prompt_text=P_TXT)
+        return synthetic_utterance(cfg, index, n_text_of(index), n_prompt_speech=P_SPK, n_prompt_text=P_TXT)
     max_ctx = 2 + chars + P_TXT + P_SPK + n_spk + K + 32
     sampling = partial(ras_sampling, top_p=0.9, top_k=10, win_size=32, tau_r=0.2)
     t_build = time.time()
@@ -339,6 +361,18 @@ def main():
     serial = None
     for _ in range(args.warmup):
         serial, got = step()
+    # BASELINE configs[1] read strictly: ONE batch of B utterances, lock-step decode grid of B sequences, no utterance of another batch in
+    # flight, stages back to back — its throughput and its latency (every utterance of the batch is complete after `latency_s`)
+    strict = None
+    if args.warmup > 0:
+        torch.cuda.synchronize()
+        t_s = time.time()
+        serial, got = step()
+        torch.cuda.synchronize()
+        t_s = time.time() - t_s
+        strict = {'value': round(serial.tokens / t_s, 1), 'unit': 'speech-tokens/s', 'rtf': round(t_s / serial.audio_seconds, 6), 'latency_s': round(t_s, 3),
+                  'utterances_in_flight_per_gpu': B, 'schedule': 'one batch of %d, lock-step decode, stages back to back, no continuous batching (one un-timed extra step after the warm-up)' % B,
+                  'stage_seconds': {'llm': round(serial.llm_seconds, 4), 'flow': round(serial.flow_seconds, 4), 'hift': round(serial.hift_seconds, 4)}}
     lm_alone = None
     if args.mode == 'continuous' and args.warmup > 0:
         # the wide decode grid alone (nothing else on the GPU): --lm-slots utterances through the engine, untimed — `roofline.alone`
@@ -362,16 +396,20 @@ def main():
     else:
         # K steps of B utterances each = K * B utterances through the continuous-batching engine; finished waveforms are handed to rank 0
         # one step's worth (B utterances) at a time, inside the timed region
-        job = [make_utt((k * world + rank) * B + i) for k in range(args.steps) for i in range(B)]
-        ready, n_handed = [], 0
+        # the job is the GLOBAL list of steps x B x world utterances (global index = sampler seed), dealt longest-first across the ranks
+        # (dp.shard_by_cost): with mixed lengths every rank gets the same amount of text, with equal lengths the deal is
+        # round-robin; no rank ever needs another's utterances, so this is still weak scaling with no data-path collective
+        n_global = args.steps * B * world
+        shards = shard_by_cost([float(n_text_of(g)) for g in range(n_global)], world)
+        mine = shards[rank]
+        assert len(mine) == args.steps * B or zero_shot
+        job = [make_utt(g) for g in mine]
+        hand = Handoff(shards, B, dst=0, keep=False)
         for i, wav, toks in pipe.synthesize_continuous(job, lm_slots=args.lm_slots, max_token_text_ratio=ratio, min_token_text_ratio=ratio,
                                                        acoustic_batch=args.acoustic_batch, acoustic_min_batch=args.acoustic_min_batch):
-            ready.append((job[i].seed, wav))
-            if len(ready) == B:
-                got = gather_waveforms([w for _, w in ready], [gid for gid, _ in ready], dst=0)
-                n_handed += len(ready)
-                ready = []
-        assert n_handed == args.steps * B and not ready
+            hand.push(job[i].seed, wav)                # one step's worth (B utterances) per hand-off, inside the timed region
+        got = hand.finish()
+        assert rank != 0 or hand.n_received == n_global
         cont = dict(pipe.last_continuous)
     barrier()
     elapsed = time.time() - t0
@@ -411,7 +449,7 @@ def main():
         llm_s, flow_s, hift_s = float(tmax[3]), float(tmax[4]), float(tmax[5])
     if rank != 0:
         return
-    assert world > 1 or len(got) == B
+    assert world > 1 or len(got) == B or cont is not None
     in_flight = {'continuous': args.lm_slots + args.acoustic_batch, 'chains': B * (max(args.lm_chains, args.acoustic_chains) + 1), 'serial': B}[args.mode]
 
     # The dominant "kernel" is the decode step: one hipGraph replay of forward + sampler + advance (~160 launches of 5-9 us, which a
@@ -489,10 +527,33 @@ def main():
     if est:
         line['roofline_other'] = [roofline_of(n, prof[n]) for _, n in est if prof[n]['work_per_launch'] > 0]
         line['kernel_time_share_ms'] = {n: round(t, 1) for t, n in est}
+    if strict is not None:
+        line['strict_batch%d' % B] = strict
+    del pipe
+    torch.cuda.empty_cache()
+    if world == 1 and not args.no_fp32_mode and not args.tiny:
+        # the parity-exact mode (fp32 LM + fp32 flow: speech-token ids bit-exact against the reference, mel / waveform within 1e-3): the
+        # same batch, strict schedule, one un-timed warm-up on a single utterance and one measured step
+        try:
+            pipe32 = HvxPipeline(cfg, llm_dtype=torch.float32, flow_dtype=torch.float32, max_batch=B, max_ctx=max_ctx, max_t=2 * (n_spk + P_SPK) + 64,
+                                 seed=1986, init='normal02', sampling=sampling, inference_head_num=K)
+            pipe32.acoustic_batch = max(1, args.acoustic_batch)
+            pipe32.synthesize(utts[:1], max_token_text_ratio=ratio, min_token_text_ratio=ratio)
+            torch.cuda.synchronize()
+            t32 = time.time()
+            _, st32 = pipe32.synthesize(utts, max_token_text_ratio=ratio, min_token_text_ratio=ratio)
+            torch.cuda.synchronize()
+            t32 = time.time() - t32
+            line['fp32_mode'] = {'value': round(st32.tokens / t32, 1), 'unit': 'speech-tokens/s', 'rtf': round(t32 / st32.audio_seconds, 6), 'latency_s': round(t32, 3),
+                                 'dtype': 'f32 (LM and flow on the exact fp32 MFMA forms; vocoder as in the headline)',
+                                 'schedule': 'one batch of %d, lock-step decode, stages back to back: compare with strict_batch%d' % (B, B),
+                                 'stage_seconds': {'llm': round(st32.llm_seconds, 4), 'flow': round(st32.flow_seconds, 4), 'hift': round(st32.hift_seconds, 4)}}
+            del pipe32
+            torch.cuda.empty_cache()
+        except Exception as e:
+            line['fp32_mode'] = {'value': None, 'error': repr(e)}
     if world == 1 and not args.no_cpu_baseline:
         try:
-            del pipe
-            torch.cuda.empty_cache()
             # separate process with a hard wall-clock limit: the GPU line must be printed whatever the host cores do
             import subprocess
             cmd = [sys.executable, os.path.abspath(__file__), '--cpu-baseline-worker', '--chars', str(chars), '--heads', str(K)] + (['--tiny'] if args.tiny else [])

@@ -209,6 +209,16 @@ def cv3w_config() -> HvxConfig:
     )
 
 
+def cv3d_config() -> HvxConfig:
+    """HydraVox-CV3 at FULL DEPTH (24 LM layers, 22 DiT blocks) and full widths; only the gather-only text vocabulary is reduced so that the
+    seeded state stays small.  The reference itself runs this on the CPU at short lengths in minutes (tests/golden/make_golden.py: gen_*_cv3d)."""
+    return HvxConfig(
+        llm=LLMConfig(text_vocab=1024),
+        flow=FlowConfig(),
+        hift=HiftConfig(noise_seconds=16),
+    )
+
+
 def tiny_config() -> HvxConfig:
     """Toy dimensions used by the parity tests and golden fixtures (same code paths)."""
     return HvxConfig(

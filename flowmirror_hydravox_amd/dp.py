@@ -25,6 +25,45 @@ def shard_by_cost(costs: Sequence[float], world: int) -> List[List[int]]:
     return [sorted(s) for s in shards]
 
 
+class Handoff:
+    """Hands a rank's finished waveforms to rank `dst` in rounds of `per_round` utterances.  gather_waveforms is a collective, so every rank
+    must enter it the same number of times although a longest-first deal gives the ranks different utterance counts: the number of rounds
+    is fixed by the largest shard (every rank knows the whole deal), `push` enters one round whenever `per_round` waveforms are ready and
+    `finish` enters the remaining ones (with whatever is left, possibly nothing)."""
+
+    def __init__(self, shards: List[List[int]], per_round: int, dst: int = 0, group=None, keep: bool = True):
+        self.per_round = max(1, int(per_round))
+        self.rounds = max((len(s) + self.per_round - 1) // self.per_round for s in shards) if shards else 0
+        self.dst, self.group = dst, group
+        self.done = 0
+        self.ready: List = []
+        self.received = {}
+        self.keep = keep                # False: only the last round's waveforms stay referenced (a long job would otherwise pile up on `dst`)
+        self.n_received = 0
+
+    def _round(self):
+        ids, wavs = [g for g, _ in self.ready], [w for _, w in self.ready]
+        got = gather_waveforms(wavs, ids, dst=self.dst, group=self.group)
+        self.n_received += len(got)
+        if self.keep:
+            self.received.update(got)
+        else:
+            self.received = got
+        self.ready = []
+        self.done += 1
+
+    def push(self, global_id: int, wav: torch.Tensor):
+        self.ready.append((global_id, wav))
+        if len(self.ready) == self.per_round:
+            self._round()
+
+    def finish(self):
+        while self.done < self.rounds:
+            self._round()
+        assert not self.ready
+        return self.received
+
+
 def gather_waveforms(wavs: List[torch.Tensor], global_ids: List[int], dst: int = 0, group=None, shortcut_single: bool = True):
     """Every rank passes its finished waveforms (1-D float32 tensors on its device) with their global utterance ids.
     Rank `dst` returns {global_id: waveform}; the others return {}.  Works on RCCL ("nccl") and gloo.

@@ -282,16 +282,34 @@ class HvxLLM:
                          int(n_text * d.get('min_token_text_ratio', 2)), int(n_text * d.get('max_token_text_ratio', 20)), NoiseStream(seed=d['seed'] if d.get('seed') is not None else _fresh_seed(), chunk=8192))
             r.tag = d.get('tag')
             return r
-        it = (to_req(d) for d in requests)
-        if max_out is None or max_prefix is None:
-            it = list(it)
-            max_out = max([r.max_len for r in it] + [1])
-            max_prefix = max([len(r.prefix) for r in it] + [1])
-            it = iter(it)
+        if hasattr(requests, 'poll'):
+            # an open-ended polling source (the queue worker): poll(block) -> request dict | None, StopIteration when closed
+            if max_out is None or max_prefix is None:
+                max_out = max_prefix = self.max_ctx
+            src = requests
+
+            class _Poll:
+                @staticmethod
+                def poll(block):
+                    d = src.poll(block)
+                    return None if d is None else to_req(d)
+            it = _Poll()
+        else:
+            it = (to_req(d) for d in requests)
+            if max_out is None or max_prefix is None:
+                it = list(it)
+                max_out = max([r.max_len for r in it] + [1])
+                max_prefix = max([len(r.prefix) for r in it] + [1])
+                it = iter(it)
         eng = _DecodeEngine(self, n_slots=n_slots, max_out=max_out, max_prefix=max_prefix)
-        for kind, r in eng.run(it):
-            if kind == 'done':
-                yield r.tag, r.out
+        gen = eng.run(it)
+        try:
+            for kind, r in gen:
+                if kind == 'done':
+                    # a request that could not run (context / output budget) comes back as (tag, the exception); the others keep running
+                    yield r.tag, (r.out if getattr(r, 'error', None) is None else r.error)
+        finally:
+            gen.close()                               # an abandoned stream: the engine drains its queued blocks and rewinds the generators
         self.last_stats = eng.stats
 
     def decode_step_bytes(self, n_seq, head_k, ctx):
@@ -340,6 +358,7 @@ class _DecodeEngine:
     def __init__(self, llm, n_slots, max_out, max_prefix, stream_first=False, sync_every=None):
         import time
         self.llm, self.S, self.max_out = llm, int(n_slots), int(max_out)
+        self.max_prefix = max(int(max_prefix), self.S * llm.head_k())
         self.K = llm.head_k()
         self.sp = sampling_params(llm.sampling)
         self.thr = rep_threshold(self.sp['win_size'], self.sp['tau_r'])
@@ -435,14 +454,23 @@ class _DecodeEngine:
     def _publish_limits(self):
         self.limit_dev.copy_(self._h2d(self.head, torch.int64), non_blocking=True)     # behind the data, on the same stream
 
+    def _refuse(self, r):
+        """None, or the error that keeps request r off the grid"""
+        if len(r.prefix) + r.max_len + self.K > self.llm.max_ctx:
+            return ValueError('context %d exceeds max_ctx=%d' % (len(r.prefix) + r.max_len + self.K, self.llm.max_ctx))
+        if r.max_len > self.max_out:
+            return ValueError("max_len %d exceeds the engine's max_out=%d" % (r.max_len, self.max_out))
+        if len(r.prefix) - 1 > self.max_prefix:
+            return ValueError("prefix of %d rows exceeds the engine's max_prefix=%d" % (len(r.prefix), self.max_prefix))
+        return None
+
     def _join(self, i, r, launched):
         """request r takes slot i (stream-ordered behind every block enqueued so far)"""
         llm = self.llm
         n = len(r.prefix) - 1
-        if len(r.prefix) + r.max_len + self.K > llm.max_ctx:
-            raise ValueError('context %d exceeds max_ctx=%d' % (len(r.prefix) + r.max_len + self.K, llm.max_ctx))
-        if r.max_len > self.max_out:
-            raise ValueError('max_len %d exceeds the engine\'s max_out=%d' % (r.max_len, self.max_out))
+        err = self._refuse(r)
+        if err is not None:
+            raise err
         if n > 0:
             tok = self._h2d(r.prefix[:n], torch.int32)
             ctrl = self._h2d([i, 0, n, n, n - 1], torch.int32)
@@ -481,17 +509,23 @@ class _DecodeEngine:
         t_setup = 0.0
         ready = []                                    # ('token', id) / ('done', request) waiting to be handed out
 
-        def pull():
+        def pull(block=False):
+            """next waiting request, if there is one.  `requests` is an iterator (next() may block: a finite job) or a polling source with
+            poll(block) -> request | None ("nothing right now"; only asked to block while the grid is idle) that raises StopIteration when closed.
+            A request that cannot run (context / output budget) is handed back at once with r.error set: the grid keeps running."""
             nonlocal waiting, exhausted
             while waiting is None and not exhausted:
                 try:
-                    waiting = next(requests)
+                    waiting = requests.poll(block) if hasattr(requests, 'poll') else next(requests)
                 except StopIteration:
                     exhausted = True
                     return
-                if waiting.max_len <= 0:              # `while len(out_tokens) < max_len` never runs (llm_multi_head_v3.py:871)
+                if waiting is None:
+                    return
+                err = self._refuse(waiting)
+                if err is not None or waiting.max_len <= 0:   # `while len(out_tokens) < max_len` never runs (llm_multi_head_v3.py:871)
                     r, waiting = waiting, None
-                    r.out, r.done = [], True
+                    r.out, r.done, r.error = [], True, err
                     r.noise.finalize(0)
                     ready.append(('done', r))
 
@@ -524,12 +558,12 @@ class _DecodeEngine:
                 j = torch.arange(int(r.cursor), self.head[i], device=dev)
                 self.noise_dev[i, j % self.ncap] = old[i, j % cap0]
 
-        def fill_free_slots():
+        def fill_free_slots(block=False):
             nonlocal waiting
             free = [i for i in range(S) if self.slot_req[i] is None or self.slot_req[i].done]
             batch = []
             for i in free:
-                pull()
+                pull(block and not batch)
                 if waiting is None:
                     break
                 batch.append((i, waiting))
@@ -555,9 +589,11 @@ class _DecodeEngine:
                 live = [r for r in self.slot_req if r is not None and not r.done]
                 if not live and launched == processed:
                     with torch.cuda.stream(stream):
-                        if fill_free_slots():         # (every sequence had finished while requests were still arriving)
+                        if fill_free_slots(block=True):   # the grid is idle: a polling source may block here until the next request arrives
                             self._publish_limits()
                             continue
+                    if ready or not exhausted:
+                        continue                      # (a refused request to hand back, or a source that had nothing yet)
                     break
                 if not draining and live:
                     need_max = max(steps_needed(r) for r in live)

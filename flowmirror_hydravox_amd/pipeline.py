@@ -27,6 +27,11 @@ class Utterance:
     prompt_text: Optional[torch.Tensor] = None
     prompt_speech_token: Optional[torch.Tensor] = None      # int32 [Np]
     prompt_feat: Optional[torch.Tensor] = None              # f32 [2*Np][80]
+    flow_prompt_token: Optional[torch.Tensor] = None        # int32 [Np']: the flow decoder's prompt tokens when they differ from the LM's (frontend_zero_shot)
+    speed: float = 1.0                                      # mel resampled to T / speed frames before the vocoder (infer_speech_model.py:583-588)
+    tag: object = None                                      # caller's handle (a queue task, ...), returned with the result
+    max_token_text_ratio: Optional[float] = None            # per-utterance overrides of the call's length ratios
+    min_token_text_ratio: Optional[float] = None
 
 
 @dataclass
@@ -65,6 +70,10 @@ def synthetic_utterance(cfg: HvxConfig, index: int, n_text: int, n_prompt_speech
     return u
 
 
+def _flow_prompt(u):
+    return u.prompt_speech_token if u.flow_prompt_token is None else u.flow_prompt_token
+
+
 class HvxPipeline:
     def __init__(self, cfg: HvxConfig, llm_sd=None, flow_sd=None, hift_sd=None, llm_dtype=torch.bfloat16, flow_dtype=torch.bfloat16,
                  device='cuda', max_batch=8, max_ctx=4096, max_t=None, seed=1986, init='normal02', hift_tables=None, sampling=None,
@@ -88,6 +97,17 @@ class HvxPipeline:
         self.acoustic_batch = 4
         self.device = torch.device(device)
 
+    @classmethod
+    def from_models(cls, cfg: HvxConfig, llm, flow, hift, acoustic_batch=4):
+        """a pipeline over model objects that already exist (the queue worker's `model_manager.models`): same engine, nothing re-loaded"""
+        p = cls.__new__(cls)
+        p.cfg, p.llm, p.flow, p.hift = cfg, llm, flow, hift
+        p._llms, p._acoustic = [llm], [(flow, hift)]
+        p._llm_kw = p._flow_kw = p._hift_kw = None
+        p.acoustic_batch = acoustic_batch
+        p.device = torch.device(llm.device)
+        return p
+
     # ---- stages -----------------------------------------------------------------------------------------------------------------
     def _speech_tokens(self, utts, max_token_text_ratio, min_token_text_ratio, llm=None):
         return (llm or self.llm).generate_batch([u.text for u in utts],
@@ -106,8 +126,8 @@ class HvxPipeline:
                 continue
             token = torch.tensor(t, dtype=torch.int32, device=dev)[None]
             kw = {}
-            if u.prompt_speech_token is not None:
-                kw = dict(prompt_token=u.prompt_speech_token.to(dev)[None], prompt_token_len=torch.tensor([len(u.prompt_speech_token)]),
+            if _flow_prompt(u) is not None:
+                kw = dict(prompt_token=_flow_prompt(u).to(dev)[None], prompt_token_len=torch.tensor([len(_flow_prompt(u))]),
                           prompt_feat=u.prompt_feat.to(dev)[None], prompt_feat_len=torch.tensor([u.prompt_feat.shape[0]]))
             mel, _ = flow.inference(token=token, token_len=torch.tensor([token.shape[1]], dtype=torch.int32), embedding=u.embedding[None].to(dev),
                                          finalize=True, **kw)
@@ -120,27 +140,30 @@ class HvxPipeline:
         flow = flow or self.flow
         dev = self.device
         mels = [None] * len(utts)
-        order = sorted((i for i in range(len(utts)) if toks[i]), key=lambda i: -(len(toks[i]) + (0 if utts[i].prompt_speech_token is None else len(utts[i].prompt_speech_token))))
+        def frames(i):
+            return len(toks[i]) + (0 if _flow_prompt(utts[i]) is None else len(_flow_prompt(utts[i])))
+        order = sorted((i for i in range(len(utts)) if toks[i]), key=lambda i: -frames(i))
         while order:
-            def frames(i):
-                return len(toks[i]) + (0 if utts[i].prompt_speech_token is None else len(utts[i].prompt_speech_token))
             top = frames(order[0])
             bucket = [i for i in order if frames(i) >= (1.0 - max_pad) * top][:max_batch]
             order = [i for i in order if i not in bucket]
             out = flow.inference_batch([torch.tensor(toks[i], dtype=torch.int32, device=dev) for i in bucket], [utts[i].embedding.to(dev) for i in bucket],
-                                       prompt_tokens=[None if utts[i].prompt_speech_token is None else utts[i].prompt_speech_token.to(dev) for i in bucket],
+                                       prompt_tokens=[None if _flow_prompt(utts[i]) is None else _flow_prompt(utts[i]).to(dev) for i in bucket],
                                        prompt_feats=[None if utts[i].prompt_feat is None else utts[i].prompt_feat.to(dev) for i in bucket])
             for i, m in zip(bucket, out):
                 mels[i] = m
         return mels
 
-    def _waves(self, mels, hift=None):
+    def _waves(self, mels, hift=None, speeds=None):
         wavs = []
         hift = hift or self.hift
-        for mel in mels:
+        for k, mel in enumerate(mels):
             if mel is None:
                 wavs.append(torch.zeros(0, device=self.device))
                 continue
+            if speeds is not None and speeds[k] != 1.0:
+                from .ops import resample_linear
+                mel = resample_linear(mel, max(1, int(mel.shape[2] / speeds[k])))
             wav, _ = hift.inference(speech_feat=mel)
             wavs.append(wav[0])
         return wavs
@@ -231,45 +254,99 @@ class HvxPipeline:
 
     @torch.inference_mode()
     def synthesize_continuous(self, utts, lm_slots=16, max_token_text_ratio=20, min_token_text_ratio=2, acoustic_batch=None, acoustic_min_batch=1):
-        """Generator over (index, waveform, tokens) in completion order — continuous batching end to end.
+        """Generator over (index, waveform, tokens) in completion order — continuous batching end to end over a finite
+        list of utterances; see `serve` (the same engine over an open-ended source).  Results equal synthesize(): every utterance carries
+        its own sampler seed.  `self.last_continuous` holds the stage accounting of the run."""
+        utts = list(utts)
+        maxr = max_token_text_ratio if isinstance(max_token_text_ratio, (list, tuple)) else [max_token_text_ratio] * len(utts)
+        minr = min_token_text_ratio if isinstance(min_token_text_ratio, (list, tuple)) else [min_token_text_ratio] * len(utts)
+        for i, u in enumerate(utts):
+            u.max_token_text_ratio, u.min_token_text_ratio = maxr[i], minr[i]
+        max_out = max([int(len(u.text) * maxr[i]) for i, u in enumerate(utts)] + [1])
+        max_prefix = max([2 + len(u.text) + (0 if u.prompt_text is None else len(u.prompt_text)) +
+                          (0 if u.prompt_speech_token is None else len(u.prompt_speech_token)) for u in utts] + [1])
+        index = {id(u): i for i, u in enumerate(utts)}
+
+        class _List:
+            def __init__(self):
+                self.it = iter(utts)
+
+            def poll(self, block):
+                return next(self.it)
+        for u, wav, toks in self.serve(_List(), lm_slots=lm_slots, acoustic_batch=acoustic_batch, acoustic_min_batch=acoustic_min_batch,
+                                       max_out=max_out, max_prefix=max_prefix):
+            if isinstance(wav, BaseException):
+                raise wav
+            yield index[id(u)], wav, toks
+
+    @torch.inference_mode()
+    def serve(self, source, lm_slots=16, acoustic_batch=None, acoustic_min_batch=1, max_out=None, max_prefix=None,
+              max_token_text_ratio=20, min_token_text_ratio=2):
+        """The continuous engine over an open-ended SOURCE of utterances: `source.poll(block)` returns the next `Utterance`, or None when
+        nothing is waiting (it is asked to block only while the decode grid is idle), and raises StopIteration when closed.  Generator over
+        (utterance, waveform | exception, tokens) in completion order.
         The LM decodes up to `lm_slots` utterances in ONE grid (HvxLLM.generate_stream: the weights are streamed once per step for all of
         them, a finished utterance's slot goes to the next waiting one), driven by a worker thread on the high-priority decode stream; every
         finished utterance goes straight to the flow decoder and the vocoder, which run here on a second stream beside the decode of the
-        utterances still in flight.  Results equal synthesize(): every utterance carries its own sampler seed.  `self.last_continuous`
-        holds the stage accounting of the run.  `acoustic_min_batch` > 1 trades latency for throughput: the acoustic stage then waits until
-        that many finished utterances are queued (or the LM is done) before it starts a padded solve."""
+        utterances still in flight, in padded solves of up to `acoustic_batch` utterances of similar length.  `acoustic_min_batch` > 1 trades
+        latency for throughput: the acoustic stage then waits until that many finished utterances are queued (or the LM is idle / done).
+        A request that cannot run (context budget) comes back as (utterance, exception, []) without disturbing the others.  If the consumer
+        stops iterating, the LM thread is cancelled: it stops taking requests and abandons the decode of those in flight."""
         acoustic_batch = acoustic_batch or self.acoustic_batch
         acoustic_min_batch = max(1, min(int(acoustic_min_batch), acoustic_batch))
         import queue
         import threading
-        utts = list(utts)
         if getattr(self, '_bg_stream', None) is None:
             self._bg_stream = torch.cuda.Stream(device=self.device, priority=0)
             self._bg_streams = [self._bg_stream]
             self._bg_pools = []
         flow, hift, stream = self._acoustic_chain(0)
         torch.cuda.synchronize(self.device)               # (everything the handles were built from is complete before other streams use it)
-        q = queue.Queue()
+        # bounded, but wide enough that a whole grid can finish at once without the decode engine waiting on this queue (it stalls inside its
+        # `yield` while the LM thread is blocked in put): only a consumer that has fallen a full grid behind holds the LM back
+        q = queue.Queue(maxsize=2 * int(lm_slots) + 2 * acoustic_batch)
+        cancel = threading.Event()
         lm_info = {}
-        maxr = max_token_text_ratio if isinstance(max_token_text_ratio, (list, tuple)) else [max_token_text_ratio] * len(utts)
-        minr = min_token_text_ratio if isinstance(min_token_text_ratio, (list, tuple)) else [min_token_text_ratio] * len(utts)
+        seen = []
+
+        class _Requests:
+            @staticmethod
+            def poll(block):
+                if cancel.is_set():
+                    raise StopIteration
+                u = source.poll(block)
+                if u is None:
+                    return None
+                seen.append(u)
+                return dict(text=u.text, prompt_text=u.prompt_text, prompt_speech_token=u.prompt_speech_token, seed=u.seed, tag=len(seen) - 1,
+                            max_token_text_ratio=max_token_text_ratio if u.max_token_text_ratio is None else u.max_token_text_ratio,
+                            min_token_text_ratio=min_token_text_ratio if u.min_token_text_ratio is None else u.min_token_text_ratio)
+
+        def put(item):
+            while not cancel.is_set():
+                try:
+                    q.put(item, timeout=0.05)
+                    return True
+                except queue.Full:
+                    pass
+            return False
 
         def lm_thread():
             try:
                 torch.cuda.set_device(stream.device)               # the current device is per thread
                 with torch.inference_mode():
-                    reqs = (dict(text=u.text, prompt_text=u.prompt_text, prompt_speech_token=u.prompt_speech_token, seed=u.seed, tag=i,
-                                 max_token_text_ratio=maxr[i], min_token_text_ratio=minr[i]) for i, u in enumerate(utts))
-                    max_out = max([int(len(u.text) * maxr[i]) for i, u in enumerate(utts)] + [1])
-                    max_prefix = max([2 + len(u.text) + (0 if u.prompt_text is None else len(u.prompt_text)) +
-                                      (0 if u.prompt_speech_token is None else len(u.prompt_speech_token)) for u in utts] + [1])
                     t0 = time.time()
-                    for tag, toks in self.llm.generate_stream(reqs, n_slots=lm_slots, max_out=max_out, max_prefix=max_prefix):
-                        q.put((tag, toks))
+                    gen = self.llm.generate_stream(_Requests(), n_slots=lm_slots, max_out=max_out, max_prefix=max_prefix)
+                    try:
+                        for tag, toks in gen:
+                            if not put((tag, toks)):
+                                break
+                    finally:
+                        gen.close()
                     lm_info.update(seconds=time.time() - t0, stats=dict(self.llm.last_stats))
-                q.put(None)
+                put(None)
             except BaseException as e:                              # surfaces in the consuming thread
-                q.put(e)
+                put(e)
 
         th = threading.Thread(target=lm_thread, name='hvx-lm', daemon=True)
         t_begin = time.time()
@@ -284,28 +361,43 @@ class HvxPipeline:
                 if isinstance(item, BaseException):
                     raise item
                 # whatever else has finished meanwhile joins this acoustic batch (up to `acoustic_batch` utterances, solved in length buckets)
-                group = [item]
+                group, tail, ended = [item], None, False
                 while len(group) < acoustic_batch:
                     try:
-                        nxt = q.get() if len(group) < acoustic_min_batch else q.get_nowait()
+                        nxt = q.get() if len(group) < acoustic_min_batch else q.get_nowait()     # (a throughput job waits for its minimum batch or the end)
                     except queue.Empty:
                         break
                     if nxt is None or isinstance(nxt, BaseException):
-                        q.put(nxt)                                 # (the sentinel / error is handled by the outer loop after this batch)
+                        tail, ended = nxt, True                    # (the sentinel / error is handled after this batch)
                         break
                     group.append(nxt)
-                idx = [i for i, _ in group]
-                t0 = time.time()
-                with torch.cuda.stream(stream):
-                    wavs = self._waves(self._mels_batched([utts[i] for i in idx], [t for _, t in group], flow, max_batch=acoustic_batch), hift)
-                    stream.synchronize()
-                acoustic += time.time() - t0
-                for (i, toks), wav in zip(group, wavs):
-                    audio += wav.numel() / float(self.cfg.sample_rate)
-                    tokens += len(toks)
-                    yield i, wav, toks
+                bad = [(i, t) for i, t in group if isinstance(t, BaseException) or not t]
+                group = [(i, t) for i, t in group if not isinstance(t, BaseException) and t]
+                for i, t in bad:
+                    yield seen[i], (t if isinstance(t, BaseException) else torch.zeros(0, device=self.device)), []
+                if group:
+                    us = [seen[i] for i, _ in group]
+                    t0 = time.time()
+                    with torch.cuda.stream(stream):
+                        wavs = self._waves(self._mels_batched(us, [t for _, t in group], flow, max_batch=acoustic_batch), hift, speeds=[u.speed for u in us])
+                        stream.synchronize()
+                    acoustic += time.time() - t0
+                    for (i, toks), wav in zip(group, wavs):
+                        audio += wav.numel() / float(self.cfg.sample_rate)
+                        tokens += len(toks)
+                        yield seen[i], wav, toks
+                if ended:
+                    if isinstance(tail, BaseException):
+                        raise tail
+                    break
         finally:
-            th.join()
+            cancel.set()
+            while th.is_alive():                                   # (keep the queue moving so that a blocked put sees the cancellation)
+                try:
+                    q.get_nowait()
+                except queue.Empty:
+                    pass
+                th.join(timeout=0.05)
             self.last_continuous = dict(tokens=tokens, audio_seconds=audio, acoustic_seconds=acoustic, total_seconds=time.time() - t_begin,
                                         llm_seconds=lm_info.get('seconds', 0.0), llm=lm_info.get('stats', {}), lm_slots=lm_slots)
 

@@ -70,94 +70,148 @@ def worker_process_tts(num_workers_gpu, task_queue, result_dict, worker_id, fron
         result_dict[task['id']] = result
 
 
-def worker_process_tts_batched(num_workers_gpu, task_queue, result_dict, worker_id, frontend_factory=None, max_batch=8):
-    """Same wire format as worker_process_tts, with real batching: whatever `tts` / `zero_shot` tasks are already waiting
-    (up to `max_batch`, same sampling parameters) are decoded together by `synthesize_many`; everything else is served one by one."""
-    import queue as _queue
+def _sampling_key(task):
+    ep = task.get('extra_params') or {}
+    return tuple(ep.get(k) for k in ('top_p', 'top_k', 'win_size', 'tau_r', 'inference_head_num'))
+
+
+class _TaskSource:
+    """The polling source HvxPipeline.serve reads (one EPOCH of the task queue): consecutive `tts` / `zero_shot` tasks with the same sampling
+    parameters become utterances as they arrive and join the decode grid while earlier ones are still in flight.  The first task that cannot
+    join — a `load_pt`, other sampling parameters (llm.sampling / inference_head_num are per-model state, server/worker.py:57-65), an unknown
+    type, the shutdown sentinel — closes the epoch: it is kept in `carry` and served after everything accepted before it has finished, so
+    arrival order around a hot swap is what the reference's one-by-one loop gives."""
+
+    def __init__(self, mm, task_queue, result_dict, first, normalise, worker_id):
+        self.mm, self.q, self.results, self.normalise, self.worker_id = mm, task_queue, result_dict, normalise, worker_id
+        self.key = _sampling_key(first)
+        self.head = first
+        self.carry = None
+        self.stop = False
+        self.closed = False
+
+    def _utterance(self, t):
+        from .pipeline import Utterance
+        fe, mm = self.mm.frontend, self.mm
+        if t['task_type'] == 'tts':
+            mi = fe.frontend_sft(fe.text_normalize(self.normalise(t['text']), split=True, text_frontend=True)[0], t['speaker_id'])
+            u = Utterance(text=mi['text'].reshape(-1), seed=None, embedding=mi['flow_embedding'].reshape(-1))
+        else:
+            p_text = fe.text_normalize(self.normalise(t.get('prompt_text', '')), split=False, text_frontend=True)
+            mi = fe.frontend_zero_shot(fe.text_normalize(self.normalise(t['tts_text']), split=True, text_frontend=True)[0], p_text,
+                                       (t['prompt_audio'], t['prompt_sample_rate']), mm.configs['sample_rate'], zero_shot_spk_id='')
+            u = Utterance(text=mi['text'].reshape(-1), seed=None, embedding=mi['flow_embedding'].reshape(-1),
+                          prompt_text=mi['prompt_text'].reshape(-1), prompt_speech_token=mi['llm_prompt_speech_token'].reshape(-1),
+                          prompt_feat=mi['prompt_speech_feat'].reshape(-1, mi['prompt_speech_feat'].shape[-1]),
+                          flow_prompt_token=mi['flow_prompt_speech_token'].reshape(-1))
+        u.seed = int(t['seed']) if t.get('seed') is not None else None       # (None: the LM draws one from the global generator)
+        u.speed = float((t.get('extra_params') or {}).get('speed', 1.0))
+        if u.speed <= 0:
+            raise ValueError('Invalid speed: %s' % u.speed)
+        u.tag = t
+        return u
+
+    def poll(self, block):
+        import queue as _queue
+        while True:
+            if self.closed:
+                raise StopIteration
+            if self.head is not None:
+                t, self.head = self.head, None
+            else:
+                try:
+                    t = self.q.get() if block else self.q.get_nowait()
+                except _queue.Empty:
+                    return None
+            if t is None:
+                self.stop = self.closed = True
+                raise StopIteration
+            if t.get('task_type') not in ('tts', 'zero_shot') or _sampling_key(t) != self.key:
+                self.carry, self.closed = t, True
+                raise StopIteration
+            try:
+                return self._utterance(t)
+            except Exception as e:                     # a frontend error fails that request only
+                logger.error('[TTS Worker-%d] Error: %s', self.worker_id, e)
+                self.results[t['id']] = {'error': str(e)}
+
+
+def worker_process_tts_batched(num_workers_gpu, task_queue, result_dict, worker_id, frontend_factory=None, lm_slots=None, acoustic_batch=4):
+    """Same wire format as worker_process_tts, served by the continuous-batching engine (replaces the one-request-at-a-time
+    loop of server/worker.py:54-102 and what server/router.py:144-156 feeds it): `tts` / `zero_shot` tasks join ONE decode grid as they arrive
+    (HvxPipeline.serve -> HvxLLM.generate_stream: the LM weights are streamed once per step for every request in flight, a finished request's
+    slot goes to the next waiting one), finished requests go to length-bucketed padded CFM solves and the vocoder beside the decode of the
+    others, and every result is written to `result_dict` the moment its waveform is complete.  `load_pt` and a change of sampling parameters
+    are epoch boundaries (FIFO: see _TaskSource).  What bench.py measures is this path."""
     os.environ['CUDA_VISIBLE_DEVICES'] = str(worker_id % num_workers_gpu)
-    from .model_manager import HvxModelManager, synthesize_many, text_to_speech, inference_zero_shot
+    from .model_manager import HvxModelManager
+    from .pipeline import HvxPipeline
     from .sampling import ras_sampling
 
     mm = HvxModelManager(frontend_factory=frontend_factory)
     mm.load_models(argparse.Namespace(config=os.getenv('TTS_CONFIG'), model_dir=os.getenv('TTS_MODEL_DIR'), bf16=_env_flag('TTS_BF_16'),
                                       fp16=_env_flag('TTS_FP_16'), cpu=_env_flag('TTS_CPU', False)))
-    normalise = _text_normaliser()                  # the same normaliser as worker_process_tts, in the batched and the one-by-one path
-    pending = []
-    stop = False
-    while not stop or pending:                      # tasks deferred behind a load_pt / other sampling parameters are served before the exit
-        if not pending:
-            pending.append(task_queue.get())
-        while not stop and len(pending) < max_batch:
+    serve_queue(mm, task_queue, result_dict, worker_id, lm_slots=lm_slots, acoustic_batch=acoustic_batch)
+
+
+def serve_queue(mm, task_queue, result_dict, worker_id=0, lm_slots=None, acoustic_batch=4, normalise=None):
+    """the loop of worker_process_tts_batched over an already loaded model manager (tests drive this directly)"""
+    from .pipeline import HvxPipeline
+    from .sampling import ras_sampling
+    normalise = normalise or _text_normaliser()
+    pipe = HvxPipeline.from_models(mm.hvx_config, mm.models['llm'], mm.models['flow'], mm.models['hift'], acoustic_batch=acoustic_batch)
+    lm_slots = lm_slots or mm.models['llm'].max_batch
+    sr = mm.configs['sample_rate']
+    carry = None
+    while True:
+        task, carry = (carry, None) if carry is not None else (task_queue.get(), None)
+        if task is None:
+            break
+        if task.get('task_type') not in ('tts', 'zero_shot'):
             try:
-                pending.append(task_queue.get_nowait())
-            except _queue.Empty:
-                break
-        if any(t is None for t in pending):
-            stop = True
-            pending = [t for t in pending if t is not None]
-        # the leading run of batchable tasks is decoded together; what follows the first task that cannot join (a load_pt, other sampling
-        # parameters) waits for the next round, so arrival order around a hot swap is what the reference's one-by-one loop gives
-        batch, rest, pending = group_batchable(pending)
-        if len(batch) > 1:
-            try:
-                apply_extra_params(mm, batch[0], ras_sampling)
-                fe = mm.frontend
-                inputs, zs = [], []
-                for t in batch:
-                    if t['task_type'] == 'tts':
-                        inputs.append(fe.frontend_sft(fe.text_normalize(normalise(t['text']), split=True, text_frontend=True)[0], t['speaker_id']))
-                        zs.append(False)
-                    else:
-                        p_text = fe.text_normalize(normalise(t.get('prompt_text', '')), split=False, text_frontend=True)
-                        inputs.append(fe.frontend_zero_shot(fe.text_normalize(normalise(t['tts_text']), split=True, text_frontend=True)[0], p_text,
-                                                            (t['prompt_audio'], t['prompt_sample_rate']), mm.configs['sample_rate'], zero_shot_spk_id=''))
-                        zs.append(True)
-                speeds = [float(t.get('extra_params', {}).get('speed', 1.0)) for t in batch]
-                sr = mm.configs['sample_rate']
-                for t, out in zip(batch, synthesize_many(mm, inputs, zs, speeds=speeds)):
-                    result_dict[t['id']] = {'output_audio': out, 'sample_rate': sr, 'format': t.get('output_format', 'wav'), 'duration': out.shape[-1] / sr}
-            except Exception as e:
-                logger.error('[TTS Worker-%d] batch error: %s', worker_id, e)
-                for t in batch:
-                    result_dict[t['id']] = {'error': str(e)}
-        else:
-            rest = batch + rest
-        for t in rest:
-            try:
-                speed = apply_extra_params(mm, t, ras_sampling)
-                if t['task_type'] == 'zero_shot':
-                    out = inference_zero_shot(mm, normalise(t['tts_text']), normalise(t.get('prompt_text', '')), t['prompt_audio'], t['prompt_sample_rate'], speed=speed)
-                    sr = mm.configs['sample_rate']
-                    result = {'output_audio': out, 'sample_rate': sr, 'format': t.get('output_format', 'wav'), 'duration': out.shape[-1] / sr}
-                elif t['task_type'] == 'tts':
-                    result = text_to_speech(mm, normalise(t['text']), t['speaker_id'], speed=speed)
-                elif t['task_type'] == 'load_pt':
-                    result = mm.load_pt(t['llm_pt'], t['flow_pt'])
+                if task.get('task_type') == 'load_pt':
+                    result = mm.load_pt(task['llm_pt'], task['flow_pt'])
                 else:
-                    result = {'error': 'unknown task_type %r' % (t['task_type'],)}
+                    result = {'error': 'unknown task_type %r' % (task.get('task_type'),)}
             except Exception as e:
                 logger.error('[TTS Worker-%d] Error: %s', worker_id, e)
                 result = {'error': str(e)}
-            result_dict[t['id']] = result
+            result_dict[task['id']] = result
+            continue
+        src = _TaskSource(mm, task_queue, result_dict, task, normalise, worker_id)
+        in_flight = {}
+        try:
+            apply_extra_params(mm, task, ras_sampling)
+            pipe.llm = mm.models['llm']
+            for u, wav, toks in pipe.serve(_Tracked(src, in_flight), lm_slots=lm_slots, acoustic_batch=acoustic_batch, acoustic_min_batch=1):
+                t = u.tag
+                in_flight.pop(t['id'], None)
+                if isinstance(wav, BaseException):
+                    logger.error('[TTS Worker-%d] Error: %s', worker_id, wav)
+                    result_dict[t['id']] = {'error': str(wav)}
+                else:
+                    out = wav.reshape(1, -1).cpu()
+                    result_dict[t['id']] = {'output_audio': out, 'sample_rate': sr, 'format': t.get('output_format', 'wav'), 'duration': out.shape[-1] / sr}
+        except Exception as e:                         # an engine failure fails what was in flight, never the worker
+            logger.error('[TTS Worker-%d] epoch error: %s', worker_id, e)
+            for tid in list(in_flight):
+                result_dict[tid] = {'error': str(e)}
+        carry = src.carry
+        if src.stop:
+            break
 
 
-def group_batchable(tasks):
-    """-> (batch, singles, later): `batch` = the leading run of synthesis tasks with the same sampling parameters (llm.sampling /
-    inference_head_num are per-model state, server/worker.py:57-65); when the head of the queue cannot be batched (load_pt, unknown type) it
-    is returned alone in `singles`; `later` = everything behind the first task that does not join, in arrival order — FIFO is kept, a
-    load_pt is never overtaken by requests that arrived after it."""
-    def key(t):
-        ep = t.get('extra_params') or {}
-        return tuple(ep.get(k) for k in ('top_p', 'top_k', 'win_size', 'tau_r', 'inference_head_num'))
-    if not tasks:
-        return [], [], []
-    if tasks[0].get('task_type') not in ('tts', 'zero_shot'):
-        return [], [tasks[0]], list(tasks[1:])
-    k0 = key(tasks[0])
-    n = 1
-    while n < len(tasks) and tasks[n].get('task_type') in ('tts', 'zero_shot') and key(tasks[n]) == k0:
-        n += 1
-    return list(tasks[:n]), [], list(tasks[n:])
+class _Tracked:
+    """notes which accepted tasks have no result yet (an engine failure must answer them)"""
+
+    def __init__(self, src, in_flight):
+        self.src, self.in_flight = src, in_flight
+
+    def poll(self, block):
+        u = self.src.poll(block)
+        if u is not None:
+            self.in_flight[u.tag['id']] = True
+        return u
 
 
 def apply_extra_params(mm, task, ras_sampling):

@@ -145,6 +145,51 @@ def gen_sampler():
     np.savez_compressed(os.path.join(HERE, 'sampler_big.npz'), **big)
 
 
+def gen_sampler_many():
+    """1000 further sampler cases (760 at V = 296, 240 at V = 6761: plain / peaked / EOS-heavy / exact ties / flat, RAS fallbacks, EOS retries,
+    max_trials exhaustion).  The INPUTS are not stored: tests/golden/sampler_cases.py regenerates case i from its own seed; the fixture holds
+    the reference's id, the number of noise values it consumed and a checksum of the regenerated log-probabilities."""
+    import hashlib
+    from cosyvoice.utils.common import ras_sampling
+    from cosyvoice.llm.llm_multi_head_v3 import CosyVoice3LM
+    from sampler_cases import make_case, N_CASES
+
+    class _Stub:
+        pass
+    ids, consumed, shas = [], [], []
+    n_fallback = n_retry = n_err = 0
+    for i in range(N_CASES):
+        c = make_case(i)
+        stub = _Stub()
+        stub.speech_token_size = c['Vs']
+        stub.sampling = partial(ras_sampling, top_p=c['top_p'], top_k=c['top_k'], win_size=c['win'], tau_r=c['tau'])
+        torch.manual_seed(c['seed'])
+        try:
+            ref_id = int(CosyVoice3LM.sampling_ids(stub, torch.from_numpy(c['logp']), list(c['hist']), 25, ignore_eos=c['ignore_eos']))
+        except RuntimeError:
+            ref_id = -1
+        probe = torch.empty(1).exponential_(1.0).item()
+        ns = sampler_ref.NoiseStream(seed=c['seed'])
+        try:
+            ora_id = sampler_ref.sampling_ids(c['logp'], list(c['hist']), ns, c['Vs'], c['ignore_eos'], top_p=c['top_p'], top_k=c['top_k'],
+                                              win_size=c['win'], tau_r=c['tau'])
+        except RuntimeError:
+            ora_id = -1
+        assert ref_id == ora_id, (i, ref_id, ora_id)
+        assert abs(float(ns.peek(ns.cursor, 1)[0]) - probe) == 0.0, 'noise consumption differs from the reference'
+        V = len(c['logp'])
+        n_fallback += ns.cursor > V
+        n_retry += ns.cursor > c['top_k'] + V
+        n_err += ref_id < 0
+        ids.append(ref_id)
+        consumed.append(ns.cursor)
+        shas.append(int.from_bytes(hashlib.sha256(c['logp'].tobytes()).digest()[:8], 'little', signed=True))
+    print('[sampler-many] %d cases (%d at V = 6761), %d hit the RAS fallback, %d needed EOS retries, %d exhausted max_trials; oracle == reference id-for-id'
+          % (N_CASES, sum(1 for i in range(N_CASES) if make_case(i, header_only=True)['Vs'] == 6561), n_fallback, n_retry, n_err))
+    np.savez_compressed(os.path.join(HERE, 'sampler_many.npz'), id=np.array(ids, dtype=np.int32), consumed=np.array(consumed, dtype=np.int64),
+                        logp_sha=np.array(shas, dtype=np.int64))
+
+
 # ------------------------------------------------------------------------------------------------
 # LLM
 # ------------------------------------------------------------------------------------------------
@@ -275,21 +320,21 @@ def gen_llm_stress():
     np.savez_compressed(os.path.join(HERE, 'llm_stress_tiny.npz'), **out)
 
 
-def gen_llm_cv3w():
+def gen_llm_cv3w(cfg=None, runs=None, pins=(1, 12), fname='llm_cv3w.npz', tag='llm-cv3w', literal_runs=(0,)):
     """The reference LM at the HydraVox-CV3 WIDTHS (hidden 896, 14:2 heads, inter 4864, vocab 6761, 5 MTP heads of 22016; 2 layers):
     first-step hidden / log-probs of all 5 heads, and token streams for K in {1, 2, 4, 5} — a set of 8 utterances at K = 2 (the batch
     the benchmark decodes) whose contexts start below and cross the 256- and 512-key attention splits."""
     import time
-    cfg = cv3w_config().llm
+    cfg = cfg or cv3w_config().llm
     seed_w = 1986
     sd = W.make_llm_state(cfg, seed=seed_w, init='fan_in', with_lm_head=True)
     out = dict(weight_seed=np.int64(seed_w), weight_sha=np.array(state_checksum(sd)))
     sampling = dict(top_p=0.9, top_k=10, win_size=32, tau_r=0.2)
     lm = build_ref_llm(cfg, sd, sampling)
     # (K, n_text, n_prompt_text, n_prompt_speech, max ratio, min ratio)
-    runs = [(2, 14, 0, 0, 3, 2), (2, 20, 6, 150, 3, 2), (2, 24, 0, 215, 3, 2), (2, 30, 8, 200, 2, 2), (2, 16, 0, 460, 4, 3), (2, 9, 0, 30, 5, 2),
-            (2, 40, 10, 180, 2, 1), (2, 12, 0, 236, 4, 2),
-            (1, 16, 0, 230, 3, 2), (1, 10, 4, 0, 4, 2), (4, 24, 0, 210, 4, 3), (4, 11, 5, 40, 5, 3), (5, 20, 0, 225, 4, 3)]
+    runs = runs or [(2, 14, 0, 0, 3, 2), (2, 20, 6, 150, 3, 2), (2, 24, 0, 215, 3, 2), (2, 30, 8, 200, 2, 2), (2, 16, 0, 460, 4, 3), (2, 9, 0, 30, 5, 2),
+                    (2, 40, 10, 180, 2, 1), (2, 12, 0, 236, 4, 2),
+                    (1, 16, 0, 230, 3, 2), (1, 10, 4, 0, 4, 2), (4, 24, 0, 210, 4, 3), (4, 11, 5, 40, 5, 3), (5, 20, 0, 225, 4, 3)]
     for r, (K, n_text, n_pt, n_ps, maxr, minr) in enumerate(runs):
         t0 = time.time()
         lm.inference_head_num = K
@@ -308,17 +353,17 @@ def gen_llm_cv3w():
         otoks = list(llm_ref.llm_inference(sd, cfg, text[0], ns, prompt_text=ptext[0], prompt_speech_token=pspeech[0], inference_head_num=K,
                                            sampling=sampling, max_token_text_ratio=maxr, min_token_text_ratio=minr, use_kv_cache=True))
         assert otoks == [int(t) for t in toks], (r, otoks[:8], toks[:8])
-        if r == 0:                                      # the literal (uncached) form once
+        if r in literal_runs:                           # the literal (uncached) form once
             o2 = list(llm_ref.llm_inference(sd, cfg, text[0], sampler_ref.NoiseStream(seed=seed), prompt_text=ptext[0], prompt_speech_token=pspeech[0],
                                             inference_head_num=K, sampling=sampling, max_token_text_ratio=maxr, min_token_text_ratio=minr))
             assert o2 == otoks
         n_ctx0 = 2 + n_text + n_pt + n_ps
-        print('[llm-cv3w] run %d K=%d: prefix %d rows, %d tokens (context %d -> %d), oracle == reference; %.1f s'
-              % (r, K, n_ctx0, len(toks), n_ctx0, n_ctx0 + len(toks), time.time() - t0))
+        print('[%s] run %d K=%d: prefix %d rows, %d tokens (context %d -> %d), oracle == reference; %.1f s'
+              % (tag, r, K, n_ctx0, len(toks), n_ctx0, n_ctx0 + len(toks), time.time() - t0))
         p = 'r%d_' % r
         out.update({p + 'K': np.int32(K), p + 'seed': np.int64(seed), p + 'text': text[0].numpy(), p + 'ptext': ptext[0].numpy(),
                     p + 'pspeech': pspeech[0].numpy(), p + 'ratios': np.array([maxr, minr], dtype=np.float64), p + 'tokens': np.array(toks, dtype=np.int32)})
-        if r in (1, 12):                                # numeric pin of the first step: all 5 heads
+        if r in pins:                                   # numeric pin of the first step: all 5 heads
             lm_input = llm_ref.build_prefix(sd, cfg, text[0], ptext[0], pspeech[0])[None]
             L = lm_input.shape[1]
             y, _ = lm.llm.forward_one_step(lm_input, masks=torch.tril(torch.ones(1, L, L)).bool(), cache=None)
@@ -327,12 +372,22 @@ def gen_llm_cv3w():
             oy = llm_ref.backbone(lm_input[0], sd, cfg)
             ol = torch.stack(llm_ref.head_logps(oy[-1], sd, cfg, cfg.head_num))
             d = [(oy - y[0]).abs().max().item(), (ol - logps).abs().max().item()]
-            assert d[0] < 5e-5 and d[1] < 5e-4, d
-            print('[llm-cv3w] run %d first step: oracle-reference max abs diff hidden %.1e logp %.1e (|y| max %.2f)' % (r, d[0], d[1], y.abs().max()))
+            assert d[0] < 2e-4 and d[1] < 2e-3, d
+            print('[%s] run %d first step: oracle-reference max abs diff hidden %.1e logp %.1e (|y| max %.2f)' % (tag, r, d[0], d[1], y.abs().max()))
             out.update({p + 'y_last': last[0, 0].numpy(), p + 'logps': logps.numpy()})
     out['sampling'] = np.array([sampling['top_p'], sampling['top_k'], sampling['win_size'], sampling['tau_r']], dtype=np.float64)
     out['n_runs'] = np.int32(len(runs))
-    np.savez_compressed(os.path.join(HERE, 'llm_cv3w.npz'), **out)
+    np.savez_compressed(os.path.join(HERE, fname), **out)
+
+
+def gen_llm_cv3d():
+    """The reference LM at FULL DEPTH (24 layers, CV3 widths; config.cv3d_config): K in {1, 2, 4}, <= 64 generated tokens per run, three K = 2
+    runs for a batched decode, and one run whose 1020-row prefix grows across context 1024 (the reference recomputes the whole prefix per step:
+    ~0.75 TFLOP per step there, so that run is short).  First-step hidden / log-probs of all 5 heads on a short and on the long prefix."""
+    from flowmirror_hydravox_amd.config import cv3d_config
+    runs = [(1, 10, 0, 0, 3, 2), (2, 16, 4, 120, 3, 2), (2, 12, 0, 40, 4, 3), (2, 20, 0, 200, 2, 2), (4, 12, 0, 60, 4, 3), (4, 16, 0, 250, 3, 2),
+            (2, 8, 0, 1010, 3, 2)]
+    gen_llm_cv3w(cfg=cv3d_config().llm, runs=runs, pins=(1, 6), fname='llm_cv3d.npz', tag='llm-cv3d', literal_runs=())
 
 
 # ------------------------------------------------------------------------------------------------
@@ -407,14 +462,14 @@ def cv3w_flow_inputs(seed, T, lens):
     return x, mask, mu, spk, cond
 
 
-def gen_flow_cv3w():
+def gen_flow_cv3w(c=None, cases=None, N=130, Np=45, fname='flow_cv3w.npz', tag_='flow-cv3w'):
     """The reference flow decoder at the HydraVox-CV3 WIDTHS (DiT 1024 x 16 heads x ff 2048, conv groups 16, pre-lookahead 1024; 2 blocks):
     estimator at T = 2176 (padded second row), estimator with the chunk mask, pre-lookahead and a whole flow.inference with a prompt."""
     from cosyvoice.flow.flow import CausalMaskedDiffWithDiT
     from cosyvoice.flow.flow_matching import CausalConditionalCFM
     from cosyvoice.flow.DiT.dit import DiT
     from cosyvoice.transformer.upsample_encoder import PreLookaheadLayer
-    c = cv3w_config().flow
+    c = c or cv3w_config().flow
     dit = DiT(dim=c.dim, depth=c.depth, heads=c.heads, dim_head=c.head_dim, ff_mult=c.ff_mult, mel_dim=c.mel, mu_dim=c.mel,
               spk_dim=c.mel, out_channels=c.mel, static_chunk_size=c.static_chunk_size)
     cfm = CausalConditionalCFM(in_channels=240, cfm_params=DictConfig(sigma_min=1e-6, solver='euler', t_scheduler='cosine',
@@ -429,21 +484,20 @@ def gen_flow_cv3w():
     flow.load_state_dict(sd)
     out = dict(weight_seed=np.int64(seed_w), weight_sha=np.array(state_checksum(sd)))
     # ---- estimator, long padded batch ----------------------------------------------------------------------------------------
-    for tag, seed, T, lens, streaming in (('e0', 41, 2176, [2176, 1900], False), ('e1', 42, 330, [330, 275], True)):
+    for tag, seed, T, lens, streaming in (cases or (('e0', 41, 2176, [2176, 1900], False), ('e1', 42, 330, [330, 275], True))):
         x, mask, mu, spk, cond = cv3w_flow_inputs(seed, T, lens)
         t = torch.tensor([0.3, 0.3]) if tag == 'e0' else torch.tensor([0.7, 0.15])
         est = dit(x, mask, mu, t, spk, cond, streaming=streaming)
         o_est = flow_ref.dit_forward(x, mask, mu, t, spk, cond, sd, c, streaming=streaming)
         d = ((o_est - est) * mask).abs().max().item()
-        assert d < 2e-4, d
-        print('[flow-cv3w] estimator %s T=%d lens=%s streaming=%s: oracle-reference max abs diff %.1e (out absmax %.2f)' % (tag, T, lens, streaming, d, (est * mask).abs().max()))
+        assert d < 1e-3, d
+        print('[' + tag_ + '] estimator %s T=%d lens=%s streaming=%s: oracle-reference max abs diff %.1e (out absmax %.2f)' % (tag, T, lens, streaming, d, (est * mask).abs().max()))
         out.update({tag + '_seed': np.int64(seed), tag + '_T': np.int32(T), tag + '_lens': np.array(lens, dtype=np.int32), tag + '_t': t.numpy(),
                     tag + '_streaming': np.int32(streaming), tag + '_in_sha': np.array(state_checksum(dict(x=x, mu=mu, spk=spk, cond=cond))),
                     tag + '_out': (est * mask).numpy()})
     # ---- pre-lookahead + whole inference with a prompt -------------------------------------------------------------------------
     g = torch.Generator()
     g.manual_seed(43)
-    N, Np = 130, 45
     token = torch.randint(0, c.vocab, (1, N), generator=g)
     ptoken = torch.randint(0, c.vocab, (1, Np), generator=g)
     pfeat = torch.randn(1, 2 * Np, 80, generator=g)
@@ -460,10 +514,18 @@ def gen_flow_cv3w():
     o_pla = flow_ref.pre_lookahead(h0, sd, c)
     o_feat = flow_ref.flow_inference(token, emb, sd, c, prompt_token=ptoken, prompt_feat=pfeat)
     d = [(o_pla - hp).abs().max().item(), (o_feat - feat).abs().max().item()]
-    assert max(d) < 5e-4, d
-    print('[flow-cv3w] inference N=%d prompt=%d: oracle-reference max abs diff pla %.1e mel %.1e (mel absmax %.2f)' % (N, Np, d[0], d[1], feat.abs().max()))
+    assert max(d) < 2e-3, d
+    print('[' + tag_ + '] inference N=%d prompt=%d: oracle-reference max abs diff pla %.1e mel %.1e (mel absmax %.2f)' % (N, Np, d[0], d[1], feat.abs().max()))
     out.update(token=token.numpy(), ptoken=ptoken.numpy(), pfeat=pfeat.numpy(), emb=emb.numpy(), h0=h0.numpy(), pla=hp.numpy(), mel=feat.numpy())
-    np.savez_compressed(os.path.join(HERE, 'flow_cv3w.npz'), **out)
+    np.savez_compressed(os.path.join(HERE, fname), **out)
+
+
+def gen_flow_cv3d():
+    """The reference flow decoder at FULL DEPTH (22 DiT blocks, config.cv3d_config): estimator at T = 256 with a padded second row (200 frames)
+    and at T = 192 with the chunk mask, and a whole 10-step CFG solve of 104 + 24 prompt tokens (T = 256)."""
+    from flowmirror_hydravox_amd.config import cv3d_config
+    gen_flow_cv3w(c=cv3d_config().flow, cases=(('e0', 51, 256, [256, 200], False), ('e1', 52, 192, [192, 150], True)), N=104, Np=24,
+                  fname='flow_cv3d.npz', tag_='flow-cv3d')
 
 
 def gen_hift_cv3w():
@@ -834,5 +896,5 @@ def gen_graft():
 if __name__ == '__main__':
     which = sys.argv[1:] or ['sampler', 'llm', 'flow', 'hift', 'matcha', 'stream', 'graft', 'llm_stress', 'llm_cv3w', 'flow_cv3w', 'hift_cv3w']
     for w in which:
-        {'llm_cv3w': gen_llm_cv3w, 'flow_cv3w': gen_flow_cv3w, 'hift_cv3w': gen_hift_cv3w, 'sampler': gen_sampler, 'llm': gen_llm, 'flow': gen_flow, 'hift': gen_hift, 'matcha': gen_matcha, 'stream': gen_stream, 'graft': gen_graft, 'llm_stress': gen_llm_stress}[w]()
+        {'llm_cv3d': gen_llm_cv3d, 'flow_cv3d': gen_flow_cv3d, 'sampler_many': gen_sampler_many, 'llm_cv3w': gen_llm_cv3w, 'flow_cv3w': gen_flow_cv3w, 'hift_cv3w': gen_hift_cv3w, 'sampler': gen_sampler, 'llm': gen_llm, 'flow': gen_flow, 'hift': gen_hift, 'matcha': gen_matcha, 'stream': gen_stream, 'graft': gen_graft, 'llm_stress': gen_llm_stress}[w]()
     print('golden fixtures written to', HERE)

@@ -621,6 +621,113 @@ def test_synthesize_many_equals_one_by_one(tiny_cfg):
         assert many[i].shape[-1] > 0
 
 
+def test_queue_worker_serves_the_continuous_engine(tiny_cfg, tmp_path):
+    """§8(f) N1 in the worker (server/worker.py:54-102, server/router.py:144-156): 14 mixed tts / zero-shot tasks, a load_pt between them, one
+    request with other sampling parameters, one that the frontend refuses and one whose context budget cannot fit go through a
+    multiprocessing.Manager().Queue() into worker.serve_queue (requests join ONE decode grid of 3 slots as they arrive; finished ones go to
+    padded CFM solves beside the decode of the rest).  Every request's waveform equals what the one-at-a-time path (`_synthesize`: llm.inference
+    -> flow.inference -> hift.inference, the reference's loop) returns for the same seed and weights; the load_pt splits the run in two epochs."""
+    import argparse
+    import dataclasses
+    import json
+    import multiprocessing as mp
+    import types
+    from functools import partial
+    from flowmirror_hydravox_amd import weights as W
+    from flowmirror_hydravox_amd.model_manager import HvxModelManager, _synthesize
+    from flowmirror_hydravox_amd.sampling import ras_sampling
+    from flowmirror_hydravox_amd.worker import serve_queue
+    from test_host_cpu import _QueueFrontend
+    c = tiny_cfg
+    d = tmp_path / 'model'
+    d.mkdir()
+    torch.save(W.make_llm_state(c.llm, seed=5, init='fan_in'), d / 'llm.pt')
+    torch.save(W.make_llm_state(c.llm, seed=8, init='fan_in'), d / 'llm2.pt')
+    torch.save(W.make_flow_state(c.flow, seed=6, init='fan_in'), d / 'flow.pt')
+    torch.save(W.make_hift_state(c.hift, seed=7, init='fan_in'), d / 'hift.pt')
+    (d / 'hvx_config.json').write_text(json.dumps({'llm': dataclasses.asdict(c.llm), 'flow': dataclasses.asdict(c.flow), 'hift': dataclasses.asdict(c.hift)}))
+
+    class FE(_QueueFrontend):
+        def _ids(self, text):
+            if 'BAD' in text:
+                raise ValueError('cannot tokenise %r' % text)
+            return torch.tensor([[(ord(ch) * 7) % c.llm.text_vocab for ch in text]], dtype=torch.int32)
+
+        def frontend_zero_shot(self, text, prompt_text, prompt, sr, zero_shot_spk_id=''):
+            g = torch.Generator().manual_seed(len(text))
+            n = 4 + len(text) % 3
+            tok = torch.randint(0, c.llm.speech_tokens, (1, n), generator=g, dtype=torch.int32)
+            return dict(text=self._ids(text), text_len=torch.tensor([len(text)], dtype=torch.int32), prompt_text=self._ids(prompt_text),
+                        prompt_text_len=torch.tensor([len(prompt_text)], dtype=torch.int32), llm_prompt_speech_token=tok,
+                        llm_prompt_speech_token_len=torch.tensor([n], dtype=torch.int32), flow_prompt_speech_token=tok,
+                        flow_prompt_speech_token_len=torch.tensor([n], dtype=torch.int32), prompt_speech_feat=torch.randn(1, 2 * n, 80, generator=g),
+                        prompt_speech_feat_len=torch.tensor([2 * n], dtype=torch.int32), llm_embedding=torch.zeros(0, 192),
+                        flow_embedding=torch.randn(1, 192, generator=g))
+
+        def frontend_sft(self, text, spk_id):
+            g = torch.Generator().manual_seed(len(spk_id))
+            return dict(text=self._ids(text), text_len=torch.tensor([len(text)], dtype=torch.int32), llm_embedding=torch.zeros(0, 192),
+                        flow_embedding=torch.randn(192, generator=g))
+
+    def make_mm(max_ctx):
+        mm = HvxModelManager(frontend_factory=lambda args, cfg: FE())
+        mm.load_models(argparse.Namespace(config=None, model_dir=str(d), bf16=True, fp16=False, cpu=False))
+        return mm
+    ep = dict(top_p=0.8, top_k=25, win_size=10, tau_r=0.1, inference_head_num=2)
+    texts = ['hello world', 'a', 'speech synthesis on one grid', 'b c', 'the quick brown fox', 'xyz', 'BAD input', 'jumps over', 'lazy dogs and cats',
+             'nine', 'ten ten', 'eleven!', 'x' * 300, 'tail one', 'tail two']
+    tasks = []
+    for i, t in enumerate(texts):
+        if i % 3 == 1:
+            tasks.append(dict(id='t%d' % i, task_type='zero_shot', tts_text=t, prompt_text='pr' + t[:2], prompt_audio=None, prompt_sample_rate=16000,
+                              extra_params=dict(ep, speed=1.0 if i != 4 else 1.2), seed=100 + i))
+        else:
+            tasks.append(dict(id='t%d' % i, task_type='tts', text=t, speaker_id='spk%d' % (i % 2), extra_params=dict(ep, speed=1.25 if i == 5 else 1.0), seed=100 + i))
+    tasks[9]['extra_params'] = dict(ep, top_k=5)                       # other sampling parameters: an epoch of its own
+    tasks.insert(8, dict(id='swap', task_type='load_pt', llm_pt=str(d / 'llm2.pt'), flow_pt=str(d / 'flow.pt')))
+    tasks.append(dict(id='odd', task_type='nonsense'))
+    with mp.Manager() as man:
+        q, results = man.Queue(), man.dict()
+        for t in tasks:
+            q.put(t)
+        q.put(None)
+        mm = make_mm(512)
+        serve_queue(mm, q, results, worker_id=0, lm_slots=3, acoustic_batch=2, normalise=lambda s: s)
+        results = dict(results)
+    assert set(results) == {t['id'] for t in tasks}                  # every request is answered, whatever happened to it
+    assert results['swap'] == {'status': 'success', 'message': 'model weights loaded'} and 'error' in results['odd']
+    assert results['t6'] == {'error': "cannot tokenise 'BAD input'"}
+    assert 'max_ctx' in results['t12']['error']                       # 300 text tokens x ratio 20 cannot fit the 4096-row context: that request only
+    # the one-at-a-time path on a fresh manager, with the same hot swap at the same place
+    ref = make_mm(512)
+    fe = ref.frontend
+    for t in tasks:
+        if t['id'] == 'swap':
+            assert ref.load_pt(t['llm_pt'], t['flow_pt'])['status'] == 'success'
+            continue
+        if t['id'] in ('odd', 't6', 't12'):
+            continue
+        e = t['extra_params']
+        ref.models['llm'].sampling = partial(ras_sampling, top_p=e['top_p'], top_k=e['top_k'], win_size=e['win_size'], tau_r=e['tau_r'])
+        ref.models['llm'].inference_head_num = e['inference_head_num']
+        if t['task_type'] == 'tts':
+            mi = fe.frontend_sft(t['text'], t['speaker_id'])
+        else:
+            mi = fe.frontend_zero_shot(t['tts_text'], t['prompt_text'], None, 24000)
+        torch.manual_seed(0)
+        llm = ref.models['llm']
+        orig = llm.inference
+        llm.inference = lambda **kw: orig(seed=t['seed'], **kw)          # (the per-request seed the queue task carries)
+        try:
+            want = _synthesize(ref, mi, float(e.get('speed', 1.0)), zero_shot=t['task_type'] == 'zero_shot')
+        finally:
+            llm.inference = orig
+        got = results[t['id']]
+        assert got['sample_rate'] == 24000 and got['output_audio'].shape == want.shape, (t['id'], got['output_audio'].shape, want.shape)
+        assert abs(got['duration'] - want.shape[-1] / 24000) < 1e-9
+        assert torch.equal(got['output_audio'], want), t['id']
+
+
 def test_packed_weight_cache_gives_the_same_models(tiny_cfg, tmp_path):
     """§8(f) N4: ModelManager with a packed-weight cache — the second start loads the device-ready tensors instead of the `.pt` files and
     synthesises the same samples; load_pt goes through the cache too."""

@@ -230,6 +230,48 @@ dist.destroy_process_group()
 '''
 
 
+_DEAL_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from flowmirror_hydravox_amd.dp import shard_by_cost, Handoff
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+dist.init_process_group('gloo')
+g = torch.Generator().manual_seed(3)
+n_text = [int(v) for v in torch.randint(64, 513, (21,), generator=g)]            # configs[3]-like mixed lengths, 21 utterances: an uneven deal
+def synth(gid):                                                                   # stands in for the pipeline: a waveform that depends on the global id only
+    return torch.sin(torch.arange(n_text[gid] * 3, dtype=torch.float32) * (gid + 1) * 1e-2)
+shards = shard_by_cost([float(v) for v in n_text], world)
+assert sorted(i for s in shards for i in s) == list(range(21)) and len(shards[0]) != len(shards[1]) or world != 2
+hand = Handoff(shards, 4, dst=0)
+for gid in reversed(shards[rank]):                                                # completion order is not arrival order
+    hand.push(gid, synth(gid))
+got = hand.finish()
+if rank == 0:
+    assert sorted(got) == list(range(21))
+    for gid in range(21):
+        assert torch.equal(got[gid], synth(gid)), gid                             # == what one rank alone produces for that global id
+    loads = [sum(n_text[i] for i in s) for s in shards]
+    assert max(loads) - min(loads) <= max(n_text)
+    print('DEAL_OK rounds', hand.rounds)
+else:
+    assert got == {}
+dist.destroy_process_group()
+'''
+
+
+def test_longest_first_deal_and_handoff_rounds_world_size_2_gloo(tmp_path):
+    """SURVEY.md §8(e): the global utterance list dealt longest-first across ranks; uneven shard sizes still enter the gather collective the
+    same number of times on every rank; rank 0 ends up with exactly the single-rank waveforms, keyed by global id."""
+    script = tmp_path / 'd.py'
+    script.write_text(_DEAL_WORKER % ROOT)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29633', WORLD_SIZE='2')
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert 'DEAL_OK' in outs[0]
+
+
 def test_waveform_gather_world_size_2_gloo(tmp_path):
     script = tmp_path / 'w.py'
     script.write_text(_GLOO_WORKER % ROOT)
@@ -253,26 +295,67 @@ def test_model_manager_surface_and_load_pt_never_raises():
             mm.load_models(argparse.Namespace(config=None, model_dir='/tmp', bf16=True, fp16=False, cpu=True))
 
 
-def test_batching_worker_groups_tasks_by_sampling_parameters():
-    from flowmirror_hydravox_amd.worker import group_batchable
+class _QueueFrontend:
+    """stands in for the reference's CosyVoiceFrontEnd (cli/frontend.py): text -> ids, fixed speaker / prompt features"""
+    def text_normalize(self, text, split=True, text_frontend=True):
+        return [text] if split else text
+
+    def _ids(self, text):
+        if 'BAD' in text:
+            raise ValueError('cannot tokenise %r' % text)
+        return torch.tensor([[(ord(c) * 7) % 500 for c in text]], dtype=torch.int32)
+
+    def frontend_sft(self, text, spk_id):
+        return dict(text=self._ids(text), flow_embedding=torch.full((192,), 0.01 * len(spk_id)))
+
+    def frontend_zero_shot(self, text, prompt_text, prompt, sr, zero_shot_spk_id=''):
+        n = 5
+        return dict(text=self._ids(text), prompt_text=self._ids(prompt_text), llm_prompt_speech_token=torch.arange(n, dtype=torch.int32)[None],
+                    flow_prompt_speech_token=torch.arange(n, dtype=torch.int32)[None], prompt_speech_feat=torch.zeros(1, 2 * n, 80),
+                    flow_embedding=torch.full((1, 192), 0.02))
+
+
+def test_queue_task_source_epochs_keep_fifo_around_hot_swaps_and_parameter_changes():
+    """worker._TaskSource (what the continuous engine polls): consecutive synthesis tasks with the same sampling parameters join one epoch as
+    they arrive; a load_pt, another parameter set, an unknown type or the sentinel closes the epoch and is carried over — never overtaken by
+    what arrived behind it (reference: one task at a time, server/worker.py:54-102).  A frontend error answers that request only."""
+    import queue
+    import types
+    from flowmirror_hydravox_amd.worker import _TaskSource
     ep = dict(top_p=0.8, top_k=25, win_size=10, tau_r=0.1, inference_head_num=2)
-    tasks = [dict(id=1, task_type='tts', text='a', speaker_id='s', extra_params=ep),
-             dict(id=2, task_type='load_pt', llm_pt='x', flow_pt='y'),
-             dict(id=3, task_type='zero_shot', tts_text='b', extra_params=dict(ep)),
-             dict(id=4, task_type='tts', text='c', speaker_id='s', extra_params=dict(ep, top_k=10)),
-             dict(id=5, task_type='tts', text='d', speaker_id='s', extra_params=dict(ep))]
-    # FIFO around a hot swap (reference: one task at a time, server/worker.py:54-102): only the LEADING run of compatible synthesis tasks is
-    # decoded together; the load_pt that arrived second is never overtaken by tasks 3..5
-    batch, singles, later = group_batchable(tasks)
-    assert [t['id'] for t in batch] == [1] and singles == [] and [t['id'] for t in later] == [2, 3, 4, 5]
-    batch, singles, later = group_batchable(later)
-    assert batch == [] and [t['id'] for t in singles] == [2] and [t['id'] for t in later] == [3, 4, 5]
-    batch, singles, later = group_batchable(later)
-    assert [t['id'] for t in batch] == [3] and [t['id'] for t in later] == [4, 5]          # task 4 has another top_k
-    same = [dict(id=i, task_type='tts', text='x', speaker_id='s', extra_params=dict(ep)) for i in range(4)]
-    batch, singles, later = group_batchable(same + [dict(id=9, task_type='load_pt')])
-    assert [t['id'] for t in batch] == [0, 1, 2, 3] and singles == [] and [t['id'] for t in later] == [9]
-    assert group_batchable([]) == ([], [], [])
+    mm = types.SimpleNamespace(frontend=_QueueFrontend(), configs={'sample_rate': 24000})
+    q, results = queue.Queue(), {}
+    tasks = [dict(id=1, task_type='tts', text='abc', speaker_id='s', extra_params=dict(ep)),
+             dict(id=2, task_type='zero_shot', tts_text='de', prompt_text='p', prompt_audio=None, prompt_sample_rate=16000, extra_params=dict(ep, speed=1.25), seed=7),
+             dict(id=3, task_type='tts', text='BAD', speaker_id='s', extra_params=dict(ep)),
+             dict(id=4, task_type='load_pt', llm_pt='x', flow_pt='y'),
+             dict(id=5, task_type='tts', text='fgh', speaker_id='s', extra_params=dict(ep)),
+             dict(id=6, task_type='tts', text='i', speaker_id='s', extra_params=dict(ep, top_k=10)),
+             None]
+    for t in tasks[1:]:
+        q.put(t)
+    src = _TaskSource(mm, q, results, tasks[0], lambda s: s, 0)
+    u1, u2 = src.poll(False), src.poll(False)
+    assert u1.tag['id'] == 1 and u1.text.tolist() == [(ord(c) * 7) % 500 for c in 'abc'] and u1.prompt_text is None and u1.speed == 1.0 and u1.seed is None
+    assert u2.tag['id'] == 2 and u2.prompt_speech_token.tolist() == [0, 1, 2, 3, 4] and tuple(u2.prompt_feat.shape) == (10, 80) and u2.speed == 1.25 and u2.seed == 7
+    with pytest.raises(StopIteration):                    # task 3 fails in the frontend (answered at once), task 4 closes the epoch
+        src.poll(False)
+    assert results == {3: {'error': "cannot tokenise 'BAD'"}} and src.carry['id'] == 4 and not src.stop
+    with pytest.raises(StopIteration):                    # (a closed source stays closed: nothing behind the load_pt is taken)
+        src.poll(True)
+    assert q.qsize() == 3
+    src = _TaskSource(mm, q, results, q.get(), lambda s: s, 0)           # the worker serves the load_pt, then starts the next epoch with task 5
+    assert src.poll(False).tag['id'] == 5
+    with pytest.raises(StopIteration):
+        src.poll(False)
+    assert src.carry['id'] == 6 and not src.stop           # other sampling parameters: llm.sampling is per-model state
+    src = _TaskSource(mm, q, results, src.carry, lambda s: s, 0)
+    assert src.poll(False).tag['id'] == 6
+    with pytest.raises(StopIteration):
+        src.poll(True)
+    assert src.stop and src.carry is None                  # the shutdown sentinel
+    empty = _TaskSource(mm, queue.Queue(), results, tasks[0], lambda s: s, 0)
+    assert empty.poll(False).tag['id'] == 1 and empty.poll(False) is None      # nothing waiting right now: not closed
 
 
 def test_stream_tts_chunk_schedule_matches_the_reference_loop():

@@ -412,3 +412,73 @@ def test_cv3w_hift_oracle_vs_reference_vectors(cv3w_cfg):
         assert np.abs(hift_ref.f0_predictor(mel, sd).numpy() - g[p + 'f0']).max() < 2e-3
         wav = hift_ref.decode(mel, torch.from_numpy(g[p + 'source']), sd, c)
         assert np.abs(wav.numpy() - g[p + 'wav']).max() < 5e-4
+
+
+# ---- round 3: 1000 more sampler cases, and the models at FULL DEPTH (24 LM layers / 22 DiT blocks), all minted from the reference -----------
+def test_sampler_thousand_cases_ids_and_noise_consumption():
+    """tests/golden/sampler_many.npz: inputs regenerated from per-case seeds (tests/golden/sampler_cases.py, checksummed), ids and noise
+    consumption == what the reference's sampling_ids returned for them (760 cases at V = 296, 240 at V = 6761)."""
+    import hashlib
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    from sampler_cases import make_case, N_CASES
+    g = load_golden('sampler_many.npz')
+    assert len(g['id']) == N_CASES >= 1000
+    n_big = 0
+    for i in range(N_CASES):
+        c = make_case(i)
+        assert int.from_bytes(hashlib.sha256(c['logp'].tobytes()).digest()[:8], 'little', signed=True) == int(g['logp_sha'][i]), i
+        n_big += c['Vs'] == 6561
+        ns = sampler_ref.NoiseStream(seed=c['seed'])
+        try:
+            got = sampler_ref.sampling_ids(c['logp'], list(c['hist']), ns, c['Vs'], c['ignore_eos'], top_p=c['top_p'], top_k=c['top_k'],
+                                           win_size=c['win'], tau_r=c['tau'])
+        except RuntimeError:
+            got = -1
+        assert got == int(g['id'][i]), i
+        assert ns.cursor == int(g['consumed'][i]), i
+    assert n_big >= 200
+
+
+def test_cv3d_flow_oracle_vs_reference_vectors():
+    """22 DiT blocks (config.cv3d_config): the chunk-masked estimator at T = 192 and the whole 10-step solve == the reference's outputs"""
+    from flowmirror_hydravox_amd.config import cv3d_config
+    g = load_golden('flow_cv3d.npz')
+    c = cv3d_config().flow
+    assert c.depth == 22
+    sd = W.make_flow_state(c, seed=int(g['weight_seed']), init='fan_in')
+    assert state_checksum(sd) == str(g['weight_sha'])
+    tag = 'e1'
+    x, mask, mu, spk, cond = cv3w_flow_inputs(int(g[tag + '_seed']), int(g[tag + '_T']), g[tag + '_lens'].tolist())
+    assert state_checksum(dict(x=x, mu=mu, spk=spk, cond=cond)) == str(g[tag + '_in_sha'])
+    est = flow_ref.dit_forward(x, mask, mu, torch.from_numpy(g[tag + '_t']), spk, cond, sd, c, streaming=bool(g[tag + '_streaming']))
+    assert np.abs((est * mask).numpy() - g[tag + '_out']).max() < 1e-3
+    mel = flow_ref.flow_inference(torch.from_numpy(g['token']), torch.from_numpy(g['emb']), sd, c, prompt_token=torch.from_numpy(g['ptoken']),
+                                  prompt_feat=torch.from_numpy(g['pfeat']))
+    assert np.abs(mel.numpy() - g['mel']).max() < 2e-3
+
+
+def test_cv3d_llm_oracle_vs_reference_vectors():
+    """24 LM layers: the K = 1 and the first K = 2 / K = 4 token streams and the first-step pin of run 1 == the reference's (the remaining runs,
+    incl. the one across context 1024, are replayed on the GPU box only: the CPU oracle needs minutes for them)"""
+    from flowmirror_hydravox_amd.config import cv3d_config
+    g = load_golden('llm_cv3d.npz')
+    cfg = cv3d_config().llm
+    assert cfg.layers == 24
+    sd = W.make_llm_state(cfg, seed=int(g['weight_seed']), init='fan_in', with_lm_head=True)
+    assert state_checksum(sd) == str(g['weight_sha'])
+    top_p, top_k, win, tau = g['sampling']
+    sampling = dict(top_p=float(top_p), top_k=int(top_k), win_size=int(win), tau_r=float(tau))
+    for r in (0, 2, 4):
+        p = 'r%d_' % r
+        toks = list(llm_ref.llm_inference(sd, cfg, torch.from_numpy(g[p + 'text']), sampler_ref.NoiseStream(seed=int(g[p + 'seed'])),
+                                          prompt_text=torch.from_numpy(g[p + 'ptext']), prompt_speech_token=torch.from_numpy(g[p + 'pspeech']),
+                                          inference_head_num=int(g[p + 'K']), sampling=sampling, max_token_text_ratio=float(g[p + 'ratios'][0]),
+                                          min_token_text_ratio=float(g[p + 'ratios'][1]), use_kv_cache=True))
+        assert toks == g[p + 'tokens'].tolist(), r
+    p = 'r1_'
+    x = llm_ref.build_prefix(sd, cfg, torch.from_numpy(g[p + 'text']), torch.from_numpy(g[p + 'ptext']), torch.from_numpy(g[p + 'pspeech']))
+    y = llm_ref.backbone(x, sd, cfg)
+    assert np.abs(y[-1].numpy() - g[p + 'y_last']).max() < 2e-4
+    lp = torch.stack(llm_ref.head_logps(y[-1], sd, cfg, cfg.head_num)).numpy()
+    assert np.abs(lp - g[p + 'logps']).max() < 2e-3
