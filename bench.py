@@ -58,6 +58,7 @@ def parse():
                          'chains: the round-1 form, --lm-chains independent decode chains of one step each; serial: stages back to back')
     ap.add_argument('--acoustic-batch', type=int, default=4, help='utterances per padded CFM solve (x CFG 2 rows per estimator call)')
     ap.add_argument('--acoustic-min-batch', type=int, default=4, help='(--mode continuous) the acoustic stage waits for this many finished utterances (throughput over latency)')
+    ap.add_argument('--lm-cus', type=int, default=0, help='(--mode continuous) compute units reserved for the decode engine; the acoustic stage runs on the others (0: both share all CUs)')
     ap.add_argument('--acoustic-chains', type=int, default=1, help='(--mode chains) kept for compatibility: more than one concurrent acoustic chain is not supported (clamped to 1)')
     ap.add_argument('--lm-chains', type=int, default=3, help='(--mode chains) batches whose LM decode runs concurrently')
     ap.add_argument('--serial', action='store_true', help='same as --mode serial')
@@ -339,6 +340,9 @@ def main():
     pipe = HvxPipeline(cfg, llm_dtype=torch.bfloat16, flow_dtype=torch.bfloat16, max_batch=B, max_ctx=max_ctx, max_t=2 * (n_spk + P_SPK) + 64,
                        seed=1986, init='normal02', sampling=sampling, inference_head_num=K)
     pipe.acoustic_batch = max(1, args.acoustic_batch)
+    pipe.lm_cus = args.lm_cus
+    if args.lm_cus > 0:
+        pipe.llm.cu_range = (0, args.lm_cus)             # (before the first decode engine exists: the engine keeps its stream)
     t_build = time.time() - t_build
     utts = [make_utt(rank * B + i) for i in range(B)]
     gids = [rank * B + i for i in range(B)]
@@ -488,6 +492,7 @@ def main():
                                 'chains': '%d independent decode chains of one step each + %d acoustic chain(s)' % (args.lm_chains, args.acoustic_chains),
                                 'serial': 'stages back to back'}[args.mode],
                    'utterances_in_flight_per_gpu': in_flight,
+                   'cu_partition': ('decode engine on %d CUs, acoustic stage on the other %d' % (args.lm_cus, lib.hvx_device_ok() - args.lm_cus)) if args.lm_cus > 0 and args.mode == 'continuous' else 'none (both stages share all CUs)',
                    'sampling': {'top_p': 0.9, 'top_k': 10, 'win_size': 32, 'tau_r': 0.2}},
         'rtf': round(elapsed / audio, 6) if audio else None,
         'llm_tokens_per_s': round(tokens / llm_s, 2) if llm_s else None,

@@ -101,6 +101,8 @@ SYMBOLS = {
     'hvx_abi_version': (c_i32, []),
     'hvx_last_error': (C.c_char_p, []),
     'hvx_device_ok': (c_i32, []),
+    'hvx_stream_create_cu_range': (c_i32, [c_i32, c_i32, C.POINTER(c_vp)]),
+    'hvx_stream_destroy': (c_i32, [c_vp]),
     'hvx_prof_enable': (c_i32, [c_i32]),
     'hvx_prof_read': (c_i32, [c_i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(c_i64), C.POINTER(c_i64), C.POINTER(C.c_double)]),
     'hvx_ras_sample': (c_i32, [C.POINTER(SampleArgs), c_vp]),
@@ -210,6 +212,14 @@ def ptr(t):
 def stream_ptr():
     import torch
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def cu_range_stream(first_cu, n_cus, device=None):
+    """a torch stream over a HIP stream confined to CUs [first_cu, first_cu + n_cus) (hvx_stream_create_cu_range); lives as long as the process"""
+    import torch
+    h = c_vp()
+    check(load().hvx_stream_create_cu_range(int(first_cu), int(n_cus), C.byref(h)), 'hvx_stream_create_cu_range')
+    return torch.cuda.ExternalStream(h.value, device=device)
 
 
 def dtype_code(torch_dtype):

@@ -74,6 +74,25 @@ int hvx_device_ok(void) {
     return p.multiProcessorCount;
 }
 
+int hvx_stream_create_cu_range(int32_t first_cu, int32_t n_cus, hvx_stream* out) {
+    if (!out || first_cu < 0 || n_cus <= 0) return set_error("hvx_stream_create_cu_range: bad arguments"), -1;
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return set_error("hvx_stream_create_cu_range: no device"), -1;
+    if (first_cu + n_cus > p.multiProcessorCount)
+        return set_error("hvx_stream_create_cu_range: CUs [%d, %d) outside the device's %d", first_cu, first_cu + n_cus, p.multiProcessorCount), -1;
+    std::vector<uint32_t> mask((p.multiProcessorCount + 31) / 32, 0u);
+    for (int i = first_cu; i < first_cu + n_cus; ++i) mask[i >> 5] |= 1u << (i & 31);
+    hipStream_t s = nullptr;
+    const hipError_t e = hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data());
+    if (e != hipSuccess) return set_error("hipExtStreamCreateWithCUMask: %s", hipGetErrorString(e)), -1;
+    *out = (hvx_stream)s;
+    return 0;
+}
+int hvx_stream_destroy(hvx_stream s) {
+    return hipStreamDestroy((hipStream_t)s) == hipSuccess ? 0 : (set_error("hipStreamDestroy failed"), -1);
+}
+
 int hvx_prof_enable(int32_t period) {
     for (auto& p : g_prof.slots) { hipEventDestroy(p.e0); hipEventDestroy(p.e1); }
     g_prof.slots.clear();

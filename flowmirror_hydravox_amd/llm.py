@@ -370,7 +370,10 @@ class _DecodeEngine:
         dev = llm.device
         S, K = self.S, self.K
         if getattr(llm, '_stream', None) is None:
-            llm._stream = torch.cuda.Stream(device=dev, priority=-1)       # decode launches go ahead of a concurrent acoustic stage
+            # decode launches go ahead of a concurrent acoustic stage (priority) — or, with llm.cu_range = (first, n), run on their own compute
+            # units: a stream priority orders dispatches, it cannot take a CU back from a 200-900 us workgroup of the acoustic stage
+            cr = getattr(llm, 'cu_range', None)
+            llm._stream = _lib.cu_range_stream(cr[0], cr[1], device=dev) if cr else torch.cuda.Stream(device=dev, priority=-1)
         self.stream = llm._stream
         self.stream.wait_stream(torch.cuda.current_stream())
         self.W = max(self.sp['win_size'] if self.sp['win_size'] > 0 else self.max_out, 1)

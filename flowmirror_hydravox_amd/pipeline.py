@@ -297,7 +297,16 @@ class HvxPipeline:
         import queue
         import threading
         if getattr(self, '_bg_stream', None) is None:
-            self._bg_stream = torch.cuda.Stream(device=self.device, priority=0)
+            lm_cus = int(getattr(self, 'lm_cus', 0) or 0)
+            if lm_cus > 0:
+                # CU partition: the decode engine on CUs [0, lm_cus), the acoustic stage on the rest — both ranges spread over all
+                # 8 XCDs.  Must be set before the first decode engine of self.llm is built (the engine keeps its stream).
+                from . import _lib
+                n_cu = _lib.load().hvx_device_ok()
+                self.llm.cu_range = (0, lm_cus)
+                self._bg_stream = _lib.cu_range_stream(lm_cus, n_cu - lm_cus, device=self.device)
+            else:
+                self._bg_stream = torch.cuda.Stream(device=self.device, priority=0)
             self._bg_streams = [self._bg_stream]
             self._bg_pools = []
         flow, hift, stream = self._acoustic_chain(0)

@@ -36,6 +36,13 @@ int hvx_device_ok(void);
 /* Sampled per-kernel timing for bench.py (diagnostics, not on the product path): every `period`-th launch of a kernel class
  * (0 decode GEMM, 1 tiled GEMM/conv, 2 attention, 3 sampler) is bracketed by hipEvents on its stream; period <= 0 disables.
  * `work` is the algorithmic bytes (class 0) or flops (classes 1, 2) of the launches. */
+/* A HIP stream whose kernels run on a subset of the compute units (hipExtStreamCreateWithCUMask): CUs [first_cu, first_cu + n_cus) of the
+ * driver's enumeration, which deals consecutive indices round-robin over the 8 XCDs, so a contiguous range is spread evenly over them.
+ * The decode engine and the acoustic stage get disjoint ranges (pipeline.py: lm_cus): the ~150 short dependent launches of a decode step
+ * then never queue behind 200-900 us workgroups of the DiT GEMMs / attention.  Destroy with hvx_stream_destroy.  Returns 0 or -1. */
+int hvx_stream_create_cu_range(int32_t first_cu, int32_t n_cus, hvx_stream* out);
+int hvx_stream_destroy(hvx_stream s);
+
 int hvx_prof_enable(int32_t period);
 int hvx_prof_read(int32_t kind, double* sampled_ms, double* sampled_work, int64_t* n_sampled, int64_t* n_launched, double* launched_work);
 
