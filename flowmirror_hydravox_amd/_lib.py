@@ -151,6 +151,7 @@ SYMBOLS = {
     'hvx_denoise': (c_i32, [c_vp, c_vp, c_sz, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp]),
     'hvx_hift_create': (c_i32, [C.POINTER(HiftConfig), C.POINTER(c_vp), c_i32, C.POINTER(c_vp)]),
     'hvx_hift_destroy': (None, [c_vp]),
+    'hvx_hift_set_weight_planes': (c_i32, [c_vp, c_vp, c_i32]),
     'hvx_hift_workspace_bytes': (c_sz, [c_vp, c_i32]),
     'hvx_hift_f0': (c_i32, [c_vp, c_vp, c_vp, c_sz, c_vp, c_i32, c_vp]),
     'hvx_hift_source': (c_i32, [c_vp, c_vp, c_vp, c_sz, c_vp, c_i32, c_vp, c_vp]),

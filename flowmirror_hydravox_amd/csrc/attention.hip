@@ -349,9 +349,23 @@ __global__ __launch_bounds__(256, 2) void attn_dit_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) T Vs[2][64 * LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
-    const int b = blockIdx.z, h = blockIdx.y;
+    // XCD-aware workgroup order: consecutive workgroup ids go round-robin to the 8 XCDs (each with its own L2), so with the plain (row block,
+    // head, batch) order the row blocks of ONE head land on all 8 XCDs and every L2 fetches that head's K / V^T (rocprofv3 FETCH_SIZE: 4.8x
+    // the algorithmic bytes, profiles/r03_pmc_traffic.json).  Remapped, XCD e walks the row blocks of heads e, e + 8, ... one head after the
+    // other: a head's K / V^T are fetched into one L2 and re-used there by all its row blocks (bijective when heads x batch is a multiple of 8).
+    int b = blockIdx.z, h = blockIdx.y, bx0 = blockIdx.x;
+    {
+        const int nx = gridDim.x, nh = gridDim.y * gridDim.z;
+        if ((nh & 7) == 0) {
+            const int L = blockIdx.x + nx * (blockIdx.y + gridDim.y * blockIdx.z);
+            const int j = L >> 3, hb = (j / nx) * 8 + (L & 7);
+            bx0 = j % nx;
+            h = hb % gridDim.y;
+            b = hb / gridDim.y;
+        }
+    }
     // with a chunk mask the work per workgroup grows with its row index: dispatch the long ones first
-    const int bx = a.chunk > 0 ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+    const int bx = a.chunk > 0 ? gridDim.x - 1 - bx0 : bx0;
     const int row0 = bx * (64 * QR) + wave * (16 * QR);
     const int kv_len = a.kv_len ? a.kv_len[b] : a.kv_len_const;
     const T* __restrict__ kb = reinterpret_cast<const T*>(a.k) + (long long)b * a.k_bs + (long long)h * a.k_hs;

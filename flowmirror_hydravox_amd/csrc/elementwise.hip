@@ -112,6 +112,33 @@ __global__ void act_rows_kernel(const float* x, int ldx, T* y, int ldy, int act,
         y[r * ldy + c] = from_f32<T>(act_apply(act, x[r * ldx + c], param, alpha ? alpha[c] : 1.0f));
     }
 }
+// the same with the result as a (hi, lo) bf16 plane pair (GemmArgs.a_planes: the operand format of gemm_x3p_kernel)
+__global__ void act_rows_planes_kernel(const float* x, int ldx, bf16_t* y, int ldy, long long plane, int act, float param, const float* alpha, long long rows, int cols4) {
+    const long long total = rows * cols4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / cols4;
+        const int c = (int)(i - r * cols4) * 4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * ldx + c);
+        const f32x4 al = alpha ? *reinterpret_cast<const f32x4*>(alpha + c) : f32x4{1, 1, 1, 1};
+        bf16x4 h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float u = act_apply(act, v[e], param, al[e]);
+            h[e] = f32_to_bf16(u);
+            l[e] = f32_to_bf16(u - bf16_to_f32(h[e]));
+        }
+        *reinterpret_cast<bf16x4*>(y + r * ldy + c) = h;
+        *reinterpret_cast<bf16x4*>(y + plane + r * ldy + c) = l;
+    }
+}
+int launch_act_rows_planes(const float* x, int ldx, void* y, int ldy, long long plane, int act, float param, const float* alpha, long long rows, int cols, hipStream_t s) {
+    if (rows <= 0 || cols <= 0) return 0;
+    if ((cols & 3) || (ldx & 3) || (ldy & 3) || (plane & 3)) return set_error("act_rows (plane pair): columns and strides must be multiples of 4"), -1;
+    const long long want = (rows * (cols / 4) + 255) / 256;
+    const int blocks = (int)(want < 8192 ? want : 8192);
+    hipLaunchKernelGGL(act_rows_planes_kernel, dim3(blocks), dim3(256), 0, s, x, ldx, (bf16_t*)y, ldy, plane, act, param, alpha, rows, cols / 4);
+    return hipGetLastError() == hipSuccess ? 0 : (set_error("act_rows (plane pair) launch failed"), -1);
+}
 int launch_act_rows(const float* x, int ldx, void* y, int ldy, int dtype, int act, float param, const float* alpha, long long rows, int cols,
                     hipStream_t s) {
     if (rows <= 0 || cols <= 0) return 0;

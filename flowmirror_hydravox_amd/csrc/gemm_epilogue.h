@@ -21,6 +21,23 @@ __device__ __forceinline__ void wave_lds_order() {
     asm volatile("" ::: "memory");
 }
 
+// fp32 values leaving as a (hi, lo) bf16 plane pair (GemmArgs.out_planes / out2_planes): four consecutive columns = two 8-byte stores
+__device__ __forceinline__ void store_planes4(bf16_t* hi, long long plane, const f32x4& v) {
+    bf16x4 h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        h[e] = f32_to_bf16(v[e]);
+        l[e] = f32_to_bf16(v[e] - bf16_to_f32(h[e]));
+    }
+    *reinterpret_cast<bf16x4*>(hi) = h;
+    *reinterpret_cast<bf16x4*>(hi + plane) = l;
+}
+__device__ __forceinline__ void store_planes1(bf16_t* hi, long long plane, float v) {
+    const bf16_t h = f32_to_bf16(v);
+    hi[0] = h;
+    hi[plane] = f32_to_bf16(v - bf16_to_f32(h));
+}
+
 // acc: the wave's MT x NT accumulator tiles whose first row / column are mw0 / nw0; scr: this wave's private fp32 LDS staging tile of
 // ((64 / WN) * 16) rows x (WN + 4) floats (the caller has passed the barrier that frees it).
 template <bool RT, int ACT, int RES, int OF32, int O2, int ACT2 = 0> struct LeanMode {
@@ -161,7 +178,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT]
                 }
                 const int row0 = mw0 + ip * 16;
                 if (has_out) {
-                    if (out_f32 || sizeof(T) != 2) {
+                    if (sizeof(T) != 2 && a.out_planes) {
+                        bf16_t* const obp = reinterpret_cast<bf16_t*>(a.out) + ob + gcw;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (row0 + rsel(q) < a.M) store_planes4(obp + (long long)(row0 + rsel(q) + a.out_row_off) * a.ldo + cof(q), a.out_plane, v[q]);
+                    } else if (out_f32 || sizeof(T) != 2) {
                         float* const ob32 = reinterpret_cast<float*>(a.out) + ob + gcw;
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
@@ -187,6 +209,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT]
                     }
                     if constexpr (sizeof(T) == 2) {
                         store_bf16(ob2, a.ldo2, a.out2_row_off, v);
+                    } else if (a.out2_planes) {
+                        bf16_t* const obp = reinterpret_cast<bf16_t*>(a.out2) + (long long)bz * a.out2_bs + gcw;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (row0 + rsel(q) < a.M) store_planes4(obp + (long long)(row0 + rsel(q) + a.out2_row_off) * a.ldo2 + cof(q), a.out2_plane, v[q]);
                     } else {
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
@@ -263,7 +290,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT]
                     v *= a.scale;
                     if (a.div != 0.0f) v = v / a.div;
                     if (a.out) {
-                        if (a.out_f32) {
+                        if (sizeof(T) != 2 && a.out_planes) {
+                            bf16_t* op = reinterpret_cast<bf16_t*>(a.out) + o1 + c4;
+                            if (vec) store_planes4(op, a.out_plane, v);
+                            else { for (int e = 0; e < 4; ++e) store_planes1(op + e, a.out_plane, v[e]); }
+                        } else if (a.out_f32) {
                             float* op = reinterpret_cast<float*>(a.out) + o1 + c4;
                             if (vec) *reinterpret_cast<f32x4*>(op) = v;
                             else { op[0] = v[0]; op[1] = v[1]; op[2] = v[2]; op[3] = v[3]; }
@@ -289,6 +320,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT]
                             bf16x4 w4 = {f32_to_bf16(u[0]), f32_to_bf16(u[1]), f32_to_bf16(u[2]), f32_to_bf16(u[3])};
                             if (vec) *reinterpret_cast<bf16x4*>(op) = w4;
                             else { op[0] = w4[0]; op[1] = w4[1]; op[2] = w4[2]; op[3] = w4[3]; }
+                        } else if (a.out2_planes) {
+                            bf16_t* opp = reinterpret_cast<bf16_t*>(a.out2) + o2 + c4;
+                            if (vec) store_planes4(opp, a.out2_plane, u);
+                            else { for (int e = 0; e < 4; ++e) store_planes1(opp + e, a.out2_plane, u[e]); }
                         } else {
                             if (vec) *reinterpret_cast<f32x4*>(op) = u;
                             else { op[0] = u[0]; op[1] = u[1]; op[2] = u[2]; op[3] = u[3]; }
@@ -319,12 +354,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT]
                     }
                     if (a.out && (col_ok || col_pad)) {
                         const long long o = ob + (long long)(row + a.out_row_off) * a.ldo + gc;
-                        if (a.out_f32) reinterpret_cast<float*>(a.out)[o] = v;
+                        if (sizeof(T) != 2 && a.out_planes) store_planes1(reinterpret_cast<bf16_t*>(a.out) + o, a.out_plane, v);
+                        else if (a.out_f32) reinterpret_cast<float*>(a.out)[o] = v;
                         else reinterpret_cast<T*>(a.out)[o] = from_f32<T>(v);
                     }
                     if (a.out2 && (col_ok || col_pad2)) {
                         const long long o2 = (long long)bz * a.out2_bs + (long long)(row + a.out2_row_off) * a.ldo2 + gc;
-                        reinterpret_cast<T*>(a.out2)[o2] = from_f32<T>(col_ok ? act_apply(a.act2, v, a.act2_param, al2) : 0.0f);
+                        const float u = col_ok ? act_apply(a.act2, v, a.act2_param, al2) : 0.0f;
+                        if (sizeof(T) != 2 && a.out2_planes) store_planes1(reinterpret_cast<bf16_t*>(a.out2) + o2, a.out2_plane, u);
+                        else reinterpret_cast<T*>(a.out2)[o2] = from_f32<T>(u);
                     }
                 }
             }

@@ -146,6 +146,126 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(GemmArgs a) {
     gemm_epilogue<float, MT, NT, WN, EPI_GENERIC, 2>(a, acc, reinterpret_cast<float*>(smem) + wave * ROWS_PASS * SLD, lane, m0 + wm0, n0 + wn0, bz, g);
 }
 
+
+// ---- the same product with BOTH operands already stored as (hi, lo) bf16 plane pairs (GemmArgs.a_planes / w_planes) ---------------------------
+// What gemm_x3_kernel spends its time on is not the matrix cores: per K-step a wave issues 48 MFMAs beside ~570 other instructions (global
+// loads into registers, eight conversions + subtractions per 8 values, LDS stores, two barriers) at a prefetch distance of one K-step.  When the
+// producer has written the pair (a GEMM epilogue with out_planes / out2_planes, or the weight loader) the tiles go from global memory straight
+// into LDS by LDS-DMA, double-buffered, one barrier per K-step, and the loop body is fragment reads + 3 MFMAs per 16 x 16 x 32 step — the
+// structure of gemm_tiled.hip's bf16 form with four planes instead of two.  Same arithmetic as above, value for value (same (hi, lo) pairs,
+// same MFMA order), so the two forms give identical results.
+// LDS image of a plane tile: [rows][32 bf16] (64-byte rows, lane-linear as the DMA deposits it); the lane that fills slot s of row r fetches
+// chunk s ^ f(r), f(r) = (-(r >> 2)) & 3, which puts the 16 reads of every ds_read_b128 lane group ({0-3, 12-15, 20-27}, ...) on 16 distinct
+// 16-byte slots (checked with SQ_LDS_BANK_CONFLICT on gemm_tiled's bf16 form: 0.1 % of the LDS cycles).
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void gemm_x3p_kernel(GemmArgs a) {
+    constexpr int BK = 32;
+    constexpr int MT = WM / 16, NT = WN / 16;
+    constexpr int WAVES_N = BN / WN;
+    static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
+    static_assert(BM % 64 == 0 && BN % 64 == 0, "a wave instruction deposits 16 rows; 4 waves");
+    constexpr int SLD = WN + 4;
+    constexpr int ROWS_PASS = (64 / WN) * 16;
+    constexpr int STAGE = 2 * (BM + BN) * BK;              // bf16 elements per stage: Ah | Al | Bh | Bl
+    constexpr int TILE_BYTES = 2 * STAGE * 2;
+    constexpr int SCR_BYTES = 4 * ROWS_PASS * SLD * 4;
+    __shared__ __attribute__((aligned(16))) char smem[TILE_BYTES > SCR_BYTES ? TILE_BYTES : SCR_BYTES];
+    bf16_t* const tiles = reinterpret_cast<bf16_t*>(smem);
+    auto Ah = [&](int buf) { return tiles + buf * STAGE; };
+    auto Al = [&](int buf) { return tiles + buf * STAGE + BM * BK; };
+    auto Bh = [&](int buf) { return tiles + buf * STAGE + 2 * BM * BK; };
+    auto Bl = [&](int buf) { return tiles + buf * STAGE + 2 * BM * BK + BN * BK; };
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int bz = blockIdx.z / a.groups, g = blockIdx.z % a.groups;
+    const bf16_t* __restrict__ Ab = reinterpret_cast<const bf16_t*>(a.A) + (long long)bz * a.a_bs + (long long)g * a.a_gs;
+    const bf16_t* __restrict__ Wb = reinterpret_cast<const bf16_t*>(a.W) + (long long)g * a.w_gs;
+    const int nk = a.K / BK;
+    const long long in_span = (long long)a.rows_in * a.up;
+
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+    const int lrow = lane >> 2, lslot = lane & 3;
+    const int gchunk = lslot ^ ((-(lrow >> 2)) & 3);
+    constexpr int A_INS = BM / 64, B_INS = BN / 64;
+    auto issue = [&](int kc, int buf) {
+        const int k0 = kc * BK;
+        const int tap = k0 / a.cin_pad;
+        const int ci = k0 - tap * a.cin_pad + gchunk * 8;
+#pragma unroll
+        for (int q = 0; q < A_INS; ++q) {
+            const int r16 = (wave * A_INS + q) * 16;
+            const int m = m0 + r16 + lrow;
+            const long long idx = (long long)m * a.conv_stride + (long long)tap * a.conv_dil - a.pad_left;
+            const bool ok = m < a.M && idx >= 0 && idx < in_span;
+            const long long src = (a.up == 1) ? idx : idx / a.up;
+            const bf16_t* gp = Ab + src * a.lda + ci;
+            const void* ph = ok ? static_cast<const void*>(gp) : static_cast<const void*>(g_zero_row);
+            const void* pl = ok ? static_cast<const void*>(gp + a.a_plane) : static_cast<const void*>(g_zero_row);
+            __builtin_amdgcn_global_load_lds((glb_ptr)ph, (lds_ptr)(Ah(buf) + r16 * BK), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr)pl, (lds_ptr)(Al(buf) + r16 * BK), 16, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < B_INS; ++q) {
+            const int r16 = (wave * B_INS + q) * 16;
+            const int n = n0 + r16 + lrow;
+            const bf16_t* gp = Wb + (long long)n * a.K + k0 + gchunk * 8;
+            const void* ph = n < a.N ? static_cast<const void*>(gp) : static_cast<const void*>(g_zero_row);
+            const void* pl = n < a.N ? static_cast<const void*>(gp + a.w_plane) : static_cast<const void*>(g_zero_row);
+            __builtin_amdgcn_global_load_lds((glb_ptr)ph, (lds_ptr)(Bh(buf) + r16 * BK), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr)pl, (lds_ptr)(Bl(buf) + r16 * BK), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+    const int fr = lane & 15, fg = lane >> 4;
+    const int fsw = (fg ^ ((-(fr >> 2)) & 3)) * 8;               // slot of this lane's fragment chunk in its row
+    auto compute = [&](int cur) {
+        bf16x8 ah[MT], al[MT], bh[NT], bl[NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            ah[i] = load8(Ah(cur) + (wm0 + i * 16 + fr) * BK + fsw);
+            al[i] = load8(Al(cur) + (wm0 + i * 16 + fr) * BK + fsw);
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            bh[j] = load8(Bh(cur) + (wn0 + j * 16 + fr) * BK + fsw);
+            bl[j] = load8(Bl(cur) + (wn0 + j * 16 + fr) * BK + fsw);
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                mma32(acc[i][j], al[i], bh[j]);
+                mma32(acc[i][j], ah[i], bl[j]);
+                mma32(acc[i][j], ah[i], bh[j]);
+            }
+    };
+    issue(0, 0);
+    for (int kc = 0; kc < nk; ++kc) {
+        __syncthreads();                                 // tile kc has landed (the barrier drains the DMA queue); buffer (kc + 1) & 1 is free
+        if (kc + 1 < nk) issue(kc + 1, (kc + 1) & 1);
+        compute(kc & 1);
+    }
+    __syncthreads();                                     // the epilogue reuses the tile memory as staging
+    gemm_epilogue<float, MT, NT, WN, EPI_GENERIC, 2>(a, acc, reinterpret_cast<float*>(smem) + wave * ROWS_PASS * SLD, lane, m0 + wm0, n0 + wn0, bz, g);
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_cfg_p(const GemmArgs& a, hipStream_t s) {
+    dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, a.batch * a.groups);
+    const int slot = prof_begin(PK_GEMM_F32, 2.0 * a.M * a.N * (double)a.K * a.batch * a.groups, s);
+    hipLaunchKernelGGL((gemm_x3p_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, s, a);
+    prof_end(slot, s);
+    return hipGetLastError() == hipSuccess ? 1 : (set_error("gemm (plane-pair form) launch failed"), -1);
+}
+
 template <int BM, int BN, int WM, int WN>
 int launch_cfg(const GemmArgs& a, hipStream_t s) {
     dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, a.batch * a.groups);
@@ -160,6 +280,12 @@ int launch_cfg(const GemmArgs& a, hipStream_t s) {
 
 // 1 = launched, 0 = not eligible, -1 = error.  Taken when the caller allows the split form (GemmArgs.x3) for an fp32 generic-epilogue GEMM.
 int launch_gemm_x3(const GemmArgs& a, hipStream_t s) {
+    if (a.a_planes || a.w_planes) {
+        // plane pairs cannot fall back to an fp32 kernel: every shape takes one of the two tile forms
+        if (!a.a_planes || !a.w_planes || a.dtype != DT_F32 || a.epi != EPI_GENERIC) return set_error("gemm (plane-pair form): both operands must be plane pairs of an fp32 generic-epilogue GEMM"), -1;
+        if ((a.lda & 7) || (a.a_plane & 7) || (a.w_plane & 7)) return set_error("gemm (plane-pair form): 16-byte alignment"), -1;
+        return a.N <= 64 ? launch_cfg_p<128, 64, 32, 64>(a, s) : launch_cfg_p<128, 128, 64, 64>(a, s);
+    }
     if (!a.x3 || a.dtype != DT_F32 || a.epi != EPI_GENERIC) return 0;
     const long long blocks128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.batch * a.groups;
     if (a.N <= 64) return a.M <= 4096 ? 0 : launch_cfg<128, 64, 32, 64>(a, s);

@@ -24,6 +24,7 @@ using namespace hvx;
 struct hvx_hift {
     hvx_hift_config c;
     std::vector<const void*> w;
+    std::vector<const void*> wp;            // per weight: its (hi, lo) bf16 plane pair [2][Cout][taps * Cin_pad], or null (hvx_hift_set_weight_planes)
     int up_total = 0;
 };
 
@@ -96,32 +97,56 @@ GemmArgs conv3(int M, int N, int taps, int cin_pad, const float* A, int lda, int
 struct WCursor {
     const void* const* w;
     int n, i = 0;
+    const void* const* wp = nullptr;        // plane pairs, parallel to w (or null)
     const float* next() { return (const float*)(i < n ? w[i++] : (i++, nullptr)); }
+    const void* planes_of_last() const { return (wp && i >= 1 && i <= n) ? wp[i - 1] : nullptr; }
 };
+
+// a convolution whose input activation and whose weight are (hi, lo) bf16 plane pairs (gemm_x3.hip: gemm_x3p_kernel); a_plane = elements
+// between the planes of the activation, the weight planes are Cout * K apart
+GemmArgs convp(int M, int N, int taps, int cin_pad, const void* A, long long a_plane, int lda, int rows_in, const void* Wp, const float* bias) {
+    GemmArgs g = conv(M, N, taps, cin_pad, (const float*)A, lda, rows_in, (const float*)Wp, bias);
+    g.x3 = 1;
+    g.a_planes = 1; g.a_plane = a_plane;
+    g.w_planes = 1; g.w_plane = (long long)N * taps * cin_pad;
+    return g;
+}
+void out_planes(GemmArgs& g, long long plane) { g.out_planes = 1; g.out_plane = plane; }
+void out2_planes(GemmArgs& g, long long plane) { g.out2_planes = 1; g.out2_plane = plane; }
 
 // One ResBlock (generator.py:110-117).  x_raw: [L][C] input (kept intact), x_act = snake(x_raw, alpha1[0]) prepared by the caller.
 // Final value v = convs2[2](...) + cur (+ res2) (/ div) goes to `out` (raw, may be null) and act2(v) to `out2` (may be null).
-int resblock(hipStream_t s, WCursor& wc, int L, int C, int k, const int* dils, const float* x_raw, const float* x_act, float* t1,
+// pp: the activated tensors (x_act, t1, actA / actB, out2) are (hi, lo) bf16 plane pairs L * Cp elements apart and the convolutions read
+// them and the weight planes by LDS-DMA; the raw residual stream (x_raw, curA / curB, out, res2) stays fp32 — it is never a GEMM operand.
+int resblock(hipStream_t s, WCursor& wc, bool pp, int L, int C, int k, const int* dils, const float* x_raw, const float* x_act, float* t1,
              float* curA, float* curB, float* actA, float* actB, float* out, const float* res2, float div, float* out2, int act2, float act2_param) {
     const int Cp = pad32(C);
+    const long long plane = (long long)L * Cp;
     const float* w1[3]; const float* b1[3]; const float* w2[3]; const float* b2[3]; const float* a1[3]; const float* a2[3];
-    for (int d = 0; d < 3; ++d) { w1[d] = wc.next(); b1[d] = wc.next(); w2[d] = wc.next(); b2[d] = wc.next(); a1[d] = wc.next(); a2[d] = wc.next(); }
+    const void* p1[3]; const void* p2[3];
+    for (int d = 0; d < 3; ++d) {
+        w1[d] = wc.next(); p1[d] = wc.planes_of_last(); b1[d] = wc.next(); w2[d] = wc.next(); p2[d] = wc.planes_of_last(); b2[d] = wc.next();
+        a1[d] = wc.next(); a2[d] = wc.next();
+        if (pp && (!p1[d] || !p2[d])) return set_error("hvx_hift_decode: a ResBlock convolution has no weight planes"), -1;
+    }
     const float* cur = x_raw;
     const float* cur_act = x_act;
     float* raw_bufs[2] = {curA, curB};
     float* act_bufs[2] = {actA, actB};
     for (int d = 0; d < 3; ++d) {
-        GemmArgs g = conv3(L, C, k, Cp, cur_act, Cp, L, w1[d], b1[d]);
+        GemmArgs g = pp ? convp(L, C, k, Cp, cur_act, plane, Cp, L, p1[d], b1[d]) : conv3(L, C, k, Cp, cur_act, Cp, L, w1[d], b1[d]);
         g.conv_dil = dils[d]; g.pad_left = (k - 1) * dils[d];
         g.act = ACT_SNAKE; g.act_alpha = a2[d];
         g.out = t1; g.out_f32 = 1; g.ldo = Cp; g.out_cols = Cp;
+        if (pp) out_planes(g, plane);
         HVX_CHECK(launch_gemm(g, s));
-        g = conv3(L, C, k, Cp, t1, Cp, L, w2[d], b2[d]);
+        g = pp ? convp(L, C, k, Cp, t1, plane, Cp, L, p2[d], b2[d]) : conv3(L, C, k, Cp, t1, Cp, L, w2[d], b2[d]);
         g.pad_left = k - 1;
         g.res = cur; g.ldres = Cp;
         if (d < 2) {
             g.out = raw_bufs[d & 1]; g.out_f32 = 1; g.ldo = Cp; g.out_cols = Cp;
             g.out2 = act_bufs[d & 1]; g.act2 = ACT_SNAKE; g.act2_alpha = a1[d + 1]; g.ldo2 = Cp; g.out2_cols = Cp;
+            if (pp) out2_planes(g, plane);
             HVX_CHECK(launch_gemm(g, s));
             cur = raw_bufs[d & 1];
             cur_act = act_bufs[d & 1];
@@ -129,6 +154,7 @@ int resblock(hipStream_t s, WCursor& wc, int L, int C, int k, const int* dils, c
             g.res2 = res2; g.ldres2 = Cp; g.div = div;
             g.out = out; g.out_f32 = 1; g.ldo = Cp; g.out_cols = Cp;
             g.out2 = out2; g.act2 = act2; g.act2_param = act2_param; g.ldo2 = Cp; g.out2_cols = Cp;
+            if (pp && out2) out2_planes(g, plane);
             HVX_CHECK(launch_gemm(g, s));
         }
     }
@@ -152,12 +178,19 @@ int hvx_hift_create(const hvx_hift_config* cfg, const void* const* weights, int3
     hvx_hift* h = new hvx_hift();
     h->c = *cfg;
     h->w.assign(weights, weights + n_weights);
+    h->wp.assign(n_weights, nullptr);
     h->up_total = cfg->hop;
     for (int i = 0; i < cfg->n_up; ++i) h->up_total *= cfg->up_rates[i];
     *out = h;
     return 0;
 }
 void hvx_hift_destroy(hvx_hift* h) { delete h; }
+
+int hvx_hift_set_weight_planes(hvx_hift* h, const void* const* planes, int32_t n) {
+    if (!h || !planes || n != (int)h->w.size()) return set_error("hvx_hift_set_weight_planes: expected %d entries", h ? (int)h->w.size() : 0), -1;
+    h->wp.assign(planes, planes + n);
+    return 0;
+}
 
 size_t hvx_hift_workspace_bytes(const hvx_hift* h, int32_t t) {
     Bufs b;
@@ -221,6 +254,15 @@ static int decode_impl(hvx_hift* h, hvx_stream stream, void* ws, size_t ws_bytes
     if (carve(h, (char*)ws, T_in, b) > ws_bytes) return set_error("hvx_hift_decode: workspace too small"), -1;
     WCursor wc{h->w.data(), (int)h->w.size()};
     wc.i = 14;                                           // skip f0 predictor (12) + source linear (2)
+    wc.wp = h->wp.data();
+    // plane-pair dataflow (see resblock): on when the caller handed over weight planes and the split-bf16 form is allowed
+    static const int allow_x3 = getenv("HVX_HIFT_FP32_MFMA") ? 0 : 1;
+    bool pp = allow_x3 != 0;
+    {
+        bool any = false;
+        for (const void* p : h->wp) any = any || p != nullptr;
+        pp = pp && any;
+    }
     const int melp = pad32(c.mel);
     const long long Ls = (long long)T * h->up_total;
     const int frames = (int)(Ls / c.hop + 1);
@@ -238,6 +280,7 @@ static int decode_impl(hvx_hift* h, hvx_stream stream, void* ws, size_t ws_bytes
         GemmArgs g = conv3(T, C0, c.conv_pre_kernel, melp, b.melT, melp, T_in, W, bias);
         g.act = ACT_LRELU; g.act_param = c.lrelu_slope;
         g.out = xin; g.out_f32 = 1; g.ldo = pad32(C0); g.out_cols = pad32(C0);
+        if (pp) out_planes(g, (long long)T * pad32(C0));
         HVX_CHECK(launch_gemm(g, s));
     }
     // source down-sampling rates: cumprod([1] + rates[::-1][:-1])[::-1]   (generator.py:637-640)
@@ -258,7 +301,10 @@ static int decode_impl(hvx_hift* h, hvx_stream stream, void* ws, size_t ws_bytes
         const long long L = last ? Lup + 1 : Lup;               // reflection pad (1, 0) on the last stage
         if ((size_t)L * Cp > b.pool_floats) return set_error("hvx_hift_decode: pool too small"), -1;
         const float* upW = wc.next();
+        const void* upP = wc.planes_of_last();
         const float* upB = wc.next();
+        if (pp && !upP) return set_error("hvx_hift_decode: an up-sampling convolution has no weight planes"), -1;
+        const long long plane = (long long)L * Cp;              // between the (hi, lo) planes of every [L][Cp] activation of this stage
         const float* sdW = wc.next();
         const float* sdB = wc.next();
         // ---- source branch: down-sample conv + ResBlock -> si [L][C]
@@ -275,15 +321,16 @@ static int decode_impl(hvx_hift* h, hvx_stream stream, void* ws, size_t ws_bytes
             g.out = sd_raw; g.out_f32 = 1; g.ldo = Cp; g.out_cols = Cp;
             // first Snake of the source ResBlock: its alpha is 4 entries ahead of the cursor (w1,b1,w2,b2,a1,...)
             g.out2 = sd_act; g.act2 = ACT_SNAKE; g.act2_alpha = (const float*)h->w[wc.i + 4]; g.ldo2 = Cp; g.out2_cols = Cp;
+            if (pp) out2_planes(g, plane);
             HVX_CHECK(launch_gemm(g, s));
-            HVX_CHECK(resblock(s, wc, (int)L, C, c.src_rb_kernels[i], c.src_rb_dils[i], sd_raw, sd_act, t1, cA, cB, aA, aB, si, nullptr, 0.0f,
+            HVX_CHECK(resblock(s, wc, pp, (int)L, C, c.src_rb_kernels[i], c.src_rb_dils[i], sd_raw, sd_act, t1, cA, cB, aA, aB, si, nullptr, 0.0f,
                                nullptr, ACT_NONE, 0.0f));
         }
         // ---- nearest-upsample + causal conv, + source branch -> x_raw (P[2]); last stage shifted by the reflection pad
         float* x_raw = P[2];
         {
             const int Cpp = pad32(Cprev);
-            GemmArgs g = conv3((int)Lup, C, ku, Cpp, xin, Cpp, (int)Lprev, upW, upB);
+            GemmArgs g = pp ? convp((int)Lup, C, ku, Cpp, xin, Lprev * Cpp, Cpp, (int)Lprev, upP, upB) : conv3((int)Lup, C, ku, Cpp, xin, Cpp, (int)Lprev, upW, upB);
             g.up = u; g.pad_left = ku - 1;
             g.res = si; g.ldres = Cp;
             g.out = x_raw; g.out_f32 = 1; g.ldo = Cp; g.out_cols = Cp;
@@ -303,8 +350,9 @@ static int decode_impl(hvx_hift* h, hvx_stream stream, void* ws, size_t ws_bytes
         for (int j = 0; j < c.n_rb; ++j) {
             const bool lastj = (j == c.n_rb - 1);
             const float* a1_0 = (const float*)h->w[wc.i + 4];
-            HVX_CHECK(launch_act_rows(x_raw, Cp, x_act, Cp, DT_F32, ACT_SNAKE, 0.0f, a1_0, L, C, s));
-            HVX_CHECK(resblock(s, wc, (int)L, C, c.rb_kernels[j], c.rb_dils[j], x_raw, x_act, t1, cA, cB, aA, aB,
+            if (pp) HVX_CHECK(launch_act_rows_planes(x_raw, Cp, x_act, Cp, plane, ACT_SNAKE, 0.0f, a1_0, L, C, s));
+            else HVX_CHECK(launch_act_rows(x_raw, Cp, x_act, Cp, DT_F32, ACT_SNAKE, 0.0f, a1_0, L, C, s));
+            HVX_CHECK(resblock(s, wc, pp, (int)L, C, c.rb_kernels[j], c.rb_dils[j], x_raw, x_act, t1, cA, cB, aA, aB,
                                lastj ? nullptr : xs, j == 0 ? nullptr : xs, lastj ? (float)c.n_rb : 0.0f,
                                lastj ? xnext : nullptr, ACT_LRELU, last ? 0.01f : c.lrelu_slope));
         }
@@ -315,9 +363,12 @@ static int decode_impl(hvx_hift* h, hvx_stream stream, void* ws, size_t ws_bytes
     // conv_post (k, left) -> exp / sin -> iSTFT -> clamp
     {
         const float* W = wc.next();
+        const void* Wp = wc.planes_of_last();
         const float* bias = wc.next();
         const int Cpp = pad32(Cprev);
-        GemmArgs g = conv3((int)Lprev, c.n_fft + 2, c.conv_post_kernel, Cpp, xin, Cpp, (int)Lprev, W, bias);
+        if (pp && !Wp) return set_error("hvx_hift_decode: conv_post has no weight planes"), -1;
+        GemmArgs g = pp ? convp((int)Lprev, c.n_fft + 2, c.conv_post_kernel, Cpp, xin, Lprev * Cpp, Cpp, (int)Lprev, Wp, bias)
+                        : conv3((int)Lprev, c.n_fft + 2, c.conv_post_kernel, Cpp, xin, Cpp, (int)Lprev, W, bias);
         g.pad_left = c.conv_post_kernel - 1;
         g.out = b.post; g.out_f32 = 1; g.ldo = 32; g.out_cols = 32;
         HVX_CHECK(launch_gemm(g, s));

@@ -52,6 +52,15 @@ struct GemmArgs {
     void* q; void* k; void* vT; int heads; int t_pad; const float* rope_cos; const float* rope_sin;   // [t][32]
     int x3;                       // fp32 operands may be split into bf16 pairs and multiplied on the bf16 matrix cores (gemm_x3.hip; ~1e-6 relative)
     float q_scale;                // != 0: q is stored multiplied by this (softmax scale * log2 e: the scores then leave the attention MFMAs in log2 units)
+    // ---- fp32 values as (hi, lo) bf16 PLANE PAIRS (dtype DT_F32, x3 path): x == hi + lo up to 2^-17 |x|, hi = bf16(x), lo = bf16(x - hi).
+    //      A pair is addressed like the fp32 tensor it stands for (same row / batch strides, in elements), the lo plane `*_plane` bf16
+    //      elements behind the hi plane.  With a_planes and w_planes the split-bf16 GEMM reads its operands straight into LDS by LDS-DMA
+    //      (gemm_x3.hip: gemm_x3p_kernel) instead of splitting fp32 values on the way in; out_planes / out2_planes make the epilogue
+    //      write a pair instead of fp32 values (any fp32 GEMM form), so the next convolution finds its operand ready.
+    int a_planes; long long a_plane;
+    int w_planes; long long w_plane;
+    int out_planes; long long out_plane;
+    int out2_planes; long long out2_plane;
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
 int launch_gemm_x3(const GemmArgs& a, hipStream_t s);    // same convention; fp32 operands on the bf16 matrix cores (GemmArgs.x3)
@@ -144,6 +153,7 @@ int launch_reduce_rmsnorm(const ReduceNormArgs& a, hipStream_t s);
 // y[r, c] = dtype(act(x[r, c])) for a [rows][cols] f32 matrix (per-column alpha for Snake)
 int launch_act_rows(const float* x, int ldx, void* y, int ldy, int dtype, int act, float param, const float* alpha, long long rows, int cols,
                     hipStream_t s);
+int launch_act_rows_planes(const float* x, int ldx, void* y, int ldy, long long plane, int act, float param, const float* alpha, long long rows, int cols, hipStream_t s);
 // gather rows: y[r,:] = x[idx[r],:] (idx[r] < 0 -> zeros)
 int launch_heads_prologue(const float* x, int ldx, const int* idx, const float* gain_f, float eps_f, const float* gain_h, float eps_h, int K,
                           int S, int H, float* ylast, float* hx, void* ha, int dtype, hipStream_t s);

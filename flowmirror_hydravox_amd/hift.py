@@ -118,6 +118,23 @@ class HvxHift:
         h = C.c_void_p()
         check(self.lib.hvx_hift_create(C.byref(cc), _lib.ptr_array(ws), len(ws), C.byref(h)), 'hvx_hift_create')
         self._h = h
+        # (hi, lo) bf16 plane pairs of the decode convolutions' weights (every 2-D tensor behind the F0 predictor / source linear / conv_pre,
+        # except the source down-sampling convolutions, whose input is the fp32 source STFT): hvx_hift_set_weight_planes
+        skip = {14}                                                           # conv_pre (its input is the fp32 mel)
+        i = 16
+        for r in range(cc.n_up):
+            skip.add(i + 2)                                                   # source_downs.r
+            i += 4 + 18 + cc.n_rb * 18
+        self._planes = []
+        for k, w in enumerate(ws):
+            if k >= 14 and w.dim() == 2 and k not in skip:
+                hi = w.to(torch.bfloat16)
+                lo = (w - hi.float()).to(torch.bfloat16)
+                self._planes.append(torch.stack([hi, lo]).contiguous())
+            else:
+                self._planes.append(None)
+        arr = (C.c_void_p * len(ws))(*[None if p is None else p.data_ptr() for p in self._planes])
+        check(self.lib.hvx_hift_set_weight_planes(self._h, arr, len(ws)), 'hvx_hift_set_weight_planes')
         return self
 
     def eval(self):

@@ -266,6 +266,11 @@ typedef struct {
 typedef struct hvx_hift hvx_hift;
 int hvx_hift_create(const hvx_hift_config* cfg, const void* const* weights, int32_t n_weights, hvx_hift** out);
 void hvx_hift_destroy(hvx_hift* h);
+/* Optional: per weight pointer of hvx_hift_create (same order, n = n_weights) either NULL or the convolution weight as a (hi, lo) bf16 plane
+ * pair [2][Cout][taps * Cin_pad] (hi = bf16(w), lo = bf16(w - hi)).  With planes for every ResBlock / up-sampling / conv_post weight the decode
+ * keeps its activations as plane pairs too and the split-bf16 convolutions read both operands by LDS-DMA (csrc/gemm_x3.hip: gemm_x3p_kernel);
+ * values are the same as without.  The caller keeps the planes alive as long as the handle. */
+int hvx_hift_set_weight_planes(hvx_hift* h, const void* const* planes, int32_t n);
 size_t hvx_hift_workspace_bytes(const hvx_hift* h, int32_t t);
 /* mel f32 (mel, T) channel-major -> f0 f32 [T] */
 int hvx_hift_f0(hvx_hift* h, hvx_stream s, void* ws, size_t ws_bytes, const float* mel, int32_t t, float* f0);
