@@ -82,6 +82,29 @@ def read_prof(lib):
 _LIB_BYTES = None
 
 
+def _kernel_in_lib(name):
+    """is the kernel rocprofv3 named `name` (mangled, or demangled with its template arguments) a symbol of the libhvx.so being benchmarked?"""
+    import re
+    if name.encode() in _LIB_BYTES:
+        return True
+    m = re.search(r'(\w+)<([^<>]*)>\(', name)
+    if m:                                                   # demangled: rebuild the Itanium template-argument list of integers / booleans
+        ident, targs, enc = m.group(1), [t.strip() for t in m.group(2).split(',')], ''
+        for t in targs:
+            if t in ('true', 'false'):
+                enc += 'Lb%dE' % (t == 'true')
+            elif re.fullmatch(r'-?\d+', t):
+                enc += 'Li%sE' % t.replace('-', 'n')
+            else:
+                enc = None                                  # a type argument (or a demangler artefact): the identifier alone has to do
+                break
+        if enc is not None:
+            return ('%d%sI%sE' % (len(ident), ident, enc)).encode() in _LIB_BYTES
+        return ('%d%s' % (len(ident), ident)).encode() in _LIB_BYTES
+    m = re.search(r'(\w+)\(', name)
+    return bool(m) and ('%d%s' % (len(m.group(1)), m.group(1))).encode() in _LIB_BYTES
+
+
 def pmc_traffic(name):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r*_pmc_traffic.json; FETCH_SIZE / WRITE_SIZE in
     separate passes with the gfx950 x2 FETCH correction).  PMC collection cannot run inside the timed bench.  An entry is used only if
@@ -99,7 +122,7 @@ def pmc_traffic(name):
                 with open(os.path.join(ROOT, 'flowmirror_hydravox_amd', 'libhvx.so'), 'rb') as f:
                     _LIB_BYTES = f.read()
             kernels = d[name].get('kernels')
-            if not kernels or any(k.encode() not in _LIB_BYTES for k in kernels):
+            if not kernels or not all(_kernel_in_lib(k) for k in kernels):
                 return None
             return int(d[name]['hbm_bytes_per_launch'])
         except Exception:

@@ -13,6 +13,7 @@
 // stride-2 down-sampler included — is one implicit-GEMM launch of gemm_tiled, every ConvTranspose1d is `stride` launches (one
 // per output phase: a k/stride-tap convolution whose rows land `stride` apart), the STFT / inverse STFT of the denoiser are
 // GEMMs against windowed DFT bases built at load time.
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -57,6 +58,14 @@ GemmArgs conv(int M, int N, int taps, int cin_pad, const void* A, int lda, int r
     g.dtype = DT_F32; g.M = M; g.N = N; g.K = taps * cin_pad; g.batch = 1; g.groups = 1;
     g.A = A; g.lda = lda; g.rows_in = rows_in; g.cin_pad = cin_pad; g.conv_stride = 1; g.conv_dil = 1; g.pad_left = 0; g.up = 1;
     g.W = W; g.epi = EPI_GENERIC; g.bias = bias; g.scale = 1.0f; g.out_f32 = 1;
+    return g;
+}
+// the HiFi-GAN v1 generator's convolutions: fp32 operands split into bf16 pairs on the bf16 matrix cores (gemm_x3.hip, ~4e-6 of the output scale,
+// the reference's contract here is 1e-3); HVX_HIFT_FP32_MFMA=1 keeps the exact fp32 MFMA form, as for the HiFT vocoder
+GemmArgs convx(int M, int N, int taps, int cin_pad, const void* A, int lda, int rows_in, const void* W, const float* bias) {
+    static const int allow = getenv("HVX_HIFT_FP32_MFMA") ? 0 : 1;
+    GemmArgs g = conv(M, N, taps, cin_pad, A, lda, rows_in, W, bias);
+    g.x3 = allow;
     return g;
 }
 void batched(GemmArgs& g, int B, long long a_bs, long long out_bs) {
@@ -370,7 +379,7 @@ int generator_core(const hvx_hifigan* h, hipStream_t s, GBufs& b, const float* m
     // conv_pre k7 p3; only lrelu(x, 0.1) is consumed (models.py:183-185)
     const void* w0 = wc.next(); const float* b0 = wc.nextf();
     int C = c.initial_channel;
-    GemmArgs g = conv(T, C, 7, melp, b.melT, melp, T, w0, b0);
+    GemmArgs g = convx(T, C, 7, melp, b.melT, melp, T, w0, b0);
     g.pad_left = 3; g.act = ACT_LRELU; g.act_param = 0.1f;
     g.out = b.x_act; g.ldo = C; g.out_cols = C;
     HVX_CHECK(launch_gemm(g, s));
@@ -382,7 +391,7 @@ int generator_core(const hvx_hifigan* h, hipStream_t s, GBufs& b, const float* m
         const float* uw = wc.nextf(); const float* ub = wc.nextf();
         // ConvTranspose1d as `r` phase convolutions: output row t*r + p, taps over input rows t + c_p - (taps-1) .. t + c_p
         for (int p = 0; p < r; ++p) {
-            g = conv((int)L, Co, taps, Ci, b.x_act, Ci, (int)L, uw + (size_t)p * Co * taps * Ci, ub);
+            g = convx((int)L, Co, taps, Ci, b.x_act, Ci, (int)L, uw + (size_t)p * Co * taps * Ci, ub);
             g.pad_left = taps - 1 - (p + pd) / r;
             g.out = b.u + (size_t)p * Cop; g.ldo = r * Cop; g.out_cols = Cop;
             g.out2 = nullptr;
@@ -399,11 +408,11 @@ int generator_core(const hvx_hifigan* h, hipStream_t s, GBufs& b, const float* m
             for (int d = 0; d < 3; ++d) {
                 const int dil = c.rb_dils[j][d];
                 const void* w1 = wc.next(); const float* b1 = wc.nextf(); const void* w2 = wc.next(); const float* b2 = wc.nextf();
-                g = conv((int)L, Co, kk, Cop, xa, Cop, (int)L, w1, b1);
+                g = convx((int)L, Co, kk, Cop, xa, Cop, (int)L, w1, b1);
                 g.conv_dil = dil; g.pad_left = dil * (kk - 1) / 2; g.act = ACT_LRELU; g.act_param = 0.1f;
                 g.out = b.t1; g.ldo = Cop; g.out_cols = Cop;
                 HVX_CHECK(launch_gemm(g, s));
-                g = conv((int)L, Co, kk, Cop, b.t1, Cop, (int)L, w2, b2);
+                g = convx((int)L, Co, kk, Cop, b.t1, Cop, (int)L, w2, b2);
                 g.pad_left = (kk - 1) / 2;
                 g.res = xr; g.ldres = Cop;
                 if (d < 2) {
@@ -428,7 +437,7 @@ int generator_core(const hvx_hifigan* h, hipStream_t s, GBufs& b, const float* m
         C = Cop;                                           // the next stage reads rows of the padded width
     }
     const void* wp = wc.next(); const float* bp = wc.nextf();
-    g = conv((int)L, 1, 7, C, b.x_act, C, (int)L, wp, bp);
+    g = convx((int)L, 1, 7, C, b.x_act, C, (int)L, wp, bp);
     g.pad_left = 3; g.act = ACT_TANH;
     g.out = wav; g.ldo = 1; g.out_cols = 1;
     HVX_CHECK(launch_gemm(g, s));
