@@ -58,6 +58,7 @@ def parse():
                          'chains: the round-1 form, --lm-chains independent decode chains of one step each; serial: stages back to back')
     ap.add_argument('--acoustic-batch', type=int, default=4, help='utterances per padded CFM solve (x CFG 2 rows per estimator call)')
     ap.add_argument('--acoustic-min-batch', type=int, default=4, help='(--mode continuous) the acoustic stage waits for this many finished utterances (throughput over latency)')
+    ap.add_argument('--lm-pace', default='', help='(--mode continuous) admission pacing of the decode grid "first,every_steps,more": open with `first` sequences, admit `more` every `every_steps` decode steps (empty: fill all slots at once)')
     ap.add_argument('--lm-cus', type=int, default=0, help='(--mode continuous) compute units reserved for the decode engine; the acoustic stage runs on the others (0: both share all CUs)')
     ap.add_argument('--acoustic-chains', type=int, default=1, help='(--mode chains) kept for compatibility: more than one concurrent acoustic chain is not supported (clamped to 1)')
     ap.add_argument('--lm-chains', type=int, default=3, help='(--mode chains) batches whose LM decode runs concurrently')
@@ -433,7 +434,8 @@ def main():
         job = [make_utt(g) for g in mine]
         hand = Handoff(shards, B, dst=0, keep=False)
         for i, wav, toks in pipe.synthesize_continuous(job, lm_slots=args.lm_slots, max_token_text_ratio=ratio, min_token_text_ratio=ratio,
-                                                       acoustic_batch=args.acoustic_batch, acoustic_min_batch=args.acoustic_min_batch):
+                                                       acoustic_batch=args.acoustic_batch, acoustic_min_batch=args.acoustic_min_batch,
+                                                       pace=[int(v) for v in args.lm_pace.split(',')] if args.lm_pace else None):
             hand.push(job[i].seed, wav)                # one step's worth (B utterances) per hand-off, inside the timed region
         got = hand.finish()
         assert rank != 0 or hand.n_received == n_global

@@ -8,23 +8,42 @@ namespace hvx {
 // ---- frame-level harmonic phase (SineGen2._f02sine, causal/eval: :233-260) --------------------------------
 // rad = (f0*(h+1)/sr) % 1 ; linear x(1/up) downsampling of the frame-constant signal returns the frame value ;
 // cumsum (torch CPU accumulates fp32 cumsum in double) ; * 2 * pi ; * up (nearest upsampling keeps it frame-constant)
-__global__ void hift_phase_kernel(const float* f0, float* phase, int T, int H, float sr, float up) {
-    const int h = threadIdx.x;
-    if (h >= H) return;
-    double cum = 0.0;
+// One workgroup per harmonic; thread i owns a contiguous run of frames: run sums in double, an exclusive prefix over the 256 runs, then the
+// run is walked again from its prefix.  (Round 2 walked all T frames in one thread per harmonic: 0.86 ms for a 5632-frame utterance.)  The
+// double-precision partial sums are re-associated, which moves a value by <= 1e-16 relative before it is rounded to fp32 — the same result
+// as the sequential sum except on an fp32 rounding boundary.
+__global__ __launch_bounds__(256) void hift_phase_kernel(const float* f0, float* phase, int T, int H, float sr, float up) {
+    __shared__ double part[256];
+    const int h = blockIdx.x, i = threadIdx.x;
     const float mult = (float)(h + 1);
-    for (int t = 0; t < T; ++t) {
-        const float fn = f0[t] * mult;
-        float rad = fn / sr;
-        rad = rad - floorf(rad);
-        cum += (double)rad;
+    const int per = (T + 255) / 256, t0 = i * per, t1 = min(T, t0 + per);
+    auto rad_of = [&](int t) {
+        float rad = (f0[t] * mult) / sr;
+        return rad - floorf(rad);
+    };
+    double sum = 0.0;
+    for (int t = t0; t < t1; ++t) sum += (double)rad_of(t);
+    part[i] = sum;
+    __syncthreads();
+    if (i == 0) {
+        double run = 0.0;
+        for (int j = 0; j < 256; ++j) {
+            const double v = part[j];
+            part[j] = run;
+            run += v;
+        }
+    }
+    __syncthreads();
+    double cum = part[i];
+    for (int t = t0; t < t1; ++t) {
+        cum += (double)rad_of(t);
         const float c = (float)cum;
         phase[(long long)t * H + h] = ((c * 2.0f) * 3.14159274101257324f) * up;
     }
 }
 int launch_hift_phase(const float* f0, float* phase, int T, int H, float sr, int up, hipStream_t s) {
     if (T <= 0) return 0;
-    hipLaunchKernelGGL(hift_phase_kernel, dim3(1), dim3(64), 0, s, f0, phase, T, H, sr, (float)up);
+    hipLaunchKernelGGL(hift_phase_kernel, dim3(H), dim3(256), 0, s, f0, phase, T, H, sr, (float)up);
     return hipGetLastError() == hipSuccess ? 0 : (set_error("hift_phase launch failed"), -1);
 }
 

@@ -266,7 +266,7 @@ class HvxLLM:
         self.last_stats = eng.stats
 
     @torch.inference_mode()
-    def generate_stream(self, requests, n_slots=None, max_out=None, max_prefix=None):
+    def generate_stream(self, requests, n_slots=None, max_out=None, max_prefix=None, pace=None):
         """Continuous batching (replaces the one-request-at-a-time loop of server/worker.py:54-102): `requests` is an
         iterable of dicts (text, prompt_text, prompt_speech_token, seed, max_token_text_ratio, min_token_text_ratio, tag).  Up to `n_slots`
         sequences share one decode grid — the weights are streamed once per step for all of them — and the slot of a finished sequence is
@@ -301,7 +301,7 @@ class HvxLLM:
                 max_out = max([r.max_len for r in it] + [1])
                 max_prefix = max([len(r.prefix) for r in it] + [1])
                 it = iter(it)
-        eng = _DecodeEngine(self, n_slots=n_slots, max_out=max_out, max_prefix=max_prefix)
+        eng = _DecodeEngine(self, n_slots=n_slots, max_out=max_out, max_prefix=max_prefix, pace=pace)
         gen = eng.run(it)
         try:
             for kind, r in gen:
@@ -355,8 +355,9 @@ class _DecodeEngine:
     hvx_llm_decode_join, noise at position 0 of the slot's ring — all ordered on the decode stream behind the blocks already enqueued."""
     NS = 8
 
-    def __init__(self, llm, n_slots, max_out, max_prefix, stream_first=False, sync_every=None):
+    def __init__(self, llm, n_slots, max_out, max_prefix, stream_first=False, sync_every=None, pace=None):
         import time
+        self.pace = tuple(int(v) for v in pace) if pace else None
         self.llm, self.S, self.max_out = llm, int(n_slots), int(max_out)
         self.max_prefix = max(int(max_prefix), self.S * llm.head_k())
         self.K = llm.head_k()
@@ -564,6 +565,13 @@ class _DecodeEngine:
         def fill_free_slots(block=False):
             nonlocal waiting
             free = [i for i in range(S) if self.slot_req[i] is None or self.slot_req[i].done]
+            if self.pace is not None:
+                # admission pacing: the grid opens with pace[0] sequences and admits pace[2] more every pace[1] decode steps.  With a backlog and a
+                # slower stage downstream (the acoustic stage takes ~1 s per 8 utterances) filling every slot at once only makes the FIRST results
+                # late — 64 sequences of equal length finish together after 1408 steps of the widest, slowest grid — while a paced grid hands
+                # over its first utterances after 1408 steps of a narrow, fast one and still stays ahead of the consumer.
+                cap = min(S, self.pace[0] + (launched * sync_every // max(1, self.pace[1])) * self.pace[2])
+                free = free[:max(0, cap - (S - len(free)))]
             batch = []
             for i in free:
                 pull(block and not batch)

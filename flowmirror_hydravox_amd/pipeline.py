@@ -253,7 +253,7 @@ class HvxPipeline:
         return wavs, st
 
     @torch.inference_mode()
-    def synthesize_continuous(self, utts, lm_slots=16, max_token_text_ratio=20, min_token_text_ratio=2, acoustic_batch=None, acoustic_min_batch=1):
+    def synthesize_continuous(self, utts, lm_slots=16, max_token_text_ratio=20, min_token_text_ratio=2, acoustic_batch=None, acoustic_min_batch=1, pace=None):
         """Generator over (index, waveform, tokens) in completion order — continuous batching end to end over a finite
         list of utterances; see `serve` (the same engine over an open-ended source).  Results equal synthesize(): every utterance carries
         its own sampler seed.  `self.last_continuous` holds the stage accounting of the run."""
@@ -274,14 +274,14 @@ class HvxPipeline:
             def poll(self, block):
                 return next(self.it)
         for u, wav, toks in self.serve(_List(), lm_slots=lm_slots, acoustic_batch=acoustic_batch, acoustic_min_batch=acoustic_min_batch,
-                                       max_out=max_out, max_prefix=max_prefix):
+                                       max_out=max_out, max_prefix=max_prefix, pace=pace):
             if isinstance(wav, BaseException):
                 raise wav
             yield index[id(u)], wav, toks
 
     @torch.inference_mode()
     def serve(self, source, lm_slots=16, acoustic_batch=None, acoustic_min_batch=1, max_out=None, max_prefix=None,
-              max_token_text_ratio=20, min_token_text_ratio=2):
+              max_token_text_ratio=20, min_token_text_ratio=2, pace=None):
         """The continuous engine over an open-ended SOURCE of utterances: `source.poll(block)` returns the next `Utterance`, or None when
         nothing is waiting (it is asked to block only while the decode grid is idle), and raises StopIteration when closed.  Generator over
         (utterance, waveform | exception, tokens) in completion order.
@@ -291,7 +291,8 @@ class HvxPipeline:
         utterances still in flight, in padded solves of up to `acoustic_batch` utterances of similar length.  `acoustic_min_batch` > 1 trades
         latency for throughput: the acoustic stage then waits until that many finished utterances are queued (or the LM is idle / done).
         A request that cannot run (context budget) comes back as (utterance, exception, []) without disturbing the others.  If the consumer
-        stops iterating, the LM thread is cancelled: it stops taking requests and abandons the decode of those in flight."""
+        stops iterating, the LM thread is cancelled: it stops taking requests and abandons the decode of those in flight.
+        `pace` = (first, every_steps, more): admission pacing of the decode grid (see _DecodeEngine.run)."""
         acoustic_batch = acoustic_batch or self.acoustic_batch
         acoustic_min_batch = max(1, min(int(acoustic_min_batch), acoustic_batch))
         import queue
@@ -345,7 +346,7 @@ class HvxPipeline:
                 torch.cuda.set_device(stream.device)               # the current device is per thread
                 with torch.inference_mode():
                     t0 = time.time()
-                    gen = self.llm.generate_stream(_Requests(), n_slots=lm_slots, max_out=max_out, max_prefix=max_prefix)
+                    gen = self.llm.generate_stream(_Requests(), n_slots=lm_slots, max_out=max_out, max_prefix=max_prefix, pace=pace)
                     try:
                         for tag, toks in gen:
                             if not put((tag, toks)):
