@@ -59,6 +59,7 @@ def parse():
     ap.add_argument('--acoustic-batch', type=int, default=4, help='utterances per padded CFM solve (x CFG 2 rows per estimator call)')
     ap.add_argument('--acoustic-min-batch', type=int, default=4, help='(--mode continuous) the acoustic stage waits for this many finished utterances (throughput over latency)')
     ap.add_argument('--lm-pace', default='', help='(--mode continuous) admission pacing of the decode grid "first,every_steps,more": open with `first` sequences, admit `more` every `every_steps` decode steps (empty: fill all slots at once)')
+    ap.add_argument('--acoustic-cus', type=int, default=0, help='(--mode continuous) confine the acoustic stage to this many compute units (the decode engine stays unconfined); 0: all')
     ap.add_argument('--lm-cus', type=int, default=0, help='(--mode continuous) compute units reserved for the decode engine; the acoustic stage runs on the others (0: both share all CUs)')
     ap.add_argument('--acoustic-chains', type=int, default=1, help='(--mode chains) kept for compatibility: more than one concurrent acoustic chain is not supported (clamped to 1)')
     ap.add_argument('--lm-chains', type=int, default=3, help='(--mode chains) batches whose LM decode runs concurrently')
@@ -365,6 +366,7 @@ def main():
                        seed=1986, init='normal02', sampling=sampling, inference_head_num=K)
     pipe.acoustic_batch = max(1, args.acoustic_batch)
     pipe.lm_cus = args.lm_cus
+    pipe.acoustic_cus = args.acoustic_cus
     if args.lm_cus > 0:
         pipe.llm.cu_range = (0, args.lm_cus)             # (before the first decode engine exists: the engine keeps its stream)
     t_build = time.time() - t_build

@@ -11,6 +11,7 @@ All arithmetic runs in libhvx (csrc/hvx_llm.hip, csrc/sampler.hip); this file on
 `generate_batch` runs several utterances in lockstep through the same kernels (the reference is batch-1).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch

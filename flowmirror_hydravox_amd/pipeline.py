@@ -306,6 +306,12 @@ class HvxPipeline:
                 n_cu = _lib.load().hvx_device_ok()
                 self.llm.cu_range = (0, lm_cus)
                 self._bg_stream = _lib.cu_range_stream(lm_cus, n_cu - lm_cus, device=self.device)
+            elif int(getattr(self, 'acoustic_cus', 0) or 0) > 0:
+                # the acoustic stage on the LAST `acoustic_cus` compute units only, the decode engine unconfined: its short launches always find
+                # the reserved CUs free instead of waiting for a 200-900 us workgroup of the acoustic stage to retire
+                from . import _lib
+                n_cu = _lib.load().hvx_device_ok()
+                self._bg_stream = _lib.cu_range_stream(n_cu - int(self.acoustic_cus), int(self.acoustic_cus), device=self.device)
             else:
                 self._bg_stream = torch.cuda.Stream(device=self.device, priority=0)
             self._bg_streams = [self._bg_stream]
