@@ -728,6 +728,54 @@ def test_queue_worker_serves_the_continuous_engine(tiny_cfg, tmp_path):
         assert torch.equal(got['output_audio'], want), t['id']
 
 
+def test_serve_cancellation_refusal_and_cu_range_streams(tiny_cfg):
+    """HvxPipeline.serve: (1) a consumer that stops after the first result returns promptly — the LM thread is cancelled, nothing keeps decoding the
+    backlog; (2) a request that cannot run comes back as that request's exception, the others are served; (3) the same job with the decode engine
+    and the acoustic stage on disjoint CU ranges (hvx_stream_create_cu_range) gives the same samples as without."""
+    import time
+    from flowmirror_hydravox_amd import _lib
+    from flowmirror_hydravox_amd.pipeline import HvxPipeline, synthetic_utterance
+    kw = dict(llm_dtype=torch.float32, flow_dtype=torch.float32, max_batch=3, max_ctx=256, max_t=1024, seed=7, init='fan_in', inference_head_num=2)
+    pipe = HvxPipeline(tiny_cfg, **kw)
+    utts = [synthetic_utterance(tiny_cfg, 70 + i, 5 + i % 4) for i in range(9)]
+    ref = {i: w for i, w, _ in pipe.synthesize_continuous(utts, lm_slots=3, max_token_text_ratio=5, min_token_text_ratio=3)}
+    assert sorted(ref) == list(range(9))
+    # (1) cancellation
+    long_job = [synthetic_utterance(tiny_cfg, 200 + i, 8) for i in range(40)]
+    t0 = time.time()
+    gen = pipe.synthesize_continuous(long_job, lm_slots=3, max_token_text_ratio=12, min_token_text_ratio=12)
+    i0, w0, toks0 = next(gen)
+    t_first = time.time() - t0
+    gen.close()
+    t_close = time.time() - t0 - t_first
+    assert w0.numel() == 960 * len(toks0) and len(toks0) == 96
+    assert t_close < max(2.0, 5 * t_first), (t_first, t_close)             # (decoding the 37 others would take ~13 x the first result)
+    again = {i: w for i, w, _ in pipe.synthesize_continuous(utts[:3], lm_slots=3, max_token_text_ratio=5, min_token_text_ratio=3)}
+    assert all(torch.equal(again[i], ref[i]) for i in range(3))             # the engine is usable afterwards
+    # (2) per-request refusal: 60 text tokens x ratio 5 = 300 > max_ctx 256
+    class Src:
+        def __init__(self, items):
+            self.it = iter(items)
+
+        def poll(self, block):
+            return next(self.it)
+    big = synthetic_utterance(tiny_cfg, 999, 60)
+    for u in utts[:2] + [big]:
+        u.max_token_text_ratio, u.min_token_text_ratio = 5, 3
+    got = {id(u): (w, t) for u, w, t in pipe.serve(Src([utts[0], big, utts[1]]), lm_slots=3)}
+    assert isinstance(got[id(big)][0], ValueError) and 'max_ctx' in str(got[id(big)][0])
+    assert torch.equal(got[id(utts[0])][0], ref[0]) and torch.equal(got[id(utts[1])][0], ref[1])
+    # (3) CU partition
+    n_cu = _lib.load().hvx_device_ok()
+    part = HvxPipeline(tiny_cfg, **kw)
+    part.lm_cus = n_cu // 4
+    part.llm.cu_range = (0, n_cu // 4)
+    out = {i: w for i, w, _ in part.synthesize_continuous(utts, lm_slots=3, max_token_text_ratio=5, min_token_text_ratio=3)}
+    assert all(torch.equal(out[i], ref[i]) for i in range(9))
+    with pytest.raises(_lib.HvxError):
+        _lib.cu_range_stream(n_cu - 4, 8)                                   # outside the device
+
+
 def test_packed_weight_cache_gives_the_same_models(tiny_cfg, tmp_path):
     """§8(f) N4: ModelManager with a packed-weight cache — the second start loads the device-ready tensors instead of the `.pt` files and
     synthesises the same samples; load_pt goes through the cache too."""
