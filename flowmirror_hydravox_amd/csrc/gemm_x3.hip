@@ -11,6 +11,8 @@
 // split -> LDS (two bf16 planes per operand, rows padded to 80 B: conflict-free ds_read_b128), next K-step's global loads in flight during
 // the MFMAs, the conv index map (tap, dilation, stride, nearest-upsample, zero padding) in the A loader.  (K-steps of 64 — half the
 // barriers, 144-byte rows — measured slower: HiFT 0.201 vs 0.173 s on 12 streams; the larger staging registers cost a wave per SIMD.)
+#include <stdlib.h>
+
 #include "gemm_epilogue.h"
 
 namespace hvx {
@@ -257,6 +259,97 @@ __global__ __launch_bounds__(256) void gemm_x3p_kernel(GemmArgs a) {
     gemm_epilogue<float, MT, NT, WN, EPI_GENERIC, 2>(a, acc, reinterpret_cast<float*>(smem) + wave * ROWS_PASS * SLD, lane, m0 + wm0, n0 + wn0, bz, g);
 }
 
+
+// ---- plane-pair convolution with the INPUT ROWS RESIDENT IN LDS (64 channels in, <= 64 out, stride 1): the last vocoder stage -------------------
+// A k-tap convolution read through gemm_x3p_kernel fetches the same input rows k times (tap t is the tile shifted by t * dil rows) and passes
+// 2 k barriers with 24 MFMAs per wave between them; at 64 channels that, not the matrix cores or HBM, sets the time (252 us for 350-690 MB of
+// traffic at 675 841 rows).  Here the workgroup's 128 output rows + their (k - 1) * dil halo rows are brought into LDS ONCE (both planes, one
+// barrier), every tap reads its fragments from that image at a row offset, and only the weight tile of a tap (16 KB) is staged per step:
+// k barriers with 48 MFMAs per wave between them and a tenth of the L2 -> LDS traffic.
+template <int MAXR>
+__global__ __launch_bounds__(256) void conv64_x3p_kernel(GemmArgs a) {
+    constexpr int BM = 128, MT = 2, NT = 4, WN = 64;
+    constexpr int SLD = WN + 4, ROWS_PASS = 16;
+    constexpr int AIMG = MAXR * 32;                        // elements of one (plane, k-half) image of the input rows: [MAXR][32]
+    constexpr int BIMG = 64 * 32;                          // one (plane, k-half) image of a tap's weights: [64][32]
+    constexpr int SCR_BYTES = 4 * ROWS_PASS * SLD * 4;
+    static_assert(2 * 4 * BIMG * 2 >= SCR_BYTES, "the epilogue staging fits the weight buffers");
+    __shared__ __attribute__((aligned(16))) bf16_t As[4 * AIMG];      // [plane][half][row][32]
+    __shared__ __attribute__((aligned(16))) bf16_t Bs[2 * 4 * BIMG];  // [buffer][plane][half][n][32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * BM;
+    const int taps = a.K / 64;
+    const int rows_tile = BM + (taps - 1) * a.conv_dil;               // <= MAXR (checked by the launcher)
+    const bf16_t* __restrict__ Ab = reinterpret_cast<const bf16_t*>(a.A);
+    const bf16_t* __restrict__ Wb = reinterpret_cast<const bf16_t*>(a.W);
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+    const int lrow = lane >> 2, lslot = lane & 3;
+    const int gchunk = lslot ^ ((-(lrow >> 2)) & 3);                  // (16-row groups start at multiples of 16: the swizzle of a row is that of row & 15)
+    // ---- input rows: tile row j = global row m0 + j - pad_left -----------------------------------------------------------------------------
+    const int groups = (rows_tile + 15) >> 4;
+    for (int q = wave; q < 4 * groups; q += 4) {
+        const int img = q / groups, g16 = q - img * groups;           // img = plane * 2 + half
+        const long long grow = (long long)m0 + g16 * 16 + lrow - a.pad_left;
+        const bool ok = grow >= 0 && grow < a.rows_in && (g16 * 16 + lrow) < rows_tile;
+        const bf16_t* gp = Ab + (img >> 1) * a.a_plane + grow * a.lda + (img & 1) * 32 + gchunk * 8;
+        const void* src = ok ? static_cast<const void*>(gp) : static_cast<const void*>(g_zero_row);
+        __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(As + img * AIMG + g16 * 16 * 32), 16, 0, 0);
+    }
+    auto issue_w = [&](int tap, int buf) {
+        // 16 instructions per tap (4 images x 64 rows), 4 per wave: wave w fills image w
+        const int img = wave;
+#pragma unroll
+        for (int g16 = 0; g16 < 4; ++g16) {
+            const int n = g16 * 16 + lrow;
+            const bf16_t* gp = Wb + (img >> 1) * a.w_plane + (long long)n * a.K + tap * 64 + (img & 1) * 32 + gchunk * 8;
+            const void* src = n < a.N ? static_cast<const void*>(gp) : static_cast<const void*>(g_zero_row);
+            __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(Bs + (buf * 4 + img) * BIMG + g16 * 16 * 32), 16, 0, 0);
+        }
+    };
+    issue_w(0, 0);
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+    const int fr = lane & 15, fg = lane >> 4;
+    const int wm0 = wave * 32;
+    const int bsw = (fg ^ ((-(fr >> 2)) & 3)) * 8;                    // weight rows n = 16 j + fr
+    for (int tap = 0; tap < taps; ++tap) {
+        __syncthreads();                                 // the weights of `tap` (and, the first time, the input rows) have landed; buffer (tap + 1) & 1 is free
+        if (tap + 1 < taps) issue_w(tap + 1, (tap + 1) & 1);
+        const int j0 = wm0 + fr + tap * a.conv_dil;      // this lane's row of the first row tile at this tap (the second is 16 rows further: same swizzle)
+        const int asw = (fg ^ ((-((j0 & 15) >> 2)) & 3)) * 8;
+        const bf16_t* const bt = Bs + (tap & 1) * 4 * BIMG;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            bf16x8 ah[MT], al[MT], bh[NT], bl[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                ah[i] = load8(As + (0 + h) * AIMG + (j0 + i * 16) * 32 + asw);
+                al[i] = load8(As + (2 + h) * AIMG + (j0 + i * 16) * 32 + asw);
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                bh[j] = load8(bt + (0 + h) * BIMG + (j * 16 + fr) * 32 + bsw);
+                bl[j] = load8(bt + (2 + h) * BIMG + (j * 16 + fr) * 32 + bsw);
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    mma32(acc[i][j], al[i], bh[j]);
+                    mma32(acc[i][j], ah[i], bl[j]);
+                    mma32(acc[i][j], ah[i], bh[j]);
+                }
+        }
+    }
+    __syncthreads();                                     // the epilogue stages through the weight buffers
+    gemm_epilogue<float, MT, NT, WN, EPI_GENERIC, 2>(a, acc, reinterpret_cast<float*>(Bs) + wave * ROWS_PASS * SLD, lane, m0 + wm0, 0, 0, 0);
+}
+
 template <int BM, int BN, int WM, int WN>
 int launch_cfg_p(const GemmArgs& a, hipStream_t s) {
     dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, a.batch * a.groups);
@@ -284,6 +377,14 @@ int launch_gemm_x3(const GemmArgs& a, hipStream_t s) {
         // plane pairs cannot fall back to an fp32 kernel: every shape takes one of the two tile forms
         if (!a.a_planes || !a.w_planes || a.dtype != DT_F32 || a.epi != EPI_GENERIC) return set_error("gemm (plane-pair form): both operands must be plane pairs of an fp32 generic-epilogue GEMM"), -1;
         if ((a.lda & 7) || (a.a_plane & 7) || (a.w_plane & 7)) return set_error("gemm (plane-pair form): 16-byte alignment"), -1;
+        static const int resident = getenv("HVX_CONV64_RESIDENT") ? atoi(getenv("HVX_CONV64_RESIDENT")) : 1;      // (A/B switch)
+        if (resident && a.N <= 64 && a.cin_pad == 64 && a.conv_stride == 1 && a.up == 1 && a.groups == 1 && a.batch == 1 && a.M >= 4096 &&
+            128 + (a.K / 64 - 1) * a.conv_dil <= 192) {
+            const int slot = prof_begin(PK_GEMM_F32, 2.0 * a.M * a.N * (double)a.K, s);
+            hipLaunchKernelGGL((conv64_x3p_kernel<192>), dim3((a.M + 127) / 128), dim3(256), 0, s, a);
+            prof_end(slot, s);
+            return hipGetLastError() == hipSuccess ? 1 : (set_error("conv (resident-row plane-pair form) launch failed"), -1);
+        }
         return a.N <= 64 ? launch_cfg_p<128, 64, 32, 64>(a, s) : launch_cfg_p<128, 128, 64, 64>(a, s);
     }
     if (!a.x3 || a.dtype != DT_F32 || a.epi != EPI_GENERIC) return 0;

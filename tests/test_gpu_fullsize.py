@@ -98,14 +98,17 @@ def test_hift_of_a_512_char_utterance_split_bf16_convs_vs_exact_fp32_convs(tmp_p
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     wavs = []
-    for name, extra in (('x3', {}), ('exact', {'HVX_HIFT_FP32_MFMA': '1'})):
+    for name, extra in (('x3', {}), ('exact', {'HVX_HIFT_FP32_MFMA': '1'}), ('x3_tiled', {'HVX_CONV64_RESIDENT': '0'})):
         out = str(tmp_path / (name + '.pt'))
-        env = {k: v for k, v in os.environ.items() if k != 'HVX_HIFT_FP32_MFMA'}
+        env = {k: v for k, v in os.environ.items() if k not in ('HVX_HIFT_FP32_MFMA', 'HVX_CONV64_RESIDENT')}
         env.update(extra)
         r = subprocess.run([sys.executable, '-c', _HIFT_SNIPPET, out, root], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-2000:]
         wavs.append(torch.load(out))
-    a, b = wavs
+    a, b, c = wavs
+    # the last stage's 64-channel convolutions: rows resident in LDS across the taps (conv64_x3p_kernel) vs the tiled plane-pair form — the same
+    # products summed in the same order
+    assert torch.equal(a, c), float((a - c).abs().max())
     assert a.shape == b.shape and a.numel() == 5632 * 480 and torch.isfinite(a).all() and torch.isfinite(b).all()
     rel = _rel(a, b)
     print('HiFT 5632 frames: split-bf16 vs exact fp32 convolutions, relative waveform difference %.2e, max |diff| %.2e' % (rel, float((a - b).abs().max())))
