@@ -23,14 +23,9 @@ namespace {
 
 constexpr int BM = 256, WM = 128, WN = 64, MT = WM / 16, NT = WN / 16;
 
-// Two forms share the code:
-//   <BN 256, BK 64, 8 waves>: one workgroup per CU (128 KiB of LDS), 2 x 4 waves
-//   <BN 128, BK 32, 4 waves>: TWO independent workgroups per CU (48 KiB each), 2 x 2 waves — the same 128 x 64 wave tile and two waves per
-//       SIMD, but the two waves of a SIMD belong to different workgroups: one's epilogue and barrier waits run under the other's K-loop.
-//       K-tile rows are 64 B: a DMA instruction deposits 16 rows, swizzle chunk ^ ((row >> 1) & 3) (conflict-free ds_read_b128, checked by
-//       enumeration of the lane groups).  Correct (GPU tests pass with it) but SLOWER than the first form — 1.5x the L2 -> LDS bytes per
-//       flop and twice the barriers cost more than the overlap returns (out_proj 154 vs 149 us, FF1 276 vs 258, FF2 279 vs 254 at
-//       M = 45056) — so it is not instantiated.
+// <BN 256, BK 64, 8 waves>: one workgroup per CU (128 KiB of LDS), 2 x 4 waves.  (A <BN 128, BK 32, 4 waves> form — TWO independent
+// workgroups per CU, 48 KiB each, so that one's epilogue runs under the other's K-loop — was correct but 3-10 % slower on every DiT Linear,
+// with or without a deliberate half-tile start offset between the two co-resident workgroups: 1.5x the L2 -> LDS bytes per flop)
 template <int EPI, int BN, int BK, int NWAVE>
 __global__ __launch_bounds__(NWAVE * 64, 2) void gemm_big_kernel(GemmArgs a, int tiles_m, int tiles_n) {
     typedef bf16_t T;
@@ -62,38 +57,33 @@ __global__ __launch_bounds__(NWAVE * 64, 2) void gemm_big_kernel(GemmArgs a, int
     // ---- LDS-DMA sources: QA instructions of A and QB of W per wave and K-tile, RPI rows each ------------------------------------------
     typedef __attribute__((address_space(3))) void* lds_ptr;
     typedef const __attribute__((address_space(1))) void* glb_ptr;
+    // (a uniform base + one 32-bit byte offset per instruction: the accumulators and the two fragment sets leave no room for eight 64-bit
+    // pointers.  Rows past M / N are clamped to the last row: their products land in accumulator rows / columns the epilogue never stores.)
     const int lrow = lane / SLOTS, lslot = lane % SLOTS;
-    const char* srcA[QA];
-    const char* srcW[QB];
-    bool okA[QA], okW[QB];
+    unsigned offA[QA], offW[QB];
 #pragma unroll
     for (int q = 0; q < QA; ++q) {
         const int r = (wave * QA + q) * RPI + lrow;               // tile row filled by this lane
         const int chunk = lslot ^ ((r >> 1) & (SLOTS - 1));
-        okA[q] = (m0 + r) < a.M;
-        srcA[q] = reinterpret_cast<const char*>(Ab + (long long)(m0 + r) * a.lda + chunk * 8);
+        const int row = (m0 + r) < a.M ? (m0 + r) : a.M - 1;
+        offA[q] = (unsigned)(((long long)row * a.lda + chunk * 8) * (long long)sizeof(T));
     }
 #pragma unroll
     for (int q = 0; q < QB; ++q) {
         const int r = (wave * QB + q) * RPI + lrow;
         const int chunk = lslot ^ ((r >> 1) & (SLOTS - 1));
-        okW[q] = (n0 + r) < a.N;
-        srcW[q] = reinterpret_cast<const char*>(Wb + (long long)(n0 + r) * a.K + chunk * 8);
+        const int row = (n0 + r) < a.N ? (n0 + r) : a.N - 1;
+        offW[q] = (unsigned)(((long long)row * a.K + chunk * 8) * (long long)sizeof(T));
     }
     auto issue = [&](int kc, int buf) {
-        const long long kb = (long long)kc * BK * sizeof(T);
+        const char* const pa = reinterpret_cast<const char*>(Ab) + (long long)kc * BK * sizeof(T);
+        const char* const pw = reinterpret_cast<const char*>(Wb) + (long long)kc * BK * sizeof(T);
         T* const As = lds + buf * TILE_ELEMS;
         T* const Bs = As + BM * BK;
 #pragma unroll
-        for (int q = 0; q < QA; ++q) {
-            const void* gp = okA[q] ? static_cast<const void*>(srcA[q] + kb) : static_cast<const void*>(g_zero_row);
-            __builtin_amdgcn_global_load_lds((glb_ptr)gp, (lds_ptr)(As + (wave * QA + q) * RPI * BK), 16, 0, 0);
-        }
+        for (int q = 0; q < QA; ++q) __builtin_amdgcn_global_load_lds((glb_ptr)(pa + offA[q]), (lds_ptr)(As + (wave * QA + q) * RPI * BK), 16, 0, 0);
 #pragma unroll
-        for (int q = 0; q < QB; ++q) {
-            const void* gp = okW[q] ? static_cast<const void*>(srcW[q] + kb) : static_cast<const void*>(g_zero_row);
-            __builtin_amdgcn_global_load_lds((glb_ptr)gp, (lds_ptr)(Bs + (wave * QB + q) * RPI * BK), 16, 0, 0);
-        }
+        for (int q = 0; q < QB; ++q) __builtin_amdgcn_global_load_lds((glb_ptr)(pw + offW[q]), (lds_ptr)(Bs + (wave * QB + q) * RPI * BK), 16, 0, 0);
     };
 
     f32x4 acc[MT][NT];
@@ -102,33 +92,56 @@ __global__ __launch_bounds__(NWAVE * 64, 2) void gemm_big_kernel(GemmArgs a, int
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
 
+    // ---- K-loop, fragments double-buffered in REGISTERS.  The compiler's own schedule of the plain "read 12 fragments, 32 MFMAs" loop keeps two A
+    // fragments live and waits on LDS every eight MFMAs (tools/gemm_lab.hip: 1.60 PF/s with no global traffic at all).  Here the twelve
+    // ds_read_b128 of the NEXT k-step are issued one per two MFMAs of the current one (sched_group_barrier pins that order), and the barrier sits
+    // between the two k-steps of a K-tile: after it, the first k-step of tile kc + 1 is read under the second k-step of tile kc, and tile kc + 2 is
+    // requested into the buffer tile kc has just left.  Same loop without the epilogue: 2.0 PF/s from LDS alone, 1.5-1.68 PF/s with the DMA.
+    static_assert(BK == 64, "two k-steps per K-tile");
     const int fr = lane & 15, fg = lane >> 4;
     const int sw = (fr >> 1) & (SLOTS - 1);                      // ((row >> 1) & (SLOTS - 1)) of every fragment row of this lane (rows = 16 i + fr)
-    auto compute = [&](int buf) {
-        const T* const As = lds + buf * TILE_ELEMS + (wm0 + fr) * BK;
-        const T* const Bs = lds + buf * TILE_ELEMS + BM * BK + (wn0 + fr) * BK;
+    const int off0 = (fg ^ sw) * 8, off1 = ((4 + fg) ^ sw) * 8;
+    bf16x8 a0[MT], b0[NT], a1[MT], b1[NT];
+    auto loadf = [&](int buf, int off, bf16x8 (&af)[MT], bf16x8 (&bf)[NT]) __attribute__((always_inline)) {
+        const T* const As = lds + buf * TILE_ELEMS + (wm0 + fr) * BK + off;
+        const T* const Bs = lds + buf * TILE_ELEMS + BM * BK + (wn0 + fr) * BK + off;
 #pragma unroll
-        for (int kk = 0; kk < BK / 32; ++kk) {
-            const int off = ((kk * 4 + fg) ^ sw) * 8;
-            bf16x8 af[MT], bf[NT];
+        for (int j = 0; j < NT; ++j) bf[j] = load8(Bs + j * 16 * BK);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) bf[j] = load8(Bs + j * 16 * BK + off);
-#pragma unroll
-            for (int i = 0; i < MT; ++i) af[i] = load8(As + i * 16 * BK + off);
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) mma32(acc[i][j], af[i], bf[j]);
-        }
+        for (int i = 0; i < MT; ++i) af[i] = load8(As + i * 16 * BK);
     };
-
+    auto mfmas = [&](const bf16x8 (&af)[MT], const bf16x8 (&bf)[NT]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) mma32(acc[i][j], af[i], bf[j]);
+    };
+    auto interleave = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < MT + NT; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);           // two MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);           // one LDS read
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, MT * NT - 2 * (MT + NT), 0);
+    };
     const int nk = a.K / BK;
+    auto iter = [&](int kc, auto DMA, auto NEXT) __attribute__((always_inline)) {
+        loadf(kc & 1, off1, a1, b1);
+        mfmas(a0, b0);
+        interleave();
+        __syncthreads();                                 // every wave has read all of tile kc (its buffer is free); tile kc + 1 has landed
+        if constexpr (decltype(DMA)::value) issue(kc + 2, kc & 1);
+        if constexpr (decltype(NEXT)::value) loadf((kc + 1) & 1, off0, a0, b0);
+        mfmas(a1, b1);
+        if constexpr (decltype(NEXT)::value) interleave();
+    };
     issue(0, 0);
-    for (int kc = 0; kc < nk; ++kc) {
-        __syncthreads();                                 // tile kc has landed (the barrier drains the DMA queue); buffer (kc+1)&1 is free
-        if (kc + 1 < nk) issue(kc + 1, (kc + 1) & 1);
-        compute(kc & 1);
-    }
+    __syncthreads();
+    if (nk > 1) issue(1, 1);
+    loadf(0, off0, a0, b0);
+    for (int kc = 0; kc < nk - 2; ++kc) iter(kc, std::true_type{}, std::true_type{});
+    if (nk >= 2) iter(nk - 2, std::false_type{}, std::true_type{});
+    iter(nk - 1, std::false_type{}, std::false_type{});
     __syncthreads();                                     // the epilogue reuses the tile memory as staging
 
     gemm_epilogue<T, MT, NT, WN, EPI, 1>(a, acc, reinterpret_cast<float*>(smem) + wave * SCR_FLOATS, lane, m0 + wm0, n0 + wn0, bz, 0);
