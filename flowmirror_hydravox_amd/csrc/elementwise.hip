@@ -275,15 +275,21 @@ int launch_log_softmax(float* x, int ld, int rows, int V, hipStream_t s) {
 }
 
 // ---- DiT adaLN: LayerNorm (no affine, biased variance, eps) then (1 + scale) * . + shift -----------------
-template <class T>
-__global__ __launch_bounds__(256) void layernorm_mod_kernel(const float* x, const float* shift, const float* scale, long long mod_bs, float eps,
+// (XT: the residual stream's storage type, float or IEEE fp16 — GemmArgs.res_f16 / out_f16)
+__device__ __forceinline__ f32x4 ln_load4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 ln_load4(const f16_t* p) {
+    const f16x4 h = *reinterpret_cast<const f16x4*>(p);
+    return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+}
+template <class T, class XT>
+__global__ __launch_bounds__(256) void layernorm_mod_kernel(const XT* x, const float* shift, const float* scale, long long mod_bs, float eps,
                                                             T* y, int T_, int D) {
     // one wave per row, 4 rows per workgroup
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int b = blockIdx.y;
     if (row >= T_) return;
     const int lane = threadIdx.x & 63;
-    const float* xr = x + ((long long)b * T_ + row) * D;
+    const XT* xr = x + ((long long)b * T_ + row) * D;
     const float* sh = shift + (long long)b * mod_bs;
     const float* sc = scale + (long long)b * mod_bs;
     T* yr = y + ((long long)b * T_ + row) * D;
@@ -295,7 +301,7 @@ __global__ __launch_bounds__(256) void layernorm_mod_kernel(const float* x, cons
 #pragma unroll
         for (int q = 0; q < 8; ++q)
             if (q < nq) {
-                v[q] = *reinterpret_cast<const f32x4*>(xr + q * 256 + lane * 4);
+                v[q] = ln_load4(xr + q * 256 + lane * 4);
                 s1 += (v[q][0] + v[q][1]) + (v[q][2] + v[q][3]);
             }
         const float mean = wave_sum(s1) / (float)D;
@@ -327,20 +333,20 @@ __global__ __launch_bounds__(256) void layernorm_mod_kernel(const float* x, cons
         return;
     }
     float s1 = 0.0f;
-    for (int c = lane; c < D; c += 64) s1 += xr[c];
+    for (int c = lane; c < D; c += 64) s1 += (float)xr[c];
     const float mean = wave_sum(s1) / (float)D;
     float s2 = 0.0f;
     for (int c = lane; c < D; c += 64) {
-        const float d = xr[c] - mean;
+        const float d = (float)xr[c] - mean;
         s2 += d * d;
     }
     const float inv = rsqrtf(wave_sum(s2) / (float)D + eps);
-    for (int c = lane; c < D; c += 64) yr[c] = from_f32<T>((xr[c] - mean) * inv * (1.0f + sc[c]) + sh[c]);
+    for (int c = lane; c < D; c += 64) yr[c] = from_f32<T>(((float)xr[c] - mean) * inv * (1.0f + sc[c]) + sh[c]);
 }
 // D == 1024 (the DiT width): a wave owns TWO rows, 8 consecutive channels per lane and step, every load of both rows in flight before the
 // first reduction (a row is 4 KB: one row per wave leaves the memory pipe idle during the two dependent wave reductions), 16-byte stores.
-template <class T>
-__global__ __launch_bounds__(256) void layernorm_mod1024_kernel(const float* __restrict__ x, const float* __restrict__ shift,
+template <class T, class XT>
+__global__ __launch_bounds__(256) void layernorm_mod1024_kernel(const XT* __restrict__ x, const float* __restrict__ shift,
                                                                 const float* __restrict__ scale, long long mod_bs, float eps, T* __restrict__ y, int T_) {
     constexpr int D = 1024;
     const int lane = threadIdx.x & 63;
@@ -348,16 +354,30 @@ __global__ __launch_bounds__(256) void layernorm_mod1024_kernel(const float* __r
     const int b = blockIdx.y;
     if (row0 >= T_) return;
     const bool two = row0 + 1 < T_;
-    const float* xr = x + ((long long)b * T_ + row0) * D;
+    const XT* xr = x + ((long long)b * T_ + row0) * D;
     f32x4 v[2][4];
+    if constexpr (sizeof(XT) == 2) {
+        f16x8 h[2][2];
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
+        for (int r = 0; r < 2; ++r)
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const float* p = xr + (r && two ? D : 0) + q * 512 + lane * 8;
-            v[r][2 * q] = *reinterpret_cast<const f32x4*>(p);
-            v[r][2 * q + 1] = *reinterpret_cast<const f32x4*>(p + 4);
-        }
+            for (int q = 0; q < 2; ++q) h[r][q] = *reinterpret_cast<const f16x8*>(xr + (r && two ? D : 0) + q * 512 + lane * 8);
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[r][2 * q][e] = (float)h[r][q][e]; v[r][2 * q + 1][e] = (float)h[r][q][4 + e]; }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const XT* p = xr + (r && two ? D : 0) + q * 512 + lane * 8;
+                v[r][2 * q] = *reinterpret_cast<const f32x4*>(p);
+                v[r][2 * q + 1] = *reinterpret_cast<const f32x4*>(p + 4);
+            }
+    }
     const float* sh = shift + (long long)b * mod_bs;
     const float* sc = scale + (long long)b * mod_bs;
     f32x4 s4[4], h4[4];
@@ -420,22 +440,32 @@ __global__ __launch_bounds__(256) void layernorm_mod1024_kernel(const float* __r
         }
     }
 }
-int launch_layernorm_mod(const float* x, const float* shift, const float* scale, long long mod_bs, float eps, void* y, int dtype, int B, int T_,
+int launch_layernorm_mod(const void* x, int x_f16, const float* shift, const float* scale, long long mod_bs, float eps, void* y, int dtype, int B, int T_,
                          int D, hipStream_t s) {
     if (B <= 0 || T_ <= 0) return 0;
+    const float* xf = reinterpret_cast<const float*>(x);
+    const f16_t* xh = reinterpret_cast<const f16_t*>(x);
     if (D == 1024 && ((mod_bs & 3) == 0) && ((((unsigned long long)shift | (unsigned long long)scale | (unsigned long long)x | (unsigned long long)y)) & 15) == 0) {
         dim3 grid((T_ + 7) / 8, B);
-        if (dtype == DT_BF16)
-            hipLaunchKernelGGL(layernorm_mod1024_kernel<bf16_t>, grid, dim3(256), 0, s, x, shift, scale, mod_bs, eps, reinterpret_cast<bf16_t*>(y), T_);
+        if (dtype == DT_BF16 && x_f16)
+            hipLaunchKernelGGL((layernorm_mod1024_kernel<bf16_t, f16_t>), grid, dim3(256), 0, s, xh, shift, scale, mod_bs, eps, reinterpret_cast<bf16_t*>(y), T_);
+        else if (dtype == DT_BF16)
+            hipLaunchKernelGGL((layernorm_mod1024_kernel<bf16_t, float>), grid, dim3(256), 0, s, xf, shift, scale, mod_bs, eps, reinterpret_cast<bf16_t*>(y), T_);
+        else if (x_f16)
+            hipLaunchKernelGGL((layernorm_mod1024_kernel<float, f16_t>), grid, dim3(256), 0, s, xh, shift, scale, mod_bs, eps, reinterpret_cast<float*>(y), T_);
         else
-            hipLaunchKernelGGL(layernorm_mod1024_kernel<float>, grid, dim3(256), 0, s, x, shift, scale, mod_bs, eps, reinterpret_cast<float*>(y), T_);
+            hipLaunchKernelGGL((layernorm_mod1024_kernel<float, float>), grid, dim3(256), 0, s, xf, shift, scale, mod_bs, eps, reinterpret_cast<float*>(y), T_);
         return hipGetLastError() == hipSuccess ? 0 : (set_error("layernorm_mod launch failed"), -1);
     }
     dim3 grid((T_ + 3) / 4, B);
-    if (dtype == DT_BF16)
-        hipLaunchKernelGGL(layernorm_mod_kernel<bf16_t>, grid, dim3(256), 0, s, x, shift, scale, mod_bs, eps, reinterpret_cast<bf16_t*>(y), T_, D);
+    if (dtype == DT_BF16 && x_f16)
+        hipLaunchKernelGGL((layernorm_mod_kernel<bf16_t, f16_t>), grid, dim3(256), 0, s, xh, shift, scale, mod_bs, eps, reinterpret_cast<bf16_t*>(y), T_, D);
+    else if (dtype == DT_BF16)
+        hipLaunchKernelGGL((layernorm_mod_kernel<bf16_t, float>), grid, dim3(256), 0, s, xf, shift, scale, mod_bs, eps, reinterpret_cast<bf16_t*>(y), T_, D);
+    else if (x_f16)
+        hipLaunchKernelGGL((layernorm_mod_kernel<float, f16_t>), grid, dim3(256), 0, s, xh, shift, scale, mod_bs, eps, reinterpret_cast<float*>(y), T_, D);
     else
-        hipLaunchKernelGGL(layernorm_mod_kernel<float>, grid, dim3(256), 0, s, x, shift, scale, mod_bs, eps, reinterpret_cast<float*>(y), T_, D);
+        hipLaunchKernelGGL((layernorm_mod_kernel<float, float>), grid, dim3(256), 0, s, xf, shift, scale, mod_bs, eps, reinterpret_cast<float*>(y), T_, D);
     return hipGetLastError() == hipSuccess ? 0 : (set_error("layernorm_mod launch failed"), -1);
 }
 

@@ -82,14 +82,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT]
         // 16-byte vector access is legal when every leading dimension / base keeps 4-float (8-bf16) alignment
         auto al = [](const void* p, long long ld, int esz) { return p == nullptr || ((((unsigned long long)p) & 15) == 0 && ((ld * esz) & 15) == 0); };
         const bool vec = al(a.bias, 0, 4) && al(a.act_alpha, 0, 4) && al(a.act2_alpha, 0, 4) && al(a.gate, a.gate_bs, 4) &&
-                         al(a.res, a.ldres, 4) && ((a.res_bs * 4) & 15) == 0 && al(a.res2, a.ldres2, 4) && ((a.res2_bs * 4) & 15) == 0 &&
-                         al(a.out, a.ldo, a.out_f32 ? 4 : (int)sizeof(T)) && ((a.out_bs * (a.out_f32 ? 4 : (int)sizeof(T))) & 15) == 0 &&
+                         al(a.res, a.ldres, a.res_f16 ? 2 : 4) && ((a.res_bs * (a.res_f16 ? 2 : 4)) & 15) == 0 && al(a.res2, a.ldres2, 4) && ((a.res2_bs * 4) & 15) == 0 &&
+                         al(a.out, a.ldo, a.out_f16 ? 2 : a.out_f32 ? 4 : (int)sizeof(T)) && ((a.out_bs * (a.out_f16 ? 2 : a.out_f32 ? 4 : (int)sizeof(T))) & 15) == 0 &&
                          al(a.out2, a.ldo2, (int)sizeof(T)) && ((a.out2_bs * (int)sizeof(T)) & 15) == 0 && ((g * a.N) & 7) == 0;
         // ---- streamlined form: whole column tiles, 16-byte alignment everywhere, no per-column activation tables, one residual --------
         // (every DiT Linear).  The column operands (bias, gate) do not depend on the pass and are loaded once; the residual rows of pass
         // p + 1 are requested before pass p is finished, so no pass waits on a cold global load; bf16 results leave as 16-byte stores.
         constexpr bool ALPHA = LEAN == 2;
-        const bool lean = LEAN && vec && (nw0 + WN) <= a.N && (ALPHA || (!a.act_alpha && !a.act2_alpha)) && a.act != ACT_SNAKEBETA && !a.res2 &&
+        const bool half_io = a.res_f16 || a.out_f16;
+        const bool lean = LEAN && (!half_io || (LEAN == 1 && WN == 64 && MT_PASS == 1 && sizeof(T) == 2 && a.res && a.res_f16 && a.out_f16 && a.out && !a.out2 && a.scale == 1.0f && a.act == ACT_NONE)) && vec && (nw0 + WN) <= a.N && (ALPHA || (!a.act_alpha && !a.act2_alpha)) && a.act != ACT_SNAKEBETA && !a.res2 &&
                           a.div == 0.0f && a.out_row_off >= 0 && a.out2_row_off >= 0 && a.res_row_off >= 0;
         if constexpr (LEAN != 0) if (lean) {
             // Lane -> (row, column) maps of a pass (PERM), chosen per mode so that every global instruction of the wave covers WHOLE contiguous
@@ -100,7 +101,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT]
             //   PERM 3 (fp32 in / out, 8 lanes per row): instruction q covers columns [32 (q & 1), + 32) of rows [8 (q >> 1), + 8) = 128 contiguous
             //           bytes per row; a second bf16 output leaves as 8-byte stores (64 contiguous bytes per row and instruction)
             const int gcw = g * a.N + nw0;
-            const float* const resw = a.res ? a.res + (long long)bz * a.res_bs + gcw : nullptr;
+            const float* const resw = (a.res && !a.res_f16) ? a.res + (long long)bz * a.res_bs + gcw : nullptr;
+            const f16_t* const resh = (a.res && a.res_f16) ? reinterpret_cast<const f16_t*>(a.res) + (long long)bz * a.res_bs + gcw : nullptr;
             auto lean_pass = [&](auto IP, auto MODE, auto PERMC, f32x4 (&bi)[4], f32x4 (&gt)[4], f32x4 (&al)[4], f32x4 (&al2)[4], f32x4 (&rs)[4])
                                  __attribute__((always_inline)) {
                 constexpr int ip = decltype(IP)::value;
@@ -129,11 +131,20 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT]
                     }
                 };
                 const int act = MD::rt ? a.act : MD::act;
-                const bool has_res = MD::rt ? (resw != nullptr) : (bool)MD::res;
+                const bool has_res = MD::rt ? (resw != nullptr) : (MD::res != 0);
                 const bool out_f32 = MD::rt ? (a.out_f32 != 0) : (bool)MD::of32;
                 const bool has_out = MD::rt ? (a.out != nullptr) : true;
                 const bool has_out2 = MD::rt ? (a.out2 != nullptr) : (bool)MD::o2;
                 auto res_load = [&](int row0, f32x4 (&r4)[4]) __attribute__((always_inline)) {
+                    if constexpr (MD::res == 2) {              // fp16 stream (PERM 2: 8 consecutive columns of rows rsel(0) and rsel(2)): raw bits until use
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int row = row0 + rsel(2 * u);
+                            const int rr = (row < a.M ? row : a.M - 1) + a.res_row_off;
+                            r4[u] = *reinterpret_cast<const f32x4*>(resh + (long long)rr * a.ldres + cof(2 * u));
+                        }
+                        return;
+                    }
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int row = row0 + rsel(q);
@@ -173,11 +184,26 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT]
                         }
                     }
                     v[q] *= gt[q];
-                    if (has_res) v[q] += rs[q];
+                    if constexpr (MD::res == 2) {
+                        const f16x8 h8 = __builtin_bit_cast(f16x8, rs[q >> 1]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[q][e] += (float)h8[(q & 1) * 4 + e];
+                    } else {
+                        if (has_res) v[q] += rs[q];
+                    }
                     v[q] *= a.scale;
                 }
                 const int row0 = mw0 + ip * 16;
-                if (has_out) {
+                if constexpr (MD::of32 == 2) {               // fp16 stream out (PERM 2): 16-byte stores, 128 contiguous bytes per row and instruction
+                    f16_t* const obh = reinterpret_cast<f16_t*>(a.out) + ob + gcw;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        f16x8 w8;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { w8[e] = (f16_t)v[2 * u][e]; w8[4 + e] = (f16_t)v[2 * u + 1][e]; }
+                        if (row0 + rsel(2 * u) < a.M) *reinterpret_cast<f16x8*>(obh + (long long)(row0 + rsel(2 * u) + a.out_row_off) * a.ldo + cof(2 * u)) = w8;
+                    }
+                } else if (has_out) {
                     if (sizeof(T) != 2 && a.out_planes) {
                         bf16_t* const obp = reinterpret_cast<bf16_t*>(a.out) + ob + gcw;
 #pragma unroll
@@ -229,7 +255,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT]
             auto lean_all = [&](auto MODE) __attribute__((always_inline)) {
                 typedef decltype(MODE) MD;
                 // the permuted maps assume 4 lanes per 64-column row and one 16-row tile per pass (the 256-tile form and the vocoder form)
-                constexpr int PERM = (MD::rt || WN != 64 || MT_PASS != 1) ? 0 : MD::o2 ? 3 : (MD::of32 || sizeof(T) != 2) ? 1 : 2;   // (PERM 3 for the plain fp32 modes measured 2-3 % slower than PERM 1)
+                constexpr int PERM = (MD::rt || WN != 64 || MT_PASS != 1) ? 0 : MD::of32 == 2 ? 2 : MD::o2 ? 3 : (MD::of32 || sizeof(T) != 2) ? 1 : 2;   // (PERM 3 for the plain fp32 modes measured 2-3 % slower than PERM 1)
                 std::integral_constant<int, PERM> pc;
                 f32x4 bi[4], gt[4], al[4], al2[4], rs[4];
                 lean_pass(std::integral_constant<int, 0>{}, MODE, pc, bi, gt, al, al2, rs);
@@ -242,6 +268,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT]
                 if constexpr (MT > 7 * MT_PASS) lean_pass(std::integral_constant<int, 7 * MT_PASS>{}, MODE, pc, bi, gt, al, al2, rs);
             };
             const bool simple = a.out && !a.out2 && a.scale == 1.0f;
+            constexpr bool HALF_OK = LEAN == 1 && WN == 64 && MT_PASS == 1 && sizeof(T) == 2;     // (the fp16 stream exists in the DiT's bf16 Linears only)
+            if constexpr (HALF_OK) {
+                if (simple && a.act == ACT_NONE && resh && a.out_f16) { lean_all(LeanMode<false, ACT_NONE, 2, 2, 0>{}); return; }   // out_proj, FF2 on the half stream
+            }
             if (simple && a.act == ACT_NONE && resw && a.out_f32) lean_all(LeanMode<false, ACT_NONE, 1, 1, 0>{});              // out_proj, FF2: x += gate * (.)
             else if (simple && a.act == ACT_GELU_TANH && !resw && !a.out_f32) lean_all(LeanMode<false, ACT_GELU_TANH, 0, 0, 0>{});   // FF1
             else if (simple && a.act == ACT_NONE && !resw && !a.out_f32) lean_all(LeanMode<false, ACT_NONE, 0, 0, 0>{});           // plain store
@@ -265,7 +295,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT]
             if (row >= a.M || (row + a.out_row_off) < 0) return;
             if (full) {
                 // four self-contained 4-column chunks (keeps the live register set small: the accumulators own most of the file)
-                const float* resp = a.res ? a.res + (long long)bz * a.res_bs + (long long)(row + a.res_row_off) * a.ldres + gc0 : nullptr;
+                const float* resp = (a.res && !a.res_f16) ? a.res + (long long)bz * a.res_bs + (long long)(row + a.res_row_off) * a.ldres + gc0 : nullptr;
+                const f16_t* resph = (a.res && a.res_f16) ? reinterpret_cast<const f16_t*>(a.res) + (long long)bz * a.res_bs + (long long)(row + a.res_row_off) * a.ldres + gc0 : nullptr;
                 const float* res2p = a.res2 ? a.res2 + (long long)bz * a.res2_bs + (long long)row * a.ldres2 + gc0 : nullptr;
                 const long long o1 = ob + (long long)(row + a.out_row_off) * a.ldo + gc0;
                 const long long o2 = (long long)bz * a.out2_bs + (long long)(row + a.out2_row_off) * a.ldo2 + gc0;
@@ -286,10 +317,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT]
                     }
                     if (a.gate) v *= ld4(a.gate + (long long)bz * a.gate_bs + gc0 + c4);
                     if (resp) v += ld4(resp + c4);
+                    if (resph) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += (float)resph[c4 + e];
+                    }
                     if (res2p) v += ld4(res2p + c4);
                     v *= a.scale;
                     if (a.div != 0.0f) v = v / a.div;
-                    if (a.out) {
+                    if (a.out && a.out_f16) {
+                        f16_t* op = reinterpret_cast<f16_t*>(a.out) + o1 + c4;
+                        const f16x4 w4 = {(f16_t)v[0], (f16_t)v[1], (f16_t)v[2], (f16_t)v[3]};
+                        if (vec) *reinterpret_cast<f16x4*>(op) = w4;
+                        else { op[0] = w4[0]; op[1] = w4[1]; op[2] = w4[2]; op[3] = w4[3]; }
+                    } else if (a.out) {
                         if (sizeof(T) != 2 && a.out_planes) {
                             bf16_t* op = reinterpret_cast<bf16_t*>(a.out) + o1 + c4;
                             if (vec) store_planes4(op, a.out_plane, v);
@@ -347,14 +387,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT]
                         const float gt = a.gate ? a.gate[(long long)bz * a.gate_bs + gc] : 1.0f;
                         const float be1 = a.act == ACT_SNAKEBETA ? a.act_alpha[a.groups * a.N + gc] : 1.0f;
                         v = act_apply(a.act, x[c] + bi, a.act_param, al1, be1) * gt;
-                        if (a.res) v += a.res[(long long)bz * a.res_bs + (long long)(row + a.res_row_off) * a.ldres + gc];
+                        if (a.res && a.res_f16) v += (float)reinterpret_cast<const f16_t*>(a.res)[(long long)bz * a.res_bs + (long long)(row + a.res_row_off) * a.ldres + gc];
+                        else if (a.res) v += a.res[(long long)bz * a.res_bs + (long long)(row + a.res_row_off) * a.ldres + gc];
                         if (a.res2) v += a.res2[(long long)bz * a.res2_bs + (long long)row * a.ldres2 + gc];
                         v *= a.scale;
                         if (a.div != 0.0f) v = v / a.div;
                     }
                     if (a.out && (col_ok || col_pad)) {
                         const long long o = ob + (long long)(row + a.out_row_off) * a.ldo + gc;
-                        if (sizeof(T) != 2 && a.out_planes) store_planes1(reinterpret_cast<bf16_t*>(a.out) + o, a.out_plane, v);
+                        if (a.out_f16) reinterpret_cast<f16_t*>(a.out)[o] = (f16_t)v;
+                        else if (sizeof(T) != 2 && a.out_planes) store_planes1(reinterpret_cast<bf16_t*>(a.out) + o, a.out_plane, v);
                         else if (a.out_f32) reinterpret_cast<float*>(a.out)[o] = v;
                         else reinterpret_cast<T*>(a.out)[o] = from_f32<T>(v);
                     }

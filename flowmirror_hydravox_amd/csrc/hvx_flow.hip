@@ -8,7 +8,9 @@
 //   flow/DiT/modules.py:115-144     CausalConvPositionEmbedding      :606-616 TimestepEmbedding
 //   flow/flow_matching.py:71-124    solve_euler (batch-2 CFG)
 // Data layout in HBM: activations are time-major rows [B][T][C] (C contiguous) so that every Linear and every
-// Conv1d is one implicit-GEMM launch; the residual stream is fp32, GEMM operands are `dtype`; q/k are written
+// Conv1d is one implicit-GEMM launch; GEMM operands are `dtype`; the DiT's residual stream is fp32 in fp32 mode and IEEE fp16 in bf16 mode
+// (hvx_flow_set_half_stream; the reference runs the whole decoder in fp16, infer_speech_model.py:103 — the updates are still formed in fp32
+// and rounded once per residual add); q/k are written
 // head-major and V already transposed by the QKV epilogue, which is what the attention kernel consumes.
 #include <string.h>
 
@@ -29,6 +31,7 @@ struct hvx_flow {
     // "valid" slot of garbage behind), and carries the event recorded behind those launches: a hit on another stream waits for it.
     float* mod_cache = nullptr;
     int mod_slots = 0;
+    bool half_stream = false;          // residual stream of the DiT blocks stored as fp16 (bf16 mode only)
     struct ModSlot {
         float t;
         hipStream_t s;
@@ -233,6 +236,9 @@ int estimator_core(const hvx_flow* h, hipStream_t s, EstBufs& b, int B, int T, c
     g.out2 = b.x0t; g.act2 = ACT_NONE; g.out2_bs = (long long)T * D; g.ldo2 = D; g.out2_cols = D;
     HVX_CHECK(launch_gemm(g, s));
     const int Cg = D / c.conv_groups, kc = c.conv_kernel;
+    // the residual stream of the blocks: fp32 in b.x, or fp16 in the memory of x0t (the bf16 copy of x0 is dead once the first conv has read it)
+    const int hs = (h->half_stream && dt == DT_BF16) ? 1 : 0;
+    void* const xs = hs ? b.x0t : static_cast<void*>(b.x);
     for (int pass = 0; pass < 2; ++pass) {
         g = linear(dt, T, Cg, kc * Cg, pass == 0 ? b.x0t : b.c1, D, w[15 + 2 * pass], (const float*)w[16 + 2 * pass]);
         g.batch = B; g.groups = c.conv_groups; g.a_bs = (long long)T * D; g.a_gs = Cg; g.rows_in = T; g.cin_pad = Cg; g.pad_left = kc - 1;
@@ -242,7 +248,7 @@ int estimator_core(const hvx_flow* h, hipStream_t s, EstBufs& b, int B, int T, c
             g.out = b.c1; g.out_f32 = 0; g.out_bs = (long long)T * D; g.ldo = D; g.out_cols = D;
         } else {
             g.res = b.x; g.res_bs = (long long)T * D; g.ldres = D;                                // conv_pos_embed(x) + x  (dit.py:97)
-            g.out = b.x; g.out_f32 = 1; g.out_bs = (long long)T * D; g.ldo = D; g.out_cols = D;
+            g.out = xs; g.out_f32 = hs ? 0 : 1; g.out_f16 = hs; g.out_bs = (long long)T * D; g.ldo = D; g.out_cols = D;
         }
         HVX_CHECK(launch_gemm(g, s));
     }
@@ -252,7 +258,7 @@ int estimator_core(const hvx_flow* h, hipStream_t s, EstBufs& b, int B, int T, c
     for (int i = 0; i < c.depth; ++i) {
         const void* const* bw = w + 19 + 10 * i;
         const float* mod = b.mods + (size_t)i * MB * 6 * D;
-        HVX_CHECK(launch_layernorm_mod(b.x, mod, mod + D, mbs, 1e-6f, b.n, dt, B, T, D, s));
+        HVX_CHECK(launch_layernorm_mod(xs, hs, mod, mod + D, mbs, 1e-6f, b.n, dt, B, T, D, s));
         g = linear(dt, T, 3 * D, D, b.n, D, bw[2], (const float*)bw[3]);
         g.batch = B; g.a_bs = (long long)T * D; g.epi = EPI_QKV_DIT;
         g.q = b.q; g.k = b.k; g.vT = b.vT; g.heads = H; g.t_pad = Tp; g.rope_cos = (const float*)w[0]; g.rope_sin = (const float*)w[1];
@@ -269,22 +275,22 @@ int estimator_core(const hvx_flow* h, hipStream_t s, EstBufs& b, int B, int T, c
         HVX_CHECK(launch_attention(at, s));
         g = linear(dt, T, D, D, b.att, D, bw[4], (const float*)bw[5]);
         g.batch = B; g.a_bs = (long long)T * D;
-        g.gate = mod + 2 * D; g.gate_bs = mbs; g.res = b.x; g.res_bs = (long long)T * D; g.ldres = D;
-        g.out = b.x; g.out_f32 = 1; g.out_bs = (long long)T * D; g.ldo = D; g.out_cols = D;
+        g.gate = mod + 2 * D; g.gate_bs = mbs; g.res = static_cast<const float*>(xs); g.res_f16 = hs; g.res_bs = (long long)T * D; g.ldres = D;
+        g.out = xs; g.out_f32 = hs ? 0 : 1; g.out_f16 = hs; g.out_bs = (long long)T * D; g.ldo = D; g.out_cols = D;
         HVX_CHECK(launch_gemm(g, s));
-        HVX_CHECK(launch_layernorm_mod(b.x, mod + 3 * D, mod + 4 * D, mbs, 1e-6f, b.n, dt, B, T, D, s));
+        HVX_CHECK(launch_layernorm_mod(xs, hs, mod + 3 * D, mod + 4 * D, mbs, 1e-6f, b.n, dt, B, T, D, s));
         g = linear(dt, T, c.ff, D, b.n, D, bw[6], (const float*)bw[7]);
         g.batch = B; g.a_bs = (long long)T * D; g.act = ACT_GELU_TANH;
         g.out = b.ffh; g.out_f32 = 0; g.out_bs = (long long)T * c.ff; g.ldo = c.ff; g.out_cols = c.ff;
         HVX_CHECK(launch_gemm(g, s));
         g = linear(dt, T, D, c.ff, b.ffh, c.ff, bw[8], (const float*)bw[9]);
         g.batch = B; g.a_bs = (long long)T * c.ff;
-        g.gate = mod + 5 * D; g.gate_bs = mbs; g.res = b.x; g.res_bs = (long long)T * D; g.ldres = D;
-        g.out = b.x; g.out_f32 = 1; g.out_bs = (long long)T * D; g.ldo = D; g.out_cols = D;
+        g.gate = mod + 5 * D; g.gate_bs = mbs; g.res = static_cast<const float*>(xs); g.res_f16 = hs; g.res_bs = (long long)T * D; g.ldres = D;
+        g.out = xs; g.out_f32 = hs ? 0 : 1; g.out_f16 = hs; g.out_bs = (long long)T * D; g.ldo = D; g.out_cols = D;
         HVX_CHECK(launch_gemm(g, s));
     }
     // ---- final adaLN (scale first, then shift: modules.py:262) + projection -------------------------------------------
-    HVX_CHECK(launch_layernorm_mod(b.x, b.fmod + D, b.fmod, fbs, 1e-6f, b.n, dt, B, T, D, s));
+    HVX_CHECK(launch_layernorm_mod(xs, hs, b.fmod + D, b.fmod, fbs, 1e-6f, b.n, dt, B, T, D, s));
     g = linear(dt, T, mel, D, b.n, D, tw[2], (const float*)tw[3]);
     g.batch = B; g.a_bs = (long long)T * D;
     g.out = b.outrow; g.out_f32 = 1; g.out_bs = (long long)T * mel; g.ldo = mel; g.out_cols = mel;
@@ -378,6 +384,13 @@ int hvx_cfm_estimator_streaming(hvx_flow* h, hvx_stream stream, void* ws, size_t
 int hvx_cfm_estimator(hvx_flow* h, hvx_stream stream, void* ws, size_t ws_bytes, int32_t batch, int32_t t_len, const float* x,
                       const int32_t* kv_len, const float* mu, const float* t, const float* spks, const float* cond, float* out) {
     return hvx_cfm_estimator_streaming(h, stream, ws, ws_bytes, batch, t_len, x, kv_len, mu, t, spks, cond, 0, out);
+}
+
+int hvx_flow_set_half_stream(hvx_flow* h, int32_t on) {
+    if (!h) return set_error("hvx_flow_set_half_stream: null handle"), -1;
+    if (on && h->c.dtype != DT_BF16) return set_error("hvx_flow_set_half_stream: the fp16 residual stream belongs to the bf16 mode"), -1;
+    h->half_stream = on != 0;
+    return 0;
 }
 
 int hvx_flow_set_mod_cache(hvx_flow* h, void* buf, size_t bytes) {

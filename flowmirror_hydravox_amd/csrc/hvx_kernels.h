@@ -61,6 +61,10 @@ struct GemmArgs {
     int w_planes; long long w_plane;
     int out_planes; long long out_plane;
     int out2_planes; long long out2_plane;
+    // ---- HALF residual stream (DiT, bf16 mode): res and / or out hold IEEE fp16 instead of fp32 (same strides, in elements).  The reference runs
+    //      its flow decoder in fp16 end to end (infer_speech_model.py:103), i.e. with an fp16 residual stream; here only the stream is fp16 — the
+    //      update gate * (acc + bias) + res is formed in fp32 and rounded once on the way out.
+    int res_f16; int out_f16;
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
 int launch_gemm_x3(const GemmArgs& a, hipStream_t s);    // same convention; fp32 operands on the bf16 matrix cores (GemmArgs.x3)
@@ -165,7 +169,7 @@ int launch_embed2(const void* speech, const void* text, int dtype, const int* to
 // logits -> log_softmax (fp32, in place) over V columns, one block per row
 int launch_log_softmax(float* x, int ld, int rows, int V, hipStream_t s);
 // DiT: y = dtype( LN(x; eps, no affine) * (1 + scale[b]) + shift[b] ); x f32 [B][T][D]; shift/scale f32 [B][.] with stride mod_bs
-int launch_layernorm_mod(const float* x, const float* shift, const float* scale, long long mod_bs, float eps, void* y, int dtype,
+int launch_layernorm_mod(const void* x, int x_f16, const float* shift, const float* scale, long long mod_bs, float eps, void* y, int dtype,
                          int B, int T, int D, hipStream_t s);
 // DiT input: y[b,t,:] = dtype( cat[x[b,:,t], cond[b,:,t], mu[b,:,t], spk[b,:]] ), inputs f32 channel-major (B,80,T)
 int launch_dit_concat(const float* x, const float* cond, const float* mu, const float* spk, void* y, int dtype, int B, int T, int mel,

@@ -177,7 +177,7 @@ int transformer_block(hipStream_t s, WCursor& wc, const MBufs& b, const hvx_matc
     const void* w1 = wc.next(); const float* b1 = wc.nextf(); const float* snake = wc.nextf();
     const void* w2 = wc.next(); const float* b2 = wc.nextf();
     const int H = c.heads, inner = H * 64, FF = c.ff_mult * C, Tp = b.t_pad;
-    HVX_CHECK(launch_layernorm_mod(x, n1_shift, n1_scale, 0, 1e-5f, b.n, DT_F32, B, T, C, s));
+    HVX_CHECK(launch_layernorm_mod(x, 0, n1_shift, n1_scale, 0, 1e-5f, b.n, DT_F32, B, T, C, s));
     GemmArgs g = conv(T, 3 * inner, 1, C, b.n, C, T, wqkv, nullptr);
     batched(g, B, (long long)T * C, 0);
     g.epi = EPI_QKV_DIT; g.q = b.q; g.k = b.k; g.vT = b.vT; g.heads = H; g.t_pad = Tp;
@@ -195,7 +195,7 @@ int transformer_block(hipStream_t s, WCursor& wc, const MBufs& b, const hvx_matc
     batched(g, B, (long long)T * inner, (long long)T * C);
     g.res = x; g.res_bs = (long long)T * C; g.ldres = C; g.out = x; g.ldo = C; g.out_cols = C;
     HVX_CHECK(launch_gemm(g, s));
-    HVX_CHECK(launch_layernorm_mod(x, n3_shift, n3_scale, 0, 1e-5f, b.n, DT_F32, B, T, C, s));
+    HVX_CHECK(launch_layernorm_mod(x, 0, n3_shift, n3_scale, 0, 1e-5f, b.n, DT_F32, B, T, C, s));
     g = conv(T, FF, 1, C, b.n, C, T, w1, b1);
     batched(g, B, (long long)T * C, (long long)T * FF);
     g.act = ACT_SNAKEBETA; g.act_alpha = snake; g.out = b.ffh; g.ldo = FF; g.out_cols = FF;

@@ -10,6 +10,8 @@ flow_matching.py:200-201) and the t-grid `1 - cos(linspace(0,1,11) * pi/2)` accu
 """
 import ctypes as C
 
+import os
+
 import torch
 
 from . import _lib
@@ -43,7 +45,7 @@ def euler_schedule(n_timesteps):
 
 
 class HvxFlow:
-    def __init__(self, cfg: FlowConfig, state_dict=None, dtype=torch.bfloat16, device='cuda', max_t=None):
+    def __init__(self, cfg: FlowConfig, state_dict=None, dtype=torch.bfloat16, device='cuda', max_t=None, half_stream=None):
         _lib.require_gpu()
         self.lib = _lib.load()
         self.cfg = cfg
@@ -51,6 +53,11 @@ class HvxFlow:
         self.device = torch.device(device)
         self.bf16 = dtype == torch.bfloat16
         self.fp16 = False
+        # bf16 mode: the DiT's residual stream is kept in fp16, the arithmetic the reference itself runs (`flow.eval().cuda().half()`,
+        # infer_speech_model.py:103); half_stream=False keeps it in fp32 (the fp32 mode always does).  HVX_FLOW_HALF_STREAM=0/1 overrides.
+        if half_stream is None:
+            half_stream = os.environ.get('HVX_FLOW_HALF_STREAM', '1') != '0'
+        self.half_stream = bool(half_stream) and self.bf16
         self.token_mel_ratio = cfg.token_mel_ratio
         self.pre_lookahead_len = cfg.pre_lookahead_len
         self.static_chunk_size = cfg.static_chunk_size            # DiT(static_chunk_size=...), dit.py:119,142
@@ -122,6 +129,7 @@ class HvxFlow:
         slot = (c.depth * 2 * 6 * c.dim + 2 * 2 * c.dim) * 4
         self._mod_cache = torch.zeros(16 * slot, dtype=torch.uint8, device=dev)
         check(self.lib.hvx_flow_set_mod_cache(self._h, ptr(self._mod_cache), self._mod_cache.numel()), 'hvx_flow_set_mod_cache')
+        check(self.lib.hvx_flow_set_half_stream(self._h, 1 if self.half_stream else 0), 'hvx_flow_set_half_stream')
         return self
 
     def eval(self):

@@ -31,6 +31,12 @@ def _r(t, emu):
     return bf16r(t) if emu else t
 
 
+def _h(t, on):
+    """resid16: the residual stream of the DiT blocks stored in IEEE fp16 (the product's bf16 mode, csrc/hvx_flow.hip half_stream; the
+    reference holds it in fp16 too when it runs `.half()`, infer_speech_model.py:103) — one rounding per residual add"""
+    return t.to(torch.float16).float() if on else t
+
+
 def _lin(x, w, b=None, emu=False):
     return F.linear(bf16r(x), bf16r(w), b) if emu else F.linear(x, w, b)
 
@@ -99,7 +105,7 @@ def _sdpa_emu(q, k, v, am):
     return bf16r(torch.matmul(e, v) / e.sum(dim=-1, keepdim=True))
 
 
-def dit_block(x, t_emb, sd, cfg, pre, freqs, key_mask, attn_mask=None, emu=False):
+def dit_block(x, t_emb, sd, cfg, pre, freqs, key_mask, attn_mask=None, emu=False, resid16=False):
     B, T, D = x.shape
     H, dh = cfg.heads, cfg.head_dim
     emb = _lin(F.silu(t_emb), sd[pre + 'attn_norm.linear.weight'], sd[pre + 'attn_norm.linear.bias'], emu)
@@ -123,11 +129,11 @@ def dit_block(x, t_emb, sd, cfg, pre, freqs, key_mask, attn_mask=None, emu=False
     a = a.transpose(1, 2).reshape(B, T, H * dh)
     a = _lin(a, sd[pre + 'attn.to_out.0.weight'], sd[pre + 'attn.to_out.0.bias'], emu)
     a = a.masked_fill(~key_mask[:, :, None], 0.0)                 # mask[:, 0, -1] row == pad mask (modules.py:400-405)
-    x = x + g_a.unsqueeze(1) * a
+    x = _h(x + g_a.unsqueeze(1) * a, resid16)
     f = F.layer_norm(x, (D,), eps=1e-6) * (1 + sc_m[:, None]) + sh_m[:, None]
     f = _lin(f, sd[pre + 'ff.ff.0.0.weight'], sd[pre + 'ff.ff.0.0.bias'], emu)
     f = _lin(F.gelu(f, approximate='tanh'), sd[pre + 'ff.ff.2.weight'], sd[pre + 'ff.ff.2.bias'], emu)
-    return x + g_m.unsqueeze(1) * f
+    return _h(x + g_m.unsqueeze(1) * f, resid16)
 
 
 def chunk_attn_mask(key_mask, chunk):
@@ -141,7 +147,7 @@ def chunk_attn_mask(key_mask, chunk):
     return am
 
 
-def dit_forward(x, mask, mu, t, spks, cond, sd, cfg, pre='decoder.estimator.', n_blocks=None, taps=None, streaming=False, emu=False):
+def dit_forward(x, mask, mu, t, spks, cond, sd, cfg, pre='decoder.estimator.', n_blocks=None, taps=None, streaming=False, emu=False, resid16=False):
     """Estimator call, TRT argument order (flow_matching.py:126-153): x,mu,cond (B,80,T); mask (B,1,T);
     t (B,); spks (B,80) -> (B,80,T).  streaming=True: static chunk mask of cfg.static_chunk_size frames."""
     x = x.transpose(1, 2)
@@ -153,7 +159,7 @@ def dit_forward(x, mask, mu, t, spks, cond, sd, cfg, pre='decoder.estimator.', n
     t_emb = time_embed(t, sd, cfg, pre, emu)
     h = torch.cat([x, cond, mu, spks[:, None, :].expand(B, T, spks.shape[-1])], dim=-1)
     h = _lin(h, sd[pre + 'input_embed.proj.weight'], sd[pre + 'input_embed.proj.bias'], emu)
-    h = causal_conv_pos_embed(h, sd, cfg, pre + 'input_embed.conv_pos_embed.', emu) + h
+    h = _h(causal_conv_pos_embed(h, sd, cfg, pre + 'input_embed.conv_pos_embed.', emu) + h, resid16)
     if taps is not None:
         taps['input_embed'] = h.clone()
     freqs = rope_freqs(T, cfg.head_dim)
@@ -161,7 +167,7 @@ def dit_forward(x, mask, mu, t, spks, cond, sd, cfg, pre='decoder.estimator.', n
     nb = cfg.depth if n_blocks is None else n_blocks
     attn_mask = chunk_attn_mask(key_mask, cfg.static_chunk_size) if streaming else None
     for i in range(nb):
-        h = dit_block(h, t_emb, sd, cfg, pre + 'transformer_blocks.%d.' % i, freqs, key_mask, attn_mask, emu)
+        h = dit_block(h, t_emb, sd, cfg, pre + 'transformer_blocks.%d.' % i, freqs, key_mask, attn_mask, emu, resid16)
         if taps is not None:
             taps['block%d' % i] = h.clone()
     emb = _lin(F.silu(t_emb), sd[pre + 'norm_out.linear.weight'], sd[pre + 'norm_out.linear.bias'], emu)
@@ -212,7 +218,7 @@ def solve_euler(x, t_span, mu, mask, spks, cond, estimator, cfg_rate):
     return traj[-1].float(), traj
 
 
-def cfm_forward(mu, mask, spks, cond, sd, cfg, noise=None, estimator=None, n_timesteps=None, streaming=False, emu=False):
+def cfm_forward(mu, mask, spks, cond, sd, cfg, noise=None, estimator=None, n_timesteps=None, streaming=False, emu=False, resid16=False):
     """CausalConditionalCFM.forward (flow_matching.py:204-228)."""
     noise = cfm_noise(cfg) if noise is None else noise
     z = noise[:, :, :mu.size(2)].to(mu.dtype)
@@ -220,12 +226,12 @@ def cfm_forward(mu, mask, spks, cond, sd, cfg, noise=None, estimator=None, n_tim
     t_span = cosine_t_span(n, mu.dtype)
     if estimator is None:
         def estimator(x, m, mu_, t, s, c):
-            return dit_forward(x, m, mu_, t, s, c, sd, cfg, streaming=streaming, emu=emu)
+            return dit_forward(x, m, mu_, t, s, c, sd, cfg, streaming=streaming, emu=emu, resid16=resid16)
     out, _ = solve_euler(z, t_span, mu, mask, spks, cond, estimator, cfg.cfg_rate)
     return out
 
 
-def flow_inference(token, embedding, sd, cfg, prompt_token=None, prompt_feat=None, noise=None, finalize=True, streaming=False, emu=False):
+def flow_inference(token, embedding, sd, cfg, prompt_token=None, prompt_feat=None, noise=None, finalize=True, streaming=False, emu=False, resid16=False):
     """flow.py:367-430, fp32; finalize=False: the last pre_lookahead_len tokens are look-ahead context only.
     token (1,N) int, embedding (1,192), prompt_token (1,Np) int, prompt_feat (1,Tp,80) -> mel (1,80,2N)."""
     emb = F.normalize(embedding.float(), dim=1)
@@ -242,5 +248,5 @@ def flow_inference(token, embedding, sd, cfg, prompt_token=None, prompt_feat=Non
     if prompt_feat is not None:
         cond[:, :mel_len1] = prompt_feat
     mask = torch.ones(1, 1, T)
-    feat = cfm_forward(h.transpose(1, 2).contiguous(), mask, emb, cond.transpose(1, 2), sd, cfg, noise=noise, streaming=streaming, emu=emu)
+    feat = cfm_forward(h.transpose(1, 2).contiguous(), mask, emb, cond.transpose(1, 2), sd, cfg, noise=noise, streaming=streaming, emu=emu, resid16=resid16)
     return feat[:, :, mel_len1:].float()

@@ -182,7 +182,7 @@ def test_flow_22_blocks_vs_reference_and_bf16_oracle(cfg, flow_setup, dtype):
         if dtype == torch.float32:
             assert e_ref < 1e-3, (tag, e_ref)
         elif tag == 'e1':                      # (the bf16-faithful oracle takes ~1 s per block on the host: the shorter case only)
-            emu = (flow_ref.dit_forward(x, mask, mu, t, spk, cond, sd, c, streaming=streaming, emu=True) * mask).numpy()
+            emu = (flow_ref.dit_forward(x, mask, mu, t, spk, cond, sd, c, streaming=streaming, emu=True, resid16=True) * mask).numpy()
             e_emu = _rel(est, emu)
             print('22 blocks, %s bf16 estimator: %.2e of the bf16-faithful oracle, %.2e of the fp32 reference' % (tag, e_emu, e_ref))
             assert e_emu < 3e-2, (tag, e_emu, e_ref)

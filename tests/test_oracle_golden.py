@@ -394,6 +394,11 @@ def test_cv3w_flow_oracle_vs_reference_vectors(cv3w_cfg):
     emu = flow_ref.dit_forward(x, mask, mu, torch.from_numpy(g[tag + '_t']), spk, cond, sd, c, streaming=bool(g[tag + '_streaming']), emu=True)
     rel = np.abs((emu * mask).numpy() - g[tag + '_out']).max() / np.abs(g[tag + '_out']).max()
     assert 1e-4 < rel < 5e-2, rel
+    # the product's bf16 mode additionally keeps the residual stream in fp16 (one rounding per residual add, as the reference's .half() run does)
+    emu16 = flow_ref.dit_forward(x, mask, mu, torch.from_numpy(g[tag + '_t']), spk, cond, sd, c, streaming=bool(g[tag + '_streaming']), emu=True, resid16=True)
+    rel16 = np.abs((emu16 * mask).numpy() - g[tag + '_out']).max() / np.abs(g[tag + '_out']).max()
+    d16 = np.abs((emu16 - emu).numpy()).max() / np.abs(g[tag + '_out']).max()
+    assert 0 < d16 < 2e-2 and rel16 < 5e-2, (rel16, d16)
     pla = flow_ref.pre_lookahead(torch.from_numpy(g['h0']), sd, c)
     assert np.abs(pla.numpy() - g['pla']).max() < 1e-4
     mel = flow_ref.flow_inference(torch.from_numpy(g['token']), torch.from_numpy(g['emb']), sd, c, prompt_token=torch.from_numpy(g['ptoken']),
