@@ -27,7 +27,7 @@ constexpr int BM = 256, WM = 128, WN = 64, MT = WM / 16, NT = WN / 16;
 // workgroups per CU, 48 KiB each, so that one's epilogue runs under the other's K-loop — was correct but 3-10 % slower on every DiT Linear,
 // with or without a deliberate half-tile start offset between the two co-resident workgroups: 1.5x the L2 -> LDS bytes per flop)
 template <int EPI, int BN, int BK, int NWAVE>
-__global__ __launch_bounds__(NWAVE * 64, 2) void gemm_big_kernel(GemmArgs a, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(NWAVE * 64, 2) void gemm_big_kernel(GemmArgs a, int tiles_m, int tiles_n, int gw) {
     typedef bf16_t T;
     constexpr int TILE_ELEMS = (BM + BN) * BK;               // one K-tile of A and W (bf16 elements)
     constexpr int WAVES_N = BN / WN;
@@ -47,7 +47,9 @@ __global__ __launch_bounds__(NWAVE * 64, 2) void gemm_big_kernel(GemmArgs a, int
     // XCD-aware tile order (bijective for any grid size)
     const int nwg = gridDim.x, xcd = blockIdx.x & 7, qn = nwg >> 3, rn = nwg & 7;
     const int wgid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (blockIdx.x >> 3);
-    const int tn = wgid % tiles_n, rt = wgid / tiles_n;
+    // column tiles in groups of gw (gw divides tiles_n): a group's W panels (gw x 256 rows x K) stay in the XCD's 4 MiB L2 while the row tiles go by
+    const int per = tiles_m * a.batch * gw, sc = wgid / per, rr = wgid - sc * per;
+    const int rt = rr / gw, tn = sc * gw + (rr - rt * gw);
     const int bz = rt / tiles_m, tm = rt - bz * tiles_m;
     const int m0 = tm * BM, n0 = tn * BN;
 
@@ -152,9 +154,15 @@ int launch_form(const GemmArgs& a, hipStream_t s, long long min_tiles) {
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
     const long long tiles = (long long)tiles_m * tiles_n * a.batch;
     if (tiles < min_tiles || tiles > 0x7fffffffLL) return 0;
+    // Column groups of 4 tiles: the W panels of a group (4 x 256 rows x K bf16 = 2-4 MiB at K = 1024-2048) fit the XCD's L2; with all 8-12 column
+    // tiles in one sweep W (4-6 MiB) is re-fetched through the fabric for every row tile (FETCH_SIZE 530 MB per QKV launch for 98 MB of operands).
+    // Measured at M = 45056: N = 3072 330 -> 302 us, N = 2048 214 -> 204 us; N = 1024 has four column tiles anyway.
+    static const int gw_env = getenv("HVX_GEMM_BIG_GW") ? atoi(getenv("HVX_GEMM_BIG_GW")) : 4;     // (tuning knob; 0 = all columns in one group)
+    int gw = tiles_n;
+    if (gw_env > 0 && gw_env < tiles_n && tiles_n % gw_env == 0) gw = gw_env;
     const int slot = prof_begin(PK_GEMM, 2.0 * a.M * a.N * (double)a.K * a.batch, s);
-    if (a.epi == EPI_GENERIC) hipLaunchKernelGGL((gemm_big_kernel<EPI_GENERIC, BN, BK, NWAVE>), dim3((unsigned)tiles), dim3(NWAVE * 64), 0, s, a, tiles_m, tiles_n);
-    else hipLaunchKernelGGL((gemm_big_kernel<EPI_QKV_DIT, BN, BK, NWAVE>), dim3((unsigned)tiles), dim3(NWAVE * 64), 0, s, a, tiles_m, tiles_n);
+    if (a.epi == EPI_GENERIC) hipLaunchKernelGGL((gemm_big_kernel<EPI_GENERIC, BN, BK, NWAVE>), dim3((unsigned)tiles), dim3(NWAVE * 64), 0, s, a, tiles_m, tiles_n, gw);
+    else hipLaunchKernelGGL((gemm_big_kernel<EPI_QKV_DIT, BN, BK, NWAVE>), dim3((unsigned)tiles), dim3(NWAVE * 64), 0, s, a, tiles_m, tiles_n, gw);
     prof_end(slot, s);
     return hipGetLastError() == hipSuccess ? 1 : (set_error("gemm (256-tile form) launch failed"), -1);
 }
