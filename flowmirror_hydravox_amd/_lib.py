@@ -40,7 +40,7 @@ class GemmArgs(C.Structure):
                 ('scale', c_f32),
                 ('out', c_vp), ('out_f32', c_i32), ('out_bs', c_i64), ('ldo', c_i32), ('out_row_off', c_i32), ('out_cols', c_i32),
                 ('out2', c_vp), ('act2', c_i32), ('act2_param', c_f32), ('act2_alpha', c_vp), ('out2_bs', c_i64),
-                ('ldo2', c_i32), ('out2_row_off', c_i32), ('out2_cols', c_i32), ('x3', c_i32)]
+                ('ldo2', c_i32), ('out2_row_off', c_i32), ('out2_cols', c_i32), ('x3', c_i32), ('res_f16', c_i32), ('out_f16', c_i32)]
 
 
 class AttnArgs(C.Structure):

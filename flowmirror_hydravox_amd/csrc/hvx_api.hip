@@ -148,6 +148,8 @@ int hvx_op_gemm(const hvx_gemm_args* a, hvx_stream s) {
     g.out = a->out; g.out_f32 = a->out_f32; g.out_bs = a->out_bs; g.ldo = a->ldo; g.out_row_off = a->out_row_off; g.out_cols = a->out_cols;
     g.out2 = a->out2; g.act2 = a->act2; g.act2_param = a->act2_param; g.act2_alpha = a->act2_alpha; g.out2_bs = a->out2_bs;
     g.ldo2 = a->ldo2; g.out2_row_off = a->out2_row_off; g.out2_cols = a->out2_cols; g.x3 = a->x3;
+    g.res_f16 = a->res_f16; g.out_f16 = a->out_f16;
+    if (g.out_f16 && g.out_f32) return set_error("hvx_op_gemm: out_f16 and out_f32 are exclusive"), -1;
     return launch_gemm(g, (hipStream_t)s);
 }
 

@@ -33,6 +33,7 @@ def conv1d(x, w_packed, bias, *, n_out, taps, cin_pad, pad_left=0, dil=1, stride
     total = groups * n_out
     if res is not None:
         a.res, a.res_bs, a.ldres, a.res_row_off = ptr(res), res.shape[1] * res.shape[2], res.shape[2], res_row_off
+        a.res_f16 = int(res.dtype == torch.float16)                 # the DiT's half residual stream (hvx_flow_set_half_stream)
     a.scale = scale
     a.x3 = int(x3)
     if out is None and out2 is None:
@@ -40,6 +41,7 @@ def conv1d(x, w_packed, bias, *, n_out, taps, cin_pad, pad_left=0, dil=1, stride
         out = torch.zeros(B, M + max(out_row_off, 0), _pad32(total) if od != torch.float32 else total, dtype=od, device=x.device)
     if out is not None:
         a.out, a.out_f32, a.out_bs, a.ldo = ptr(out), int(out.dtype == torch.float32), out.shape[1] * out.shape[2], out.shape[2]
+        a.out_f16 = int(out.dtype == torch.float16)
         a.out_row_off, a.out_cols = out_row_off, out.shape[2]
     if out2 is not None:
         assert out2.dtype == x.dtype

@@ -84,6 +84,8 @@ typedef struct {
     void* out; int32_t out_f32; int64_t out_bs; int32_t ldo, out_row_off, out_cols;
     void* out2; int32_t act2; float act2_param; const float* act2_alpha; int64_t out2_bs; int32_t ldo2, out2_row_off, out2_cols;
     int32_t x3;   /* fp32 only: allow the split-bf16 form (each operand as a bf16 pair, three bf16 MFMAs per step; ~1e-6 relative) */
+    int32_t res_f16;   /* res holds IEEE fp16 instead of fp32 (same strides, in elements): the DiT's half residual stream, hvx_flow_set_half_stream */
+    int32_t out_f16;   /* out holds IEEE fp16 (out_f32 must be 0) */
 } hvx_gemm_args;
 /* implicit-GEMM Conv1d / Linear on MFMA (torch.nn.functional.conv1d / linear call sites of the path) */
 int hvx_op_gemm(const hvx_gemm_args* a, hvx_stream s);

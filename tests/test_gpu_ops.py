@@ -160,6 +160,37 @@ def test_linear_256_tile_form_dit_epilogue_modes(mode, M, N, K, B):
         torch.testing.assert_close(out.cpu(), lin, rtol=2e-3, atol=2e-3)
 
 
+@pytest.mark.parametrize('M,N,K,B', [(8205, 1024, 1024, 1), (4211, 1024, 2048, 2), (700, 1024, 1024, 2), (333, 1088, 256, 1), (130, 104, 64, 3)])
+def test_linear_half_residual_stream(M, N, K, B):
+    """The DiT's residual Linears on the fp16 stream (hvx_flow_set_half_stream; GemmArgs.res_f16 / out_f16): x16 <- fp16(gate * (a W^T + b) + x16),
+    the sum formed in fp32 from the fp32 accumulators and rounded ONCE.  Shapes take every branch of gemm_epilogue.h: the 256-tile form's own
+    lane-mapped mode (>= 128 tiles; ragged last row tile, per-batch gate), the generic pass of the 128-tile kernels (few tiles), a partial column
+    tile (N = 1088) and a leading dimension without 16-byte rows (N = 104: scalar accesses).  Also fp32 residual in -> fp16 out (the position-embedding
+    convolution that opens the stream).  Bound: one fp16 rounding of the exact fp32 result (2^-11 relative) + the bf16-operand GEMM's fp32 summation order."""
+    _lib, ops, packing = _mods()
+    a = _rand(B, M, K, seed=90).bfloat16()
+    w = (_rand(N, K, seed=91) / math.sqrt(K)).bfloat16()
+    b = _rand(N, seed=92)
+    gate = _rand(B, N, seed=93)
+    x16 = (_rand(B, M, N, seed=94) * 4.0).half()
+    want = (x16.float() + gate[:, None, :] * (a.float() @ w.float().t() + b))
+    xd = x16.to(DEV)
+    ops.conv1d(a.to(DEV), w.to(DEV), b.to(DEV), n_out=N, taps=1, cin_pad=K, gate=gate.to(DEV), res=xd, out=xd)
+    got = xd.cpu()
+    assert got.dtype == torch.float16
+    err = (got.float() - want).abs() / (want.abs() + 1.0)
+    assert err.max().item() < 1.5e-3, err.max().item()
+    # at most one fp16 ulp from the correctly rounded value almost everywhere (fp32 summation order moves a few results across a rounding boundary)
+    exact = want.half()
+    assert (got != exact).float().mean().item() < 2e-2
+    # fp32 residual in, fp16 stream out
+    x32 = _rand(B, M, N, seed=95)
+    out = torch.zeros(B, M, N, dtype=torch.float16, device=DEV)
+    ops.conv1d(a.to(DEV), w.to(DEV), b.to(DEV), n_out=N, taps=1, cin_pad=K, res=x32.to(DEV), out=out)
+    want2 = x32 + (a.float() @ w.float().t() + b)
+    assert ((out.cpu().float() - want2).abs() / (want2.abs() + 1.0)).max().item() < 1.5e-3
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('cin,cout,k,dil,T', [(80, 64, 5, 1, 50), (64, 64, 11, 5, 333), (32, 48, 3, 3, 130), (18, 32, 1, 1, 77), (512, 256, 7, 1, 90)])
 def test_causal_conv_left_and_right(dtype, cin, cout, k, dil, T):
