@@ -317,6 +317,34 @@ def test_flow_stages_vs_reference(tiny_cfg, flow_setup, dtype, tol):
             assert e[0] < 2e-2 and e[1] < 2e-2, (r, e)
 
 
+def test_flow_bf16_residual_stream_fp16_vs_fp32(tiny_cfg, flow_setup):
+    """bf16 mode with the DiT's residual stream in fp16 (the default: the reference's own `.half()` arithmetic) against the same handle arithmetic with
+    the stream kept in fp32 (half_stream=False): each within its bf16-faithful oracle's bound (with / without the stream rounding), and the two
+    estimators within a few fp16 roundings of each other; the fp32 mode refuses the option."""
+    from flowmirror_hydravox_amd.flow import HvxFlow
+    from flowmirror_hydravox_amd._lib import HvxError, check as _lib_check
+    from oracle import flow_ref
+    g, sd = flow_setup
+    p = 'r0_'
+    T = g[p + 'est_x'].shape[-1]
+    args = (torch.from_numpy(g[p + 'est_x']), torch.ones(2, 1, T), torch.from_numpy(g[p + 'est_mu']), torch.from_numpy(g[p + 'est_t']),
+            torch.from_numpy(g[p + 'est_spk']), torch.from_numpy(g[p + 'est_cond']))
+    est = {}
+    for hs in (True, False):
+        flow = HvxFlow(tiny_cfg.flow, sd, dtype=torch.bfloat16, max_t=512, half_stream=hs)
+        assert flow.half_stream is hs
+        est[hs] = flow.estimator(*args).cpu().numpy()
+        o = flow_ref.dit_forward(*args, sd, tiny_cfg.flow, emu=True, resid16=hs).numpy()
+        assert _rel(est[hs], o) < 2e-2, (hs, _rel(est[hs], o))
+    d = _rel(est[True], est[False])
+    print('bf16 estimator, fp16 vs fp32 residual stream: %.2e of the output scale' % d)
+    assert 0 < d < 1e-2, d
+    f32 = HvxFlow(tiny_cfg.flow, sd, dtype=torch.float32, max_t=512, half_stream=True)
+    assert f32.half_stream is False
+    with pytest.raises(HvxError):
+        _lib_check(f32.lib.hvx_flow_set_half_stream(f32._h, 1))
+
+
 def test_flow_estimator_key_padding_mask(tiny_cfg, flow_setup):
     """padded batch rows: keys beyond the mask must not influence valid frames (mask path of dit.py:163-166)."""
     from flowmirror_hydravox_amd.flow import HvxFlow
