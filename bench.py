@@ -60,6 +60,7 @@ def parse():
     ap.add_argument('--acoustic-min-batch', type=int, default=4, help='(--mode continuous) the acoustic stage waits for this many finished utterances (throughput over latency)')
     ap.add_argument('--lm-pace', default='', help='(--mode continuous) admission pacing of the decode grid "first,every_steps,more": open with `first` sequences, admit `more` every `every_steps` decode steps (empty: fill all slots at once)')
     ap.add_argument('--acoustic-cus', type=int, default=0, help='(--mode continuous) confine the acoustic stage to this many compute units (the decode engine stays unconfined); 0: all')
+    ap.add_argument('--lm-cus-only', type=int, default=0, help='(--mode continuous) confine ONLY the decode engine to this many compute units; the acoustic stage keeps all of them')
     ap.add_argument('--lm-cus', type=int, default=0, help='(--mode continuous) compute units reserved for the decode engine; the acoustic stage runs on the others (0: both share all CUs)')
     ap.add_argument('--acoustic-chains', type=int, default=1, help='(--mode chains) kept for compatibility: more than one concurrent acoustic chain is not supported (clamped to 1)')
     ap.add_argument('--lm-chains', type=int, default=3, help='(--mode chains) batches whose LM decode runs concurrently')
@@ -366,6 +367,9 @@ def main():
                        seed=1986, init='normal02', sampling=sampling, inference_head_num=K)
     pipe.acoustic_batch = max(1, args.acoustic_batch)
     pipe.lm_cus = args.lm_cus
+    pipe.lm_cus_only = args.lm_cus_only
+    if args.lm_cus_only > 0:
+        pipe.llm.cu_range = (0, args.lm_cus_only)
     pipe.acoustic_cus = args.acoustic_cus
     if args.lm_cus > 0:
         pipe.llm.cu_range = (0, args.lm_cus)             # (before the first decode engine exists: the engine keeps its stream)
@@ -519,7 +523,7 @@ def main():
                                 'chains': '%d independent decode chains of one step each + %d acoustic chain(s)' % (args.lm_chains, args.acoustic_chains),
                                 'serial': 'stages back to back'}[args.mode],
                    'utterances_in_flight_per_gpu': in_flight,
-                   'cu_partition': ('decode engine on %d CUs, acoustic stage on the other %d' % (args.lm_cus, lib.hvx_device_ok() - args.lm_cus)) if args.lm_cus > 0 and args.mode == 'continuous' else 'none (both stages share all CUs)',
+                   'cu_partition': ('decode engine on %d CUs, acoustic stage on the other %d' % (args.lm_cus, lib.hvx_device_ok() - args.lm_cus)) if args.lm_cus > 0 and args.mode == 'continuous' else ('decode engine confined to %d CUs, acoustic stage on all' % args.lm_cus_only) if args.lm_cus_only > 0 and args.mode == 'continuous' else 'none (both stages share all CUs)',
                    'sampling': {'top_p': 0.9, 'top_k': 10, 'win_size': 32, 'tau_r': 0.2}},
         'rtf': round(elapsed / audio, 6) if audio else None,
         'llm_tokens_per_s': round(tokens / llm_s, 2) if llm_s else None,

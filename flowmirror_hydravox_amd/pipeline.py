@@ -313,6 +313,9 @@ class HvxPipeline:
                 n_cu = _lib.load().hvx_device_ok()
                 self._bg_stream = _lib.cu_range_stream(n_cu - int(self.acoustic_cus), int(self.acoustic_cus), device=self.device)
             else:
+                # (lm_cus_only: the decode engine alone is confined — to CUs [0, lm_cus_only) — and the acoustic stage may use every CU)
+                if int(getattr(self, 'lm_cus_only', 0) or 0) > 0:
+                    self.llm.cu_range = (0, int(self.lm_cus_only))
                 self._bg_stream = torch.cuda.Stream(device=self.device, priority=0)
             self._bg_streams = [self._bg_stream]
             self._bg_pools = []
