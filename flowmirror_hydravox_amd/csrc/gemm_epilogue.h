@@ -200,7 +200,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT]
                     for (int u = 0; u < 2; ++u) {
                         f16x8 w8;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { w8[e] = (f16_t)v[2 * u][e]; w8[4 + e] = (f16_t)v[2 * u + 1][e]; }
+                        for (int e = 0; e < 4; ++e) { w8[e] = f32_to_f16_sat(v[2 * u][e]); w8[4 + e] = f32_to_f16_sat(v[2 * u + 1][e]); }
                         if (row0 + rsel(2 * u) < a.M) *reinterpret_cast<f16x8*>(obh + (long long)(row0 + rsel(2 * u) + a.out_row_off) * a.ldo + cof(2 * u)) = w8;
                     }
                 } else if (has_out) {
@@ -326,7 +326,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT]
                     if (a.div != 0.0f) v = v / a.div;
                     if (a.out && a.out_f16) {
                         f16_t* op = reinterpret_cast<f16_t*>(a.out) + o1 + c4;
-                        const f16x4 w4 = {(f16_t)v[0], (f16_t)v[1], (f16_t)v[2], (f16_t)v[3]};
+                        const f16x4 w4 = {f32_to_f16_sat(v[0]), f32_to_f16_sat(v[1]), f32_to_f16_sat(v[2]), f32_to_f16_sat(v[3])};
                         if (vec) *reinterpret_cast<f16x4*>(op) = w4;
                         else { op[0] = w4[0]; op[1] = w4[1]; op[2] = w4[2]; op[3] = w4[3]; }
                     } else if (a.out) {
@@ -395,7 +395,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT]
                     }
                     if (a.out && (col_ok || col_pad)) {
                         const long long o = ob + (long long)(row + a.out_row_off) * a.ldo + gc;
-                        if (a.out_f16) reinterpret_cast<f16_t*>(a.out)[o] = (f16_t)v;
+                        if (a.out_f16) reinterpret_cast<f16_t*>(a.out)[o] = f32_to_f16_sat(v);
                         else if (sizeof(T) != 2 && a.out_planes) store_planes1(reinterpret_cast<bf16_t*>(a.out) + o, a.out_plane, v);
                         else if (a.out_f32) reinterpret_cast<float*>(a.out)[o] = v;
                         else reinterpret_cast<T*>(a.out)[o] = from_f32<T>(v);

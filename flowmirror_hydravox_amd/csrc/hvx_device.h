@@ -23,6 +23,9 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 
+// fp32 -> IEEE fp16, round-to-nearest-even, SATURATING at +-65504 (one v_med3_f32): a residual stream that outgrows fp16 clips instead of turning
+// the rest of the network into NaNs (the reference's own fp16 run would overflow to inf at the same place)
+__device__ __forceinline__ f16_t f32_to_f16_sat(float v) { return (f16_t)__builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f); }
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return (float)v; }
 __device__ __forceinline__ bf16_t f32_to_bf16(float v) { return (bf16_t)v; }   // round-to-nearest-even
 

@@ -231,7 +231,7 @@ int hvx_cfm_estimator_streaming(hvx_flow* h, hvx_stream s, void* ws, size_t ws_b
                                 int32_t static_chunk_size, float* out);
 /* bf16 mode only: keep the residual stream of the DiT blocks in IEEE fp16 instead of fp32 (on != 0).  The reference runs its flow decoder in
  * fp16 end to end (infer_speech_model.py:103 `flow.eval().cuda().half()`), so an fp16 stream is the reference's own arithmetic; every update
- * gate * (Linear + bias) + x is still formed in fp32 and rounded once.  Halves the HBM traffic of the two residual Linears and of the adaLN
+ * gate * (Linear + bias) + x is still formed in fp32 and rounded once (saturating at +-65504).  Halves the HBM traffic of the two residual Linears and of the adaLN
  * passes of every block.  Off by default at the C level; the Python host turns it on for bf16 handles (HvxFlow(half_stream=True)). */
 int hvx_flow_set_half_stream(hvx_flow* h, int32_t on);
 /* optional persistent device buffer in which hvx_cfm_solve keeps the adaLN modulation vectors of each distinct step time t

@@ -189,6 +189,10 @@ def test_linear_half_residual_stream(M, N, K, B):
     ops.conv1d(a.to(DEV), w.to(DEV), b.to(DEV), n_out=N, taps=1, cin_pad=K, res=x32.to(DEV), out=out)
     want2 = x32 + (a.float() @ w.float().t() + b)
     assert ((out.cpu().float() - want2).abs() / (want2.abs() + 1.0)).max().item() < 1.5e-3
+    # a stream that outgrows fp16 clips at +-65504 instead of becoming inf (csrc/hvx_device.h: f32_to_f16_sat)
+    big = torch.full((B, M, N), 60000.0).half().to(DEV)
+    ops.conv1d(a.to(DEV), w.to(DEV), (b.abs() + 9000.0).to(DEV), n_out=N, taps=1, cin_pad=K, res=big, out=big)
+    assert torch.isfinite(big).all() and float(big.max()) == 65504.0 and float(big.min()) > 60000.0
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
