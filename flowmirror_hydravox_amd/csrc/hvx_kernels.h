@@ -68,6 +68,7 @@ struct GemmArgs {
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
 int launch_gemm_x3(const GemmArgs& a, hipStream_t s);    // same convention; fp32 operands on the bf16 matrix cores (GemmArgs.x3)
+int launch_conv_resident(const GemmArgs& a, hipStream_t s);   // same convention; bf16 k-tap convolutions over 64 channels per group, input rows resident in LDS (conv_resident.hip)
 int launch_gemm_big(const GemmArgs& a, hipStream_t s);   // 1 = launched, 0 = not eligible (launch_gemm falls through), -1 = error
 
 // ------------------------------------------------------------------------------------------------

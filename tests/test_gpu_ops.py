@@ -256,6 +256,31 @@ def test_grouped_causal_conv_mish_residual(dtype):
     torch.testing.assert_close(out.cpu(), ref, **_tol(dtype))
 
 
+@pytest.mark.parametrize('T,k,dil,B', [(2300, 31, 1, 2), (4096, 31, 1, 1), (2177, 7, 3, 3), (2050, 3, 1, 1)])
+def test_grouped_causal_conv_resident_rows(T, k, dil, B):
+    """conv_resident.hip: bf16 convolutions over 64 channels per group with the tile's input rows + halo resident in LDS (the DiT's position-embedding
+    convolutions: D = 1024, 16 groups, k = 31), both epilogues the flow launches — Mish -> bf16, and Mish + fp32 residual -> fp32 / fp16 stream — plus
+    dilation, a single tap stage's odd tail (k odd), ragged last row tile, batch; against an fp32 convolution of the same bf16 operands."""
+    _lib, ops, packing = _mods()
+    D, groups = 1024, 16
+    x = _rand(B, D, T, seed=113).bfloat16().float()
+    w = (_rand(D, D // groups, k, seed=114) / math.sqrt(D // groups * k)).bfloat16().float()
+    b = _rand(D, seed=115)
+    res = _rand(B, T, D, seed=116)
+    lin = F.mish(F.conv1d(F.pad(x, ((k - 1) * dil, 0)), w, b, groups=groups, dilation=dil)).transpose(1, 2)
+    wp = packing.grouped_conv_weight(w, groups).bfloat16().to(DEV)
+    kw = dict(n_out=D // groups, taps=k, cin_pad=D // groups, pad_left=(k - 1) * dil, dil=dil, groups=groups, act=_lib.ACT_MISH)
+    xr = _rows(x, torch.bfloat16, D).to(DEV)
+    o16 = torch.zeros(B, T, D, dtype=torch.bfloat16, device=DEV)
+    ops.conv1d(xr, wp, b.to(DEV), out=o16, **kw)
+    torch.testing.assert_close(o16.float().cpu(), lin, rtol=1e-2, atol=1e-2)
+    o32 = ops.conv1d(xr, wp, b.to(DEV), res=res.to(DEV), **kw)
+    torch.testing.assert_close(o32.cpu(), lin + res, rtol=2e-3, atol=2e-3)
+    oh = torch.zeros(B, T, D, dtype=torch.float16, device=DEV)
+    ops.conv1d(xr, wp, b.to(DEV), res=res.to(DEV), out=oh, **kw)
+    torch.testing.assert_close(oh.float().cpu(), lin + res, rtol=3e-3, atol=3e-3)
+
+
 def test_epilogue_activations_gate_and_second_output():
     _lib, ops, packing = _mods()
     M, N, K = 130, 96, 64
