@@ -40,7 +40,7 @@ KINDS = {0: ('llm_decode_gemm', 'hbm'), 1: ('dit_gemm_bf16', 'mfma'), 2: ('dit_a
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=8)
+    ap.add_argument('--steps', type=int, default=20, help='timed steps of 8 utterances; 20 (160 utterances through 64 decode slots) is the steady state of the continuous engine — 8 would let all utterances start at once and run LM-then-acoustic in series')
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--batch', type=int, default=8, help='utterances per GPU per step')
     ap.add_argument('--chars', type=int, default=512, help='text tokens per utterance')
