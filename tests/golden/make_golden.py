@@ -528,6 +528,34 @@ def gen_flow_cv3d():
                   fname='flow_cv3d.npz', tag_='flow-cv3d')
 
 
+def gen_flow_half():
+    """The reference DiT run the way the reference deploys it — `flow.eval().cuda().half()` (infer_speech_model.py:103), here on the CPU — next to its
+    fp32 run, at the CV3 widths (2 blocks, T = 330, chunk mask) and at full depth (22 blocks, T = 192): how far the reference's OWN production
+    arithmetic sits from fp32.  The product's bf16 mode is held to a multiple of that distance (tests/test_gpu_cv3d.py)."""
+    import copy
+    from cosyvoice.flow.DiT.dit import DiT
+    from flowmirror_hydravox_amd.config import cv3d_config
+    out = {}
+    for name, c, seed, T, lens, t in (('w', cv3w_config().flow, 42, 330, [330, 275], [0.7, 0.15]), ('d', cv3d_config().flow, 52, 192, [192, 150], [0.7, 0.15])):
+        dit = DiT(dim=c.dim, depth=c.depth, heads=c.heads, dim_head=c.head_dim, ff_mult=c.ff_mult, mel_dim=c.mel, mu_dim=c.mel,
+                  spk_dim=c.mel, out_channels=c.mel, static_chunk_size=c.static_chunk_size).eval()
+        sd = W.make_flow_state(c, seed=1987, init='fan_in')
+        dit.load_state_dict({k[len('decoder.estimator.'):]: v for k, v in sd.items() if k.startswith('decoder.estimator.')})
+        x, mask, mu, spk, cond = cv3w_flow_inputs(seed, T, lens)
+        tt = torch.tensor(t)
+        with torch.inference_mode():
+            est = dit(x, mask, mu, tt, spk, cond, streaming=True) * mask
+            dh = copy.deepcopy(dit).half()
+            est_h = (dh(x.half(), mask, mu.half(), tt.half(), spk.half(), cond.half(), streaming=True).float() * mask)
+        scale = est.abs().max().item()
+        d = (est_h - est).abs().max().item() / scale
+        print('[flow-half] %s (%d blocks, T = %d): reference fp16 vs reference fp32: %.2e of the output scale (absmax %.2f)' % (name, c.depth, T, d, scale))
+        out.update({name + '_seed': np.int64(seed), name + '_T': np.int32(T), name + '_lens': np.array(lens, dtype=np.int32), name + '_t': tt.numpy(),
+                    name + '_out_f32': est.numpy(), name + '_out_f16': est_h.numpy(), name + '_half_vs_f32': np.float64(d),
+                    name + '_in_sha': np.array(state_checksum(dict(x=x, mu=mu, spk=spk, cond=cond))), name + '_weight_sha': np.array(state_checksum(sd))})
+    np.savez_compressed(os.path.join(HERE, 'flow_half.npz'), **out)
+
+
 def gen_hift_cv3w():
     """The reference HiFT vocoder at full width (base 512, F0 predictor 512): stage outputs for T in {8, 50, 160}."""
     from cosyvoice.hifigan.generator import CausalHiFTGenerator
@@ -896,5 +924,5 @@ def gen_graft():
 if __name__ == '__main__':
     which = sys.argv[1:] or ['sampler', 'llm', 'flow', 'hift', 'matcha', 'stream', 'graft', 'llm_stress', 'llm_cv3w', 'flow_cv3w', 'hift_cv3w']
     for w in which:
-        {'llm_cv3d': gen_llm_cv3d, 'flow_cv3d': gen_flow_cv3d, 'sampler_many': gen_sampler_many, 'llm_cv3w': gen_llm_cv3w, 'flow_cv3w': gen_flow_cv3w, 'hift_cv3w': gen_hift_cv3w, 'sampler': gen_sampler, 'llm': gen_llm, 'flow': gen_flow, 'hift': gen_hift, 'matcha': gen_matcha, 'stream': gen_stream, 'graft': gen_graft, 'llm_stress': gen_llm_stress}[w]()
+        {'flow_half': gen_flow_half, 'llm_cv3d': gen_llm_cv3d, 'flow_cv3d': gen_flow_cv3d, 'sampler_many': gen_sampler_many, 'llm_cv3w': gen_llm_cv3w, 'flow_cv3w': gen_flow_cv3w, 'hift_cv3w': gen_hift_cv3w, 'sampler': gen_sampler, 'llm': gen_llm, 'flow': gen_flow, 'hift': gen_hift, 'matcha': gen_matcha, 'stream': gen_stream, 'graft': gen_graft, 'llm_stress': gen_llm_stress}[w]()
     print('golden fixtures written to', HERE)

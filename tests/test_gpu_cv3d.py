@@ -186,6 +186,14 @@ def test_flow_22_blocks_vs_reference_and_bf16_oracle(cfg, flow_setup, dtype):
             e_emu = _rel(est, emu)
             print('22 blocks, %s bf16 estimator: %.2e of the bf16-faithful oracle, %.2e of the fp32 reference' % (tag, e_emu, e_ref))
             assert e_emu < 3e-2, (tag, e_emu, e_ref)
+            # The reference deploys this network in fp16 (`flow.eval().cuda().half()`, infer_speech_model.py:103): its OWN fp16 run of this very case
+            # (tests/golden/flow_half.npz, minted on the CPU by make_golden.py: gen_flow_half) is 1.4e-3 of the output scale from its fp32 run.
+            # bf16 operands carry 8x the rounding unit of fp16; the product's bf16 mode has to stay within 6x the reference's own distance.
+            h = load_golden('flow_half.npz')
+            assert str(h['d_in_sha']) == str(g[tag + '_in_sha']) and np.abs(h['d_out_f32'] - g[tag + '_out']).max() < 1e-5
+            e_half = float(h['d_half_vs_f32'])
+            print('   the reference in fp16 (its deployed dtype) on the same case: %.2e of the fp32 reference; product bf16 / reference fp16 = %.1f' % (e_half, e_ref / e_half))
+            assert e_ref < 6.0 * e_half, (e_ref, e_half)
         else:
             print('22 blocks, %s bf16 estimator: %.2e of the fp32 reference' % (tag, e_ref))
             assert e_ref < 3e-2, (tag, e_ref)

@@ -399,6 +399,12 @@ def test_cv3w_flow_oracle_vs_reference_vectors(cv3w_cfg):
     rel16 = np.abs((emu16 * mask).numpy() - g[tag + '_out']).max() / np.abs(g[tag + '_out']).max()
     d16 = np.abs((emu16 - emu).numpy()).max() / np.abs(g[tag + '_out']).max()
     assert 0 < d16 < 2e-2 and rel16 < 5e-2, (rel16, d16)
+    # the reference's own fp16 run of this case (flow_half.npz: `flow.half()`, its deployed dtype) sits between fp32 and the bf16 emulation
+    h = load_golden('flow_half.npz')
+    assert str(h['w_in_sha']) == str(g[tag + '_in_sha']) and str(h['w_weight_sha']) == str(g['weight_sha'])
+    assert np.abs(h['w_out_f32'] - g[tag + '_out']).max() < 1e-5
+    half = np.abs(h['w_out_f16'] - g[tag + '_out']).max() / np.abs(g[tag + '_out']).max()
+    assert abs(half - float(h['w_half_vs_f32'])) < 1e-6 and 1e-4 < half < rel16, (half, rel16)
     pla = flow_ref.pre_lookahead(torch.from_numpy(g['h0']), sd, c)
     assert np.abs(pla.numpy() - g['pla']).max() < 1e-4
     mel = flow_ref.flow_inference(torch.from_numpy(g['token']), torch.from_numpy(g['emb']), sd, c, prompt_token=torch.from_numpy(g['ptoken']),
