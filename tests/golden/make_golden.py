@@ -390,6 +390,40 @@ def gen_llm_cv3d():
     gen_llm_cv3w(cfg=cv3d_config().llm, runs=runs, pins=(1, 6), fname='llm_cv3d.npz', tag='llm-cv3d', literal_runs=())
 
 
+def gen_llm_bf16():
+    """The reference LM run the way the reference deploys it — `llm.eval().cuda().to(torch.bfloat16)` (infer_speech_model.py:102), here on the CPU —
+    next to its fp32 run: first-step hidden state and the log-probs of the heads on pin run 1 of llm_cv3d.npz (24 layers, 142-row prefix).  How far
+    the reference's OWN production arithmetic sits from fp32; the product's bf16 mode is held to a multiple of that (tests/test_gpu_cv3d.py)."""
+    import copy
+    from flowmirror_hydravox_amd.config import cv3d_config
+    cfg = cv3d_config().llm
+    sd = W.make_llm_state(cfg, seed=1986, init='fan_in', with_lm_head=True)
+    lm = build_ref_llm(cfg, sd, dict(top_p=0.9, top_k=10, win_size=32, tau_r=0.2))
+    g0 = np.load(os.path.join(HERE, 'llm_cv3d.npz'))
+    assert str(g0['weight_sha']) == state_checksum(sd)
+    p = 'r1_'
+    text, ptext, pspeech = (torch.from_numpy(g0[p + k]) for k in ('text', 'ptext', 'pspeech'))
+    lm_input = llm_ref.build_prefix(sd, cfg, text, ptext, pspeech)[None]
+    L = lm_input.shape[1]
+    masks = torch.tril(torch.ones(1, L, L)).bool()
+    out = {}
+    with torch.inference_mode():
+        y, _ = lm.llm.forward_one_step(lm_input, masks=masks, cache=None)
+        last = y[:, -1:, :]
+        logps = torch.stack([lm.llm_decoder(lm.mtp_block[j](last)[0][:, -1]).log_softmax(dim=-1)[0] for j in range(cfg.head_num)])
+        assert (last[0, 0] - torch.from_numpy(g0[p + 'y_last'])).abs().max().item() < 1e-5
+        lb = copy.deepcopy(lm).to(torch.bfloat16)
+        yb, _ = lb.llm.forward_one_step(lm_input.to(torch.bfloat16), masks=masks, cache=None)
+        lastb = yb[:, -1:, :]
+        logpsb = torch.stack([lb.llm_decoder(lb.mtp_block[j](lastb)[0][:, -1]).float().log_softmax(dim=-1)[0] for j in range(cfg.head_num)])
+    dy = (lastb.float() - last).abs().max().item() / last.abs().max().item()
+    dl = (logpsb - logps).abs().max().item()
+    print('[llm-bf16] 24 layers, %d-row prefix: reference bf16 vs reference fp32: hidden %.2e of its scale, log-probs %.2e (max abs)' % (L, dy, dl))
+    out.update(prefix_rows=np.int32(L), y_last_f32=last[0, 0].numpy(), y_last_bf16=lastb[0, 0].float().numpy(), logps_f32=logps.numpy(), logps_bf16=logpsb.numpy(),
+               hidden_bf16_vs_f32=np.float64(dy), logp_bf16_vs_f32=np.float64(dl), weight_sha=np.array(state_checksum(sd)))
+    np.savez_compressed(os.path.join(HERE, 'llm_bf16.npz'), **out)
+
+
 # ------------------------------------------------------------------------------------------------
 # flow
 # ------------------------------------------------------------------------------------------------
@@ -924,5 +958,5 @@ def gen_graft():
 if __name__ == '__main__':
     which = sys.argv[1:] or ['sampler', 'llm', 'flow', 'hift', 'matcha', 'stream', 'graft', 'llm_stress', 'llm_cv3w', 'flow_cv3w', 'hift_cv3w']
     for w in which:
-        {'flow_half': gen_flow_half, 'llm_cv3d': gen_llm_cv3d, 'flow_cv3d': gen_flow_cv3d, 'sampler_many': gen_sampler_many, 'llm_cv3w': gen_llm_cv3w, 'flow_cv3w': gen_flow_cv3w, 'hift_cv3w': gen_hift_cv3w, 'sampler': gen_sampler, 'llm': gen_llm, 'flow': gen_flow, 'hift': gen_hift, 'matcha': gen_matcha, 'stream': gen_stream, 'graft': gen_graft, 'llm_stress': gen_llm_stress}[w]()
+        {'flow_half': gen_flow_half, 'llm_bf16': gen_llm_bf16, 'llm_cv3d': gen_llm_cv3d, 'flow_cv3d': gen_flow_cv3d, 'sampler_many': gen_sampler_many, 'llm_cv3w': gen_llm_cv3w, 'flow_cv3w': gen_flow_cv3w, 'hift_cv3w': gen_hift_cv3w, 'sampler': gen_sampler, 'llm': gen_llm, 'flow': gen_flow, 'hift': gen_hift, 'matcha': gen_matcha, 'stream': gen_stream, 'graft': gen_graft, 'llm_stress': gen_llm_stress}[w]()
     print('golden fixtures written to', HERE)

@@ -147,6 +147,15 @@ def test_llm_24_layers_bf16_first_step_vs_bf16_oracle(cfg, llm_setup):
          np.abs(logp.cpu().numpy() - g[p + 'logps']).max())
     print('24 layers bf16 first step: hidden %.2e / log-probs %.2e of the bf16-faithful oracle; %.2e / %.2e of the fp32 reference' % e)
     assert e[0] < 3e-2 and e[1] < 0.25, e
+    # The reference deploys this LM in bf16 (`llm.eval().cuda().to(torch.bfloat16)`, infer_speech_model.py:102) with bf16 residual stream, norms and
+    # softmax; its OWN bf16 run of this very prefix (tests/golden/llm_bf16.npz, minted on the CPU by make_golden.py: gen_llm_bf16) is 2.1e-2 / 0.15
+    # from its fp32 run.  The product's bf16 mode (bf16 operands, fp32 residual stream / norms / softmax / accumulation) has to be CLOSER to fp32 than that.
+    rb = load_golden('llm_bf16.npz')
+    assert str(rb['weight_sha']) == str(g['weight_sha']) and np.abs(rb['y_last_f32'] - g[p + 'y_last']).max() < 1e-5
+    ref_h, ref_l = float(rb['hidden_bf16_vs_f32']), float(rb['logp_bf16_vs_f32'])
+    print('   the reference in bf16 (its deployed dtype) on the same prefix: hidden %.2e / log-probs %.2e of its fp32 run; product / reference = %.2f / %.2f'
+          % (ref_h, ref_l, e[2] / ref_h, e[3] / ref_l))
+    assert e[2] < ref_h and e[3] < ref_l, (e, ref_h, ref_l)
     for h in range(c.head_num):
         top = int(lo[h].argmax())
         assert float(logp[h].max().cpu()) - float(logp[h, top].cpu()) < 0.25, h

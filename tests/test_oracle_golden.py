@@ -493,3 +493,19 @@ def test_cv3d_llm_oracle_vs_reference_vectors():
     assert np.abs(y[-1].numpy() - g[p + 'y_last']).max() < 2e-4
     lp = torch.stack(llm_ref.head_logps(y[-1], sd, cfg, cfg.head_num)).numpy()
     assert np.abs(lp - g[p + 'logps']).max() < 2e-3
+
+
+def test_reference_deployed_dtype_fixtures_are_consistent():
+    """llm_bf16.npz / flow_half.npz hold the reference run in the dtypes it deploys (llm bf16, flow fp16; make_golden.py: gen_llm_bf16, gen_flow_half)
+    beside its fp32 run of the SAME case as the full-depth fixtures: same weights, same fp32 outputs, and the recorded distances are those of the arrays."""
+    lb, ld = load_golden('llm_bf16.npz'), load_golden('llm_cv3d.npz')
+    assert str(lb['weight_sha']) == str(ld['weight_sha'])
+    assert np.abs(lb['y_last_f32'] - ld['r1_y_last']).max() < 1e-5 and np.abs(lb['logps_f32'] - ld['r1_logps']).max() < 1e-4
+    dy = np.abs(lb['y_last_bf16'] - lb['y_last_f32']).max() / np.abs(lb['y_last_f32']).max()
+    dl = np.abs(lb['logps_bf16'] - lb['logps_f32']).max()
+    assert abs(dy - float(lb['hidden_bf16_vs_f32'])) < 1e-6 and abs(dl - float(lb['logp_bf16_vs_f32'])) < 1e-5
+    assert 5e-3 < dy < 5e-2 and 2e-2 < dl < 0.5            # bf16 through 24 layers: percent-level, as the reference itself runs
+    fh, fd = load_golden('flow_half.npz'), load_golden('flow_cv3d.npz')
+    assert str(fh['d_in_sha']) == str(fd['e1_in_sha']) and np.abs(fh['d_out_f32'] - fd['e1_out']).max() < 1e-5
+    dh = np.abs(fh['d_out_f16'] - fh['d_out_f32']).max() / np.abs(fh['d_out_f32']).max()
+    assert abs(dh - float(fh['d_half_vs_f32'])) < 1e-6 and 2e-4 < dh < 5e-3
