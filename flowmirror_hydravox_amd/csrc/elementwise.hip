@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256) void layernorm_mod_kernel(const XT* x, const f
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = (v[q][e] - mean) * inv * (1.0f + s4[e]) + h4[e];
                 if constexpr (sizeof(T) == 2) {
-                    *reinterpret_cast<bf16x4*>(yr + c) = bf16x4{f32_to_bf16(o[0]), f32_to_bf16(o[1]), f32_to_bf16(o[2]), f32_to_bf16(o[3])};
+                    *reinterpret_cast<typename Vec4<T>::type*>(yr + c) = typename Vec4<T>::type{from_f32<T>(o[0]), from_f32<T>(o[1]), from_f32<T>(o[2]), from_f32<T>(o[3])};
                 } else {
                     *reinterpret_cast<f32x4*>(yr + c) = o;
                 }
@@ -440,32 +440,29 @@ __global__ __launch_bounds__(256) void layernorm_mod1024_kernel(const XT* __rest
         }
     }
 }
+template <class T>
+static void launch_ln_t(const void* x, int x_f16, const float* shift, const float* scale, long long mod_bs, float eps, void* y, int B, int T_, int D, bool fast, hipStream_t s) {
+    const float* xf = reinterpret_cast<const float*>(x);
+    const f16_t* xh = reinterpret_cast<const f16_t*>(x);
+    T* yt = reinterpret_cast<T*>(y);
+    if (fast) {
+        dim3 grid((T_ + 7) / 8, B);
+        if (x_f16) hipLaunchKernelGGL((layernorm_mod1024_kernel<T, f16_t>), grid, dim3(256), 0, s, xh, shift, scale, mod_bs, eps, yt, T_);
+        else hipLaunchKernelGGL((layernorm_mod1024_kernel<T, float>), grid, dim3(256), 0, s, xf, shift, scale, mod_bs, eps, yt, T_);
+    } else {
+        dim3 grid((T_ + 3) / 4, B);
+        if (x_f16) hipLaunchKernelGGL((layernorm_mod_kernel<T, f16_t>), grid, dim3(256), 0, s, xh, shift, scale, mod_bs, eps, yt, T_, D);
+        else hipLaunchKernelGGL((layernorm_mod_kernel<T, float>), grid, dim3(256), 0, s, xf, shift, scale, mod_bs, eps, yt, T_, D);
+    }
+}
+// dtype: the OUTPUT type (DT_F32 / DT_BF16 / DT_F16); x_f16: the residual stream is stored as fp16
 int launch_layernorm_mod(const void* x, int x_f16, const float* shift, const float* scale, long long mod_bs, float eps, void* y, int dtype, int B, int T_,
                          int D, hipStream_t s) {
     if (B <= 0 || T_ <= 0) return 0;
-    const float* xf = reinterpret_cast<const float*>(x);
-    const f16_t* xh = reinterpret_cast<const f16_t*>(x);
-    if (D == 1024 && ((mod_bs & 3) == 0) && ((((unsigned long long)shift | (unsigned long long)scale | (unsigned long long)x | (unsigned long long)y)) & 15) == 0) {
-        dim3 grid((T_ + 7) / 8, B);
-        if (dtype == DT_BF16 && x_f16)
-            hipLaunchKernelGGL((layernorm_mod1024_kernel<bf16_t, f16_t>), grid, dim3(256), 0, s, xh, shift, scale, mod_bs, eps, reinterpret_cast<bf16_t*>(y), T_);
-        else if (dtype == DT_BF16)
-            hipLaunchKernelGGL((layernorm_mod1024_kernel<bf16_t, float>), grid, dim3(256), 0, s, xf, shift, scale, mod_bs, eps, reinterpret_cast<bf16_t*>(y), T_);
-        else if (x_f16)
-            hipLaunchKernelGGL((layernorm_mod1024_kernel<float, f16_t>), grid, dim3(256), 0, s, xh, shift, scale, mod_bs, eps, reinterpret_cast<float*>(y), T_);
-        else
-            hipLaunchKernelGGL((layernorm_mod1024_kernel<float, float>), grid, dim3(256), 0, s, xf, shift, scale, mod_bs, eps, reinterpret_cast<float*>(y), T_);
-        return hipGetLastError() == hipSuccess ? 0 : (set_error("layernorm_mod launch failed"), -1);
-    }
-    dim3 grid((T_ + 3) / 4, B);
-    if (dtype == DT_BF16 && x_f16)
-        hipLaunchKernelGGL((layernorm_mod_kernel<bf16_t, f16_t>), grid, dim3(256), 0, s, xh, shift, scale, mod_bs, eps, reinterpret_cast<bf16_t*>(y), T_, D);
-    else if (dtype == DT_BF16)
-        hipLaunchKernelGGL((layernorm_mod_kernel<bf16_t, float>), grid, dim3(256), 0, s, xf, shift, scale, mod_bs, eps, reinterpret_cast<bf16_t*>(y), T_, D);
-    else if (x_f16)
-        hipLaunchKernelGGL((layernorm_mod_kernel<float, f16_t>), grid, dim3(256), 0, s, xh, shift, scale, mod_bs, eps, reinterpret_cast<float*>(y), T_, D);
-    else
-        hipLaunchKernelGGL((layernorm_mod_kernel<float, float>), grid, dim3(256), 0, s, xf, shift, scale, mod_bs, eps, reinterpret_cast<float*>(y), T_, D);
+    const bool fast = D == 1024 && ((mod_bs & 3) == 0) && ((((unsigned long long)shift | (unsigned long long)scale | (unsigned long long)x | (unsigned long long)y)) & 15) == 0;
+    if (dtype == DT_BF16) launch_ln_t<bf16_t>(x, x_f16, shift, scale, mod_bs, eps, y, B, T_, D, fast, s);
+    else if (dtype == DT_F16) launch_ln_t<f16_t>(x, x_f16, shift, scale, mod_bs, eps, y, B, T_, D, fast, s);
+    else launch_ln_t<float>(x, x_f16, shift, scale, mod_bs, eps, y, B, T_, D, fast, s);
     return hipGetLastError() == hipSuccess ? 0 : (set_error("layernorm_mod launch failed"), -1);
 }
 

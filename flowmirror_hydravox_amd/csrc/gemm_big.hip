@@ -26,9 +26,10 @@ constexpr int BM = 256, WM = 128, WN = 64, MT = WM / 16, NT = WN / 16;
 // <BN 256, BK 64, 8 waves>: one workgroup per CU (128 KiB of LDS), 2 x 4 waves.  (A <BN 128, BK 32, 4 waves> form — TWO independent
 // workgroups per CU, 48 KiB each, so that one's epilogue runs under the other's K-loop — was correct but 3-10 % slower on every DiT Linear,
 // with or without a deliberate half-tile start offset between the two co-resident workgroups: 1.5x the L2 -> LDS bytes per flop)
-template <int EPI, int BN, int BK, int NWAVE>
+// T: the operand type — bf16, or IEEE fp16 for the DiT block Linears of a handle that runs them in the reference's deployed dtype (DT_F16); the QKV
+// epilogue writes q / k / V^T for the attention in bf16 either way
+template <int EPI, int BN, int BK, int NWAVE, class T>
 __global__ __launch_bounds__(NWAVE * 64, 2) void gemm_big_kernel(GemmArgs a, int tiles_m, int tiles_n, int gw) {
-    typedef bf16_t T;
     constexpr int TILE_ELEMS = (BM + BN) * BK;               // one K-tile of A and W (bf16 elements)
     constexpr int WAVES_N = BN / WN;
     constexpr int SLOTS = BK / 8;                            // 16-byte chunks per K-tile row
@@ -103,8 +104,9 @@ __global__ __launch_bounds__(NWAVE * 64, 2) void gemm_big_kernel(GemmArgs a, int
     const int fr = lane & 15, fg = lane >> 4;
     const int sw = (fr >> 1) & (SLOTS - 1);                      // ((row >> 1) & (SLOTS - 1)) of every fragment row of this lane (rows = 16 i + fr)
     const int off0 = (fg ^ sw) * 8, off1 = ((4 + fg) ^ sw) * 8;
-    bf16x8 a0[MT], b0[NT], a1[MT], b1[NT];
-    auto loadf = [&](int buf, int off, bf16x8 (&af)[MT], bf16x8 (&bf)[NT]) __attribute__((always_inline)) {
+    typename Vec8<T>::type a0[MT], b0[NT], a1[MT], b1[NT];
+    typedef typename Vec8<T>::type frag_t;
+    auto loadf = [&](int buf, int off, frag_t (&af)[MT], frag_t (&bf)[NT]) __attribute__((always_inline)) {
         const T* const As = lds + buf * TILE_ELEMS + (wm0 + fr) * BK + off;
         const T* const Bs = lds + buf * TILE_ELEMS + BM * BK + (wn0 + fr) * BK + off;
 #pragma unroll
@@ -112,7 +114,7 @@ __global__ __launch_bounds__(NWAVE * 64, 2) void gemm_big_kernel(GemmArgs a, int
 #pragma unroll
         for (int i = 0; i < MT; ++i) af[i] = load8(As + i * 16 * BK);
     };
-    auto mfmas = [&](const bf16x8 (&af)[MT], const bf16x8 (&bf)[NT]) __attribute__((always_inline)) {
+    auto mfmas = [&](const frag_t (&af)[MT], const frag_t (&bf)[NT]) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(NWAVE * 64, 2) void gemm_big_kernel(GemmArgs a, int
     iter(nk - 1, std::false_type{}, std::false_type{});
     __syncthreads();                                     // the epilogue reuses the tile memory as staging
 
-    gemm_epilogue<T, MT, NT, WN, EPI, 1>(a, acc, reinterpret_cast<float*>(smem) + wave * SCR_FLOATS, lane, m0 + wm0, n0 + wn0, bz, 0);
+    gemm_epilogue<T, MT, NT, WN, EPI, 1, bf16_t>(a, acc, reinterpret_cast<float*>(smem) + wave * SCR_FLOATS, lane, m0 + wm0, n0 + wn0, bz, 0);
 }
 
 template <int BN, int BK, int NWAVE>
@@ -161,8 +163,14 @@ int launch_form(const GemmArgs& a, hipStream_t s, long long min_tiles) {
     int gw = tiles_n;
     if (gw_env > 0 && gw_env < tiles_n && tiles_n % gw_env == 0) gw = gw_env;
     const int slot = prof_begin(PK_GEMM, 2.0 * a.M * a.N * (double)a.K * a.batch, s);
-    if (a.epi == EPI_GENERIC) hipLaunchKernelGGL((gemm_big_kernel<EPI_GENERIC, BN, BK, NWAVE>), dim3((unsigned)tiles), dim3(NWAVE * 64), 0, s, a, tiles_m, tiles_n, gw);
-    else hipLaunchKernelGGL((gemm_big_kernel<EPI_QKV_DIT, BN, BK, NWAVE>), dim3((unsigned)tiles), dim3(NWAVE * 64), 0, s, a, tiles_m, tiles_n, gw);
+    const dim3 grid((unsigned)tiles), block(NWAVE * 64);
+    if (a.dtype == DT_F16) {
+        if (a.epi == EPI_GENERIC) hipLaunchKernelGGL((gemm_big_kernel<EPI_GENERIC, BN, BK, NWAVE, f16_t>), grid, block, 0, s, a, tiles_m, tiles_n, gw);
+        else hipLaunchKernelGGL((gemm_big_kernel<EPI_QKV_DIT, BN, BK, NWAVE, f16_t>), grid, block, 0, s, a, tiles_m, tiles_n, gw);
+    } else {
+        if (a.epi == EPI_GENERIC) hipLaunchKernelGGL((gemm_big_kernel<EPI_GENERIC, BN, BK, NWAVE, bf16_t>), grid, block, 0, s, a, tiles_m, tiles_n, gw);
+        else hipLaunchKernelGGL((gemm_big_kernel<EPI_QKV_DIT, BN, BK, NWAVE, bf16_t>), grid, block, 0, s, a, tiles_m, tiles_n, gw);
+    }
     prof_end(slot, s);
     return hipGetLastError() == hipSuccess ? 1 : (set_error("gemm (256-tile form) launch failed"), -1);
 }
@@ -172,9 +180,14 @@ int launch_form(const GemmArgs& a, hipStream_t s, long long min_tiles) {
 // Eligible: bf16 plain Linear (one tap, one group, no stride / up-sampling / padding), K a multiple of 64, wide N and enough tiles to fill
 // the chip.  Returns 1 when the launch was taken, 0 when the caller should use the generic tile forms, -1 on error.
 int launch_gemm_big(const GemmArgs& a, hipStream_t s) {
-    if (a.dtype != DT_BF16 || a.groups != 1 || a.cin_pad != a.K || a.conv_stride != 1 || a.conv_dil != 1 || a.pad_left != 0 || a.up != 1 ||
-        a.rows_in != a.M || (a.K & 63) || a.N < 256 || (a.N & 63))
-        return 0;
+    const bool shape_ok = !(a.groups != 1 || a.cin_pad != a.K || a.conv_stride != 1 || a.conv_dil != 1 || a.pad_left != 0 || a.up != 1 ||
+                            a.rows_in != a.M || (a.K & 63) || a.N < 256 || (a.N & 63));
+    if (a.dtype == DT_F16) {
+        // fp16 operands exist in this form only (the DiT block Linears): every size takes it, however few tiles
+        if (!shape_ok) return set_error("gemm: fp16 operands are supported for plain Linears with K %% 64 == 0, N >= 256, N %% 64 == 0 only"), -1;
+        return launch_form<256, 64, 8>(a, s, 0);
+    }
+    if (a.dtype != DT_BF16 || !shape_ok) return 0;
     // below half a round of the 256 CUs the 128 x 128 form (2-3 workgroups per CU, four times as many tiles) balances better (measured: M = 11264,
     // N = 1024: 176 tiles tie; M = 2816: 44 tiles lose 177 vs 267 TF/s)
     static const long long min_tiles = [] { const char* e = getenv("HVX_GEMM_BIG_MIN_TILES"); return e ? atoll(e) : 128LL; }();   // (tuning knob)

@@ -46,7 +46,8 @@ template <bool RT, int ACT, int RES, int OF32, int O2, int ACT2 = 0> struct Lean
 };
 
 // LEAN: compile the streamlined pass for whole, aligned column tiles (costs ~50 VGPRs: only the one-workgroup-per-CU 256-tile form takes it)
-template <class T, int MT, int NT, int WN, int EPI, int LEAN = 0>       // LEAN 1: DiT Linears (no per-column activation tables); 2: + Snake tables (vocoder)
+// QT: the storage type of q / k / V^T in EPI_QKV_DIT (the attention's operand type; differs from T only for fp16-operand Linears, whose attention stays bf16)
+template <class T, int MT, int NT, int WN, int EPI, int LEAN = 0, class QT = T>       // LEAN 1: DiT Linears (no per-column activation tables); 2: + Snake tables (vocoder)
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT][NT], float* scr, int lane, int mw0, int nw0, int bz, int g) {
     constexpr int SLD = WN + 4;                      // staging row stride (floats)
     constexpr int ROWS_PASS = (64 / WN) * 16;        // rows a wave stages per pass: 64 lanes x 16 columns each
@@ -117,16 +118,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT]
                     if constexpr (PERM == 0 || PERM == 2) {
 #pragma unroll
                         for (int u = 0; u < 2; ++u) {
-                            bf16x8 w8;
+                            typename Vec8<T>::type w8;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) { w8[e] = f32_to_bf16(v[2 * u][e]); w8[4 + e] = f32_to_bf16(v[2 * u + 1][e]); }
+                            for (int e = 0; e < 4; ++e) { w8[e] = from_f32<T>(v[2 * u][e]); w8[4 + e] = from_f32<T>(v[2 * u + 1][e]); }
                             if (mw0 + ip * 16 + rsel(2 * u) < a.M) store8(base + (long long)(mw0 + ip * 16 + rsel(2 * u) + row_off) * ld + cof(2 * u), w8);
                         }
                     } else {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            const bf16x4 w4 = {f32_to_bf16(v[q][0]), f32_to_bf16(v[q][1]), f32_to_bf16(v[q][2]), f32_to_bf16(v[q][3])};
-                            if (mw0 + ip * 16 + rsel(q) < a.M) *reinterpret_cast<bf16x4*>(base + (long long)(mw0 + ip * 16 + rsel(q) + row_off) * ld + cof(q)) = w4;
+                            const typename Vec4<T>::type w4 = {from_f32<T>(v[q][0]), from_f32<T>(v[q][1]), from_f32<T>(v[q][2]), from_f32<T>(v[q][3])};
+                            if (mw0 + ip * 16 + rsel(q) < a.M) *reinterpret_cast<typename Vec4<T>::type*>(base + (long long)(mw0 + ip * 16 + rsel(q) + row_off) * ld + cof(q)) = w4;
                         }
                     }
                 };
@@ -341,8 +342,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT]
                         } else {
                             T* op = reinterpret_cast<T*>(a.out) + o1 + c4;
                             if constexpr (sizeof(T) == 2) {
-                                bf16x4 w4 = {f32_to_bf16(v[0]), f32_to_bf16(v[1]), f32_to_bf16(v[2]), f32_to_bf16(v[3])};
-                                if (vec) *reinterpret_cast<bf16x4*>(op) = w4;
+                                typename Vec4<T>::type w4 = {from_f32<T>(v[0]), from_f32<T>(v[1]), from_f32<T>(v[2]), from_f32<T>(v[3])};
+                                if (vec) *reinterpret_cast<typename Vec4<T>::type*>(op) = w4;
                                 else { op[0] = w4[0]; op[1] = w4[1]; op[2] = w4[2]; op[3] = w4[3]; }
                             } else {
                                 if (vec) *reinterpret_cast<f32x4*>(op) = v;
@@ -357,8 +358,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT]
                         u = act_apply4(a.act2, v, a.act2_param, al2, f32x4{1, 1, 1, 1});
                         T* op = reinterpret_cast<T*>(a.out2) + o2 + c4;
                         if constexpr (sizeof(T) == 2) {
-                            bf16x4 w4 = {f32_to_bf16(u[0]), f32_to_bf16(u[1]), f32_to_bf16(u[2]), f32_to_bf16(u[3])};
-                            if (vec) *reinterpret_cast<bf16x4*>(op) = w4;
+                            typename Vec4<T>::type w4 = {from_f32<T>(u[0]), from_f32<T>(u[1]), from_f32<T>(u[2]), from_f32<T>(u[3])};
+                            if (vec) *reinterpret_cast<typename Vec4<T>::type*>(op) = w4;
                             else { op[0] = w4[0]; op[1] = w4[1]; op[2] = w4[2]; op[3] = w4[3]; }
                         } else if (a.out2_planes) {
                             bf16_t* opp = reinterpret_cast<bf16_t*>(a.out2) + o2 + c4;
@@ -437,7 +438,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT]
                 f32x4 bi[2];
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) bi[hh] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + cw + c8 + hh * 4) : f32x4{0, 0, 0, 0};
-                T* const dbase = reinterpret_cast<T*>(which == 0 ? a.q : a.k) + (((long long)bz * a.heads + h) * a.t_pad) * 64 + c8;
+                QT* const dbase = reinterpret_cast<QT*>(which == 0 ? a.q : a.k) + (((long long)bz * a.heads + h) * a.t_pad) * 64 + c8;
                 auto qk_pass = [&](auto IP, auto ROPE) __attribute__((always_inline)) {
                     constexpr int ip = decltype(IP)::value;
                     constexpr bool rope = decltype(ROPE)::value;       // compile-time: the pass stays one basic block (see LeanMode)
@@ -470,9 +471,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT]
                     }
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
-                        typename Vec8<T>::type w8;
+                        typename Vec8<QT>::type w8;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { w8[e] = from_f32<T>(v[2 * u][e] * qs); w8[4 + e] = from_f32<T>(v[2 * u + 1][e] * qs); }
+                        for (int e = 0; e < 4; ++e) { w8[e] = from_f32<QT>(v[2 * u][e] * qs); w8[4 + e] = from_f32<QT>(v[2 * u + 1][e] * qs); }
                         if (row0 + 8 * u < a.M) store8(dbase + (long long)(row0 + 8 * u) * 64, w8);
                     }
                 };
@@ -500,7 +501,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT]
                 float bi[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) bi[i] = a.bias ? a.bias[cw + i * 16 + ch4] : 0.0f;
-                T* const dbase = reinterpret_cast<T*>(a.vT) + (((long long)bz * a.heads + h) * 64 + ((cb + ch4) & 63)) * a.t_pad + tq * 8;
+                QT* const dbase = reinterpret_cast<QT*>(a.vT) + (((long long)bz * a.heads + h) * 64 + ((cb + ch4) & 63)) * a.t_pad + tq * 8;
                 auto v_pass = [&](auto IP) __attribute__((always_inline)) {
                     constexpr int ip = decltype(IP)::value;
 #pragma unroll
@@ -518,13 +519,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT]
                     unstage();
                     const int row0 = mw0 + ip * 16;
                     if (row0 >= a.M) return;
-                    T* dst = dbase + row0;
+                    QT* dst = dbase + row0;
                     if (row0 + 32 <= a.M) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            typename Vec8<T>::type w8;
+                            typename Vec8<QT>::type w8;
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) w8[e] = from_f32<T>(x[i][e]);
+                            for (int e = 0; e < 8; ++e) w8[e] = from_f32<QT>(x[i][e]);
                             store8(dst + (long long)i * 16 * a.t_pad, w8);
                         }
                     } else {
@@ -532,7 +533,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT]
                         for (int i = 0; i < 4; ++i)
 #pragma unroll
                             for (int e = 0; e < 8; ++e)
-                                if (row0 + tq * 8 + e < a.M) dst[(long long)i * 16 * a.t_pad + e] = from_f32<T>(x[i][e]);
+                                if (row0 + tq * 8 + e < a.M) dst[(long long)i * 16 * a.t_pad + e] = from_f32<QT>(x[i][e]);
                     }
                 };
                 v_pass(std::integral_constant<int, 0>{});
@@ -573,12 +574,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT]
 #pragma unroll
                     for (int c = 0; c < 16; ++c) x[c] *= a.q_scale;
                 }
-                T* dst = reinterpret_cast<T*>(which == 0 ? a.q : a.k) + ((((long long)bz * a.heads + h) * a.t_pad) + row) * 64 + d0;
+                QT* dst = reinterpret_cast<QT*>(which == 0 ? a.q : a.k) + ((((long long)bz * a.heads + h) * a.t_pad) + row) * 64 + d0;
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    typename Vec8<T>::type w8;
+                    typename Vec8<QT>::type w8;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) w8[e] = from_f32<T>(x[q * 8 + e]);
+                    for (int e = 0; e < 8; ++e) w8[e] = from_f32<QT>(x[q * 8 + e]);
                     store8(dst + q * 8, w8);
                 }
             } else {
@@ -592,17 +593,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT]
                 if (!wave_ok || row0 >= a.M) return;
                 const float bi = a.bias ? a.bias[cw + pc] : 0.0f;
                 const int d = (cb + pc) & 63;
-                T* dst = reinterpret_cast<T*>(a.vT) + (((long long)bz * a.heads + h) * 64 + d) * a.t_pad + row0;
+                QT* dst = reinterpret_cast<QT*>(a.vT) + (((long long)bz * a.heads + h) * 64 + d) * a.t_pad + row0;
                 if (row0 + 16 <= a.M) {
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
-                        typename Vec8<T>::type w8;
+                        typename Vec8<QT>::type w8;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) w8[e] = from_f32<T>(x[q * 8 + e] + bi);
+                        for (int e = 0; e < 8; ++e) w8[e] = from_f32<QT>(x[q * 8 + e] + bi);
                         store8(dst + q * 8, w8);
                     }
                 } else {
-                    for (int r = 0; r < 16 && row0 + r < a.M; ++r) dst[r] = from_f32<T>(x[r] + bi);
+                    for (int r = 0; r < 16 && row0 + r < a.M; ++r) dst[r] = from_f32<QT>(x[r] + bi);
                 }
             }
         };

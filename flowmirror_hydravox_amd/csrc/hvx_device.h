@@ -32,12 +32,23 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float v) { return (bf16_t)v; }   /
 template <class T> struct Vec8;
 template <> struct Vec8<bf16_t> { typedef bf16x8 type; };
 template <> struct Vec8<float> { typedef f32x8 type; };
+template <> struct Vec8<f16_t> { typedef f16x8 type; };
+template <class T> struct Vec4;
+template <> struct Vec4<bf16_t> { typedef bf16x4 type; };
+template <> struct Vec4<f16_t> { typedef f16x4 type; };
+template <> struct Vec4<float> { typedef f32x4 type; };
 
 template <class T> __device__ __forceinline__ typename Vec8<T>::type zero8();
 template <> __device__ __forceinline__ bf16x8 zero8<bf16_t>() {
     bf16x8 z;
 #pragma unroll
     for (int i = 0; i < 8; ++i) z[i] = (bf16_t)0.0f;
+    return z;
+}
+template <> __device__ __forceinline__ f16x8 zero8<f16_t>() {
+    f16x8 z;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) z[i] = (f16_t)0.0f;
     return z;
 }
 template <> __device__ __forceinline__ f32x8 zero8<float>() {
@@ -47,6 +58,7 @@ template <> __device__ __forceinline__ f32x8 zero8<float>() {
 
 // 8 consecutive elements from global / LDS (address must be 16-byte aligned)
 __device__ __forceinline__ bf16x8 load8(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
+__device__ __forceinline__ f16x8 load8(const f16_t* p) { return *reinterpret_cast<const f16x8*>(p); }
 __device__ __forceinline__ f32x8 load8(const float* p) {
     const f32x4 a = *reinterpret_cast<const f32x4*>(p);
     const f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
@@ -62,6 +74,7 @@ __device__ __forceinline__ f32x8 load8_nt(const float* p) {
     return r;
 }
 __device__ __forceinline__ void store8(bf16_t* p, bf16x8 v) { *reinterpret_cast<bf16x8*>(p) = v; }
+__device__ __forceinline__ void store8(f16_t* p, f16x8 v) { *reinterpret_cast<f16x8*>(p) = v; }
 __device__ __forceinline__ void store8(float* p, f32x8 v) {
     f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
     *reinterpret_cast<f32x4*>(p) = a;
@@ -72,6 +85,10 @@ __device__ __forceinline__ void store8(float* p, f32x8 v) {
 __device__ __forceinline__ void mma32(f32x4& acc, const bf16x8& a, const bf16x8& b) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
 }
+// IEEE fp16 operands (the DiT's Linears when the handle runs them in the reference's own deployed dtype): same fragment layout, same rate
+__device__ __forceinline__ void mma32(f32x4& acc, const f16x8& a, const f16x8& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
+}
 __device__ __forceinline__ void mma32(f32x4& acc, const f32x8& a, const f32x8& b) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc, 0, 0, 0);
@@ -80,8 +97,10 @@ __device__ __forceinline__ void mma32(f32x4& acc, const f32x8& a, const f32x8& b
 template <class T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return f32_to_bf16(v); }
+template <> __device__ __forceinline__ f16_t from_f32<f16_t>(float v) { return f32_to_f16_sat(v); }
 __device__ __forceinline__ float to_f32(float v) { return v; }
 __device__ __forceinline__ float to_f32(bf16_t v) { return bf16_to_f32(v); }
+__device__ __forceinline__ float to_f32(f16_t v) { return (float)v; }
 
 // ---- activations (fp32 math) ---------------------------------------------------------------------
 enum Act : int {

@@ -32,6 +32,7 @@ struct hvx_flow {
     float* mod_cache = nullptr;
     int mod_slots = 0;
     bool half_stream = false;          // residual stream of the DiT blocks stored as fp16 (bf16 mode only)
+    bool f16_linears = false;          // the four Linears of every DiT block take IEEE fp16 operands (their weights were packed as fp16): bf16 mode only
     struct ModSlot {
         float t;
         hipStream_t s;
@@ -254,12 +255,14 @@ int estimator_core(const hvx_flow* h, hipStream_t s, EstBufs& b, int B, int T, c
     }
 
     // ---- DiT blocks ---------------------------------------------------------------------------------------------------
+    // operand type of the four Linears of a block (and of the activations that feed them: adaLN outputs, attention output, FF hidden)
+    const int ldt = (h->f16_linears && dt == DT_BF16) ? DT_F16 : dt;
     HIP_OK(hipMemsetAsync(b.vT, 0, (size_t)B * H * Tp * 64 * es, s));       // padded key columns must be finite
     for (int i = 0; i < c.depth; ++i) {
         const void* const* bw = w + 19 + 10 * i;
         const float* mod = b.mods + (size_t)i * MB * 6 * D;
-        HVX_CHECK(launch_layernorm_mod(xs, hs, mod, mod + D, mbs, 1e-6f, b.n, dt, B, T, D, s));
-        g = linear(dt, T, 3 * D, D, b.n, D, bw[2], (const float*)bw[3]);
+        HVX_CHECK(launch_layernorm_mod(xs, hs, mod, mod + D, mbs, 1e-6f, b.n, ldt, B, T, D, s));
+        g = linear(ldt, T, 3 * D, D, b.n, D, bw[2], (const float*)bw[3]);
         g.batch = B; g.a_bs = (long long)T * D; g.epi = EPI_QKV_DIT;
         g.q = b.q; g.k = b.k; g.vT = b.vT; g.heads = H; g.t_pad = Tp; g.rope_cos = (const float*)w[0]; g.rope_sin = (const float*)w[1];
         g.q_scale = 0.125f * 1.4426950408889634f;              // dim_head^-0.5 (modules.py:391, SDPA default scale) in log2 units, rounded once with q
@@ -271,19 +274,19 @@ int estimator_core(const hvx_flow* h, hipStream_t s, EstBufs& b, int B, int T, c
         at.k = b.k; at.k_bs = at.q_bs; at.k_hs = at.q_hs;
         at.vT = b.vT; at.v_bs = at.q_bs; at.v_hs = (long long)64 * Tp; at.v_ld = Tp;
         at.kv_len = kv_len; at.kv_len_const = T; at.causal = 0; at.chunk = chunk; at.scale = 0.125f; at.q_log2 = 1;
-        at.out = b.att; at.o_bs = (long long)T * D; at.o_hs = 64; at.o_lo = D; at.n_splits = 1;
+        at.out = b.att; at.o_bs = (long long)T * D; at.o_hs = 64; at.o_lo = D; at.n_splits = 1; at.out_f16 = ldt == DT_F16;
         HVX_CHECK(launch_attention(at, s));
-        g = linear(dt, T, D, D, b.att, D, bw[4], (const float*)bw[5]);
+        g = linear(ldt, T, D, D, b.att, D, bw[4], (const float*)bw[5]);
         g.batch = B; g.a_bs = (long long)T * D;
         g.gate = mod + 2 * D; g.gate_bs = mbs; g.res = static_cast<const float*>(xs); g.res_f16 = hs; g.res_bs = (long long)T * D; g.ldres = D;
         g.out = xs; g.out_f32 = hs ? 0 : 1; g.out_f16 = hs; g.out_bs = (long long)T * D; g.ldo = D; g.out_cols = D;
         HVX_CHECK(launch_gemm(g, s));
-        HVX_CHECK(launch_layernorm_mod(xs, hs, mod + 3 * D, mod + 4 * D, mbs, 1e-6f, b.n, dt, B, T, D, s));
-        g = linear(dt, T, c.ff, D, b.n, D, bw[6], (const float*)bw[7]);
+        HVX_CHECK(launch_layernorm_mod(xs, hs, mod + 3 * D, mod + 4 * D, mbs, 1e-6f, b.n, ldt, B, T, D, s));
+        g = linear(ldt, T, c.ff, D, b.n, D, bw[6], (const float*)bw[7]);
         g.batch = B; g.a_bs = (long long)T * D; g.act = ACT_GELU_TANH;
         g.out = b.ffh; g.out_f32 = 0; g.out_bs = (long long)T * c.ff; g.ldo = c.ff; g.out_cols = c.ff;
         HVX_CHECK(launch_gemm(g, s));
-        g = linear(dt, T, D, c.ff, b.ffh, c.ff, bw[8], (const float*)bw[9]);
+        g = linear(ldt, T, D, c.ff, b.ffh, c.ff, bw[8], (const float*)bw[9]);
         g.batch = B; g.a_bs = (long long)T * c.ff;
         g.gate = mod + 5 * D; g.gate_bs = mbs; g.res = static_cast<const float*>(xs); g.res_f16 = hs; g.res_bs = (long long)T * D; g.ldres = D;
         g.out = xs; g.out_f32 = hs ? 0 : 1; g.out_f16 = hs; g.out_bs = (long long)T * D; g.ldo = D; g.out_cols = D;
@@ -390,6 +393,14 @@ int hvx_flow_set_half_stream(hvx_flow* h, int32_t on) {
     if (!h) return set_error("hvx_flow_set_half_stream: null handle"), -1;
     if (on && h->c.dtype != DT_BF16) return set_error("hvx_flow_set_half_stream: the fp16 residual stream belongs to the bf16 mode"), -1;
     h->half_stream = on != 0;
+    return 0;
+}
+
+int hvx_flow_set_f16_linears(hvx_flow* h, int32_t on) {
+    if (!h) return set_error("hvx_flow_set_f16_linears: null handle"), -1;
+    if (on && h->c.dtype != DT_BF16) return set_error("hvx_flow_set_f16_linears: fp16 Linear operands belong to the bf16 mode"), -1;
+    if (on && ((h->c.dim & 63) || h->c.dim < 256 || (h->c.ff & 63))) return set_error("hvx_flow_set_f16_linears: needs dim >= 256 and dim, ff multiples of 64"), -1;
+    h->f16_linears = on != 0;
     return 0;
 }
 

@@ -6,8 +6,9 @@
 
 namespace hvx {
 
-enum DType : int { DT_F32 = 0, DT_BF16 = 1 };
-inline size_t dtype_size(int dt) { return dt == DT_BF16 ? 2 : 4; }
+// DT_F16: operands of the DiT block Linears (256-tile form only) and the activations feeding them, when the flow handle runs them in fp16
+enum DType : int { DT_F32 = 0, DT_BF16 = 1, DT_F16 = 2 };
+inline size_t dtype_size(int dt) { return dt == DT_F32 ? 4 : 2; }
 
 void set_error(const char* fmt, ...);
 
@@ -132,6 +133,7 @@ struct AttnArgs {
     float scale;
     int q_log2;                   // q already multiplied by scale * log2(e) (fused QKV epilogue, GemmArgs.q_scale): scale is ignored
     void* out; long long o_bs, o_hs, o_hi, o_lo;      // dtype
+    int out_f16;                  // bf16 operands only: the output is written as IEEE fp16 (it feeds an fp16-operand Linear, DT_F16)
     int n_splits; int split_chunk;                    // keys per split (multiple of 32) when n_splits > 1
     int sub_chunk;                                    // > 0 (needs n_rows <= 32): one workgroup per split, its 4 waves take sub_chunk keys
                                                       // each and merge their (m, l, o) in LDS, so the combine reads 4x fewer partials

@@ -45,7 +45,7 @@ def euler_schedule(n_timesteps):
 
 
 class HvxFlow:
-    def __init__(self, cfg: FlowConfig, state_dict=None, dtype=torch.bfloat16, device='cuda', max_t=None, half_stream=None):
+    def __init__(self, cfg: FlowConfig, state_dict=None, dtype=torch.bfloat16, device='cuda', max_t=None, half_stream=None, f16_linears=None):
         _lib.require_gpu()
         self.lib = _lib.load()
         self.cfg = cfg
@@ -58,6 +58,12 @@ class HvxFlow:
         if half_stream is None:
             half_stream = os.environ.get('HVX_FLOW_HALF_STREAM', '1') != '0'
         self.half_stream = bool(half_stream) and self.bf16
+        # bf16 mode: the four Linears of every DiT block on IEEE fp16 operands (the reference deploys this decoder as `.half()`): with them the mode sits at
+        # the reference's own fp16 distance from fp32 instead of 3.5x it (tools/dit_rounding_study.py); q / k / v and the attention stay bf16.  Off unless
+        # asked for (f16_linears=True or HVX_FLOW_F16_LINEARS=1); needs dim >= 256, dim and ff multiples of 64.
+        if f16_linears is None:
+            f16_linears = os.environ.get('HVX_FLOW_F16_LINEARS', '0') == '1'
+        self.f16_linears = bool(f16_linears) and self.bf16 and cfg.dim >= 256 and cfg.dim % 64 == 0 and (cfg.dim * cfg.ff_mult) % 64 == 0
         self.token_mel_ratio = cfg.token_mel_ratio
         self.pre_lookahead_len = cfg.pre_lookahead_len
         self.static_chunk_size = cfg.static_chunk_size            # DiT(static_chunk_size=...), dit.py:119,142
@@ -87,6 +93,9 @@ class HvxFlow:
         def mat(t):
             return t.to(dt).contiguous()
 
+        def lmat(t):                                       # a DiT block Linear: fp16 operands when the handle runs them so
+            return t.to(torch.float16 if self.f16_linears else dt).contiguous()
+
         def vec(t):
             return t.float().contiguous()
 
@@ -107,9 +116,9 @@ class HvxFlow:
             p = e + 'transformer_blocks.%d.' % i
             wqkv = torch.cat([W(p + 'attn.to_q.weight'), W(p + 'attn.to_k.weight'), W(p + 'attn.to_v.weight')], 0)
             bqkv = torch.cat([W(p + 'attn.to_q.bias'), W(p + 'attn.to_k.bias'), W(p + 'attn.to_v.bias')], 0)
-            ws += [mat(W(p + 'attn_norm.linear.weight')), vec(W(p + 'attn_norm.linear.bias')), mat(wqkv), vec(bqkv),
-                   mat(W(p + 'attn.to_out.0.weight')), vec(W(p + 'attn.to_out.0.bias')),
-                   mat(W(p + 'ff.ff.0.0.weight')), vec(W(p + 'ff.ff.0.0.bias')), mat(W(p + 'ff.ff.2.weight')), vec(W(p + 'ff.ff.2.bias'))]
+            ws += [mat(W(p + 'attn_norm.linear.weight')), vec(W(p + 'attn_norm.linear.bias')), lmat(wqkv), vec(bqkv),
+                   lmat(W(p + 'attn.to_out.0.weight')), vec(W(p + 'attn.to_out.0.bias')),
+                   lmat(W(p + 'ff.ff.0.0.weight')), vec(W(p + 'ff.ff.0.0.bias')), lmat(W(p + 'ff.ff.2.weight')), vec(W(p + 'ff.ff.2.bias'))]
         ws += [mat(W(e + 'norm_out.linear.weight')), vec(W(e + 'norm_out.linear.bias')), mat(W(e + 'proj_out.weight')), vec(W(e + 'proj_out.bias'))]
         return ws
 
@@ -117,6 +126,8 @@ class HvxFlow:
         c, dt, dev = self.cfg, self.dtype, self.device
         ws = [w.to(dev) for w in ws]
         self._weights = ws
+        if self.bf16 and c.depth > 0:
+            self.f16_linears = ws[19 + 2].dtype == torch.float16          # (packed weights say how the block Linears were packed)
         cc = _lib.FlowConfig(dtype=_lib.dtype_code(dt), vocab=c.vocab, mel=c.mel, spk_dim=c.spk_embed_dim, pla_channels=c.pre_lookahead_channels,
                              pla_len=c.pre_lookahead_len, dim=c.dim, depth=c.depth, heads=c.heads, ff=c.ff, conv_kernel=c.conv_kernel,
                              conv_groups=c.conv_groups, time_freq_dim=c.time_freq_dim, max_t=self.max_t, cfg_rate=c.cfg_rate)
@@ -130,6 +141,7 @@ class HvxFlow:
         self._mod_cache = torch.zeros(16 * slot, dtype=torch.uint8, device=dev)
         check(self.lib.hvx_flow_set_mod_cache(self._h, ptr(self._mod_cache), self._mod_cache.numel()), 'hvx_flow_set_mod_cache')
         check(self.lib.hvx_flow_set_half_stream(self._h, 1 if self.half_stream else 0), 'hvx_flow_set_half_stream')
+        check(self.lib.hvx_flow_set_f16_linears(self._h, 1 if self.f16_linears else 0), 'hvx_flow_set_f16_linears')
         return self
 
     def eval(self):

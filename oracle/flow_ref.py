@@ -37,7 +37,10 @@ def _h(t, on):
     return t.to(torch.float16).float() if on else t
 
 
-def _lin(x, w, b=None, emu=False):
+def _lin(x, w, b=None, emu=False, f16=False):
+    """f16: the product runs this Linear on IEEE fp16 operands (the four Linears of a DiT block with hvx_flow_set_f16_linears)"""
+    if emu and f16:
+        return F.linear(x.to(torch.float16).float(), w.to(torch.float16).float(), b)
     return F.linear(bf16r(x), bf16r(w), b) if emu else F.linear(x, w, b)
 
 
@@ -105,15 +108,15 @@ def _sdpa_emu(q, k, v, am):
     return bf16r(torch.matmul(e, v) / e.sum(dim=-1, keepdim=True))
 
 
-def dit_block(x, t_emb, sd, cfg, pre, freqs, key_mask, attn_mask=None, emu=False, resid16=False):
+def dit_block(x, t_emb, sd, cfg, pre, freqs, key_mask, attn_mask=None, emu=False, resid16=False, lin16=False):
     B, T, D = x.shape
     H, dh = cfg.heads, cfg.head_dim
     emb = _lin(F.silu(t_emb), sd[pre + 'attn_norm.linear.weight'], sd[pre + 'attn_norm.linear.bias'], emu)
     sh_a, sc_a, g_a, sh_m, sc_m, g_m = torch.chunk(emb, 6, dim=1)
     n = F.layer_norm(x, (D,), eps=1e-6) * (1 + sc_a[:, None]) + sh_a[:, None]
-    q = _lin(n, sd[pre + 'attn.to_q.weight'], sd[pre + 'attn.to_q.bias'], emu)
-    k = _lin(n, sd[pre + 'attn.to_k.weight'], sd[pre + 'attn.to_k.bias'], emu)
-    v = _lin(n, sd[pre + 'attn.to_v.weight'], sd[pre + 'attn.to_v.bias'], emu)
+    q = _lin(n, sd[pre + 'attn.to_q.weight'], sd[pre + 'attn.to_q.bias'], emu, lin16)
+    k = _lin(n, sd[pre + 'attn.to_k.weight'], sd[pre + 'attn.to_k.bias'], emu, lin16)
+    v = _lin(n, sd[pre + 'attn.to_v.weight'], sd[pre + 'attn.to_v.bias'], emu, lin16)
     q = apply_rope_first(q, freqs)
     k = apply_rope_first(k, freqs)
     q = _r(q, emu).view(B, T, H, dh).transpose(1, 2)
@@ -127,12 +130,12 @@ def dit_block(x, t_emb, sd, cfg, pre, freqs, key_mask, attn_mask=None, emu=False
     else:
         a = F.scaled_dot_product_attention(q, k, v, attn_mask=am, dropout_p=0.0, is_causal=False)
     a = a.transpose(1, 2).reshape(B, T, H * dh)
-    a = _lin(a, sd[pre + 'attn.to_out.0.weight'], sd[pre + 'attn.to_out.0.bias'], emu)
+    a = _lin(a, sd[pre + 'attn.to_out.0.weight'], sd[pre + 'attn.to_out.0.bias'], emu, lin16)
     a = a.masked_fill(~key_mask[:, :, None], 0.0)                 # mask[:, 0, -1] row == pad mask (modules.py:400-405)
     x = _h(x + g_a.unsqueeze(1) * a, resid16)
     f = F.layer_norm(x, (D,), eps=1e-6) * (1 + sc_m[:, None]) + sh_m[:, None]
-    f = _lin(f, sd[pre + 'ff.ff.0.0.weight'], sd[pre + 'ff.ff.0.0.bias'], emu)
-    f = _lin(F.gelu(f, approximate='tanh'), sd[pre + 'ff.ff.2.weight'], sd[pre + 'ff.ff.2.bias'], emu)
+    f = _lin(f, sd[pre + 'ff.ff.0.0.weight'], sd[pre + 'ff.ff.0.0.bias'], emu, lin16)
+    f = _lin(F.gelu(f, approximate='tanh'), sd[pre + 'ff.ff.2.weight'], sd[pre + 'ff.ff.2.bias'], emu, lin16)
     return _h(x + g_m.unsqueeze(1) * f, resid16)
 
 
@@ -147,7 +150,7 @@ def chunk_attn_mask(key_mask, chunk):
     return am
 
 
-def dit_forward(x, mask, mu, t, spks, cond, sd, cfg, pre='decoder.estimator.', n_blocks=None, taps=None, streaming=False, emu=False, resid16=False):
+def dit_forward(x, mask, mu, t, spks, cond, sd, cfg, pre='decoder.estimator.', n_blocks=None, taps=None, streaming=False, emu=False, resid16=False, lin16=False):
     """Estimator call, TRT argument order (flow_matching.py:126-153): x,mu,cond (B,80,T); mask (B,1,T);
     t (B,); spks (B,80) -> (B,80,T).  streaming=True: static chunk mask of cfg.static_chunk_size frames."""
     x = x.transpose(1, 2)
@@ -167,7 +170,7 @@ def dit_forward(x, mask, mu, t, spks, cond, sd, cfg, pre='decoder.estimator.', n
     nb = cfg.depth if n_blocks is None else n_blocks
     attn_mask = chunk_attn_mask(key_mask, cfg.static_chunk_size) if streaming else None
     for i in range(nb):
-        h = dit_block(h, t_emb, sd, cfg, pre + 'transformer_blocks.%d.' % i, freqs, key_mask, attn_mask, emu, resid16)
+        h = dit_block(h, t_emb, sd, cfg, pre + 'transformer_blocks.%d.' % i, freqs, key_mask, attn_mask, emu, resid16, lin16)
         if taps is not None:
             taps['block%d' % i] = h.clone()
     emb = _lin(F.silu(t_emb), sd[pre + 'norm_out.linear.weight'], sd[pre + 'norm_out.linear.bias'], emu)
@@ -218,7 +221,7 @@ def solve_euler(x, t_span, mu, mask, spks, cond, estimator, cfg_rate):
     return traj[-1].float(), traj
 
 
-def cfm_forward(mu, mask, spks, cond, sd, cfg, noise=None, estimator=None, n_timesteps=None, streaming=False, emu=False, resid16=False):
+def cfm_forward(mu, mask, spks, cond, sd, cfg, noise=None, estimator=None, n_timesteps=None, streaming=False, emu=False, resid16=False, lin16=False):
     """CausalConditionalCFM.forward (flow_matching.py:204-228)."""
     noise = cfm_noise(cfg) if noise is None else noise
     z = noise[:, :, :mu.size(2)].to(mu.dtype)
@@ -226,12 +229,12 @@ def cfm_forward(mu, mask, spks, cond, sd, cfg, noise=None, estimator=None, n_tim
     t_span = cosine_t_span(n, mu.dtype)
     if estimator is None:
         def estimator(x, m, mu_, t, s, c):
-            return dit_forward(x, m, mu_, t, s, c, sd, cfg, streaming=streaming, emu=emu, resid16=resid16)
+            return dit_forward(x, m, mu_, t, s, c, sd, cfg, streaming=streaming, emu=emu, resid16=resid16, lin16=lin16)
     out, _ = solve_euler(z, t_span, mu, mask, spks, cond, estimator, cfg.cfg_rate)
     return out
 
 
-def flow_inference(token, embedding, sd, cfg, prompt_token=None, prompt_feat=None, noise=None, finalize=True, streaming=False, emu=False, resid16=False):
+def flow_inference(token, embedding, sd, cfg, prompt_token=None, prompt_feat=None, noise=None, finalize=True, streaming=False, emu=False, resid16=False, lin16=False):
     """flow.py:367-430, fp32; finalize=False: the last pre_lookahead_len tokens are look-ahead context only.
     token (1,N) int, embedding (1,192), prompt_token (1,Np) int, prompt_feat (1,Tp,80) -> mel (1,80,2N)."""
     emb = F.normalize(embedding.float(), dim=1)
@@ -248,5 +251,5 @@ def flow_inference(token, embedding, sd, cfg, prompt_token=None, prompt_feat=Non
     if prompt_feat is not None:
         cond[:, :mel_len1] = prompt_feat
     mask = torch.ones(1, 1, T)
-    feat = cfm_forward(h.transpose(1, 2).contiguous(), mask, emb, cond.transpose(1, 2), sd, cfg, noise=noise, streaming=streaming, emu=emu, resid16=resid16)
+    feat = cfm_forward(h.transpose(1, 2).contiguous(), mask, emb, cond.transpose(1, 2), sd, cfg, noise=noise, streaming=streaming, emu=emu, resid16=resid16, lin16=lin16)
     return feat[:, :, mel_len1:].float()

@@ -219,3 +219,42 @@ def test_flow_22_blocks_vs_reference_and_bf16_oracle(cfg, flow_setup, dtype):
         e = _rel(mel.cpu().numpy(), g['mel'])
         print('22 blocks, bf16 10-step mel: %.2e of the fp32 reference' % e)
         assert e < 2e-2, e
+
+
+def test_flow_22_blocks_fp16_linear_operands(cfg, flow_setup):
+    """bf16 mode with the four Linears of every DiT block on IEEE fp16 operands (HvxFlow(f16_linears=True) -> hvx_flow_set_f16_linears; the attention and
+    q / k / v stay bf16, the residual stream is fp16): the reference deploys this decoder in fp16, and with fp16 Linear operands the product sits at the
+    block Linears stop contributing to the distance from fp32 — what remains (tools/dit_rounding_study.py) is the bf16 of the input / output projections
+    and of the adaLN modulation Linears, which this option does not touch yet.  Chunk-masked estimator (T = 192: few tiles, the 256-tile kernel takes
+    every fp16 Linear whatever the size) against the faithful oracle with the same rounding points and against the fp32 reference; padded estimator at
+    T = 256; 10-step mel with a prompt."""
+    from flowmirror_hydravox_amd.flow import HvxFlow
+    from oracle import flow_ref
+    g, sd = flow_setup
+    c = cfg.flow
+    flow = HvxFlow(c, sd, dtype=torch.bfloat16, max_t=512, f16_linears=True)
+    assert flow.f16_linears and flow.half_stream
+    h = load_golden('flow_half.npz')
+    e_half = float(h['d_half_vs_f32'])
+    for tag in ('e0', 'e1'):
+        T, lens, streaming = int(g[tag + '_T']), g[tag + '_lens'].tolist(), bool(g[tag + '_streaming'])
+        x, mask, mu, spk, cond = cv3w_flow_inputs(int(g[tag + '_seed']), T, lens)
+        t = torch.from_numpy(g[tag + '_t'])
+        est = (flow.estimator(x, mask, mu, t, spk, cond, streaming=streaming).cpu() * mask).numpy()
+        e_ref = _rel(est, g[tag + '_out'])
+        if tag == 'e1':
+            emu = (flow_ref.dit_forward(x, mask, mu, t, spk, cond, sd, c, streaming=streaming, emu=True, resid16=True, lin16=True) * mask).numpy()
+            e_emu = _rel(est, emu)
+            print('22 blocks, fp16 Linear operands, %s estimator: %.2e of the faithful oracle, %.2e of the fp32 reference (the reference in fp16: %.2e)' % (tag, e_emu, e_ref, e_half))
+            assert e_emu < 1e-2 and e_ref < 5e-3, (e_emu, e_ref, e_half)
+        else:
+            print('22 blocks, fp16 Linear operands, %s estimator: %.2e of the fp32 reference' % (tag, e_ref))
+            assert e_ref < 5e-3, e_ref
+    token, ptoken, pfeat, emb = (torch.from_numpy(g[k]) for k in ('token', 'ptoken', 'pfeat', 'emb'))
+    mel, _ = flow.inference(token=token.to(DEV), token_len=torch.tensor([token.shape[1]], dtype=torch.int32), embedding=emb.to(DEV), finalize=True,
+                            prompt_token=ptoken.to(DEV), prompt_token_len=torch.tensor([ptoken.shape[1]], dtype=torch.int32),
+                            prompt_feat=pfeat.to(DEV), prompt_feat_len=torch.tensor([pfeat.shape[1]], dtype=torch.int32))
+    e = _rel(mel.cpu().numpy(), g['mel'])
+    print('22 blocks, fp16 Linear operands, 10-step mel: %.2e of the fp32 reference' % e)
+    assert e < 5e-3, e
+

@@ -57,3 +57,34 @@ for name, kw in (('product bf16 mode (bf16 operands, fp16 stream)', dict(lin16=F
                  ('  + q, k, v, P, attention output in fp16 (Linears stay bf16)', dict(lin16=False, qkv16=True)),
                  ('  everything in fp16', dict(lin16=True, qkv16=True))):
     print('%-68s %.2e' % (name + ':', run(**kw)))
+
+# ---- second question: with the four block Linears on fp16 operands (hvx_flow_set_f16_linears), which of the REMAINING bf16 Linears carry the rest? ----
+import torch.nn.functional as F  # noqa: E402
+
+names = {id(v): k for k, v in sd.items()}
+blk = lambda n: any(s_ in n for s_ in ('attn.to_', 'ff.ff.'))
+
+
+def run2(rule):
+    orig = flow_ref._lin
+
+    def lin(a, w, b=None, emu=False, f16=False):
+        m = rule(names.get(id(w), '?'))
+        if not emu or m == 'f32':
+            return F.linear(a, w, b)
+        if m == 'f16':
+            return F.linear(a.to(torch.float16).float(), w.to(torch.float16).float(), b)
+        return F.linear(flow_ref.bf16r(a), flow_ref.bf16r(w), b)
+    flow_ref._lin = lin
+    try:
+        out = flow_ref.dit_forward(x, mask, mu, t, spk, cond, sd, c, streaming=True, emu=True, resid16=True, lin16=True) * mask
+    finally:
+        flow_ref._lin = orig
+    return np.abs(out.numpy() - ref).max() / scale
+
+
+mod = lambda n: 'norm' in n and 'linear' in n
+print('block Linears fp16, everything else bf16 (hvx_flow_set_f16_linears today):  %.2e' % run2(lambda n: 'f16' if blk(n) else 'bf16'))
+print('  + adaLN modulation Linears exact fp32:                                    %.2e' % run2(lambda n: 'f16' if blk(n) else ('f32' if mod(n) else 'bf16')))
+print('  + time MLP exact fp32:                                                    %.2e' % run2(lambda n: 'f16' if blk(n) else ('f32' if mod(n) or 'time_mlp' in n else 'bf16')))
+print('  + input projection and output projection exact fp32:                      %.2e' % run2(lambda n: 'f16' if blk(n) else 'f32'))
