@@ -133,6 +133,7 @@ SYMBOLS = {
     'hvx_flow_set_mod_cache': (c_i32, [c_vp, c_vp, c_sz]),
     'hvx_flow_set_half_stream': (c_i32, [c_vp, c_i32]),
     'hvx_flow_set_f16_linears': (c_i32, [c_vp, c_i32]),
+    'hvx_flow_set_f32_small': (c_i32, [c_vp, c_i32]),
     'hvx_cfm_solve_batch': (c_i32, [c_vp, c_vp, c_vp, c_sz, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, C.POINTER(c_f32), C.POINTER(c_f32), c_i32]),
     'hvx_cfm_solve': (c_i32, [c_vp, c_vp, c_vp, c_sz, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, C.POINTER(c_f32), C.POINTER(c_f32)]),
     'hvx_matcha_create': (c_i32, [C.POINTER(MatchaConfig), C.POINTER(c_vp), c_i32, C.POINTER(c_vp)]),

@@ -32,6 +32,7 @@ struct hvx_flow {
     float* mod_cache = nullptr;
     int mod_slots = 0;
     bool half_stream = false;          // residual stream of the DiT blocks stored as fp16 (bf16 mode only)
+    bool f32_small = false;            // time MLP, adaLN modulation Linears, input and output projection in fp32 (their weights were packed as fp32): bf16 mode only
     bool f16_linears = false;          // the four Linears of every DiT block take IEEE fp16 operands (their weights were packed as fp16): bf16 mode only
     struct ModSlot {
         float t;
@@ -84,12 +85,12 @@ size_t carve_est(const hvx_flow_config& c, char* base, int B, int T, EstBufs& b)
     const int Tp = (T + 63) & ~63;                 // the LDS-staged attention walks 64-key tiles
     b.t_pad = Tp;
     Carve cv(base);
-    b.tsin = cv.take<void>((size_t)B * c.time_freq_dim * es);
-    b.th = cv.take<void>((size_t)B * D * es);
-    b.tsilu = cv.take<void>((size_t)B * D * es);
+    b.tsin = cv.take<void>((size_t)B * c.time_freq_dim * 4);      // (4-byte elements: these and hin are fp32 when the small Linears run in fp32)
+    b.th = cv.take<void>((size_t)B * D * 4);
+    b.tsilu = cv.take<void>((size_t)B * D * 4);
     b.mods = cv.take<float>((size_t)c.depth * B * 6 * D * 4);
     b.fmod = cv.take<float>((size_t)B * 2 * D * 4);
-    b.hin = cv.take<void>((size_t)B * T * 4 * c.mel * es);
+    b.hin = cv.take<void>((size_t)B * T * 4 * c.mel * 4);
     b.x0t = cv.take<void>((size_t)B * T * D * es);
     b.c1 = cv.take<void>((size_t)B * T * D * es);
     b.x = cv.take<float>((size_t)B * T * D * 4);
@@ -209,33 +210,44 @@ int estimator_core(const hvx_flow* h, hipStream_t s, EstBufs& b, int B, int T, c
     // ---- time embedding -> SiLU(t_emb) -> all adaLN modulation vectors --------------------------------------------
     GemmArgs g;
     const void* const* tw = w + 19 + 10 * c.depth;
+    // operand type of the SMALL Linears (time MLP, adaLN modulation, input / output projection): exact fp32 when the handle was told so — with fp16 block
+    // Linears these carry the bf16 mode's remaining distance from fp32 (tools/dit_rounding_study.py); a few ms per solve
+    const int sdt = (h->f32_small && dt == DT_BF16) ? DT_F32 : dt;
     if (!skip_mods) {
-    HVX_CHECK(launch_time_sinus(t, b.tsin, dt, MB, c.time_freq_dim, s));
-    g = linear(dt, MB, D, c.time_freq_dim, b.tsin, c.time_freq_dim, w[9], (const float*)w[10]);
+    HVX_CHECK(launch_time_sinus(t, b.tsin, sdt, MB, c.time_freq_dim, s));
+    g = linear(sdt, MB, D, c.time_freq_dim, b.tsin, c.time_freq_dim, w[9], (const float*)w[10]);
     g.act = ACT_SILU; g.out = b.th; g.ldo = D; g.out_cols = D;
     HVX_CHECK(launch_gemm(g, s));
-    g = linear(dt, MB, D, D, b.th, D, w[11], (const float*)w[12]);
+    g = linear(sdt, MB, D, D, b.th, D, w[11], (const float*)w[12]);
     g.out2 = b.tsilu; g.act2 = ACT_SILU; g.ldo2 = D; g.out2_cols = D;
     HVX_CHECK(launch_gemm(g, s));
     for (int i = 0; i < c.depth; ++i) {
         const void* const* bw = w + 19 + 10 * i;
-        g = linear(dt, MB, 6 * D, D, b.tsilu, D, bw[0], (const float*)bw[1]);
+        g = linear(sdt, MB, 6 * D, D, b.tsilu, D, bw[0], (const float*)bw[1]);
         g.out = b.mods + (size_t)i * MB * 6 * D; g.out_f32 = 1; g.ldo = 6 * D; g.out_cols = 6 * D;
         HVX_CHECK(launch_gemm(g, s));
     }
-    g = linear(dt, MB, 2 * D, D, b.tsilu, D, tw[0], (const float*)tw[1]);
+    g = linear(sdt, MB, 2 * D, D, b.tsilu, D, tw[0], (const float*)tw[1]);
     g.out = b.fmod; g.out_f32 = 1; g.ldo = 2 * D; g.out_cols = 2 * D;
     HVX_CHECK(launch_gemm(g, s));
     }
 
     // ---- input embedding: Linear(cat[x, cond, mu, spks]) + causal grouped conv position embedding ------------------
-    HVX_CHECK(launch_dit_concat(x, cond, mu, spks, b.hin, dt, B, T, mel, s));
+    HVX_CHECK(launch_dit_concat(x, cond, mu, spks, b.hin, sdt, B, T, mel, s));
     const int IN = 4 * mel;
-    g = linear(dt, T, D, IN, b.hin, IN, w[13], (const float*)w[14]);
+    g = linear(sdt, T, D, IN, b.hin, IN, w[13], (const float*)w[14]);
     g.batch = B; g.a_bs = (long long)T * IN;
     g.out = b.x; g.out_f32 = 1; g.out_bs = (long long)T * D; g.ldo = D; g.out_cols = D;           // x0 (fp32, residual of the conv branch)
-    g.out2 = b.x0t; g.act2 = ACT_NONE; g.out2_bs = (long long)T * D; g.ldo2 = D; g.out2_cols = D;
-    HVX_CHECK(launch_gemm(g, s));
+    if (sdt == dt) {
+        g.out2 = b.x0t; g.act2 = ACT_NONE; g.out2_bs = (long long)T * D; g.ldo2 = D; g.out2_cols = D;
+        HVX_CHECK(launch_gemm(g, s));
+    } else {
+        // fp32 operands on the bf16 matrix cores as (hi, lo) pairs (1e-6, a third of the exact form's time) where ONE batch entry already fills the
+        // split form's tile grid: the choice must not depend on the batch, or an utterance's mel would depend on its neighbours in the solve
+        g.x3 = ((long long)((T + 127) / 128) * ((D + 127) / 128) >= 256) ? 1 : 0;
+        HVX_CHECK(launch_gemm(g, s));
+        HVX_CHECK(launch_rows_to_dtype(b.x, D, b.x0t, dt, D, B * T, D, D, s));     // the position-embedding convolutions read x0 in `dtype`
+    }
     const int Cg = D / c.conv_groups, kc = c.conv_kernel;
     // the residual stream of the blocks: fp32 in b.x, or fp16 in the memory of x0t (the bf16 copy of x0 is dead once the first conv has read it)
     const int hs = (h->half_stream && dt == DT_BF16) ? 1 : 0;
@@ -293,8 +305,14 @@ int estimator_core(const hvx_flow* h, hipStream_t s, EstBufs& b, int B, int T, c
         HVX_CHECK(launch_gemm(g, s));
     }
     // ---- final adaLN (scale first, then shift: modules.py:262) + projection -------------------------------------------
-    HVX_CHECK(launch_layernorm_mod(xs, hs, b.fmod + D, b.fmod, fbs, 1e-6f, b.n, dt, B, T, D, s));
-    g = linear(dt, T, mel, D, b.n, D, tw[2], (const float*)tw[3]);
+    // (when the output projection runs in fp32 the last adaLN output is fp32 too: it goes into the FF hidden buffer, dead after the last block and at
+    // least as large — ff x 2 bytes >= dim x 4 bytes for every ff_mult >= 2)
+    const bool f32_out = sdt != dt;
+    if (f32_out && (size_t)c.ff * es < (size_t)D * 4) return set_error("estimator: f32_small needs ff >= 2 dim"), -1;
+    void* const nl = f32_out ? b.ffh : b.n;
+    HVX_CHECK(launch_layernorm_mod(xs, hs, b.fmod + D, b.fmod, fbs, 1e-6f, nl, f32_out ? (int)DT_F32 : dt, B, T, D, s));
+    g = linear(f32_out ? (int)DT_F32 : dt, T, mel, D, nl, D, tw[2], (const float*)tw[3]);
+    g.x3 = 0;                                                  // (N = mel: exact fp32 form whatever the batch — same reason)
     g.batch = B; g.a_bs = (long long)T * D;
     g.out = b.outrow; g.out_f32 = 1; g.out_bs = (long long)T * mel; g.ldo = mel; g.out_cols = mel;
     HVX_CHECK(launch_gemm(g, s));
@@ -393,6 +411,14 @@ int hvx_flow_set_half_stream(hvx_flow* h, int32_t on) {
     if (!h) return set_error("hvx_flow_set_half_stream: null handle"), -1;
     if (on && h->c.dtype != DT_BF16) return set_error("hvx_flow_set_half_stream: the fp16 residual stream belongs to the bf16 mode"), -1;
     h->half_stream = on != 0;
+    return 0;
+}
+
+int hvx_flow_set_f32_small(hvx_flow* h, int32_t on) {
+    if (!h) return set_error("hvx_flow_set_f32_small: null handle"), -1;
+    if (on && h->c.dtype != DT_BF16) return set_error("hvx_flow_set_f32_small: belongs to the bf16 mode"), -1;
+    h->f32_small = on != 0;
+    h->drop_mods();                                     // cached modulation vectors were computed in the other arithmetic
     return 0;
 }
 

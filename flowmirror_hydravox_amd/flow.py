@@ -45,7 +45,7 @@ def euler_schedule(n_timesteps):
 
 
 class HvxFlow:
-    def __init__(self, cfg: FlowConfig, state_dict=None, dtype=torch.bfloat16, device='cuda', max_t=None, half_stream=None, f16_linears=None):
+    def __init__(self, cfg: FlowConfig, state_dict=None, dtype=torch.bfloat16, device='cuda', max_t=None, half_stream=None, f16_linears=None, f32_small=None):
         _lib.require_gpu()
         self.lib = _lib.load()
         self.cfg = cfg
@@ -58,12 +58,18 @@ class HvxFlow:
         if half_stream is None:
             half_stream = os.environ.get('HVX_FLOW_HALF_STREAM', '1') != '0'
         self.half_stream = bool(half_stream) and self.bf16
-        # bf16 mode: the four Linears of every DiT block on IEEE fp16 operands (the reference deploys this decoder as `.half()`): with them the mode sits at
-        # the reference's own fp16 distance from fp32 instead of 3.5x it (tools/dit_rounding_study.py); q / k / v and the attention stay bf16.  Off unless
-        # asked for (f16_linears=True or HVX_FLOW_F16_LINEARS=1); needs dim >= 256, dim and ff multiples of 64.
+        # bf16 mode: the four Linears of every DiT block on IEEE fp16 operands (the reference deploys this decoder as `.half()`); q / k / v and the attention
+        # stay bf16.  Together with f32_small below the mode sits at the reference's own fp16 distance from fp32 instead of 3.5x it (tools/
+        # dit_rounding_study.py, tests/test_gpu_cv3d.py) for 2 % of the flow's time: ON by default where the 256-tile kernel applies (dim >= 256, dim and ff
+        # multiples of 64); f16_linears=False / HVX_FLOW_F16_LINEARS=0 turn it off.
         if f16_linears is None:
-            f16_linears = os.environ.get('HVX_FLOW_F16_LINEARS', '0') == '1'
+            f16_linears = os.environ.get('HVX_FLOW_F16_LINEARS', '1') != '0'
         self.f16_linears = bool(f16_linears) and self.bf16 and cfg.dim >= 256 and cfg.dim % 64 == 0 and (cfg.dim * cfg.ff_mult) % 64 == 0
+        # ... and the small Linears (time MLP, adaLN modulation, input / output projection) in fp32: with fp16 block Linears they carry what is left of the
+        # bf16 mode's distance from fp32.  ON by default (ff >= 2 dim); f32_small=False / HVX_FLOW_F32_SMALL=0 turn it off.
+        if f32_small is None:
+            f32_small = os.environ.get('HVX_FLOW_F32_SMALL', '1') != '0'
+        self.f32_small = bool(f32_small) and self.bf16 and cfg.ff_mult >= 2
         self.token_mel_ratio = cfg.token_mel_ratio
         self.pre_lookahead_len = cfg.pre_lookahead_len
         self.static_chunk_size = cfg.static_chunk_size            # DiT(static_chunk_size=...), dit.py:119,142
@@ -93,6 +99,9 @@ class HvxFlow:
         def mat(t):
             return t.to(dt).contiguous()
 
+        def smat(t):                                       # a small Linear of the estimator: fp32 operands when the handle runs them so
+            return t.float().contiguous() if self.f32_small else t.to(dt).contiguous()
+
         def lmat(t):                                       # a DiT block Linear: fp16 operands when the handle runs them so
             return t.to(torch.float16 if self.f16_linears else dt).contiguous()
 
@@ -105,9 +114,9 @@ class HvxFlow:
               vec(W('spk_embed_affine_layer.bias')),
               mat(conv_weight(W('pre_lookahead_layer.conv1.weight'), melp)), vec(W('pre_lookahead_layer.conv1.bias')),
               mat(conv_weight(W('pre_lookahead_layer.conv2.weight'))), vec(W('pre_lookahead_layer.conv2.bias')),
-              mat(W(e + 'time_embed.time_mlp.0.weight')), vec(W(e + 'time_embed.time_mlp.0.bias')),
-              mat(W(e + 'time_embed.time_mlp.2.weight')), vec(W(e + 'time_embed.time_mlp.2.bias')),
-              mat(linear_weight(W(e + 'input_embed.proj.weight'))), vec(W(e + 'input_embed.proj.bias')),
+              smat(W(e + 'time_embed.time_mlp.0.weight')), vec(W(e + 'time_embed.time_mlp.0.bias')),
+              smat(W(e + 'time_embed.time_mlp.2.weight')), vec(W(e + 'time_embed.time_mlp.2.bias')),
+              smat(linear_weight(W(e + 'input_embed.proj.weight'))), vec(W(e + 'input_embed.proj.bias')),
               mat(grouped_conv_weight(W(e + 'input_embed.conv_pos_embed.conv1.0.weight'), c.conv_groups)),
               vec(W(e + 'input_embed.conv_pos_embed.conv1.0.bias')),
               mat(grouped_conv_weight(W(e + 'input_embed.conv_pos_embed.conv2.0.weight'), c.conv_groups)),
@@ -116,10 +125,10 @@ class HvxFlow:
             p = e + 'transformer_blocks.%d.' % i
             wqkv = torch.cat([W(p + 'attn.to_q.weight'), W(p + 'attn.to_k.weight'), W(p + 'attn.to_v.weight')], 0)
             bqkv = torch.cat([W(p + 'attn.to_q.bias'), W(p + 'attn.to_k.bias'), W(p + 'attn.to_v.bias')], 0)
-            ws += [mat(W(p + 'attn_norm.linear.weight')), vec(W(p + 'attn_norm.linear.bias')), lmat(wqkv), vec(bqkv),
+            ws += [smat(W(p + 'attn_norm.linear.weight')), vec(W(p + 'attn_norm.linear.bias')), lmat(wqkv), vec(bqkv),
                    lmat(W(p + 'attn.to_out.0.weight')), vec(W(p + 'attn.to_out.0.bias')),
                    lmat(W(p + 'ff.ff.0.0.weight')), vec(W(p + 'ff.ff.0.0.bias')), lmat(W(p + 'ff.ff.2.weight')), vec(W(p + 'ff.ff.2.bias'))]
-        ws += [mat(W(e + 'norm_out.linear.weight')), vec(W(e + 'norm_out.linear.bias')), mat(W(e + 'proj_out.weight')), vec(W(e + 'proj_out.bias'))]
+        ws += [smat(W(e + 'norm_out.linear.weight')), vec(W(e + 'norm_out.linear.bias')), smat(W(e + 'proj_out.weight')), vec(W(e + 'proj_out.bias'))]
         return ws
 
     def load_packed(self, ws):
@@ -128,6 +137,8 @@ class HvxFlow:
         self._weights = ws
         if self.bf16 and c.depth > 0:
             self.f16_linears = ws[19 + 2].dtype == torch.float16          # (packed weights say how the block Linears were packed)
+        if self.bf16:
+            self.f32_small = ws[9].dtype == torch.float32
         cc = _lib.FlowConfig(dtype=_lib.dtype_code(dt), vocab=c.vocab, mel=c.mel, spk_dim=c.spk_embed_dim, pla_channels=c.pre_lookahead_channels,
                              pla_len=c.pre_lookahead_len, dim=c.dim, depth=c.depth, heads=c.heads, ff=c.ff, conv_kernel=c.conv_kernel,
                              conv_groups=c.conv_groups, time_freq_dim=c.time_freq_dim, max_t=self.max_t, cfg_rate=c.cfg_rate)
@@ -142,6 +153,7 @@ class HvxFlow:
         check(self.lib.hvx_flow_set_mod_cache(self._h, ptr(self._mod_cache), self._mod_cache.numel()), 'hvx_flow_set_mod_cache')
         check(self.lib.hvx_flow_set_half_stream(self._h, 1 if self.half_stream else 0), 'hvx_flow_set_half_stream')
         check(self.lib.hvx_flow_set_f16_linears(self._h, 1 if self.f16_linears else 0), 'hvx_flow_set_f16_linears')
+        check(self.lib.hvx_flow_set_f32_small(self._h, 1 if self.f32_small else 0), 'hvx_flow_set_f32_small')
         return self
 
     def eval(self):

@@ -239,6 +239,11 @@ int hvx_flow_set_half_stream(hvx_flow* h, int32_t on);
  * have passed THOSE weight matrices (weights[19 + 10 i + {2, 4, 6, 8}]) as fp16 instead of bf16; q / k / v and the attention itself stay bf16.
  * Brings the bf16 mode's distance from the fp32 reference (4.7e-3 of the output scale through 22 blocks) to the reference's own fp16 distance (1.4-1.7e-3). */
 int hvx_flow_set_f16_linears(hvx_flow* h, int32_t on);
+/* bf16 mode only: the SMALL Linears of the estimator — time MLP (weights[9], [11]), every adaLN modulation Linear (weights[19 + 10 i + 0], and
+ * weights[19 + 10 depth + 0]), the input projection (weights[13]) and the output projection (weights[19 + 10 depth + 2]) — run in fp32; the caller must have
+ * passed THOSE matrices as fp32.  Together with hvx_flow_set_f16_linears and the fp16 stream this is the mode that sits at the reference's own fp16 distance
+ * from fp32.  Needs ff >= 2 dim (the fp32 adaLN output of the last layer borrows the FF hidden buffer). */
+int hvx_flow_set_f32_small(hvx_flow* h, int32_t on);
 /* optional persistent device buffer in which hvx_cfm_solve keeps the adaLN modulation vectors of each distinct step time t
  * (they depend on t and the weights only); pass NULL to disable.  Must be re-set after the weights change. */
 int hvx_flow_set_mod_cache(hvx_flow* h, void* buf, size_t bytes);

@@ -67,7 +67,7 @@ def sinus_pos_emb(t, dim, scale=1000.0):
     return torch.cat((e.sin(), e.cos()), dim=-1)
 
 
-def time_embed(t, sd, cfg, pre, emu=False):
+def time_embed(t, sd, cfg, pre, emu=False):   # (callers pass emu=False for the product's f32_small mode)
     h = sinus_pos_emb(t, cfg.time_freq_dim).to(t.dtype)
     h = _lin(h, sd[pre + 'time_embed.time_mlp.0.weight'], sd[pre + 'time_embed.time_mlp.0.bias'], emu)
     return _lin(F.silu(h), sd[pre + 'time_embed.time_mlp.2.weight'], sd[pre + 'time_embed.time_mlp.2.bias'], emu)
@@ -108,10 +108,10 @@ def _sdpa_emu(q, k, v, am):
     return bf16r(torch.matmul(e, v) / e.sum(dim=-1, keepdim=True))
 
 
-def dit_block(x, t_emb, sd, cfg, pre, freqs, key_mask, attn_mask=None, emu=False, resid16=False, lin16=False):
+def dit_block(x, t_emb, sd, cfg, pre, freqs, key_mask, attn_mask=None, emu=False, resid16=False, lin16=False, small32=False):
     B, T, D = x.shape
     H, dh = cfg.heads, cfg.head_dim
-    emb = _lin(F.silu(t_emb), sd[pre + 'attn_norm.linear.weight'], sd[pre + 'attn_norm.linear.bias'], emu)
+    emb = _lin(F.silu(t_emb), sd[pre + 'attn_norm.linear.weight'], sd[pre + 'attn_norm.linear.bias'], emu and not small32)
     sh_a, sc_a, g_a, sh_m, sc_m, g_m = torch.chunk(emb, 6, dim=1)
     n = F.layer_norm(x, (D,), eps=1e-6) * (1 + sc_a[:, None]) + sh_a[:, None]
     q = _lin(n, sd[pre + 'attn.to_q.weight'], sd[pre + 'attn.to_q.bias'], emu, lin16)
@@ -150,7 +150,8 @@ def chunk_attn_mask(key_mask, chunk):
     return am
 
 
-def dit_forward(x, mask, mu, t, spks, cond, sd, cfg, pre='decoder.estimator.', n_blocks=None, taps=None, streaming=False, emu=False, resid16=False, lin16=False):
+def dit_forward(x, mask, mu, t, spks, cond, sd, cfg, pre='decoder.estimator.', n_blocks=None, taps=None, streaming=False, emu=False, resid16=False, lin16=False, small32=False):
+    # small32: the product's f32_small mode — time MLP, adaLN modulation, input and output projection in fp32 (hvx_flow_set_f32_small)
     """Estimator call, TRT argument order (flow_matching.py:126-153): x,mu,cond (B,80,T); mask (B,1,T);
     t (B,); spks (B,80) -> (B,80,T).  streaming=True: static chunk mask of cfg.static_chunk_size frames."""
     x = x.transpose(1, 2)
@@ -159,9 +160,9 @@ def dit_forward(x, mask, mu, t, spks, cond, sd, cfg, pre='decoder.estimator.', n
     B, T, _ = x.shape
     if t.ndim == 0:
         t = t.repeat(B)
-    t_emb = time_embed(t, sd, cfg, pre, emu)
+    t_emb = time_embed(t, sd, cfg, pre, emu and not small32)
     h = torch.cat([x, cond, mu, spks[:, None, :].expand(B, T, spks.shape[-1])], dim=-1)
-    h = _lin(h, sd[pre + 'input_embed.proj.weight'], sd[pre + 'input_embed.proj.bias'], emu)
+    h = _lin(h, sd[pre + 'input_embed.proj.weight'], sd[pre + 'input_embed.proj.bias'], emu and not small32)
     h = _h(causal_conv_pos_embed(h, sd, cfg, pre + 'input_embed.conv_pos_embed.', emu) + h, resid16)
     if taps is not None:
         taps['input_embed'] = h.clone()
@@ -170,13 +171,13 @@ def dit_forward(x, mask, mu, t, spks, cond, sd, cfg, pre='decoder.estimator.', n
     nb = cfg.depth if n_blocks is None else n_blocks
     attn_mask = chunk_attn_mask(key_mask, cfg.static_chunk_size) if streaming else None
     for i in range(nb):
-        h = dit_block(h, t_emb, sd, cfg, pre + 'transformer_blocks.%d.' % i, freqs, key_mask, attn_mask, emu, resid16, lin16)
+        h = dit_block(h, t_emb, sd, cfg, pre + 'transformer_blocks.%d.' % i, freqs, key_mask, attn_mask, emu, resid16, lin16, small32)
         if taps is not None:
             taps['block%d' % i] = h.clone()
-    emb = _lin(F.silu(t_emb), sd[pre + 'norm_out.linear.weight'], sd[pre + 'norm_out.linear.bias'], emu)
+    emb = _lin(F.silu(t_emb), sd[pre + 'norm_out.linear.weight'], sd[pre + 'norm_out.linear.bias'], emu and not small32)
     scale, shift = torch.chunk(emb, 2, dim=1)
     h = F.layer_norm(h, (h.shape[-1],), eps=1e-6) * (1 + scale)[:, None, :] + shift[:, None, :]
-    return _lin(h, sd[pre + 'proj_out.weight'], sd[pre + 'proj_out.bias'], emu).transpose(1, 2)
+    return _lin(h, sd[pre + 'proj_out.weight'], sd[pre + 'proj_out.bias'], emu and not small32).transpose(1, 2)
 
 
 def cosine_t_span(n_timesteps, dtype=torch.float32):
@@ -221,7 +222,7 @@ def solve_euler(x, t_span, mu, mask, spks, cond, estimator, cfg_rate):
     return traj[-1].float(), traj
 
 
-def cfm_forward(mu, mask, spks, cond, sd, cfg, noise=None, estimator=None, n_timesteps=None, streaming=False, emu=False, resid16=False, lin16=False):
+def cfm_forward(mu, mask, spks, cond, sd, cfg, noise=None, estimator=None, n_timesteps=None, streaming=False, emu=False, resid16=False, lin16=False, small32=False):
     """CausalConditionalCFM.forward (flow_matching.py:204-228)."""
     noise = cfm_noise(cfg) if noise is None else noise
     z = noise[:, :, :mu.size(2)].to(mu.dtype)
@@ -229,12 +230,12 @@ def cfm_forward(mu, mask, spks, cond, sd, cfg, noise=None, estimator=None, n_tim
     t_span = cosine_t_span(n, mu.dtype)
     if estimator is None:
         def estimator(x, m, mu_, t, s, c):
-            return dit_forward(x, m, mu_, t, s, c, sd, cfg, streaming=streaming, emu=emu, resid16=resid16, lin16=lin16)
+            return dit_forward(x, m, mu_, t, s, c, sd, cfg, streaming=streaming, emu=emu, resid16=resid16, lin16=lin16, small32=small32)
     out, _ = solve_euler(z, t_span, mu, mask, spks, cond, estimator, cfg.cfg_rate)
     return out
 
 
-def flow_inference(token, embedding, sd, cfg, prompt_token=None, prompt_feat=None, noise=None, finalize=True, streaming=False, emu=False, resid16=False, lin16=False):
+def flow_inference(token, embedding, sd, cfg, prompt_token=None, prompt_feat=None, noise=None, finalize=True, streaming=False, emu=False, resid16=False, lin16=False, small32=False):
     """flow.py:367-430, fp32; finalize=False: the last pre_lookahead_len tokens are look-ahead context only.
     token (1,N) int, embedding (1,192), prompt_token (1,Np) int, prompt_feat (1,Tp,80) -> mel (1,80,2N)."""
     emb = F.normalize(embedding.float(), dim=1)
@@ -251,5 +252,5 @@ def flow_inference(token, embedding, sd, cfg, prompt_token=None, prompt_feat=Non
     if prompt_feat is not None:
         cond[:, :mel_len1] = prompt_feat
     mask = torch.ones(1, 1, T)
-    feat = cfm_forward(h.transpose(1, 2).contiguous(), mask, emb, cond.transpose(1, 2), sd, cfg, noise=noise, streaming=streaming, emu=emu, resid16=resid16, lin16=lin16)
+    feat = cfm_forward(h.transpose(1, 2).contiguous(), mask, emb, cond.transpose(1, 2), sd, cfg, noise=noise, streaming=streaming, emu=emu, resid16=resid16, lin16=lin16, small32=small32)
     return feat[:, :, mel_len1:].float()

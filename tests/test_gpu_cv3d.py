@@ -180,7 +180,8 @@ def test_flow_22_blocks_vs_reference_and_bf16_oracle(cfg, flow_setup, dtype):
     from oracle import flow_ref
     g, sd = flow_setup
     c = cfg.flow
-    flow = HvxFlow(c, sd, dtype=dtype, max_t=512)
+    # (the historical bf16 mode: bf16 operands everywhere + fp16 stream; the default handle adds fp16 block Linears and fp32 small Linears, tested below)
+    flow = HvxFlow(c, sd, dtype=dtype, max_t=512, f16_linears=False, f32_small=False)
     for tag in ('e0', 'e1'):
         T, lens, streaming = int(g[tag + '_T']), g[tag + '_lens'].tolist(), bool(g[tag + '_streaming'])
         x, mask, mu, spk, cond = cv3w_flow_inputs(int(g[tag + '_seed']), T, lens)
@@ -232,8 +233,8 @@ def test_flow_22_blocks_fp16_linear_operands(cfg, flow_setup):
     from oracle import flow_ref
     g, sd = flow_setup
     c = cfg.flow
-    flow = HvxFlow(c, sd, dtype=torch.bfloat16, max_t=512, f16_linears=True)
-    assert flow.f16_linears and flow.half_stream
+    flow = HvxFlow(c, sd, dtype=torch.bfloat16, max_t=512, f16_linears=True, f32_small=False)
+    assert flow.f16_linears and flow.half_stream and not flow.f32_small
     h = load_golden('flow_half.npz')
     e_half = float(h['d_half_vs_f32'])
     for tag in ('e0', 'e1'):
@@ -257,4 +258,39 @@ def test_flow_22_blocks_fp16_linear_operands(cfg, flow_setup):
     e = _rel(mel.cpu().numpy(), g['mel'])
     print('22 blocks, fp16 Linear operands, 10-step mel: %.2e of the fp32 reference' % e)
     assert e < 5e-3, e
+
+
+def test_flow_22_blocks_reference_precision_mode(cfg, flow_setup):
+    """bf16 mode + fp16 stream + fp16 block Linears + fp32 small Linears (HvxFlow(f16_linears=True, f32_small=True)): the configuration the host study
+    (tools/dit_rounding_study.py) puts at the reference's OWN fp16 distance from fp32.  Estimators against the faithful oracle with the same rounding
+    points and against the fp32 reference — held to 1.6x the distance of the reference's own fp16 run of the same case (tests/golden/flow_half.npz) — and
+    the 10-step mel with a prompt."""
+    from flowmirror_hydravox_amd.flow import HvxFlow
+    from oracle import flow_ref
+    g, sd = flow_setup
+    c = cfg.flow
+    flow = HvxFlow(c, sd, dtype=torch.bfloat16, max_t=512)                      # the default bf16 handle
+    assert flow.f16_linears and flow.f32_small and flow.half_stream
+    e_half = float(load_golden('flow_half.npz')['d_half_vs_f32'])
+    for tag in ('e0', 'e1'):
+        T, lens, streaming = int(g[tag + '_T']), g[tag + '_lens'].tolist(), bool(g[tag + '_streaming'])
+        x, mask, mu, spk, cond = cv3w_flow_inputs(int(g[tag + '_seed']), T, lens)
+        t = torch.from_numpy(g[tag + '_t'])
+        est = (flow.estimator(x, mask, mu, t, spk, cond, streaming=streaming).cpu() * mask).numpy()
+        e_ref = _rel(est, g[tag + '_out'])
+        if tag == 'e1':
+            emu = (flow_ref.dit_forward(x, mask, mu, t, spk, cond, sd, c, streaming=streaming, emu=True, resid16=True, lin16=True, small32=True) * mask).numpy()
+            e_emu = _rel(est, emu)
+            print('22 blocks, reference-precision mode, %s estimator: %.2e of the faithful oracle, %.2e of the fp32 reference (the reference in fp16: %.2e)' % (tag, e_emu, e_ref, e_half))
+            assert e_emu < 5e-3 and e_ref < 1.6 * e_half, (e_emu, e_ref, e_half)
+        else:
+            print('22 blocks, reference-precision mode, %s estimator: %.2e of the fp32 reference' % (tag, e_ref))
+            assert e_ref < 3e-3, e_ref
+    token, ptoken, pfeat, emb = (torch.from_numpy(g[k]) for k in ('token', 'ptoken', 'pfeat', 'emb'))
+    mel, _ = flow.inference(token=token.to(DEV), token_len=torch.tensor([token.shape[1]], dtype=torch.int32), embedding=emb.to(DEV), finalize=True,
+                            prompt_token=ptoken.to(DEV), prompt_token_len=torch.tensor([ptoken.shape[1]], dtype=torch.int32),
+                            prompt_feat=pfeat.to(DEV), prompt_feat_len=torch.tensor([pfeat.shape[1]], dtype=torch.int32))
+    e = _rel(mel.cpu().numpy(), g['mel'])
+    print('22 blocks, reference-precision mode, 10-step mel: %.2e of the fp32 reference' % e)
+    assert e < 2.5e-3, e
 

@@ -254,7 +254,7 @@ def test_flow_estimator_vs_reference_and_bf16_oracle(cfg, flow_setup, dtype):
         if dtype == torch.float32:
             assert e_ref < 1e-3, (tag, e_ref)
         else:
-            emu = (flow_ref.dit_forward(x, mask, mu, t, spk, cond, sd, c, streaming=streaming, emu=True, resid16=True) * mask).numpy()
+            emu = (flow_ref.dit_forward(x, mask, mu, t, spk, cond, sd, c, streaming=streaming, emu=True, resid16=flow.half_stream, lin16=flow.f16_linears, small32=flow.f32_small) * mask).numpy()
             e_emu = _rel(est, emu)
             print('%s bf16 estimator: %.2e of the bf16-faithful oracle, %.2e of the fp32 reference' % (tag, e_emu, e_ref))
             assert e_emu < 2e-2, (tag, e_emu, e_ref)
@@ -281,7 +281,7 @@ def test_flow_inference_vs_reference_and_bf16_oracle(cfg, flow_setup, dtype):
         assert _rel(mel.cpu().numpy(), g['mel']) < 1e-3, _rel(mel.cpu().numpy(), g['mel'])
     else:
         o_pla = flow_ref.pre_lookahead(torch.from_numpy(g['h0']), sd, c, emu=True)[0].numpy()
-        o_mel = flow_ref.flow_inference(token, emb, sd, c, prompt_token=ptoken, prompt_feat=pfeat, emu=True, resid16=True).numpy()
+        o_mel = flow_ref.flow_inference(token, emb, sd, c, prompt_token=ptoken, prompt_feat=pfeat, emu=True, resid16=flow.half_stream, lin16=flow.f16_linears, small32=flow.f32_small).numpy()
         e = [_rel(pla, o_pla), _rel(mel.cpu().numpy(), o_mel), _rel(mel.cpu().numpy(), g['mel'])]
         print('bf16 flow: pre-lookahead %.2e, mel %.2e of the bf16-faithful oracle; mel %.2e of the fp32 reference' % tuple(e))
         assert e[0] < 1e-2 and e[1] < 2e-2, e

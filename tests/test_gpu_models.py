@@ -309,9 +309,9 @@ def test_flow_stages_vs_reference(tiny_cfg, flow_setup, dtype, tol):
             # production dtype: against the bf16-faithful oracle (same rounding points), 2e-2 for the estimator and the 10-step mel
             from oracle import flow_ref
             o_est = flow_ref.dit_forward(torch.from_numpy(g[p + 'est_x']), torch.ones(2, 1, T), torch.from_numpy(g[p + 'est_mu']), torch.from_numpy(g[p + 'est_t']),
-                                         torch.from_numpy(g[p + 'est_spk']), torch.from_numpy(g[p + 'est_cond']), sd, tiny_cfg.flow, emu=True, resid16=True)
+                                         torch.from_numpy(g[p + 'est_spk']), torch.from_numpy(g[p + 'est_cond']), sd, tiny_cfg.flow, emu=True, resid16=flow.half_stream, lin16=flow.f16_linears, small32=flow.f32_small)
             o_mel = flow_ref.flow_inference(token, torch.from_numpy(g[p + 'emb']), sd, tiny_cfg.flow, prompt_token=ptoken if has_p else None,
-                                            prompt_feat=torch.from_numpy(g[p + 'pfeat']) if has_p else None, emu=True, resid16=True)
+                                            prompt_feat=torch.from_numpy(g[p + 'pfeat']) if has_p else None, emu=True, resid16=flow.half_stream, lin16=flow.f16_linears, small32=flow.f32_small)
             e = [_rel(est.cpu().numpy(), o_est.numpy()), _rel(mel.cpu().numpy(), o_mel.numpy()), _rel(mel.cpu().numpy(), g[p + 'mel'])]
             print('bf16 flow run %d: estimator %.2e, mel %.2e of the bf16-faithful oracle; mel %.2e of the fp32 reference' % (r, *e))
             assert e[0] < 2e-2 and e[1] < 2e-2, (r, e)
@@ -334,7 +334,7 @@ def test_flow_bf16_residual_stream_fp16_vs_fp32(tiny_cfg, flow_setup):
         flow = HvxFlow(tiny_cfg.flow, sd, dtype=torch.bfloat16, max_t=512, half_stream=hs)
         assert flow.half_stream is hs
         est[hs] = flow.estimator(*args).cpu().numpy()
-        o = flow_ref.dit_forward(*args, sd, tiny_cfg.flow, emu=True, resid16=hs).numpy()
+        o = flow_ref.dit_forward(*args, sd, tiny_cfg.flow, emu=True, resid16=hs, lin16=flow.f16_linears, small32=flow.f32_small).numpy()
         assert _rel(est[hs], o) < 2e-2, (hs, _rel(est[hs], o))
     d = _rel(est[True], est[False])
     print('bf16 estimator, fp16 vs fp32 residual stream: %.2e of the output scale' % d)
