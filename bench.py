@@ -524,6 +524,10 @@ def main():
                                 'serial': 'stages back to back'}[args.mode],
                    'utterances_in_flight_per_gpu': in_flight,
                    'cu_partition': ('decode engine on %d CUs, acoustic stage on the other %d' % (args.lm_cus, lib.hvx_device_ok() - args.lm_cus)) if args.lm_cus > 0 and args.mode == 'continuous' else ('decode engine confined to %d CUs, acoustic stage on all' % args.lm_cus_only) if args.lm_cus_only > 0 and args.mode == 'continuous' else 'none (both stages share all CUs)',
+                   'flow_arithmetic': ('bf16 attention operands; fp16 residual stream%s%s' % (
+                       ', fp16 block Linear operands' if getattr(pipe.flow, 'f16_linears', False) else ', bf16 block Linear operands',
+                       ', fp32 time MLP / adaLN modulation / input + output projection (the reference deploys this decoder in fp16: this mode sits at its fp16 run\'s distance from fp32, tests/test_gpu_cv3d.py)'
+                       if getattr(pipe.flow, 'f32_small', False) else ', bf16 small Linears')) if getattr(pipe.flow, 'half_stream', False) else 'bf16 operands, fp32 residual stream',
                    'sampling': {'top_p': 0.9, 'top_k': 10, 'win_size': 32, 'tau_r': 0.2}},
         'rtf': round(elapsed / audio, 6) if audio else None,
         'llm_tokens_per_s': round(tokens / llm_s, 2) if llm_s else None,

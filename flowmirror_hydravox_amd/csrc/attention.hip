@@ -22,12 +22,6 @@
 
 namespace hvx {
 
-// the attention output in `T`, or — bf16 operands, AttnArgs.out_f16 — as IEEE fp16 (same element size, same addressing)
-template <class T> __device__ __forceinline__ void store_out(T* p, float v, int f16) {
-    if (sizeof(T) == 2 && f16) *reinterpret_cast<f16_t*>(p) = f32_to_f16_sat(v);
-    else *p = from_f32<T>(v);
-}
-
 __device__ __forceinline__ bf16x4 load4(const bf16_t* p) { return *reinterpret_cast<const bf16x4*>(p); }
 __device__ __forceinline__ f32x4 load4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
@@ -259,7 +253,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) store_out(op + dt * 16 + fg * 4 + e, o_acc[i][dt][e] * inv, a.out_f16);
+                for (int e = 0; e < 4; ++e) op[dt * 16 + fg * 4 + e] = from_f32<T>(o_acc[i][dt][e] * inv);
         } else {
             const long long base = (((long long)b * a.heads + h) * a.n_splits + sp) * a.n_rows_pad + r;
             float* po = a.part_o + base * 64;
@@ -320,7 +314,7 @@ __global__ void attn_combine_kernel(AttnArgs a) {
         m = mb;
     }
     T* op = reinterpret_cast<T*>(a.out) + (long long)b * a.o_bs + (long long)h * a.o_hs + (long long)rh * a.o_hi + (long long)rl * a.o_lo;
-    store_out(op + d, l > 0.0f ? acc / l : 0.0f, a.out_f16);
+    op[d] = from_f32<T>(l > 0.0f ? acc / l : 0.0f);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -691,17 +685,10 @@ __global__ __launch_bounds__(256, 2) void attn_dit_kernel(AttnArgs a) {
         T* op = reinterpret_cast<T*>(a.out) + (long long)b * a.o_bs + (long long)h * a.o_hs + (long long)r * a.o_lo;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-            if (a.out_f16) {
-                f16x4 h4;
+            bf16x4 o4;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) h4[e] = f32_to_f16_sat(o_acc[i][dt][e] * inv);
-                *reinterpret_cast<f16x4*>(op + dt * 16 + fg * 4) = h4;
-            } else {
-                bf16x4 o4;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o4[e] = f32_to_bf16(o_acc[i][dt][e] * inv);
-                *reinterpret_cast<bf16x4*>(op + dt * 16 + fg * 4) = o4;
-            }
+            for (int e = 0; e < 4; ++e) o4[e] = f32_to_bf16(o_acc[i][dt][e] * inv);
+            *reinterpret_cast<bf16x4*>(op + dt * 16 + fg * 4) = o4;
         }
     }
 }

@@ -33,7 +33,7 @@ struct hvx_flow {
     int mod_slots = 0;
     bool half_stream = false;          // residual stream of the DiT blocks stored as fp16 (bf16 mode only)
     bool f32_small = false;            // time MLP, adaLN modulation Linears, input and output projection in fp32 (their weights were packed as fp32): bf16 mode only
-    bool f16_linears = false;          // the four Linears of every DiT block take IEEE fp16 operands (their weights were packed as fp16): bf16 mode only
+    bool f16_linears = false;          // QKV, FF1 and FF2 of every DiT block take IEEE fp16 operands (their weights were packed as fp16): bf16 mode only
     struct ModSlot {
         float t;
         hipStream_t s;
@@ -267,7 +267,8 @@ int estimator_core(const hvx_flow* h, hipStream_t s, EstBufs& b, int B, int T, c
     }
 
     // ---- DiT blocks ---------------------------------------------------------------------------------------------------
-    // operand type of the four Linears of a block (and of the activations that feed them: adaLN outputs, attention output, FF hidden)
+    // operand type of the QKV / FF1 / FF2 Linears of a block (and of the activations that feed them: adaLN outputs, FF hidden); the attention and the
+    // Linear behind it stay bf16
     const int ldt = (h->f16_linears && dt == DT_BF16) ? DT_F16 : dt;
     HIP_OK(hipMemsetAsync(b.vT, 0, (size_t)B * H * Tp * 64 * es, s));       // padded key columns must be finite
     for (int i = 0; i < c.depth; ++i) {
@@ -286,9 +287,9 @@ int estimator_core(const hvx_flow* h, hipStream_t s, EstBufs& b, int B, int T, c
         at.k = b.k; at.k_bs = at.q_bs; at.k_hs = at.q_hs;
         at.vT = b.vT; at.v_bs = at.q_bs; at.v_hs = (long long)64 * Tp; at.v_ld = Tp;
         at.kv_len = kv_len; at.kv_len_const = T; at.causal = 0; at.chunk = chunk; at.scale = 0.125f; at.q_log2 = 1;
-        at.out = b.att; at.o_bs = (long long)T * D; at.o_hs = 64; at.o_lo = D; at.n_splits = 1; at.out_f16 = ldt == DT_F16;
+        at.out = b.att; at.o_bs = (long long)T * D; at.o_hs = 64; at.o_lo = D; at.n_splits = 1;
         HVX_CHECK(launch_attention(at, s));
-        g = linear(ldt, T, D, D, b.att, D, bw[4], (const float*)bw[5]);
+        g = linear(dt, T, D, D, b.att, D, bw[4], (const float*)bw[5]);      // (bf16 operands: the attention writes bf16, which is exact in fp16 — fp16 weights here change nothing)
         g.batch = B; g.a_bs = (long long)T * D;
         g.gate = mod + 2 * D; g.gate_bs = mbs; g.res = static_cast<const float*>(xs); g.res_f16 = hs; g.res_bs = (long long)T * D; g.ldres = D;
         g.out = xs; g.out_f32 = hs ? 0 : 1; g.out_f16 = hs; g.out_bs = (long long)T * D; g.ldo = D; g.out_cols = D;

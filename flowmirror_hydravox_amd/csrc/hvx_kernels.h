@@ -133,7 +133,6 @@ struct AttnArgs {
     float scale;
     int q_log2;                   // q already multiplied by scale * log2(e) (fused QKV epilogue, GemmArgs.q_scale): scale is ignored
     void* out; long long o_bs, o_hs, o_hi, o_lo;      // dtype
-    int out_f16;                  // bf16 operands only: the output is written as IEEE fp16 (it feeds an fp16-operand Linear, DT_F16)
     int n_splits; int split_chunk;                    // keys per split (multiple of 32) when n_splits > 1
     int sub_chunk;                                    // > 0 (needs n_rows <= 32): one workgroup per split, its 4 waves take sub_chunk keys
                                                       // each and merge their (m, l, o) in LDS, so the combine reads 4x fewer partials

@@ -126,7 +126,7 @@ class HvxFlow:
             wqkv = torch.cat([W(p + 'attn.to_q.weight'), W(p + 'attn.to_k.weight'), W(p + 'attn.to_v.weight')], 0)
             bqkv = torch.cat([W(p + 'attn.to_q.bias'), W(p + 'attn.to_k.bias'), W(p + 'attn.to_v.bias')], 0)
             ws += [smat(W(p + 'attn_norm.linear.weight')), vec(W(p + 'attn_norm.linear.bias')), lmat(wqkv), vec(bqkv),
-                   lmat(W(p + 'attn.to_out.0.weight')), vec(W(p + 'attn.to_out.0.bias')),
+                   mat(W(p + 'attn.to_out.0.weight')), vec(W(p + 'attn.to_out.0.bias')),
                    lmat(W(p + 'ff.ff.0.0.weight')), vec(W(p + 'ff.ff.0.0.bias')), lmat(W(p + 'ff.ff.2.weight')), vec(W(p + 'ff.ff.2.bias'))]
         ws += [smat(W(e + 'norm_out.linear.weight')), vec(W(e + 'norm_out.linear.bias')), smat(W(e + 'proj_out.weight')), vec(W(e + 'proj_out.bias'))]
         return ws

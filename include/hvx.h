@@ -234,9 +234,10 @@ int hvx_cfm_estimator_streaming(hvx_flow* h, hvx_stream s, void* ws, size_t ws_b
  * gate * (Linear + bias) + x is still formed in fp32 and rounded once (saturating at +-65504).  Halves the HBM traffic of the two residual Linears and of the adaLN
  * passes of every block.  Off by default at the C level; the Python host turns it on for bf16 handles (HvxFlow(half_stream=True)). */
 int hvx_flow_set_half_stream(hvx_flow* h, int32_t on);
-/* bf16 mode only: the four Linears of every DiT block (QKV, attention out, FF1, FF2) take IEEE fp16 operands — the reference's deployed dtype
- * (infer_speech_model.py:103) — and the activations that feed them (adaLN outputs, attention output, FF hidden) are stored as fp16.  The caller must
- * have passed THOSE weight matrices (weights[19 + 10 i + {2, 4, 6, 8}]) as fp16 instead of bf16; q / k / v and the attention itself stay bf16.
+/* bf16 mode only: the QKV, FF1 and FF2 Linears of every DiT block take IEEE fp16 operands — the reference's deployed dtype
+ * (infer_speech_model.py:103) — and the activations that feed them (adaLN outputs, FF hidden) are stored as fp16.  The caller must have passed THOSE
+ * weight matrices (weights[19 + 10 i + {2, 6, 8}]) as fp16 instead of bf16; q / k / v, the attention and the Linear behind it stay bf16 (its input is
+ * the attention's bf16 output, exact in fp16: fp16 weights there measured no different).
  * Brings the bf16 mode's distance from the fp32 reference (4.7e-3 of the output scale through 22 blocks) to the reference's own fp16 distance (1.4-1.7e-3). */
 int hvx_flow_set_f16_linears(hvx_flow* h, int32_t on);
 /* bf16 mode only: the SMALL Linears of the estimator — time MLP (weights[9], [11]), every adaLN modulation Linear (weights[19 + 10 i + 0], and

@@ -130,7 +130,7 @@ def dit_block(x, t_emb, sd, cfg, pre, freqs, key_mask, attn_mask=None, emu=False
     else:
         a = F.scaled_dot_product_attention(q, k, v, attn_mask=am, dropout_p=0.0, is_causal=False)
     a = a.transpose(1, 2).reshape(B, T, H * dh)
-    a = _lin(a, sd[pre + 'attn.to_out.0.weight'], sd[pre + 'attn.to_out.0.bias'], emu, lin16)
+    a = _lin(a, sd[pre + 'attn.to_out.0.weight'], sd[pre + 'attn.to_out.0.bias'], emu)          # (stays bf16 in the product: its input is the attention's bf16 output)
     a = a.masked_fill(~key_mask[:, :, None], 0.0)                 # mask[:, 0, -1] row == pad mask (modules.py:400-405)
     x = _h(x + g_a.unsqueeze(1) * a, resid16)
     f = F.layer_norm(x, (D,), eps=1e-6) * (1 + sc_m[:, None]) + sh_m[:, None]
