@@ -146,7 +146,7 @@ def roofline_of(name, p):
              launches_per_timed_region=p['launches'], sampled_launches=p['sampled'])
     if name.endswith('f32'):
         d['peak_note'] = 'fp32-equivalent flops of the convolution; every step is 3 bf16 MFMAs on (hi, lo) operand pairs, so the peak is the dense bf16 peak / 3'
-        d['includes'] = 'every split-bf16 GEMM launch of the timed region: the vocoder convolutions and, in the flow\'s reference-precision mode, its fp32 input projection (2 per estimator call of the first Euler step batch: ~5 % of the launches)'
+        d['includes'] = 'every split-bf16 GEMM launch of the timed region: the vocoder convolutions and, in the flow\'s reference-precision mode, the fp32 input projection of its estimator calls'
     return d
 
 
