@@ -22,7 +22,10 @@ import torch.nn.functional as F
 
 # bf16-faithful mode (`emu=True`, see oracle/llm_ref.py): every GEMM / conv / attention operand rounded to bf16 where the product's bf16
 # path holds it in bf16 (weights, adaLN-modulated rows, q / k / v, probabilities, GELU / Mish / LeakyReLU outputs that feed the next
-# GEMM), fp32 accumulation, fp32 residual stream, fp32 Euler state (csrc/hvx_flow.hip).
+# GEMM), fp32 accumulation, fp32 residual stream, fp32 Euler state (csrc/hvx_flow.hip).  Three switches follow the product's bf16-mode options:
+#   resid16  the DiT's residual stream rounded to IEEE fp16 after every residual add          (hvx_flow_set_half_stream; default on)
+#   lin16    QKV / FF1 / FF2 of every block on fp16 operands instead of bf16                   (hvx_flow_set_f16_linears; default on)
+#   small32  time MLP, adaLN modulation Linears, input and output projection left in fp32      (hvx_flow_set_f32_small;   default on)
 def bf16r(t):
     return t.to(torch.bfloat16).float()
 
