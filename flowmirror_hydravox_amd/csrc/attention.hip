@@ -31,7 +31,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float fmax2(float a, float b) { return __builtin_fmaxf(a, b); }
 __device__ __forceinline__ float fmax3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 
-template <class T, int QT, bool MERGE>
+// KVF: K / V^T are the LLM's fragment-order caches — every operand fragment is ONE contiguous load (1 KiB per wave instruction at bf16) instead of
+// 16 key rows x 64 B (K) or 64 channel rows x 8 B twice (V^T)
+template <class T, int QT, bool MERGE, bool KVF>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     typedef typename Vec8<T>::type V8;
     typedef typename Vec4<T>::type V4;
@@ -118,6 +120,19 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         for (int ks = 0; ks < KS; ++ks) {
             // a step that starts past the end (only the second of a trip can) re-reads the first one and is skipped below
             const int kbase = (key0 + 32 * ks < key_end) ? key0 + 32 * ks : key0;
+            if constexpr (KVF) {
+                // (a step may reach up to 31 keys past kv_len: the cache holds them — capacity is a multiple of 32 — and their scores are masked)
+                const T* kp = kb + (long long)(kbase >> 4) * 1024 + lane * 8;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) {
+                    kf[ks][kt][0] = load8(kp + kt * 1024);
+                    kf[ks][kt][1] = load8(kp + kt * 1024 + 512);
+                }
+                const T* vp = vb + (long long)(kbase >> 5) * 2048 + lane * 8;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) vf[ks][dt] = load8(vp + dt * 512);
+                continue;
+            }
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) {
                 int key = kbase + kt * 16 + fr;
@@ -248,8 +263,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         const int rh = r / a.kn;
         if (a.n_splits == 1) {
             const float inv = l > 0.0f ? 1.0f / l : 0.0f;
-            T* op = reinterpret_cast<T*>(a.out) + (long long)b * a.o_bs + (long long)h * a.o_hs + (long long)rh * a.o_hi +
-                    (long long)r_lo[i] * a.o_lo;
+            const long long off = (long long)b * a.o_bs + (long long)h * a.o_hs + (long long)rh * a.o_hi + (long long)r_lo[i] * a.o_lo;
+            T* op = reinterpret_cast<T*>(a.out) + off;
+            if (a.o_frag_kt > 0) {                            // fragment-order activation matrix (the o_proj of a wide decode grid reads it)
+                const int ncol = a.o_frag_kt * 32, orow = (int)(off / ncol), ocol = (int)(off - (long long)orow * ncol);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        reinterpret_cast<T*>(a.out)[frag_index(orow, ocol + dt * 16 + fg * 4 + e, a.o_frag_kt)] = from_f32<T>(o_acc[i][dt][e] * inv);
+                continue;
+            }
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
@@ -313,7 +337,12 @@ __global__ void attn_combine_kernel(AttnArgs a) {
         }
         m = mb;
     }
-    T* op = reinterpret_cast<T*>(a.out) + (long long)b * a.o_bs + (long long)h * a.o_hs + (long long)rh * a.o_hi + (long long)rl * a.o_lo;
+    const long long off = (long long)b * a.o_bs + (long long)h * a.o_hs + (long long)rh * a.o_hi + (long long)rl * a.o_lo;
+    T* op = reinterpret_cast<T*>(a.out) + off;
+    if (a.o_frag_kt > 0) {                                    // fragment-order activation matrix (the o_proj of a wide decode grid reads it)
+        const int ncol = a.o_frag_kt * 32, orow = (int)(off / ncol), ocol = (int)(off - (long long)orow * ncol);
+        op = reinterpret_cast<T*>(a.out) + frag_index(orow, ocol + d, a.o_frag_kt) - d;
+    }
     op[d] = from_f32<T>(l > 0.0f ? acc / l : 0.0f);
 }
 
@@ -730,10 +759,15 @@ static int launch_t(const AttnArgs& a_in, hipStream_t s) {
     // QK^T + PV flops when the key length is known on the host (DiT); 0 for the device-length LLM calls
     const double flops = a.kv_len ? 0.0 : 4.0 * a.n_rows * (double)a.kv_len_const * 64.0 * a.heads * a.batch * (a.causal ? 0.5 : 1.0);
     const int slot = prof_begin(a.kv_len ? PK_ATTN_LLM : PK_ATTN, flops, s);
-    if (merge && a.n_rows > 16) hipLaunchKernelGGL((attn_fwd_kernel<T, 2, true>), grid, dim3(256), 0, s, a);      // decode, 17..32 rows (K = 3, 4)
-    else if (merge) hipLaunchKernelGGL((attn_fwd_kernel<T, 1, true>), grid, dim3(256), 0, s, a);
-    else if (big) hipLaunchKernelGGL((attn_fwd_kernel<T, 2, false>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((attn_fwd_kernel<T, 1, false>), grid, dim3(256), 0, s, a);
+    if (a.kv_frag) {
+        if (merge && a.n_rows > 16) hipLaunchKernelGGL((attn_fwd_kernel<T, 2, true, true>), grid, dim3(256), 0, s, a);      // decode, 17..32 rows (K = 3, 4)
+        else if (merge) hipLaunchKernelGGL((attn_fwd_kernel<T, 1, true, true>), grid, dim3(256), 0, s, a);
+        else if (big) hipLaunchKernelGGL((attn_fwd_kernel<T, 2, false, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((attn_fwd_kernel<T, 1, false, true>), grid, dim3(256), 0, s, a);
+    } else if (merge && a.n_rows > 16) hipLaunchKernelGGL((attn_fwd_kernel<T, 2, true, false>), grid, dim3(256), 0, s, a);
+    else if (merge) hipLaunchKernelGGL((attn_fwd_kernel<T, 1, true, false>), grid, dim3(256), 0, s, a);
+    else if (big) hipLaunchKernelGGL((attn_fwd_kernel<T, 2, false, false>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<T, 1, false, false>), grid, dim3(256), 0, s, a);
     if (a.n_splits > 1) {
         dim3 g2((a.n_rows + 3) / 4, a.heads, a.batch);
         hipLaunchKernelGGL((attn_combine_kernel<T>), g2, dim3(256), 0, s, a);
@@ -749,6 +783,8 @@ int launch_attention(const AttnArgs& a_in, hipStream_t s) {
 
     if (a.kn < 1) a.kn = a.n_rows;
     if (a.n_splits == 1 || a.n_rows > 32 || a.sub_chunk * 4 != a.split_chunk || (a.sub_chunk & 31)) a.sub_chunk = 0;
+    if (a.kv_frag && (a.chunk > 0 || !a.causal)) return set_error("launch_attention: fragment-order caches serve the causal LLM calls only"), -1;
+    if (a.o_frag_kt > 0 && a.dtype == DT_F32) return set_error("launch_attention: fragment-order output is 16-bit only"), -1;
     if ((a.v_ld & 31) || (a.n_splits > 1 && ((a.split_chunk & 31) || !a.part_o || !a.part_ml || a.n_rows_pad < a.n_rows))) {
         set_error("launch_attention: bad geometry v_ld=%d split_chunk=%d", a.v_ld, a.split_chunk);
         return -1;

@@ -40,7 +40,8 @@ __global__ __launch_bounds__(256) void reduce_rmsnorm_kernel(ReduceNormArgs a) {
     if (part && (H & 3) == 0 && (a.part_stride & 3) == 0 && (a.ldx & 3) == 0) {
         // plain copy (no statistics needed): y leaves from the registers that hold the new x — no barrier, no re-read of x through memory
         const bool y_inline = a.y && !a.do_norm && (a.ldy & 3) == 0;
-        T* const yr = reinterpret_cast<T*>(a.y) + (long long)m * a.ldy;
+        const int KTy = H >> 5;
+        T* const yr = reinterpret_cast<T*>(a.y) + (a.y_frag ? 0 : (long long)m * a.ldy);
         y_done = y_inline;
         // 16-byte columns, all split partials of a column in flight at once (the loads are independent; only the adds are ordered)
         for (int c = threadIdx.x * 4; c < H; c += 1024) {
@@ -59,7 +60,8 @@ __global__ __launch_bounds__(256) void reduce_rmsnorm_kernel(ReduceNormArgs a) {
             if (bias) v += *reinterpret_cast<const f32x4*>(bias + c);
             *reinterpret_cast<f32x4*>(xr + c) = v;
             if (y_inline) {
-                if constexpr (sizeof(T) == 2) *reinterpret_cast<bf16x4*>(yr + c) = bf16x4{f32_to_bf16(v[0]), f32_to_bf16(v[1]), f32_to_bf16(v[2]), f32_to_bf16(v[3])};
+                // (fragment order keeps 4 consecutive columns of a row contiguous: c % 4 == 0)
+                if constexpr (sizeof(T) == 2) *reinterpret_cast<bf16x4*>(yr + (a.y_frag ? frag_index(m, c, KTy) : (long long)c)) = bf16x4{f32_to_bf16(v[0]), f32_to_bf16(v[1]), f32_to_bf16(v[2]), f32_to_bf16(v[3])};
                 else *reinterpret_cast<f32x4*>(yr + c) = v;
             }
             ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
@@ -83,6 +85,10 @@ __global__ __launch_bounds__(256) void reduce_rmsnorm_kernel(ReduceNormArgs a) {
     if (!a.y) return;
     T* y = reinterpret_cast<T*>(a.y) + (long long)m * a.ldy;
     if (!a.do_norm) {
+        if (a.y_frag) {
+            for (int c = threadIdx.x; c < H; c += 256) reinterpret_cast<T*>(a.y)[frag_index(m, c, H >> 5)] = from_f32<T>(xr[c]);
+            return;
+        }
         for (int c = threadIdx.x; c < H; c += 256) y[c] = from_f32<T>(xr[c]);
         return;
     }
@@ -98,6 +104,7 @@ int launch_reduce_rmsnorm(const ReduceNormArgs& a_in, hipStream_t s) {
     ReduceNormArgs a = a_in;
     if (a.M <= 0) return 0;
     if (a.rows_per_z <= 0) a.rows_per_z = a.M;
+    if (a.y_frag && (a.do_norm || a.dtype == DT_F32 || (a.H & 31))) return set_error("reduce_rmsnorm: fragment-order output is a plain 16-bit cast with H %% 32 == 0"), -1;
     if (a.dtype == DT_BF16) hipLaunchKernelGGL(reduce_rmsnorm_kernel<bf16_t>, dim3(a.M), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(reduce_rmsnorm_kernel<float>, dim3(a.M), dim3(256), 0, s, a);
     return hipGetLastError() == hipSuccess ? 0 : (set_error("reduce_rmsnorm launch failed"), -1);
@@ -223,21 +230,23 @@ int launch_embed(const void* table, int table_dtype, const int* tok, float* x, i
 }
 
 template <class T>
-__global__ void embed2_kernel(const T* speech, const T* text, const int* tok, float* x, int ldx, T* x_copy, int H) {
+__global__ void embed2_kernel(const T* speech, const T* text, const int* tok, float* x, int ldx, T* x_copy, int H, int copy_frag) {
     const int r = blockIdx.x;
     const int t = tok[r];
     const T* src = t >= 0 ? speech + (long long)t * H : (t <= -2 ? text + (long long)(-t - 2) * H : nullptr);
     for (int c = threadIdx.x; c < H; c += blockDim.x) {
         x[(long long)r * ldx + c] = src ? to_f32(src[c]) : 0.0f;
-        if (x_copy) x_copy[(long long)r * ldx + c] = src ? src[c] : from_f32<T>(0.0f);      // the table row itself
+        if (x_copy) x_copy[copy_frag ? frag_index(r, c, H >> 5) : (long long)r * ldx + c] = src ? src[c] : from_f32<T>(0.0f);      // the table row itself
     }
 }
-int launch_embed2(const void* speech, const void* text, int dtype, const int* tok, float* x, int ldx, void* x_copy, int rows, int H, hipStream_t s) {
+int launch_embed2(const void* speech, const void* text, int dtype, const int* tok, float* x, int ldx, void* x_copy, int rows, int H, hipStream_t s,
+                  int copy_frag) {
     if (rows <= 0) return 0;
+    if (copy_frag && (dtype != DT_BF16 || (H & 31))) return set_error("embed2: fragment-order copy needs bf16 and H %% 32 == 0"), -1;
     if (dtype == DT_BF16)
-        hipLaunchKernelGGL(embed2_kernel<bf16_t>, dim3(rows), dim3(256), 0, s, (const bf16_t*)speech, (const bf16_t*)text, tok, x, ldx, (bf16_t*)x_copy, H);
+        hipLaunchKernelGGL(embed2_kernel<bf16_t>, dim3(rows), dim3(256), 0, s, (const bf16_t*)speech, (const bf16_t*)text, tok, x, ldx, (bf16_t*)x_copy, H, copy_frag);
     else
-        hipLaunchKernelGGL(embed2_kernel<float>, dim3(rows), dim3(256), 0, s, (const float*)speech, (const float*)text, tok, x, ldx, (float*)x_copy, H);
+        hipLaunchKernelGGL(embed2_kernel<float>, dim3(rows), dim3(256), 0, s, (const float*)speech, (const float*)text, tok, x, ldx, (float*)x_copy, H, 0);
     return hipGetLastError() == hipSuccess ? 0 : (set_error("embed2 launch failed"), -1);
 }
 

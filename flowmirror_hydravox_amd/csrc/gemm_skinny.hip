@@ -131,9 +131,11 @@ __device__ __forceinline__ void skinny_finish(const SkinnyArgs& a, f32x4 (&acc)[
                 if (q_which == 0) {
                     reinterpret_cast<T*>(a.qbuf)[((long long)row * a.q_heads + q_hh) * 64 + q_d] = from_f32<T>(x);
                 } else if (q_which == 1) {
-                    reinterpret_cast<T*>(a.kcache)[(((long long)c.slot * a.kv_heads + q_hh) * a.max_ctx + c.pos) * 64 + q_d] = from_f32<T>(x);
+                    const long long blk = ((long long)c.slot * a.kv_heads + q_hh) * a.max_ctx * 64;
+                    reinterpret_cast<T*>(a.kcache)[blk + (a.kv_frag ? frag_index(c.pos, q_d, 2) : (long long)c.pos * 64 + q_d)] = from_f32<T>(x);
                 } else {
-                    reinterpret_cast<T*>(a.vTcache)[(((long long)c.slot * a.kv_heads + q_hh) * 64 + q_d) * a.max_ctx + c.pos] = from_f32<T>(x);
+                    const long long blk = ((long long)c.slot * a.kv_heads + q_hh) * a.max_ctx * 64;
+                    reinterpret_cast<T*>(a.vTcache)[blk + (a.kv_frag ? vfrag_index(c.pos, q_d) : (long long)q_d * a.max_ctx + c.pos)] = from_f32<T>(x);
                 }
             }
         }

@@ -94,6 +94,22 @@ __device__ __forceinline__ void mma32(f32x4& acc, const f32x8& a, const f32x8& b
     for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc, 0, 0, 0);
 }
 
+// ---- "fragment order" of a 16-bit activation matrix [rows][K] (K % 32 == 0, rows padded to 16) ---------------------------------------
+// The matrix is stored as the MFMA operand fragments its consumer will load: [row tile of 16][k-step of 32][64 lanes][8], lane
+// (row & 15) + 16 * ((k & 31) >> 3), element k & 7.  A wave then fetches a whole 16 x 32 fragment with ONE contiguous 1 KiB load
+// instead of 16 row pieces of 64 B (tools/dec_lab.hip: the decode GEMMs run 1.2-1.5x faster on it).  KT = K / 32.
+__device__ __forceinline__ long long frag_index(int row, int k, int KT) {
+    return ((long long)(row >> 4) * KT + (k >> 5)) * 512 + (((row & 15) + ((k & 24) << 1)) << 3) + (k & 7);
+}
+
+// The LLM's KV cache in the same spirit (per (slot, kv head); element indices, any element type): K [ctx][64] is a fragment-order matrix with two
+// k-steps per row (frag_index(pos, d, 2): a 16-key tile = the two A fragments of the score MFMAs, 1 KiB each at bf16); V is stored as the B fragments
+// of the PV MFMAs: per 32-key block four d-tiles of [64 lanes][8], lane (d & 15) + 16 g holding keys {4g..4g+3, 16+4g..16+4g+3} of the block.
+__device__ __forceinline__ long long vfrag_index(int pos, int d) {
+    const int kk = pos & 31;
+    return (long long)(pos >> 5) * 2048 + ((d >> 4) << 9) + (((d & 15) + ((kk & 12) << 2)) << 3) + ((kk >> 4) << 2) + (kk & 3);
+}
+
 template <class T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return f32_to_bf16(v); }

@@ -101,6 +101,7 @@ struct SkinnyArgs {
     void* qbuf;                   // [n_seq][kn][q_heads*64]              (dtype)
     void* kcache; void* vTcache;  // [slot][kv_heads][max_ctx][64] / [slot][kv_heads][64][max_ctx]   (dtype)
     int max_ctx;
+    int kv_frag;                  // the caches are in fragment order (hvx_device.h: frag_index(pos, d, 2) / vfrag_index(pos, d) per (slot, kv head)); max_ctx % 32 == 0
     // layer-batched launches (MTP heads): blockIdx.z = head j, all pointers advance by these strides
     int nz; long long w_zs; long long a_zs; long long bias_zs; long long out_zs; long long part_zs;
     int n_valid;                  // SK_STORE: columns >= n_valid are not stored (0 = N)
@@ -110,8 +111,15 @@ struct SkinnyArgs {
     // SK_RESID: optional copy of the updated rows in `dtype` (the A operand of the next fused-norm GEMM)
     void* out2; int ldo2;
     int w_narrow;                 // SK_RESID: W is packed [N/4][K/128][64][8] (packing.pack_narrow4) for the 4-column workgroup form
+    // ---- wide decode grids (33..128 rows, bf16): activations in fragment order (hvx_device.h: frag_index) -----------------------
+    int a_frag;                   // A is [ceil(M/16)][K/32][64][8] instead of row-major (launch_dec_gemm only)
+    int out_frag;                 // SK_SWIGLU: out, SK_RESID: out2 are written in fragment order (their consumer is another launch_dec_gemm)
 };
 int launch_skinny(const SkinnyArgs& a, hipStream_t s);
+// The same GEMMs for 33..128 rows in the A-stationary / weight-ring form (gemm_dec.hip).  Returns 1 when the launch was taken, 0 when the
+// shape is not one of its instantiations (the caller then uses launch_skinny on row-major activations), -1 on error.
+int launch_dec_gemm(const SkinnyArgs& a, hipStream_t s);
+bool dec_gemm_shape_ok(int M, int N, int K, int epi, int split_k);
 
 // ------------------------------------------------------------------------------------------------
 // Attention (flash-style online softmax, head_dim 64, one wave per (q-tile, key-split)).
@@ -138,6 +146,10 @@ struct AttnArgs {
                                                       // each and merge their (m, l, o) in LDS, so the combine reads 4x fewer partials
     float* part_o; float* part_ml;                    // [batch][heads][n_splits][n_rows_pad][64], [...][n_rows_pad][2]
     int n_rows_pad;
+    int kv_frag;                                      // k / vT are the LLM's fragment-order caches (hvx_device.h: frag_index(key, d, 2), vfrag_index(key, d)
+                                                      // per (batch, head) block of k_hs / v_hs elements); v_ld = the cache's context capacity
+    int o_frag_kt;                                    // > 0 (LLM decode, 16-bit): out is the [batch * kn][heads * rows_hi * 64] activation matrix in fragment
+                                                      // order (hvx_device.h: frag_index) with this many k-steps per row; the o_* strides are ignored
 };
 int launch_attention(const AttnArgs& a, hipStream_t s);
 
@@ -154,6 +166,7 @@ struct ReduceNormArgs {
     const float* gain; long long gain_zs; float eps; int do_norm;
     void* y; int ldy; int dtype;
     int M, H, rows_per_z;
+    int y_frag;                   // y (16-bit) is written in fragment order (hvx_device.h: frag_index, KT = H / 32); plain cast only
 };
 int launch_reduce_rmsnorm(const ReduceNormArgs& a, hipStream_t s);
 // y[r, c] = dtype(act(x[r, c])) for a [rows][cols] f32 matrix (per-column alpha for Snake)
@@ -167,7 +180,9 @@ int launch_gather_rows_f32(const float* x, int ldx, const int* idx, float* y, in
 // embedding: x[r,:] = table[tok[r],:] as f32 (tok < 0 -> zeros); table dtype f32/bf16
 int launch_embed(const void* table, int table_dtype, const int* tok, float* x, int ldx, int rows, int H, hipStream_t s);
 // LLM input rows: tok >= 0 -> speech[tok]; tok <= -2 -> text[-tok-2]; tok == -1 -> zeros   (llm_multi_head_v3.py:941-952)
-int launch_embed2(const void* speech, const void* text, int dtype, const int* tok, float* x, int ldx, void* x_copy, int rows, int H, hipStream_t s);
+//   copy_frag: x_copy (16-bit) is written in fragment order (hvx_device.h: frag_index)
+int launch_embed2(const void* speech, const void* text, int dtype, const int* tok, float* x, int ldx, void* x_copy, int rows, int H, hipStream_t s,
+                  int copy_frag = 0);
 // logits -> log_softmax (fp32, in place) over V columns, one block per row
 int launch_log_softmax(float* x, int ld, int rows, int V, hipStream_t s);
 // DiT: y = dtype( LN(x; eps, no affine) * (1 + scale[b]) + shift[b] ); x f32 [B][T][D]; shift/scale f32 [B][.] with stride mod_bs

@@ -11,6 +11,7 @@
 // attention | o_proj (+residual, in place) | gate/up (RMSNorm folded in, +SwiGLU) | down (+residual).  The residual stream x stays
 // fp32 (bf16 mode keeps a bf16 copy beside it for the fused-norm GEMMs); GEMM operands are `dtype` (bf16 production / f32 parity).
 // hvx_llm_decode_steps replays {forward, RAS sampler, advance} as one hipGraph per step: the decode loop lives on the device.
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -75,7 +76,12 @@ struct hvx_llm {
 namespace {
 
 constexpr int MAX_SPLIT = 16;
-constexpr int ATT_CHUNK = 256;     // keys per decode-attention split (one workgroup); its 4 waves take 64 keys each and merge in LDS
+// keys per decode-attention split (one workgroup); its 4 waves take a quarter each and merge in LDS.  256 on the whole chip; a decode engine confined
+// to a few compute units (hvx_stream_create_cu_range) wants fewer, longer workgroups (HVX_ATT_CHUNK, a multiple of 128)
+static int att_chunk_keys() {
+    static const int v = [] { const char* e = getenv("HVX_ATT_CHUNK"); const int c = e ? atoi(e) : 256; return (c >= 128 && c % 128 == 0) ? c : 256; }();
+    return v;
+}
 
 size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
@@ -107,17 +113,18 @@ size_t carve(hvx_llm* h, char* base, int S, int R, int max_ctx) {
     const size_t es = dtype_size(c.dtype);
     const int H = c.hidden, Q = c.q_heads * 64, A = c.mtp_attn_dim, hn = c.head_num;
     Carve cv(base);
+    const size_t R16 = ((size_t)R + 15) / 16 * 16;                    // the fragment-order activation matrices of a wide decode grid come in 16-row tiles
     h->x = cv.take<float>((size_t)R * H * 4);
-    h->a = cv.take<void>((size_t)R * H * es);
+    h->a = cv.take<void>(R16 * H * es);
     h->qbuf = cv.take<void>((size_t)R * Q * es);
-    h->attn = cv.take<void>((size_t)R * Q * es);
-    h->hmlp = cv.take<void>((size_t)R * c.inter * es);
+    h->attn = cv.take<void>(R16 * Q * es);
+    h->hmlp = cv.take<void>(R16 * c.inter * es);
     const size_t part_rows = (size_t)(R > hn * S ? R : hn * S);
     h->part = cv.take<float>((size_t)MAX_SPLIT * part_rows * H * 4);
     // attention split partials are only used for short query grids (decode): rows per (seq, kv head) = G * kn
     const int G = c.q_heads / c.kv_heads;
-    h->att_chunk = ATT_CHUNK;
-    h->att_splits = (max_ctx + ATT_CHUNK - 1) / ATT_CHUNK;
+    h->att_chunk = att_chunk_keys();
+    h->att_splits = (max_ctx + h->att_chunk - 1) / h->att_chunk;
     h->att_rows_pad = ((G * 8 + 31) / 32) * 32;                       // kn <= 8 on the split path
     h->att_o = cv.take<float>((size_t)S * c.kv_heads * h->att_splits * h->att_rows_pad * 64 * 4);
     h->att_ml = cv.take<float>((size_t)S * c.kv_heads * h->att_splits * h->att_rows_pad * 2 * 4);
@@ -348,7 +355,18 @@ static int forward_impl(hvx_llm* h, hipStream_t s, int32_t n_seq, int32_t kn, co
     // the embedding and the residual epilogues keep beside the fp32 stream (half the bytes per workgroup)
     void* const xa = dt == DT_F32 ? (void*)h->x : h->a;
     void* const xcopy = dt == DT_F32 ? nullptr : h->a;
-    if (launch_embed2(w[4], w[5], dt, tok, h->x, H, xcopy, R, H, s)) return -1;
+    // Wide decode grids (33..128 rows, bf16, the backbone's own dimensions): the four GEMMs of a layer take the A-stationary / weight-ring form
+    // (gemm_dec.hip), and every 16-bit activation matrix between them — the copy of x, the attention output, the MLP hidden rows — lives in
+    // fragment order (hvx_device.h: frag_index), written that way by its producer.
+    const int down_split = c.inter / 32 / 19;
+    const bool dec = dt == DT_BF16 && dec_gemm_shape_ok(R, (c.q_heads + 2 * c.kv_heads) * 64, H, SK_QKV_ROPE, 1) && dec_gemm_shape_ok(R, H, Q, SK_RESID, 1) &&
+                     dec_gemm_shape_ok(R, 2 * c.inter, H, SK_SWIGLU, 1) && down_split <= MAX_SPLIT && dec_gemm_shape_ok(R, H, c.inter, SK_PARTIAL, down_split);
+    auto gemm = [&](const SkinnyArgs& g) {
+        if (!dec) return launch_skinny(g, s);
+        const int rc = launch_dec_gemm(g, s);
+        return rc == 1 ? 0 : (rc == 0 ? (set_error("hvx_llm_forward: decode GEMM form refused a shape it had accepted"), -1) : -1);
+    };
+    if (launch_embed2(w[4], w[5], dt, tok, h->x, H, xcopy, R, H, s, dec ? 1 : 0)) return -1;
     // Five launches per layer: both RMSNorms ride inside the GEMM that consumes them (gain folded into the weights, 1/rms applied to
     // the accumulator; gemm_skinny.hip) and both residual adds in the epilogue of the GEMM that produces them (x += ..., one writer
     // per element).
@@ -370,8 +388,9 @@ static int forward_impl(hvx_llm* h, hipStream_t s, int32_t n_seq, int32_t kn, co
         // cache layout [layer][slot][kv_head][...]: the slot stride is what the kernels index with
         g.kcache = (char*)h->kcache + (size_t)l * h->n_slots * layer_kv;
         g.vTcache = (char*)h->vTcache + (size_t)l * h->n_slots * layer_kv;
-        g.max_ctx = h->max_ctx;
-        if (launch_skinny(g, s)) return -1;
+        g.max_ctx = h->max_ctx; g.kv_frag = 1;
+        g.a_frag = dec;
+        if (gemm(g)) return -1;
         // 2. attention, GQA-packed: rows = G query heads x kn new positions per KV head
         AttnArgs at;
         memset(&at, 0, sizeof(at));
@@ -379,9 +398,10 @@ static int forward_impl(hvx_llm* h, hipStream_t s, int32_t n_seq, int32_t kn, co
         at.q = h->qbuf; at.q_bs = (long long)kn * Q; at.q_hs = (long long)G * 64; at.q_hi = 64; at.q_lo = Q;
         at.k = g.kcache; at.k_bs = (long long)c.kv_heads * h->max_ctx * 64; at.k_hs = (long long)h->max_ctx * 64;
         at.vT = g.vTcache; at.v_bs = at.k_bs; at.v_hs = (long long)64 * h->max_ctx; at.v_ld = h->max_ctx;
+        at.kv_frag = 1;
         at.kv_slot = d_slot; at.kv_len = d_kvlen; at.causal = 1; at.pos0 = d_pos0; at.n_valid_lo = d_nnew;
         at.scale = 0.125f;
-        at.out = h->attn; at.o_bs = at.q_bs; at.o_hs = at.q_hs; at.o_hi = 64; at.o_lo = Q;
+        at.out = h->attn; at.o_bs = at.q_bs; at.o_hs = at.q_hs; at.o_hi = 64; at.o_lo = Q; at.o_frag_kt = dec ? Q / 32 : 0;
         if (use_split) {
             at.n_splits = h->att_splits; at.split_chunk = h->att_chunk; at.sub_chunk = h->att_chunk / 4; at.part_o = h->att_o; at.part_ml = h->att_ml; at.n_rows_pad = h->att_rows_pad;
         } else {
@@ -392,18 +412,30 @@ static int forward_impl(hvx_llm* h, hipStream_t s, int32_t n_seq, int32_t kn, co
         memset(&g, 0, sizeof(g));
         g.dtype = dt; g.M = R; g.N = H; g.K = Q; g.A = h->attn; g.lda = Q; g.W = lw[3]; g.nz = 1; g.split_k = 1;
         g.epi = SK_RESID; g.out = h->x; g.out_f32 = 1; g.ldo = H; g.out2 = xcopy; g.ldo2 = H; g.w_narrow = 1;
-        if (R > 256 ? resid_wide(h, g, lw[7], xcopy, s) : launch_skinny(g, s)) return -1;      // K = q*64 is short: the 4-column form holds up to 16 row tiles
+        if (dec) {
+            g.W = lw[7]; g.w_narrow = 0; g.a_frag = 1; g.out_frag = 1;                          // (fragment-packed copy of the weights)
+            if (gemm(g)) return -1;
+        } else if (R > 256 ? resid_wide(h, g, lw[7], xcopy, s) : launch_skinny(g, s)) return -1;      // K = q*64 is short: the 4-column form holds up to 16 row tiles
         // 4. hmlp = SwiGLU(RMSNorm(x) * ln2)
         memset(&g, 0, sizeof(g));
         g.dtype = dt; g.M = R; g.N = 2 * c.inter; g.K = H; g.A = xa; g.lda = H; g.W = lw[5]; g.split_k = 1; g.nz = 1;
         g.a_norm = 1; g.norm_eps = c.rms_eps;               // post_attention_layernorm gain is folded into lw[5]
-        g.epi = SK_SWIGLU; g.out = h->hmlp; g.ldo = c.inter;
-        if (launch_skinny(g, s)) return -1;
+        g.epi = SK_SWIGLU; g.out = h->hmlp; g.ldo = c.inter; g.a_frag = dec; g.out_frag = dec;
+        if (gemm(g)) return -1;
         // 5. x += down(hmlp)
         memset(&g, 0, sizeof(g));
         g.dtype = dt; g.M = R; g.N = H; g.K = c.inter; g.A = h->hmlp; g.lda = c.inter; g.W = lw[6]; g.nz = 1; g.split_k = 1;
         g.epi = SK_RESID; g.out = h->x; g.out_f32 = 1; g.ldo = H; g.out2 = xcopy; g.ldo2 = H; g.w_narrow = 1;
-        if (wide ? resid_wide(h, g, lw[8], xcopy, s) : launch_skinny(g, s)) return -1;
+        if (dec) {
+            // split-K partials (8 K slices of 19 k-steps) + the fixed-order reduce, which also writes the fragment-order copy of x
+            g.W = lw[8]; g.w_narrow = 0; g.a_frag = 1; g.split_k = down_split; g.epi = SK_PARTIAL; g.part = h->part; g.out = nullptr; g.out2 = nullptr;
+            if (gemm(g)) return -1;
+            ReduceNormArgs r;
+            memset(&r, 0, sizeof(r));
+            r.x = h->x; r.ldx = H; r.part = h->part; r.split_k = down_split; r.part_stride = (long long)R * H; r.do_norm = 0;
+            r.y = xcopy; r.ldy = H; r.dtype = dt; r.M = R; r.H = H; r.rows_per_z = R; r.y_frag = 1;
+            if (launch_reduce_rmsnorm(r, s)) return -1;
+        } else if (wide ? resid_wide(h, g, lw[8], xcopy, s) : launch_skinny(g, s)) return -1;
     }
     if (head_k <= 0) return 0;
 

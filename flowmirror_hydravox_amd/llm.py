@@ -359,6 +359,8 @@ class _DecodeEngine:
     def __init__(self, llm, n_slots, max_out, max_prefix, stream_first=False, sync_every=None, pace=None):
         import time
         self.pace = tuple(int(v) for v in pace) if pace else None
+        if self.pace is not None and (len(self.pace) != 3 or self.pace[0] < 1 or self.pace[1] < 1 or self.pace[2] < 0):
+            raise ValueError('pace = (first >= 1, every_steps >= 1, more >= 0), got %r' % (pace,))       # (first == 0 would leave the idle grid spinning)
         self.llm, self.S, self.max_out = llm, int(n_slots), int(max_out)
         self.max_prefix = max(int(max_prefix), self.S * llm.head_k())
         self.K = llm.head_k()
@@ -521,7 +523,8 @@ class _DecodeEngine:
             nonlocal waiting, exhausted
             while waiting is None and not exhausted:
                 try:
-                    waiting = requests.poll(block) if hasattr(requests, 'poll') else next(requests)
+                    # (never block while something is waiting to be handed out: a refused request, a finished one — the source may stay silent for ever)
+                    waiting = requests.poll(block and not ready) if hasattr(requests, 'poll') else next(requests)
                 except StopIteration:
                     exhausted = True
                     return
@@ -600,6 +603,18 @@ class _DecodeEngine:
                     yield ready.pop(0)
                 live = [r for r in self.slot_req if r is not None and not r.done]
                 if not live and launched == processed:
+                    # the grid is idle.  Ids of finished sequences that are still on their way are waited for HERE, before the source may block:
+                    # nothing else would ever look at them again if no further request arrived
+                    while pending_out:
+                        ev, out_pin, r = pending_out.pop(0)
+                        ev.synchronize()
+                        r.out = out_pin[:r.state[1]].tolist()
+                        r.noise.finalize(r.cursor)
+                        n_done += 1
+                        n_tokens += len(r.out)
+                        ready.append(('done', r))
+                    if ready:
+                        continue
                     with torch.cuda.stream(stream):
                         if fill_free_slots(block=True):   # the grid is idle: a polling source may block here until the next request arrives
                             self._publish_limits()

@@ -300,25 +300,34 @@ def inference_tts_with_segmentation(model_manager, text, spk_id, max_length=30, 
     return torch.cat(parts, dim=-1)
 
 
+def resolve_tts_request(model_manager, text, speaker_id):
+    """the checks text_to_speech makes before it synthesises (infer_speech_model.py:743-780): models loaded, text not empty, a known speaker —
+    or the first available one when the request names none.  Returns the speaker id to use; raises ValueError otherwise."""
+    if not model_manager.is_loaded:
+        raise ValueError('models are not loaded')
+    if not text or not text.strip():
+        raise ValueError('text is empty')
+    speakers = [str(s['speaker_id'] if isinstance(s, dict) else s) for s in model_manager.get_available_speakers()]
+    if speaker_id:
+        if speakers and speaker_id not in speakers:
+            raise ValueError('invalid speaker_id %s; available: %s' % (speaker_id, speakers))
+        return speaker_id
+    if speakers:
+        return speakers[0]                                     # (:771-777) default: the first available speaker
+    raise ValueError('no speaker available')
+
+
+SEGMENTED_TEXT_CHARS = 5000        # longer texts take the segmented path (:782)
+
+
 def text_to_speech(model_manager, text, speaker_id, speed=1.0):
     """-> {"output_audio": Tensor(1, L) cpu, "sample_rate", "format": "wav", "duration", "speaker_id", "segments_info"} (:743-820).
     Texts over 5000 characters take the segmented path (max 30 / min 10 characters per piece, speaker TTS for every piece, :782-800);
     `segments_info` is then {"total_segments", "segments"} and None otherwise, as in the reference."""
     try:
-        if not model_manager.is_loaded:
-            raise ValueError('models are not loaded')
-        if not text or not text.strip():
-            raise ValueError('text is empty')
-        speakers = [str(s['speaker_id'] if isinstance(s, dict) else s) for s in model_manager.get_available_speakers()]
-        if speaker_id:
-            if speakers and speaker_id not in speakers:
-                raise ValueError('invalid speaker_id %s; available: %s' % (speaker_id, speakers))
-        elif speakers:
-            speaker_id = speakers[0]                             # (:771-777) default: the first available speaker
-        else:
-            raise ValueError('no speaker available')
+        speaker_id = resolve_tts_request(model_manager, text, speaker_id)
         segments_info = None
-        if len(text) > 5000:
+        if len(text) > SEGMENTED_TEXT_CHARS:
             audio = inference_tts_with_segmentation(model_manager, text, speaker_id, max_length=30, min_length=10, last_prompt=False, speed=speed)
             segs = merge_short_segments(split_text_by_punctuation(text, 30, 10), 10)
             segments_info = {'total_segments': len(segs), 'segments': segs}

@@ -198,6 +198,8 @@ class HvxPipeline:
     def _acoustic_chain(self, k):
         """k-th acoustic chain: (flow, vocoder) handles with their own workspaces over the same packed weights, and a stream"""
         while len(self._acoustic) <= k:
+            if self._flow_kw is None:
+                raise ValueError('a pipeline built with from_models() owns one acoustic chain (it does not know how its models were constructed)')
             flow = HvxFlow(self.cfg.flow, None, **self._flow_kw)
             flow.load_packed(self.flow._weights)
             hift = HvxHift(self.cfg.hift, None, **self._hift_kw)
@@ -225,6 +227,8 @@ class HvxPipeline:
     def _lm_chain(self, k):
         """k-th LM decode chain: a further native handle (own KV cache, workspace, stream, graphs) over the SAME packed weight tensors"""
         while len(self._llms) <= k:
+            if self._llm_kw is None:
+                raise ValueError('a pipeline built with from_models() owns one LM chain (it does not know how its models were constructed)')
             clone = HvxLLM(self.cfg.llm, None, **self._llm_kw)
             clone.load_packed(self.llm._weights)
             self._llms.append(clone)
@@ -326,18 +330,28 @@ class HvxPipeline:
         q = queue.Queue(maxsize=2 * int(lm_slots) + 2 * acoustic_batch)
         cancel = threading.Event()
         lm_info = {}
-        seen = []
+        seen = {}                                          # running id -> utterance in flight; an entry goes when its result is handed out
+        n_seen = [0]
 
         class _Requests:
             @staticmethod
             def poll(block):
+                # The source is asked to block only while the decode grid is idle, and a well-behaved source blocks for a bounded time (returning
+                # None): `cancel` is looked at again on every call, so a consumer that stopped — or an acoustic-stage failure — ends the LM thread
+                # within that bound instead of when the next request happens to arrive.
                 if cancel.is_set():
                     raise StopIteration
                 u = source.poll(block)
                 if u is None:
                     return None
-                seen.append(u)
-                return dict(text=u.text, prompt_text=u.prompt_text, prompt_speech_token=u.prompt_speech_token, seed=u.seed, tag=len(seen) - 1,
+                if cancel.is_set():                        # fetched while the engine was being cancelled: hand it back rather than fail it
+                    if hasattr(source, 'unpoll'):
+                        source.unpoll(u)
+                    raise StopIteration
+                tag = n_seen[0]
+                n_seen[0] += 1
+                seen[tag] = u
+                return dict(text=u.text, prompt_text=u.prompt_text, prompt_speech_token=u.prompt_speech_token, seed=u.seed, tag=tag,
                             max_token_text_ratio=max_token_text_ratio if u.max_token_text_ratio is None else u.max_token_text_ratio,
                             min_token_text_ratio=min_token_text_ratio if u.min_token_text_ratio is None else u.min_token_text_ratio)
 
@@ -393,7 +407,7 @@ class HvxPipeline:
                 bad = [(i, t) for i, t in group if isinstance(t, BaseException) or not t]
                 group = [(i, t) for i, t in group if not isinstance(t, BaseException) and t]
                 for i, t in bad:
-                    yield seen[i], (t if isinstance(t, BaseException) else torch.zeros(0, device=self.device)), []
+                    yield seen.pop(i), (t if isinstance(t, BaseException) else torch.zeros(0, device=self.device)), []
                 if group:
                     us = [seen[i] for i, _ in group]
                     t0 = time.time()
@@ -404,7 +418,7 @@ class HvxPipeline:
                     for (i, toks), wav in zip(group, wavs):
                         audio += wav.numel() / float(self.cfg.sample_rate)
                         tokens += len(toks)
-                        yield seen[i], wav, toks
+                        yield seen.pop(i), wav, toks
                 if ended:
                     if isinstance(tail, BaseException):
                         raise tail

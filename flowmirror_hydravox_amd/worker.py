@@ -70,6 +70,18 @@ def worker_process_tts(num_workers_gpu, task_queue, result_dict, worker_id, fron
         result_dict[task['id']] = result
 
 
+def _is_segmented(task, normalise):
+    """a `tts` task whose text takes the reference's segmented path (over 5000 characters, infer_speech_model.py:782-800): many short speaker-TTS
+    calls concatenated — served one by one through text_to_speech, as an epoch boundary of the batched worker"""
+    from .model_manager import SEGMENTED_TEXT_CHARS
+    if task.get('task_type') != 'tts':
+        return False
+    try:
+        return len(normalise(task.get('text') or '')) > SEGMENTED_TEXT_CHARS
+    except Exception:
+        return False
+
+
 def _sampling_key(task):
     ep = task.get('extra_params') or {}
     return tuple(ep.get(k) for k in ('top_p', 'top_k', 'win_size', 'tau_r', 'inference_head_num'))
@@ -90,12 +102,26 @@ class _TaskSource:
         self.stop = False
         self.closed = False
 
+    POLL_SECONDS = 0.1
+
+    def unpoll(self, u):
+        """an utterance the engine fetched while it was being cancelled: its task opens the next epoch instead of failing with this one"""
+        self.carry, self.closed = u.tag, True
+
     def _utterance(self, t):
         from .pipeline import Utterance
+        from .model_manager import resolve_tts_request
         fe, mm = self.mm.frontend, self.mm
         if t['task_type'] == 'tts':
-            mi = fe.frontend_sft(fe.text_normalize(self.normalise(t['text']), split=True, text_frontend=True)[0], t['speaker_id'])
+            # the same checks and the same default speaker as the one-by-one path (model_manager.text_to_speech, infer_speech_model.py:743-780)
+            try:
+                text = self.normalise(t['text'])
+                speaker = resolve_tts_request(mm, text, t.get('speaker_id'))
+            except Exception as e:
+                raise ValueError('TTS failed: %s' % e)
+            mi = fe.frontend_sft(fe.text_normalize(text, split=True, text_frontend=True)[0], speaker)
             u = Utterance(text=mi['text'].reshape(-1), seed=None, embedding=mi['flow_embedding'].reshape(-1))
+            u.speaker_id = speaker
         else:
             p_text = fe.text_normalize(self.normalise(t.get('prompt_text', '')), split=False, text_frontend=True)
             mi = fe.frontend_zero_shot(fe.text_normalize(self.normalise(t['tts_text']), split=True, text_frontend=True)[0], p_text,
@@ -120,13 +146,15 @@ class _TaskSource:
                 t, self.head = self.head, None
             else:
                 try:
-                    t = self.q.get() if block else self.q.get_nowait()
+                    # bounded: the engine asks again (and looks at its cancellation flag) every time this returns None — a blocking get()
+                    # would hold a cancelled engine, and the error replies of its requests, until the next task arrived
+                    t = self.q.get(timeout=self.POLL_SECONDS) if block else self.q.get_nowait()
                 except _queue.Empty:
                     return None
             if t is None:
                 self.stop = self.closed = True
                 raise StopIteration
-            if t.get('task_type') not in ('tts', 'zero_shot') or _sampling_key(t) != self.key:
+            if t.get('task_type') not in ('tts', 'zero_shot') or _sampling_key(t) != self.key or _is_segmented(t, self.normalise):
                 self.carry, self.closed = t, True
                 raise StopIteration
             try:
@@ -167,10 +195,13 @@ def serve_queue(mm, task_queue, result_dict, worker_id=0, lm_slots=None, acousti
         task, carry = (carry, None) if carry is not None else (task_queue.get(), None)
         if task is None:
             break
-        if task.get('task_type') not in ('tts', 'zero_shot'):
+        if task.get('task_type') not in ('tts', 'zero_shot') or _is_segmented(task, normalise):
             try:
                 if task.get('task_type') == 'load_pt':
                     result = mm.load_pt(task['llm_pt'], task['flow_pt'])
+                elif task.get('task_type') == 'tts':               # segmented text: the one-by-one path, with this request's own knobs
+                    from .model_manager import text_to_speech
+                    result = text_to_speech(mm, normalise(task['text']), task.get('speaker_id'), speed=apply_extra_params(mm, task, ras_sampling))
                 else:
                     result = {'error': 'unknown task_type %r' % (task.get('task_type'),)}
             except Exception as e:
@@ -191,7 +222,11 @@ def serve_queue(mm, task_queue, result_dict, worker_id=0, lm_slots=None, acousti
                     result_dict[t['id']] = {'error': str(wav)}
                 else:
                     out = wav.reshape(1, -1).cpu()
-                    result_dict[t['id']] = {'output_audio': out, 'sample_rate': sr, 'format': t.get('output_format', 'wav'), 'duration': out.shape[-1] / sr}
+                    if t['task_type'] == 'tts':                 # the result keys of text_to_speech (infer_speech_model.py:802-812)
+                        result_dict[t['id']] = {'output_audio': out, 'sample_rate': sr, 'format': 'wav', 'duration': out.shape[-1] / sr,
+                                                'speaker_id': getattr(u, 'speaker_id', t.get('speaker_id')), 'segments_info': None}
+                    else:                                      # ... and of the worker's zero_shot branch (server/worker.py:76-83)
+                        result_dict[t['id']] = {'output_audio': out, 'sample_rate': sr, 'format': t.get('output_format', 'wav'), 'duration': out.shape[-1] / sr}
         except Exception as e:                         # an engine failure fails what was in flight, never the worker
             logger.error('[TTS Worker-%d] epoch error: %s', worker_id, e)
             for tid in list(in_flight):
@@ -212,6 +247,10 @@ class _Tracked:
         if u is not None:
             self.in_flight[u.tag['id']] = True
         return u
+
+    def unpoll(self, u):
+        self.in_flight.pop(u.tag['id'], None)
+        self.src.unpoll(u)
 
 
 def apply_extra_params(mm, task, ras_sampling):

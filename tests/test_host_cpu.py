@@ -323,7 +323,7 @@ def test_queue_task_source_epochs_keep_fifo_around_hot_swaps_and_parameter_chang
     import types
     from flowmirror_hydravox_amd.worker import _TaskSource
     ep = dict(top_p=0.8, top_k=25, win_size=10, tau_r=0.1, inference_head_num=2)
-    mm = types.SimpleNamespace(frontend=_QueueFrontend(), configs={'sample_rate': 24000})
+    mm = types.SimpleNamespace(frontend=_QueueFrontend(), configs={'sample_rate': 24000}, is_loaded=True, get_available_speakers=lambda: ['s', 'tt'])
     q, results = queue.Queue(), {}
     tasks = [dict(id=1, task_type='tts', text='abc', speaker_id='s', extra_params=dict(ep)),
              dict(id=2, task_type='zero_shot', tts_text='de', prompt_text='p', prompt_audio=None, prompt_sample_rate=16000, extra_params=dict(ep, speed=1.25), seed=7),
@@ -356,6 +356,53 @@ def test_queue_task_source_epochs_keep_fifo_around_hot_swaps_and_parameter_chang
     assert src.stop and src.carry is None                  # the shutdown sentinel
     empty = _TaskSource(mm, queue.Queue(), results, tasks[0], lambda s: s, 0)
     assert empty.poll(False).tag['id'] == 1 and empty.poll(False) is None      # nothing waiting right now: not closed
+
+
+def test_queue_task_source_validates_like_text_to_speech_and_never_blocks_for_ever():
+    """the batched worker's `tts` requests get the checks and the default speaker of model_manager.text_to_speech
+    (infer_speech_model.py:743-780) — empty text and unknown speakers fail that request only, a request without speaker_id takes the first
+    available speaker; texts over 5000 characters (the reference's segmented path) close the epoch and are carried to the one-by-one path; a
+    blocking poll returns None after a bounded wait (the engine re-checks its cancellation flag), and an utterance handed back with unpoll()
+    opens the next epoch instead of failing with a cancelled one."""
+    import queue
+    import time
+    import types
+    from flowmirror_hydravox_amd.worker import _TaskSource, _Tracked
+    ep = dict(top_p=0.8, top_k=25, win_size=10, tau_r=0.1, inference_head_num=2)
+    mm = types.SimpleNamespace(frontend=_QueueFrontend(), configs={'sample_rate': 24000}, is_loaded=True, get_available_speakers=lambda: ['s', 'tt'])
+    q, results = queue.Queue(), {}
+    first = dict(id=1, task_type='tts', text='abc', speaker_id='', extra_params=dict(ep))
+    for t in [dict(id=2, task_type='tts', text='   ', speaker_id='s', extra_params=dict(ep)),
+              dict(id=3, task_type='tts', text='abc', speaker_id='nobody', extra_params=dict(ep)),
+              dict(id=4, task_type='tts', text='de', speaker_id='tt', extra_params=dict(ep)),
+              dict(id=5, task_type='tts', text='x' * 5001, speaker_id='s', extra_params=dict(ep)),
+              dict(id=6, task_type='tts', text='fg', speaker_id='s', extra_params=dict(ep))]:
+        q.put(t)
+    src = _TaskSource(mm, q, results, first, lambda s: s, 0)
+    u1 = src.poll(False)
+    assert u1.tag['id'] == 1 and u1.speaker_id == 's'                      # no speaker in the request: the first available one
+    assert float(u1.embedding[0]) == pytest.approx(0.01 * len('s'))
+    u4 = src.poll(False)                                                   # tasks 2 and 3 are answered with errors on the way
+    assert u4.tag['id'] == 4 and u4.speaker_id == 'tt'
+    assert results[2] == {'error': 'TTS failed: text is empty'} and results[3]['error'].startswith('TTS failed: invalid speaker_id nobody')
+    with pytest.raises(StopIteration):
+        src.poll(False)
+    assert src.carry['id'] == 5 and not src.stop                           # segmented text: an epoch boundary, nothing behind it is taken
+    assert q.qsize() == 1
+    # a blocking poll on an empty queue comes back (None) after a bounded wait
+    idle = _TaskSource(mm, queue.Queue(), results, first, lambda s: s, 0)
+    assert idle.poll(True).tag['id'] == 1
+    t0 = time.time()
+    assert idle.poll(True) is None and time.time() - t0 < 5 * idle.POLL_SECONDS + 1.0
+    # unpoll: the utterance's task is carried into the next epoch and no longer counts as in flight
+    in_flight = {}
+    tr = _Tracked(_TaskSource(mm, queue.Queue(), results, first, lambda s: s, 0), in_flight)
+    u = tr.poll(False)
+    assert in_flight == {1: True}
+    tr.unpoll(u)
+    assert in_flight == {} and tr.src.carry['id'] == 1 and tr.src.closed
+    with pytest.raises(StopIteration):
+        tr.poll(True)
 
 
 def test_stream_tts_chunk_schedule_matches_the_reference_loop():

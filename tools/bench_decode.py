@@ -24,6 +24,7 @@ def main():
     ap.add_argument('--steps', type=int, default=300)
     ap.add_argument('--fp32', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--cus', type=int, default=0, help='confine the stream to this many compute units (hvx_stream_create_cu_range)')
     args = ap.parse_args()
     from flowmirror_hydravox_amd import _lib, cv3_config
     from flowmirror_hydravox_amd.llm import HvxLLM
@@ -35,7 +36,7 @@ def main():
     llm = HvxLLM(cfg, make_llm_state(cfg, seed=1986), dtype=dt, inference_head_num=K, max_batch=S, max_ctx=args.ctx + 64,
                  use_graph=not args.no_graph)
     dev = llm.device
-    stream = torch.cuda.Stream(device=dev)
+    stream = _lib.cu_range_stream(0, args.cus, device=dev) if args.cus > 0 else torch.cuda.Stream(device=dev)
     with torch.cuda.stream(stream):
         llm._bind(S, S * K)
         llm._kv.zero_()
@@ -61,7 +62,7 @@ def main():
     kv = 2 * S * c.kv_heads * args.ctx * 64 * es
     total = c.layers * (layer_w + kv)
     us = e0.elapsed_time(e1) * 1e3 / args.steps
-    print(json.dumps({'us_per_step_gpu': round(us, 1), 'us_per_step_wall': round(wall * 1e6, 1), 'seqs': S, 'heads': K, 'ctx': args.ctx,
+    print(json.dumps({'us_per_step_gpu': round(us, 1), 'us_per_step_wall': round(wall * 1e6, 1), 'seqs': S, 'heads': K, 'ctx': args.ctx, 'cus': args.cus,
                       'backbone_MB_per_step': round(total / 1e6, 1), 'backbone_GBps': round(total / us / 1e3, 1),
                       'finite': bool(torch.isfinite(logp).all())}))
 
