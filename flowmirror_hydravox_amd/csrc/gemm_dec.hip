@@ -138,18 +138,14 @@ __global__ __launch_bounds__(256, 2) void gemm_dec_kernel(SkinnyArgs a, int n_gr
     // flushing vmcnt(0) — DMA prologue included — in the loop preheader)
     float inv[4] = {1.0f, 1.0f, 1.0f, 1.0f};
     if constexpr (ANORM) {
-        float ss = 0.0f;
+        // sum of squares of the 16 rows ON THE MATRIX CORES: frag x frag^T accumulates sum_k x[i][k] x[j][k]; its diagonal (tile row i == tile column
+        // i: lane 20 g + r holds row 4 g + r in accumulator element r) is what is wanted.  28 MFMAs on a pipe that has nothing else to do yet,
+        // against ~450 VALU instructions per wave for the convert-and-fma form (QKV 7.8 -> us per launch at 128 rows).
+        f32x4 ssq = {0, 0, 0, 0};
 #pragma unroll
-        for (int ks = 0; ks < KT; ++ks) {
-            float x[8];
+        for (int ks = 0; ks < KT; ++ks) mma32(ssq, af[ks], af[ks]);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) x[e] = bf16_to_f32(af[ks][e]);
-            ss += ((x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3])) + ((x[4] * x[4] + x[5] * x[5]) + (x[6] * x[6] + x[7] * x[7]));
-        }
-        ss += __shfl_xor(ss, 16, 64);
-        ss += __shfl_xor(ss, 32, 64);                          // every lane: sum of squares of row (lane & 15)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) inv[r] = rsqrtf(__shfl(ss, fg * 4 + r, 64) / (float)a.K + a.norm_eps);
+        for (int r = 0; r < 4; ++r) inv[r] = rsqrtf(__shfl(ssq[r], fg * 20 + r, 64) / (float)a.K + a.norm_eps);
     } else {
         asm volatile("" ::"v"(af[KT - 1]));
     }
@@ -320,7 +316,9 @@ int env_int(const char* name, int dflt) {
 // shape stays on the generic kernels of gemm_skinny.hip.
 bool dec_gemm_shape_ok(int M, int N, int K, int epi, int split_k) {
     static const bool off = env_int("HVX_DEC_GEMM", 1) == 0;          // (A / B switch for tools/bench_decode.py and the parity tests)
-    if (off || M <= 32 || M > 128 || (N & 15) || (K & 31)) return false;
+    // (rows come in chunks of 64 per workgroup: 33..128 rows are the two-chunk geometry the lab tuned; up to 256 rows — 128 sequences x 2 heads — the
+    // weights are read once per chunk from the XCD's L2)
+    if (off || M <= 32 || M > 256 || (N & 15) || (K & 31)) return false;
     const int kt = K / 32;
     switch (epi) {
         case SK_QKV_ROPE: return kt == 28 && split_k == 1;
