@@ -52,7 +52,8 @@ template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& 
 
 // NTG column tiles per group (SwiGLU: a (gate, up) pair), KT k-steps (the workgroup's whole K range), SF k-steps per ring stage, D stages.
 // Grid (1-D, XCD-aware): id -> xcd = id & 7, j = id >> 3, row chunk = j % mch, K split = (j / mch) % split_k, column group =
-// (j / mch / split_k) * 8 + xcd — the row chunks of one column group land on the same XCD (same L2: the second chunk finds the weights there).
+// (j / mch / split_k) * 8 + xcd — the row chunks of one column group land on the same XCD (same L2: the second chunk finds the weights there);
+// with exactly 8 K splits: K split = xcd, column group = j / mch.
 template <int NTG, int EPI, int ANORM, int KT, int SF, int D>
 __global__ __launch_bounds__(256, 2) void gemm_dec_kernel(SkinnyArgs a, int n_groups, int gpw, int n_cg, int mch) {
 #if defined(__HIP_DEVICE_COMPILE__)      // (the host pass has no __amdgpu_buffer_rsrc_t and drops the stub of a kernel whose body it cannot build)
@@ -66,7 +67,9 @@ __global__ __launch_bounds__(256, 2) void gemm_dec_kernel(SkinnyArgs a, int n_gr
     const int fr = lane & 15, fg = lane >> 4;
     const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
     const int chunk = jj % mch, j2 = jj / mch;
-    const int ksplit = j2 % a.split_k, cg = (j2 / a.split_k) * 8 + xcd;
+    // eight K slices (down_proj): slice = XCD, so every slice of the activation matrix is fetched into ONE L2 instead of all eight (FETCH_SIZE of the
+    // launch 18.7 -> MB: the 1.2 MB of MLP rows used to arrive 8 x)
+    const int ksplit = a.split_k == 8 ? xcd : j2 % a.split_k, cg = a.split_k == 8 ? j2 : (j2 / a.split_k) * 8 + xcd;
     if (cg >= n_cg) return;
     const int g0 = cg * gpw;
     const int ng = min(n_groups - g0, gpw);
@@ -297,7 +300,7 @@ int launch_form(const SkinnyArgs& a, int gpw, hipStream_t s) {
     const int n_groups = a.N / 16 / NTG;
     const int n_cg = (n_groups + gpw - 1) / gpw;
     const int mch = (a.M + 63) / 64;
-    const int grid = 8 * mch * a.split_k * ((n_cg + 7) / 8);
+    const int grid = a.split_k == 8 ? 8 * mch * n_cg : 8 * mch * a.split_k * ((n_cg + 7) / 8);
     const double bytes = (double)a.N * a.K * 2 + (double)a.M * a.K * 2 + (double)a.M * a.N * (EPI == SK_PARTIAL ? 4.0 * a.split_k : 2.0);
     const int slot = prof_begin(PK_SKINNY, bytes, s);
     hipLaunchKernelGGL((gemm_dec_kernel<NTG, EPI, ANORM, KT, SF, D>), dim3(grid), dim3(256), 0, s, a, n_groups, gpw, n_cg, mch);

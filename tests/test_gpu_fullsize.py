@@ -178,3 +178,19 @@ def test_llm_decode_grid_at_full_depth_vs_teacher_forced_prefill(S):
     assert torch.isfinite(dec).all()
     # measured 0.034 / 0.064 at 64 rows (log-probs of the 25 most likely of 6761 tokens, 24 layers + the 22016-wide MTP heads in bf16)
     assert worst[0] < 0.1 and worst[1] < 0.2, worst
+
+
+@pytest.mark.parametrize('S,K', [(20, 2), (64, 2), (25, 4), (100, 2)])
+def test_wide_grid_decode_gemm_form_agrees_with_the_generic_kernels(S, K):
+    """gemm_dec.hip (A-stationary / weight-ring GEMMs over fragment-order activations, 33..256 rows) against the generic skinny kernels on
+    row-major activations (HVX_DEC_GEMM=0): one decode step of a 2-layer CV3-width LM over a random KV cache, ragged positions and row counts
+    (40 rows: a partial last row tile; 128: two 64-row chunks; 100 and 200: partial chunks, three and four chunks).  The two differ in the fp32
+    summation order of every GEMM (K is not split inside a workgroup any more) and in where bf16 roundings fall after it: log-probs of the
+    sampler's candidates within 3e-2 (measured 1.2e-2), appended K / V rows within 2e-2."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    import dec_ab
+    r = dec_ab.compare(seqs=S, heads=K, ctx=300, layers=2)
+    print(S, K, r)
+    assert r['finite'] and r['max_logp'] < 3e-2 and r['mean_logp'] < 5e-3 and r['kv_max'] < 2e-2 and r['argmax'] > 0.95, r

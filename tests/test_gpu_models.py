@@ -804,6 +804,68 @@ def test_serve_cancellation_refusal_and_cu_range_streams(tiny_cfg):
         _lib.cu_range_stream(n_cu - 4, 8)                                   # outside the device
 
 
+def test_serve_hands_out_results_while_an_open_source_stays_silent(tiny_cfg):
+    """an open-ended source (the task queue of a worker) that goes quiet must not strand anything.  (1) a request that is refused while
+    the grid is idle is answered at once, not when the next task arrives; (2) the last finished utterance comes out although nothing follows it;
+    (3) when the consumer stops while the grid is idle — the LM thread sits in the source's blocking poll — serve() returns within the poll bound,
+    and an utterance the source handed over during the cancellation is given back (unpoll) instead of being dropped."""
+    import threading
+    import time
+    from flowmirror_hydravox_amd.pipeline import HvxPipeline, synthetic_utterance
+    pipe = HvxPipeline(tiny_cfg, llm_dtype=torch.float32, flow_dtype=torch.float32, max_batch=3, max_ctx=256, max_t=1024, seed=7, init='fan_in', inference_head_num=2)
+
+    class Quiet:
+        """hands out `items`, then nothing for ever (poll(block=True) waits 50 ms and returns None, like worker._TaskSource)"""
+        def __init__(self, items):
+            self.items, self.polls_after_end, self.returned = list(items), 0, []
+            self.late = None
+
+        def poll(self, block):
+            if self.items:
+                return self.items.pop(0)
+            self.polls_after_end += 1
+            if self.late is not None and self.polls_after_end >= 3:
+                u, self.late = self.late, None
+                return u
+            if block:
+                time.sleep(0.05)
+            return None
+
+        def unpoll(self, u):
+            self.returned.append(u)
+
+    ok = synthetic_utterance(tiny_cfg, 71, 6)
+    big = synthetic_utterance(tiny_cfg, 999, 60)
+    for u in (ok, big):
+        u.max_token_text_ratio, u.min_token_text_ratio = 5, 3
+    # (1) + (2): [refused] alone, then [ok] alone — each must come out while the source stays silent afterwards
+    for item, check in ((big, lambda w: isinstance(w, ValueError)), (ok, lambda w: torch.is_tensor(w) and w.numel() > 0)):
+        src = Quiet([item])
+        gen = pipe.serve(src, lm_slots=3)
+        box = {}
+        th = threading.Thread(target=lambda: box.update(r=next(gen)), daemon=True)
+        t0 = time.time()
+        th.start()
+        th.join(timeout=60)
+        assert not th.is_alive(), 'result stranded behind a silent source'
+        u, w, toks = box['r']
+        assert u is item and check(w), (type(w),)
+        # (3) the grid is idle and the LM thread polls the silent source: closing the generator returns promptly
+        t1 = time.time()
+        gen.close()
+        assert time.time() - t1 < 5.0
+    # an utterance fetched during the cancellation goes back to the source
+    src = Quiet([ok])
+    gen = pipe.serve(src, lm_slots=3)
+    u, w, toks = next(gen)
+    late = synthetic_utterance(tiny_cfg, 72, 5)
+    late.max_token_text_ratio, late.min_token_text_ratio = 5, 3
+    src.late = late                                        # will be handed to one of the next polls
+    gen.close()                                            # ... while the engine is being cancelled (or just before: then it is simply abandoned)
+    assert src.late is None or src.late is late
+    assert all(r is late for r in src.returned)
+
+
 def test_packed_weight_cache_gives_the_same_models(tiny_cfg, tmp_path):
     """§8(f) N4: ModelManager with a packed-weight cache — the second start loads the device-ready tensors instead of the `.pt` files and
     synthesises the same samples; load_pt goes through the cache too."""

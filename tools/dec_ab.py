@@ -42,6 +42,25 @@ def child(args, out):
     np.savez(out, logp=logp.cpu().numpy(), kv=llm._kv.view(torch.bfloat16).float().cpu().numpy().reshape(-1)[:: 7])
 
 
+def compare(seqs=64, heads=2, ctx=300, layers=24):
+    """-> dict(max_logp, mean_logp, argmax, kv_max, kv_changed, finite) of the new form against the generic kernels"""
+    res = {}
+    with tempfile.TemporaryDirectory() as td:
+        for flag in ('1', '0'):
+            out = os.path.join(td, 'r%s.npz' % flag)
+            env = dict(os.environ, HVX_DEC_GEMM=flag)
+            subprocess.run([sys.executable, os.path.abspath(__file__), '--seqs', str(seqs), '--heads', str(heads), '--ctx', str(ctx),
+                            '--layers', str(layers), '--child', out], check=True, env=env)
+            res[flag] = dict(np.load(out))
+    a, b = res['1'], res['0']
+    finite = bool(np.isfinite(a['logp']).all() and np.isfinite(b['logp']).all())
+    top = np.argsort(-b['logp'], axis=-1)[..., :25]
+    da = np.abs(np.take_along_axis(a['logp'], top, -1) - np.take_along_axis(b['logp'], top, -1))
+    dk = np.abs(a['kv'] - b['kv'])
+    return dict(max_logp=float(da.max()), mean_logp=float(da.mean()), argmax=float((a['logp'].argmax(-1) == b['logp'].argmax(-1)).mean()),
+                kv_max=float(dk.max()), kv_changed=float((dk > 0).mean()), finite=finite)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--seqs', type=int, default=64)
@@ -52,25 +71,11 @@ def main():
     args = ap.parse_args()
     if args.child:
         return child(args, args.child)
-    res = {}
-    with tempfile.TemporaryDirectory() as td:
-        for flag in ('1', '0'):
-            out = os.path.join(td, 'r%s.npz' % flag)
-            env = dict(os.environ, HVX_DEC_GEMM=flag)
-            subprocess.run([sys.executable, os.path.abspath(__file__), '--seqs', str(args.seqs), '--heads', str(args.heads), '--ctx', str(args.ctx),
-                            '--layers', str(args.layers), '--child', out], check=True, env=env)
-            res[flag] = dict(np.load(out))
-    a, b = res['1'], res['0']
-    top = np.argsort(-b['logp'], axis=-1)[..., :25]
-    da = np.take_along_axis(a['logp'], top, -1) - np.take_along_axis(b['logp'], top, -1)
-    print('rows %d  layers %d  ctx %d   non-finite: new %.4f old %.4f' % (args.seqs * args.heads, args.layers, args.ctx, 1 - np.isfinite(a['logp']).mean(), 1 - np.isfinite(b['logp']).mean()))
-    fin = np.isfinite(a['logp']) & np.isfinite(b['logp'])
-    a['logp'] = np.where(fin, a['logp'], -1e30)
-    b['logp'] = np.where(fin, b['logp'], -1e30)
-    print('log-prob (top 25 tokens of every row): max |diff| %.4f  mean |diff| %.5f   finite %s' % (np.abs(da).max(), np.abs(da).mean(), np.isfinite(a['logp']).all()))
-    print('argmax agreement: %.4f' % (a['logp'].argmax(-1) == b['logp'].argmax(-1)).mean())
-    dk = np.abs(a['kv'] - b['kv'])
-    print('kv cache sample: max |diff| %.4f  mean %.6f  changed %.4f' % (dk.max(), dk.mean(), (dk > 0).mean()))
+    r = compare(args.seqs, args.heads, args.ctx, args.layers)
+    print('rows %d  layers %d  ctx %d  finite %s' % (args.seqs * args.heads, args.layers, args.ctx, r['finite']))
+    print('log-prob (top 25 tokens of every row): max |diff| %.4f  mean |diff| %.5f' % (r['max_logp'], r['mean_logp']))
+    print('argmax agreement: %.4f' % r['argmax'])
+    print('kv cache sample: max |diff| %.4f  changed %.4f' % (r['kv_max'], r['kv_changed']))
 
 
 if __name__ == '__main__':
