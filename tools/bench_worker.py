@@ -53,7 +53,8 @@ llm = HvxLLM(cfg.llm, W.make_llm_state(cfg.llm, seed=1986), dtype=torch.bfloat16
 flow = HvxFlow(cfg.flow, W.make_flow_state(cfg.flow, seed=1987), dtype=torch.bfloat16, max_t=2 * n_spk + 64)
 hift = HvxHift(cfg.hift, W.make_hift_state(cfg.hift, seed=1988))
 mm = types.SimpleNamespace(models={'llm': llm, 'flow': flow, 'hift': hift}, device='cuda', configs={'sample_rate': 24000}, frontend=Frontend(),
-                           hvx_config=cfg, load_pt=lambda *x: {'status': 'error', 'message': 'not in this probe'})
+                           hvx_config=cfg, load_pt=lambda *x: {'status': 'error', 'message': 'not in this probe'}, is_loaded=True,
+                           get_available_speakers=lambda: [])        # (no speaker table: any speaker_id the tasks name is accepted)
 # random weights never emit EOS sensibly: pin the length through the ratios, as bench.py does (the queue protocol has no such field: patch the defaults)
 import flowmirror_hydravox_amd.pipeline as P  # noqa: E402
 _serve = P.HvxPipeline.serve
