@@ -78,23 +78,6 @@ __global__ __launch_bounds__(256, 2) void gemm_dec_kernel(SkinnyArgs a, int n_gr
     const int ks0 = ksplit * KT;
     const int m0 = chunk * 64 + wave * 16;                    // this wave's 16 rows
 
-    // ---- per-row controls of the QKV epilogue (position, cache slot): dependent loads, fetched before anything else is in flight ------------
-    int rc_ok[4] = {0, 0, 0, 0}, rc_pos[4] = {0, 0, 0, 0}, rc_slot[4] = {0, 0, 0, 0};
-    if constexpr (EPI == SK_QKV_ROPE) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = m0 + fg * 4 + r;
-            if (row < a.M) {
-                const int si = row / a.kn, lt = row - si * a.kn;
-                if (lt < a.n_new[si]) {
-                    rc_ok[r] = 1;
-                    rc_pos[r] = a.pos0[si] + lt;
-                    rc_slot[r] = a.slot[si];
-                }
-            }
-        }
-    }
-
     // ---- activation fragments of this wave's rows over the workgroup's K range (fragment order: 1 KiB per load) -----------------------------------
     bf16x8 af[KT];
     {
@@ -135,6 +118,24 @@ __global__ __launch_bounds__(256, 2) void gemm_dec_kernel(SkinnyArgs a, int n_gr
         constexpr int p = decltype(P)::value;
         issue(0, std::integral_constant<int, p / NST>{}, std::integral_constant<int, p % NST>{}, p);
     });
+
+    // ---- per-row controls of the QKV epilogue (position, cache slot, active or not).  Unconditional loads on clamped indices, requested BEHIND the
+    // operand streams: a load under a branch on another load's value kept the wave from issuing anything else for a round trip at the kernel's start
+    int rc_ok[4] = {0, 0, 0, 0}, rc_pos[4] = {0, 0, 0, 0}, rc_slot[4] = {0, 0, 0, 0};
+    if constexpr (EPI == SK_QKV_ROPE) {
+        int nn[4], lt[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = min(m0 + fg * 4 + r, a.M - 1);
+            const int si = row / a.kn;
+            lt[r] = row - si * a.kn;
+            nn[r] = a.n_new[si];
+            rc_pos[r] = a.pos0[si] + lt[r];
+            rc_slot[r] = a.slot[si];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rc_ok[r] = (m0 + fg * 4 + r < a.M) && (lt[r] < nn[r]);
+    }
 
     // ---- fused RMSNorm: 1 / rms of this wave's rows from the very fragments the MFMAs consume (the gain is folded into W, llm.py) --------------
     // (also the first use of the activation fragments outside the loop: hipcc then waits for them with a counted vmcnt here instead of
@@ -193,8 +194,9 @@ __global__ __launch_bounds__(256, 2) void gemm_dec_kernel(SkinnyArgs a, int n_gr
                     const int f = 8 * t + (fr & 7);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        e_cs[j][r] = a.rope_cos[(long long)rc_pos[r] * 32 + f];
-                        e_sn[j][r] = a.rope_sin[(long long)rc_pos[r] * 32 + f];
+                        const long long pr = rc_ok[r] ? rc_pos[r] : 0;               // (an inactive row's position may lie past the tables)
+                        e_cs[j][r] = a.rope_cos[pr * 32 + f];
+                        e_sn[j][r] = a.rope_sin[pr * 32 + f];
                     }
                 }
             }

@@ -78,6 +78,10 @@ namespace {
 constexpr int MAX_SPLIT = 16;
 // keys per decode-attention split (one workgroup); its 4 waves take a quarter each and merge in LDS.  256 on the whole chip; a decode engine confined
 // to a few compute units (hvx_stream_create_cu_range) wants fewer, longer workgroups (HVX_ATT_CHUNK, a multiple of 128)
+static bool att_chunk_from_env() {
+    static const bool v = getenv("HVX_ATT_CHUNK") != nullptr;
+    return v;
+}
 static int att_chunk_keys() {
     static const int v = [] { const char* e = getenv("HVX_ATT_CHUNK"); const int c = e ? atoi(e) : 256; return (c >= 128 && c % 128 == 0) ? c : 256; }();
     return v;
@@ -403,7 +407,11 @@ static int forward_impl(hvx_llm* h, hipStream_t s, int32_t n_seq, int32_t kn, co
         at.scale = 0.125f;
         at.out = h->attn; at.o_bs = at.q_bs; at.o_hs = at.q_hs; at.o_hi = 64; at.o_lo = Q; at.o_frag_kt = dec ? Q / 32 : 0;
         if (use_split) {
-            at.n_splits = h->att_splits; at.split_chunk = h->att_chunk; at.sub_chunk = h->att_chunk / 4; at.part_o = h->att_o; at.part_ml = h->att_ml; at.n_rows_pad = h->att_rows_pad;
+            // keys per split: the partial buffers are carved for h->att_chunk (256); a wide grid (>= 32 sequences) takes splits of twice that — with
+            // the fragment-order cache two 64-key trips per wave cost less than twice the workgroups (64 sequences: 1.346 -> 1.335 ms per step at
+            // context 1536, 1.517 -> 1.473 at 2560, and -2 % beside the acoustic stage); narrow grids lose with it (8 sequences: 0.977 -> 1.009 ms)
+            const int chunk = (n_seq >= 32 && !att_chunk_from_env()) ? 2 * h->att_chunk : h->att_chunk;
+            at.n_splits = (h->max_ctx + chunk - 1) / chunk; at.split_chunk = chunk; at.sub_chunk = chunk / 4; at.part_o = h->att_o; at.part_ml = h->att_ml; at.n_rows_pad = h->att_rows_pad;
         } else {
             at.n_splits = 1;
         }
