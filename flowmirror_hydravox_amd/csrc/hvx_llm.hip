@@ -479,6 +479,14 @@ static int forward_impl(hvx_llm* h, hipStream_t s, int32_t n_seq, int32_t kn, co
     memset(&g, 0, sizeof(g));
     g.dtype = dt; g.M = S; g.N = H; g.K = I; g.A = h->hm; g.lda = I; g.a_zs = (long long)S * I; g.W = mw[6]; g.w_zs = (long long)H * I;
     g.split_k = pick_split(H, I, K); g.nz = K; g.epi = SK_PARTIAL; g.part = h->part; g.part_zs = (long long)g.split_k * S * H;
+    {   // wide grids (the mid-M form, 33..128 rows): a workgroup walks its K slice serially, and pick_split's 3 slices leave 84 workgroups to pull
+        // 39 MB per head (57 us for two heads); 8 slices of ~43 K-tiles: 30 us (decode step 1.314 -> 1.287 ms at 64 sequences; 6 / 12 / 16 slices
+        // 1.293 / 1.292 / 1.292).  bf16 only: the fp32 parity mode keeps its summation order.
+        static const int force = [] { const char* e = getenv("HVX_HEAD_DOWN_SPLIT"); return e ? atoi(e) : 0; }();
+        int want = force > 0 ? force : ((dt == DT_BF16 && I / 64 / 12 >= 8) ? 8 : 0);
+        if (want > MAX_SPLIT) want = MAX_SPLIT;
+        if (want > g.split_k && S > 32 && S <= 128) { g.split_k = want; g.part_zs = (long long)g.split_k * S * H; }
+    }
     if (launch_skinny(g, s)) return -1;
     hn.part = h->part; hn.split_k = g.split_k; hn.part_stride = (long long)S * H; hn.part_zs = g.part_zs; hn.gain = nullptr; hn.do_norm = 0;   // plain cast
     if (launch_reduce_rmsnorm(hn, s)) return -1;
