@@ -50,6 +50,7 @@ def parse():
                          'prompt: 75 speech tokens + 150 mel frames + 20 prompt-text tokens, 8 per GPU and step); acoustic: configs[4] (flow + vocoder only on pre-tokenised streams)')
     ap.add_argument('--streams', type=int, default=64, help='(--config acoustic) pre-tokenised speech-token streams per GPU, lengths U{352..2816}')
     ap.add_argument('--tiny', action='store_true', help='toy dimensions (plumbing check only; INVALID as a benchmark)')
+    ap.add_argument('--llm-dtype', choices=['bf16', 'fp32'], default='bf16', help='fp32: the speech-token LM on the exact fp32 forms (ids bit-exact against the reference) with the flow decoder / vocoder as in the headline')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fp32-mode', action='store_true', help='skip the extra, untimed step in the parity-exact fp32 mode (the `fp32_mode` object of the line)')
     ap.add_argument('--lm-slots', type=int, default=64, help='sequences decoded in one grid (continuous batching): utterances of later steps join as earlier ones finish')
@@ -364,7 +365,7 @@ def main():
     max_ctx = 2 + chars + P_TXT + P_SPK + n_spk + K + 32
     sampling = partial(ras_sampling, top_p=0.9, top_k=10, win_size=32, tau_r=0.2)
     t_build = time.time()
-    pipe = HvxPipeline(cfg, llm_dtype=torch.bfloat16, flow_dtype=torch.bfloat16, max_batch=B, max_ctx=max_ctx, max_t=2 * (n_spk + P_SPK) + 64,
+    pipe = HvxPipeline(cfg, llm_dtype=torch.float32 if args.llm_dtype == 'fp32' else torch.bfloat16, flow_dtype=torch.bfloat16, max_batch=B, max_ctx=max_ctx, max_t=2 * (n_spk + P_SPK) + 64,
                        seed=1986, init='normal02', sampling=sampling, inference_head_num=K)
     pipe.acoustic_batch = max(1, args.acoustic_batch)
     pipe.lm_cus = args.lm_cus
@@ -512,10 +513,11 @@ def main():
         'metric': 'speech-tokens/sec + RTF, HydraVox-CV3 head_num=%d, %s' % (K, '%d-char batch' % chars if not zero_shot else 'zero-shot mixed-length batch'),
         'value': round(tokens / elapsed, 2), 'unit': 'speech-tokens/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 2),
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16' if args.llm_dtype == 'bf16' else 'f32 (LM) + bf16 (flow)', 'data': 'synthetic',
         'config': {'workload': 'HydraVox-CV3%s inference_head_num=%d, batch=%dx%d-char utterances per GPU (%d text -> %d speech tokens -> %d mel frames '
-                               'each), llm+flow bf16 / hift fp32, llm->flow->hift end to end, seeded N(0,0.02) weights'
-                               % (' [TINY DIMS - NOT A BENCHMARK]' if args.tiny else '', K, B, chars, chars, n_spk, 2 * n_spk),
+                               'each), %s / hift fp32, llm->flow->hift end to end, seeded N(0,0.02) weights'
+                               % (' [TINY DIMS - NOT A BENCHMARK]' if args.tiny else '', K, B, chars, chars, n_spk, 2 * n_spk,
+                                  'llm+flow bf16' if args.llm_dtype == 'bf16' else 'llm fp32 (speech-token ids bit-exact against the reference) + flow bf16'),
                    'baseline_config': {'tts': 'configs[1]', 'stress': 'configs[2]', 'zero_shot': 'configs[3]: text lengths U{64..512} per utterance (the chars figure above is the maximum), '
                                        'prompt = 75 speech tokens + 150 mel frames + 20 prompt-text tokens'}[args.config],
                    'global_batch': B * world, 'parallelism': 'utterance-dp%d' % world,
@@ -593,6 +595,35 @@ def main():
             torch.cuda.empty_cache()
         except Exception as e:
             line['fp32_mode'] = {'value': None, 'error': repr(e)}
+    if world == 1 and not args.no_fp32_mode and not args.tiny and args.mode == 'continuous' and args.llm_dtype == 'bf16' and args.config == 'tts':
+        # the mode that meets north_star's parity clause as written — speech-token ids BIT-EXACT against the reference (LM on the exact fp32 forms) with
+        # the flow decoder at the reference's own fp16 precision and the vocoder as in the headline — through the SAME continuous engine and the same
+        # number of steps (not part of the line's `value`; the clock below is its own)
+        try:
+            pipex = HvxPipeline(cfg, llm_dtype=torch.float32, flow_dtype=torch.bfloat16, max_batch=B, max_ctx=max_ctx, max_t=2 * (n_spk + P_SPK) + 64,
+                                seed=1986, init='normal02', sampling=sampling, inference_head_num=K)
+            pipex.acoustic_batch = max(1, args.acoustic_batch)
+            pipex.synthesize(utts[:1], max_token_text_ratio=ratio, min_token_text_ratio=ratio)
+            n_x = args.steps
+            jobx = [make_utt(g) for g in range(n_x * B)]
+            torch.cuda.synchronize()
+            tx = time.time()
+            tokx = 0
+            for i, wav, toks in pipex.synthesize_continuous(jobx, lm_slots=args.lm_slots, max_token_text_ratio=ratio, min_token_text_ratio=ratio,
+                                                            acoustic_batch=args.acoustic_batch, acoustic_min_batch=args.acoustic_min_batch):
+                tokx += len(toks)
+            torch.cuda.synchronize()
+            tx = time.time() - tx
+            cx = dict(pipex.last_continuous)
+            line['ids_exact_mode'] = {'value': round(tokx / tx, 1), 'unit': 'speech-tokens/s', 'rtf': round(tx / cx['audio_seconds'], 6), 'steps': n_x, 'ms_per_step': round(1e3 * tx / n_x, 2),
+                                      'dtype': 'f32 LM (speech-token ids bit-exact against the reference: tests/test_gpu_cv3w.py, test_gpu_cv3d.py) + the flow decoder and '
+                                               'vocoder of the headline (mel within the reference\'s own fp16 distance of fp32)',
+                                      'schedule': 'the continuous engine of the headline, %d slots, %d utterances' % (args.lm_slots, n_x * B),
+                                      'decode_step_us': round(cx['llm'].get('decode_step_us', 0.0), 1)}
+            del pipex
+            torch.cuda.empty_cache()
+        except Exception as e:
+            line['ids_exact_mode'] = {'value': None, 'error': repr(e)}
     if world == 1 and not args.no_cpu_baseline:
         try:
             # separate process with a hard wall-clock limit: the GPU line must be printed whatever the host cores do

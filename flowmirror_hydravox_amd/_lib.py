@@ -96,6 +96,10 @@ class HifiGanConfig(C.Structure):
                 ('n_rb', c_i32), ('rb_kernels', c_i32 * 4), ('rb_dils', (c_i32 * 3) * 4)]
 
 
+class NdDesc(C.Structure):
+    _fields_ = [('ndim', c_i32), ('shape', c_i32 * 6), ('stride_a', c_i64 * 6), ('stride_b', c_i64 * 6), ('stride_c', c_i64 * 6)]
+
+
 # every symbol include/hvx.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     'hvx_abi_version': (c_i32, []),
@@ -160,6 +164,11 @@ SYMBOLS = {
     'hvx_hift_source': (c_i32, [c_vp, c_vp, c_vp, c_sz, c_vp, c_i32, c_vp, c_vp]),
     'hvx_hift_decode': (c_i32, [c_vp, c_vp, c_vp, c_sz, c_vp, c_vp, c_i32, c_vp]),
     'hvx_hift_decode_chunk': (c_i32, [c_vp, c_vp, c_vp, c_sz, c_vp, c_vp, c_i32, c_i32, c_vp]),
+    'hvx_nd_elementwise': (c_i32, [c_i32, C.POINTER(NdDesc), c_vp, c_vp, c_vp, C.c_float, C.c_float, c_vp, c_vp]),
+    'hvx_rows_reduce': (c_i32, [c_i32, c_vp, c_i64, c_i64, c_vp, c_vp]),
+    'hvx_rows_softmax': (c_i32, [c_vp, c_i64, c_i64, c_vp, c_vp]),
+    'hvx_avgpool_rows': (c_i32, [c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp]),
+    'hvx_conv2d': (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
 }
 
 _lib = None

@@ -119,3 +119,50 @@ class HvxKaldiFbank(_FramedFeatures):
         cfg = _lib.FeatureConfig(frame_len=416, hop=160, reflect_pad=0, n_frames=frames, bins=257, power=1, mag_eps=0.0, n_mels=self.num_mel_bins,
                                  log_floor=1.1920928955078125e-07, log_scale=1.0, post=2 if self.subtract_mean else 0, time_major=1)
         return self._run(a, cfg, torch.empty(frames, self.num_mel_bins, dtype=torch.float32, device=self.device))
+
+
+class HvxSpeechTokenizer:
+    """`CosyVoiceFrontEnd._extract_speech_token` on the device (cosyvoice/cli/frontend.py:92-103): 16 kHz prompt audio -> whisper 128-bin log-mel
+    (HvxWhisperLogMel) -> the speech-tokenizer ONNX graph through the device executor (onnx_graph.OnnxRunner instead of an onnxruntime CPU session) ->
+    (speech_token int32 [1][N], speech_token_len int32 [1]).  The graph's inputs are taken by position, as the reference does
+    (`session.get_inputs()[0]` = the features [1][128][T], `[1]` = their length as int32 [1]); a graph with a single input gets the features only.
+    `speech_tokenizer_v3.onnx` itself is an asset of the weights repository (not in the tree): parity with onnxruntime on it is unpinned."""
+
+    def __init__(self, onnx_model, device='cuda'):
+        from .onnx_graph import OnnxRunner
+        self.runner = OnnxRunner(onnx_model, device=device)
+        self.feat = HvxWhisperLogMel(128, device=device)
+        self.device = torch.device(device)
+
+    @torch.inference_mode()
+    def __call__(self, speech_16k):
+        speech = speech_16k.reshape(1, -1)
+        if speech.shape[1] / 16000 > 30:
+            raise AssertionError('do not support extract speech token for audio longer than 30s')          # (frontend.py:94)
+        feat = self.feat(speech)                                                            # [1][128][T]
+        names = self.runner.g.inputs
+        feeds = {names[0]: feat}                                                            # (stays on the device)
+        if len(names) > 1:
+            import numpy as np
+            feeds[names[1]] = np.array([feat.shape[2]], dtype=np.int32)
+        out = self.runner.run(feeds)[self.runner.g.outputs[0]]
+        tok = torch.tensor([out.reshape(-1).tolist()], dtype=torch.int32, device=self.device)
+        return tok, torch.tensor([tok.shape[1]], dtype=torch.int32, device=self.device)
+
+
+class HvxSpeakerEncoder:
+    """`CosyVoiceFrontEnd._extract_spk_embedding` on the device (cosyvoice/cli/frontend.py:105-115): 16 kHz prompt audio -> kaldi 80-bin fbank with
+    mean subtraction (HvxKaldiFbank) -> the CAM++ ONNX graph through the device executor -> embedding float32 [1][D] (D = 192 for campplus.onnx, an
+    asset that is not in the tree: parity with onnxruntime on it is unpinned)."""
+
+    def __init__(self, onnx_model, device='cuda'):
+        from .onnx_graph import OnnxRunner
+        self.runner = OnnxRunner(onnx_model, device=device)
+        self.feat = HvxKaldiFbank(80, 16000, subtract_mean=True, device=device)
+        self.device = torch.device(device)
+
+    @torch.inference_mode()
+    def __call__(self, speech_16k):
+        feat = self.feat(speech_16k.reshape(1, -1))                                         # [frames][80]
+        out = self.runner.run({self.runner.g.inputs[0]: feat.unsqueeze(0)})[self.runner.g.outputs[0]]
+        return torch.tensor([out.reshape(-1).tolist()], dtype=torch.float32, device=self.device)

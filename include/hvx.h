@@ -384,6 +384,37 @@ int hvx_stft_magnitude(hvx_stream s, void* ws, size_t ws_bytes, const float* aud
 int hvx_denoise(hvx_stream s, void* ws, size_t ws_bytes, const float* audio, int32_t L, int32_t n_fft, int32_t hop, const float* stft_basis,
                 const float* istft_basis, const float* wsq, const float* bias, float strength, float* out);
 
+/* ---- ONNX graph operators ---------------------------------------------------------------------------------------------
+ * The zero-shot frontend of the reference runs `speech_tokenizer_v3.onnx` and `campplus.onnx` through onnxruntime on the prompt audio
+ * (server/model_utils/cosyvoice/cli/frontend.py:92-115).  flowmirror_hydravox_amd/onnx_graph.py executes such graphs on the device: Conv /
+ * MatMul / Gemm through hvx_op_gemm (exact fp32 MFMA forms), everything else through the fp32 kernels below.  Tensors are dense fp32;
+ * integer (shape) tensors stay on the host. */
+enum {  /* hvx_nd_elementwise operators: unary on a | binary on (a, b) | select */
+    HVX_EW_COPY = 0, HVX_EW_RELU, HVX_EW_SIGMOID, HVX_EW_TANH, HVX_EW_ERF, HVX_EW_SQRT, HVX_EW_EXP, HVX_EW_LOG, HVX_EW_NEG, HVX_EW_ABS, HVX_EW_ROUND,
+    HVX_EW_FLOOR, HVX_EW_CEIL, HVX_EW_RECIP, HVX_EW_CLIP /* [p0, p1] */, HVX_EW_LEAKY_RELU /* slope p0 */, HVX_EW_SOFTPLUS, HVX_EW_SIN, HVX_EW_COS,
+    HVX_EW_ADD = 32, HVX_EW_SUB, HVX_EW_MUL, HVX_EW_DIV, HVX_EW_POW, HVX_EW_MAX, HVX_EW_MIN, HVX_EW_EQUAL, HVX_EW_LESS, HVX_EW_GREATER,
+    HVX_EW_WHERE = 48   /* out = a != 0 ? b : c */
+};
+enum { HVX_RED_SUM = 0, HVX_RED_MEAN = 1, HVX_RED_MAX = 2, HVX_RED_MIN = 3, HVX_RED_SUMSQ = 4 };
+typedef struct {
+    int32_t ndim;                         /* 1..6 */
+    int32_t shape[6];                     /* extents of the (contiguous, row-major) output */
+    int64_t stride_a[6], stride_b[6], stride_c[6];   /* element strides of the operands along the output axes; 0 broadcasts */
+} hvx_nd;
+/* out[i] = op(a[..], b[..], c[..]) over the output index space of d: the arithmetic of an ONNX graph (Add, Mul, Relu, Sigmoid, Erf, Clip, Where ...)
+ * and, with HVX_EW_COPY, its data movement (Transpose, Slice, Expand and Concat pieces are strided copies) */
+int hvx_nd_elementwise(int32_t op, const hvx_nd* d, const float* a, const float* b, const float* c, float p0, float p1, float* out, hvx_stream s);
+/* out[r] = reduce(x[r][0..cols)) (ReduceSum / ReduceMean / ReduceMax / ReduceMin / sum of squares over the last axis of a [rows][cols] view) */
+int hvx_rows_reduce(int32_t op, const float* x, int64_t rows, int64_t cols, float* out, hvx_stream s);
+/* out[r][:] = softmax(x[r][:]) (ONNX Softmax, axis = last) */
+int hvx_rows_softmax(const float* x, int64_t rows, int64_t cols, float* out, hvx_stream s);
+/* ONNX AveragePool over the last axis of [rows][t_in] -> [rows][t_out] (the caller computes t_out, with ceil_mode if the node asks for it) */
+int hvx_avgpool_rows(const float* x, int64_t rows, int32_t t_in, int32_t kernel, int32_t stride, int32_t pad, int32_t count_include_pad, float* y,
+                     int32_t t_out, hvx_stream s);
+/* ONNX Conv, 2-D, group 1, dilation 1: x [B][Cin][H][W], w [Cout][Cin][kh][kw], bias [Cout] or NULL -> y [B][Cout][Ho][Wo] (the CAM++ front module) */
+int hvx_conv2d(const float* x, const float* w, const float* bias, int32_t B, int32_t Cin, int32_t H, int32_t W, int32_t Cout, int32_t kh, int32_t kw,
+               int32_t sh, int32_t sw, int32_t ph, int32_t pw, float* y, hvx_stream s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -179,3 +179,35 @@ def test_kaldi_fbank_vs_oracle(n):
         assert out.shape == ref.shape == (1 + (n - 400) // 160, 80)
         assert (out - ref).abs().max().item() < 5e-3, (sub, (out - ref).abs().max().item())
     assert HvxKaldiFbank(80)(y[:399]).shape == (0, 80)
+
+
+def test_zero_shot_frontend_graphs_run_on_the_device():
+    """SURVEY.md §8(f) N2, the rest of the row: `_extract_speech_token` / `_extract_spk_embedding` (cosyvoice/cli/frontend.py:92-115) with the ONNX graphs
+    executed on the device (frontend.HvxSpeechTokenizer / HvxSpeakerEncoder over onnx_graph.OnnxRunner) instead of onnxruntime CPU sessions.  The real
+    assets are absent, so the graphs are the synthetic ones of tests/onnx_synth.py at the real input widths (128 mels / 80 fbank bins); the device result
+    is held to the numpy oracle of the graph applied to the device features.  Return types and shapes are the reference's."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import onnx_synth
+    from flowmirror_hydravox_amd import onnx_graph as og
+    from flowmirror_hydravox_amd.frontend import HvxSpeechTokenizer, HvxSpeakerEncoder
+    from oracle import onnx_ref
+    g = torch.Generator().manual_seed(11)
+    speech = (0.1 * torch.randn(1, 16000 * 2 + 123, generator=g)).clamp(-1, 1)
+    tok_model = og.save_onnx(onnx_synth.tokenizer_like(n_mels=128))
+    tk = HvxSpeechTokenizer(tok_model)
+    tok, tok_len = tk(speech)
+    T = speech.shape[1] // 160
+    assert tok.dtype == torch.int32 and tuple(tok.shape) == (1, (T + 1) // 2) and tok_len.tolist() == [(T + 1) // 2] and tok.is_cuda
+    ref = onnx_ref.run(og.load_onnx(tok_model), {'mel': tk.feat(speech).cpu().numpy()})
+    safe = (np.abs(np.abs(ref['latent'] * 0.999) - 0.5) > 1e-3).all(-1)
+    assert safe.mean() > 0.9 and np.array_equal(tok.cpu().numpy()[safe], ref['tokens'][safe])
+    with pytest.raises(AssertionError):
+        tk(torch.zeros(1, 16000 * 30 + 1))                                      # (frontend.py:94)
+    spk_model = og.save_onnx(onnx_synth.campplus_like(emb=192))
+    enc = HvxSpeakerEncoder(spk_model)
+    emb = enc(speech)
+    assert emb.dtype == torch.float32 and tuple(emb.shape) == (1, 192) and emb.is_cuda
+    ref = onnx_ref.run(og.load_onnx(spk_model), {'fbank': enc.feat(speech).unsqueeze(0).cpu().numpy()})['embedding']
+    assert np.abs(emb.cpu().numpy() - ref).max() < 2e-4 * max(1.0, np.abs(ref).max())

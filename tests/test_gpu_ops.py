@@ -1,4 +1,5 @@
 """Parity of the HIP building-block kernels (through the C-ABI) against plain PyTorch fp32 math and the oracle."""
+import os
 import math
 
 import numpy as np
@@ -490,3 +491,78 @@ def test_resample_linear_matches_torch_interpolate(t_in, speed):
     out = ops.resample_linear(x.to(DEV), t_out)
     assert out.shape == ref.shape
     torch.testing.assert_close(out.cpu(), ref, rtol=1e-6, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# ONNX graph executor
+# ------------------------------------------------------------------------------------------------------------------------
+def test_nd_elementwise_broadcast_strided_and_reductions():
+    """hvx_nd_elementwise / hvx_rows_reduce / hvx_rows_softmax / hvx_avgpool_rows / hvx_conv2d against numpy / torch CPU: broadcasting in both
+    operands, strided sources (Transpose, negative-step Slice), more than 6 axes that merge, select, every unary operator."""
+    import torch.nn.functional as F
+    from flowmirror_hydravox_amd import onnx_graph as og
+    r = og.OnnxRunner(og.Graph([], {}, [], []))
+    rng = np.random.default_rng(5)
+    a = rng.standard_normal((2, 1, 5, 1, 7)).astype(np.float32)
+    b = rng.standard_normal((3, 1, 4, 7)).astype(np.float32)
+    for op, fn in (('ADD', np.add), ('SUB', np.subtract), ('MUL', np.multiply), ('DIV', np.divide), ('MAX', np.maximum), ('MIN', np.minimum)):
+        np.testing.assert_allclose(r._binary(op, r._up(a), r._up(b)).cpu().numpy(), fn(a, b), rtol=1e-6, atol=1e-6)
+    np.testing.assert_array_equal(r._binary('LESS', r._up(a), r._up(b)).cpu().numpy(), (a < b).astype(np.float32))
+    x = rng.standard_normal((2, 3, 4, 5, 2, 3, 2)).astype(np.float32)           # 7 axes: contiguous ones merge
+    np.testing.assert_allclose(r._unary('TANH', r._up(x)).cpu().numpy(), np.tanh(x), rtol=1e-6, atol=1e-6)
+    np.testing.assert_array_equal(r._permute(r._up(x[..., 0, 0]), [3, 0, 4, 1, 2]).cpu().numpy(), np.transpose(x[..., 0, 0], [3, 0, 4, 1, 2]))
+    for name, fn in (('RELU', lambda v: np.maximum(v, 0)), ('SIGMOID', lambda v: 1 / (1 + np.exp(-v))), ('EXP', np.exp), ('NEG', np.negative), ('ABS', np.abs),
+                     ('ROUND', np.round), ('FLOOR', np.floor), ('CEIL', np.ceil), ('SIN', np.sin), ('COS', np.cos)):
+        np.testing.assert_allclose(r._unary(name, r._up(a)).cpu().numpy(), fn(a), rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(r._unary('ERF', r._up(a)).cpu().numpy(), torch.erf(torch.from_numpy(a)).numpy(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(r._unary('CLIP', r._up(a), -0.3, 0.8).cpu().numpy(), np.clip(a, -0.3, 0.8))
+    sl = og.Node('Slice', ['x', 's', 'e', 'a', 'st'], ['y'], {})
+    got = r._node(sl, [r._up(b), np.asarray([2, 6]), np.asarray([-5, 0]), np.asarray([2, 3]), np.asarray([-1, -2])])
+    np.testing.assert_array_equal(got.cpu().numpy(), b[:, :, 2::-1, 6:0:-2])
+    for axes in ([4], [0, 2], [1, 3, 4], None):
+        for op, fn in (('MEAN', np.mean), ('SUM', np.sum), ('MAX', np.max), ('MIN', np.min)):
+            want = fn(a.astype(np.float64), axis=None if axes is None else tuple(axes), keepdims=True)
+            np.testing.assert_allclose(r._reduce(op, r._up(a), axes, True).cpu().numpy(), want, rtol=1e-5, atol=1e-6)
+    sm = r._node(og.Node('Softmax', ['x'], ['y'], {'axis': 1}), [r._up(b)])
+    np.testing.assert_allclose(sm.cpu().numpy(), torch.softmax(torch.from_numpy(b), 1).numpy(), rtol=1e-5, atol=1e-6)
+    for T, k, s, p, cm, cip in ((37, 10, 10, 0, 1, 0), (40, 10, 10, 0, 1, 0), (23, 4, 3, 1, 1, 1), (9, 5, 5, 2, 1, 0)):
+        xa = rng.standard_normal((2, 3, T)).astype(np.float32)
+        nd = og.Node('AveragePool', ['x'], ['y'], dict(kernel_shape=[k], strides=[s], pads=[p, p], ceil_mode=cm, count_include_pad=cip))
+        want = F.avg_pool1d(torch.from_numpy(xa), k, s, p, ceil_mode=bool(cm), count_include_pad=bool(cip)).numpy()
+        np.testing.assert_allclose(r._node(nd, [r._up(xa)]).cpu().numpy(), want, rtol=1e-5, atol=1e-6)
+    x4, w4, b4 = rng.standard_normal((2, 3, 11, 9)).astype(np.float32), rng.standard_normal((4, 3, 3, 3)).astype(np.float32), rng.standard_normal(4).astype(np.float32)
+    nd = og.Node('Conv', ['x', 'w', 'b'], ['y'], dict(kernel_shape=[3, 3], strides=[2, 1], pads=[1, 1, 1, 1]))
+    want = F.conv2d(torch.from_numpy(x4), torch.from_numpy(w4), torch.from_numpy(b4), stride=(2, 1), padding=1).numpy()
+    np.testing.assert_allclose(r._node(nd, [r._up(x4), w4, b4]).cpu().numpy(), want, rtol=1e-5, atol=1e-5)
+    x1, w1, b1 = rng.standard_normal((2, 6, 37)).astype(np.float32), rng.standard_normal((8, 3, 5)).astype(np.float32), rng.standard_normal(8).astype(np.float32)
+    nd = og.Node('Conv', ['x', 'w', 'b'], ['y'], dict(kernel_shape=[5], strides=[2], dilations=[3], pads=[4, 7], group=2))
+    want = F.conv1d(F.pad(torch.from_numpy(x1), (4, 7)), torch.from_numpy(w1), torch.from_numpy(b1), stride=2, dilation=3, groups=2).numpy()
+    np.testing.assert_allclose(r._node(nd, [r._up(x1), w1, b1]).cpu().numpy(), want, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize('T', [57, 200])
+def test_onnx_frontend_graphs_on_device_vs_oracle(T):
+    """The two synthetic frontend graphs (tests/onnx_synth.py: the operator mix of campplus.onnx and speech_tokenizer_v3.onnx at toy widths) through the
+    device executor against the numpy oracle: speaker embedding and FSQ latent within 2e-4 of the output scale; token ids equal wherever the latent is
+    not within 1e-3 of a rounding boundary.  Parity against onnxruntime on the real assets is unpinned (absent here)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import onnx_synth
+    from flowmirror_hydravox_amd import onnx_graph as og
+    from oracle import onnx_ref
+    rng = np.random.default_rng(T)
+    g = og.load_onnx(og.save_onnx(onnx_synth.campplus_like()))
+    feed = {'fbank': rng.standard_normal((1, T, 80)).astype(np.float32)}
+    run = og.OnnxRunner(g)
+    got, want = run.run(feed)['embedding'], onnx_ref.run(g, feed)['embedding']
+    assert got.shape == want.shape == (1, 24)
+    assert np.abs(got - want).max() < 2e-4 * max(1.0, np.abs(want).max()), np.abs(got - want).max()
+    assert {'Conv', 'BatchNormalization', 'AveragePool', 'Gemm', 'Expand', 'Slice'} <= set(run.op_counts)
+    g = og.load_onnx(og.save_onnx(onnx_synth.tokenizer_like()))
+    feed = {'mel': rng.standard_normal((1, 16, T)).astype(np.float32)}
+    out, ref = og.OnnxRunner(g).run(feed), onnx_ref.run(g, feed)
+    assert out['tokens'].dtype == np.int64 and out['tokens'].shape == ref['tokens'].shape == (1, (T + 1) // 2)
+    assert np.abs(out['latent'] - ref['latent']).max() < 2e-4
+    z = ref['latent'] * 0.999
+    safe = (np.abs(np.abs(z) - 0.5) > 1e-3).all(-1)
+    assert safe.mean() > 0.9 and np.array_equal(out['tokens'][safe], ref['tokens'][safe])

@@ -61,12 +61,12 @@ def test_ctypes_struct_sizes_match_the_c_header(tmp_path):
     """sizeof() of every argument struct as seen by a C compiler == the ctypes mirror (catches field drift)."""
     from flowmirror_hydravox_amd import _lib
     c = tmp_path / 's.c'
-    c.write_text('#include <stdio.h>\n#include "hvx.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(hvx_sample_args), '
-                 'sizeof(hvx_gemm_args), sizeof(hvx_attn_args), sizeof(hvx_llm_config), sizeof(hvx_flow_config), sizeof(hvx_hift_config), sizeof(hvx_decode_args));return 0;}\n')
+    c.write_text('#include <stdio.h>\n#include "hvx.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(hvx_sample_args), '
+                 'sizeof(hvx_gemm_args), sizeof(hvx_attn_args), sizeof(hvx_llm_config), sizeof(hvx_flow_config), sizeof(hvx_hift_config), sizeof(hvx_decode_args), sizeof(hvx_nd));return 0;}\n')
     exe = tmp_path / 's'
     subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), str(c), '-o', str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
-    want = [ctypes.sizeof(t) for t in (_lib.SampleArgs, _lib.GemmArgs, _lib.AttnArgs, _lib.LLMConfig, _lib.FlowConfig, _lib.HiftConfig, _lib.DecodeArgs)]
+    want = [ctypes.sizeof(t) for t in (_lib.SampleArgs, _lib.GemmArgs, _lib.AttnArgs, _lib.LLMConfig, _lib.FlowConfig, _lib.HiftConfig, _lib.DecodeArgs, _lib.NdDesc)]
     assert got == want
 
 

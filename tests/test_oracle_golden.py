@@ -509,3 +509,64 @@ def test_reference_deployed_dtype_fixtures_are_consistent():
     assert str(fh['d_in_sha']) == str(fd['e1_in_sha']) and np.abs(fh['d_out_f32'] - fd['e1_out']).max() < 1e-5
     dh = np.abs(fh['d_out_f16'] - fh['d_out_f32']).max() / np.abs(fh['d_out_f32']).max()
     assert abs(dh - float(fh['d_half_vs_f32'])) < 1e-6 and 2e-4 < dh < 5e-3
+
+
+def test_onnx_container_round_trip_and_oracle_operators_vs_torch():
+    """(1) the ONNX container reader / writer of the product (protobuf wire format, no `onnx` package) round-trips the two synthetic
+    frontend graphs — node list, attributes of every type, initializers bit for bit; (2) the numpy oracle of the operator set (oracle/onnx_ref.py: published
+    ONNX semantics; onnxruntime and the real graphs are absent -> parity unpinned) agrees with torch's CPU functional forms of the same operators where
+    torch has one (Conv 1-D / 2-D with stride, dilation, padding and groups; AveragePool with ceil_mode; LayerNorm; BatchNorm; Softmax; GELU)."""
+    import sys
+    import os
+    import torch.nn.functional as F
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import onnx_synth
+    from flowmirror_hydravox_amd import onnx_graph as og
+    from oracle import onnx_ref
+    for mk in (onnx_synth.campplus_like, onnx_synth.tokenizer_like):
+        g = mk()
+        g2 = og.load_onnx(og.save_onnx(g))
+        assert g2.inputs == g.inputs and g2.outputs == g.outputs and g2.opset == g.opset and len(g2.nodes) == len(g.nodes)
+        assert set(g2.initializers) == set(g.initializers)
+        for k, a in g.initializers.items():
+            assert a.dtype == g2.initializers[k].dtype and np.array_equal(a, g2.initializers[k])
+        for a, b in zip(g.nodes, g2.nodes):
+            assert (a.op, a.inputs, a.outputs, sorted(a.attrs)) == (b.op, b.inputs, b.outputs, sorted(b.attrs))
+            for k, val in a.attrs.items():
+                assert (abs(val - b.attrs[k]) < 1e-7) if isinstance(val, float) else (val == b.attrs[k]), (a.op, k)
+    N = og.Node
+    rng = np.random.default_rng(3)
+
+    def one(op, ins, **attrs):
+        return onnx_ref._node(N(op, ['i%d' % i for i in range(len(ins))], ['o'], attrs), ins, 17)
+
+    x = rng.standard_normal((2, 6, 37)).astype(np.float32)
+    w = rng.standard_normal((8, 3, 5)).astype(np.float32)
+    b = rng.standard_normal(8).astype(np.float32)
+    got = one('Conv', [x, w, b], kernel_shape=[5], strides=[2], dilations=[3], pads=[4, 7], group=2)
+    want = F.conv1d(F.pad(torch.from_numpy(x), (4, 7)), torch.from_numpy(w), torch.from_numpy(b), stride=2, dilation=3, groups=2).numpy()
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5)
+    x4 = rng.standard_normal((1, 3, 11, 9)).astype(np.float32)
+    w4 = rng.standard_normal((4, 3, 3, 3)).astype(np.float32)
+    got = one('Conv', [x4, w4], kernel_shape=[3, 3], strides=[2, 1], pads=[1, 1, 1, 1])
+    np.testing.assert_allclose(got, F.conv2d(torch.from_numpy(x4), torch.from_numpy(w4), stride=(2, 1), padding=1).numpy(), rtol=1e-5, atol=1e-5)
+    for T, k, s, p, cm, cip in ((37, 10, 10, 0, 1, 0), (40, 10, 10, 0, 1, 0), (23, 4, 3, 1, 1, 1), (23, 4, 3, 1, 0, 0), (9, 5, 5, 2, 1, 0)):
+        xa = rng.standard_normal((2, 3, T)).astype(np.float32)
+        got = one('AveragePool', [xa], kernel_shape=[k], strides=[s], pads=[p, p], ceil_mode=cm, count_include_pad=cip)
+        want = F.avg_pool1d(torch.from_numpy(xa), k, s, p, ceil_mode=bool(cm), count_include_pad=bool(cip)).numpy()
+        assert got.shape == want.shape, (T, k, s, p, cm, got.shape, want.shape)
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6)
+    xs = rng.standard_normal((2, 5, 16)).astype(np.float32)
+    g_, b_ = rng.standard_normal(16).astype(np.float32), rng.standard_normal(16).astype(np.float32)
+    np.testing.assert_allclose(one('LayerNormalization', [xs, g_, b_], axis=-1, epsilon=1e-5),
+                               F.layer_norm(torch.from_numpy(xs), (16,), torch.from_numpy(g_), torch.from_numpy(b_)).numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(one('Softmax', [xs], axis=1), torch.softmax(torch.from_numpy(xs), 1).numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(one('Gelu', [xs]), F.gelu(torch.from_numpy(xs)).numpy(), rtol=1e-5, atol=1e-6)
+    p = [rng.standard_normal(5).astype(np.float32) for _ in range(3)] + [(0.5 + rng.random(5)).astype(np.float32)]
+    np.testing.assert_allclose(one('BatchNormalization', [xs] + p, epsilon=1e-5),
+                               F.batch_norm(torch.from_numpy(xs), torch.from_numpy(p[2]), torch.from_numpy(p[3]), torch.from_numpy(p[0]), torch.from_numpy(p[1]), False, 0.0, 1e-5).numpy(),
+                               rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(one('Gemm', [xs[0], g_.reshape(1, 16).repeat(3, 0), b_[:3]], transB=1, alpha=0.5, beta=2.0),
+                               0.5 * xs[0] @ g_.reshape(1, 16).repeat(3, 0).T + 2.0 * b_[:3], rtol=1e-5, atol=1e-5)
+    assert np.array_equal(one('Round', [np.asarray([0.5, 1.5, 2.5, -0.5, -1.5], np.float32)]), np.asarray([0, 2, 2, -0, -2], np.float32))
+    assert np.array_equal(one('Slice', [np.arange(10), np.asarray([8]), np.asarray([-11]), np.asarray([0]), np.asarray([-3])]), np.asarray([8, 5, 2]))
