@@ -690,7 +690,7 @@ class OnnxRunner:
         # ---- arithmetic ---------------------------------------------------------------------------------------------------------------------
         if op in _UNARY:
             return self._unary(_UNARY[op], x)
-        if op in _BINARY:
+        if op in _BINARY and len(v) == 2:
             return self._binary(_BINARY[op], v[0], v[1])
         if op == 'Clip':
             lo = v[1] if len(v) > 1 and v[1] is not None else at.get('min', -3.4e38)
@@ -700,6 +700,55 @@ class OnnxRunner:
             return self._unary('LEAKY_RELU', x, float(at.get('alpha', 0.01)))
         if op == 'Not':
             return self._binary('EQUAL', x, np.zeros(1, np.float32))
+        one, zero = np.ones(1, np.float32), np.zeros(1, np.float32)
+        if op in ('And', 'Or', 'Xor'):                              # booleans are 0 / 1 floats on the device
+            a, b = self._dev(np.asarray(v[0], np.float32) if not self._is_dev(v[0]) else v[0]), self._dev(np.asarray(v[1], np.float32) if not self._is_dev(v[1]) else v[1])
+            return self._binary('MUL', a, b) if op == 'And' else (self._binary('MAX', a, b) if op == 'Or' else self._binary('EQUAL', self._binary('EQUAL', a, b), zero))
+        if op in ('Sum', 'Mean') or (op in ('Max', 'Min') and len(v) != 2):
+            acc = self._dev(v[0])
+            for t in v[1:]:
+                acc = self._binary({'Sum': 'ADD', 'Mean': 'ADD', 'Max': 'MAX', 'Min': 'MIN'}[op], acc, t)
+            return self._binary('DIV', acc, np.asarray([float(len(v))], np.float32)) if op == 'Mean' else acc
+        if op == 'PRelu':
+            return self._binary('ADD', self._unary('RELU', x), self._binary('MUL', self._binary('MIN', x, zero), v[1]))
+        if op == 'Elu':
+            neg = self._binary('MUL', self._binary('SUB', self._unary('EXP', self._binary('MIN', x, zero)), one), np.asarray([float(at.get('alpha', 1.0))], np.float32))
+            return self._binary('ADD', self._unary('RELU', x), neg)
+        if op == 'HardSigmoid':
+            y = self._binary('ADD', self._binary('MUL', x, np.asarray([float(at.get('alpha', 0.2))], np.float32)), np.asarray([float(at.get('beta', 0.5))], np.float32))
+            return self._unary('CLIP', y, 0.0, 1.0)
+        if op == 'Sign':
+            return self._binary('SUB', self._binary('GREATER', x, zero), self._binary('LESS', x, zero))
+        if op == 'LogSoftmax':
+            sm = self._node(Node('Softmax', node.inputs, node.outputs, {'axis': at.get('axis', -1)}), v)
+            return self._unary('LOG', sm)
+        if op in ('ArgMax', 'ArgMin'):
+            # first index of the extremum: min over where(x == extremum, index, n) — three elementwise passes and two reductions, no dedicated kernel
+            ax = int(at.get('axis', 0)) % x.dim()
+            if int(at.get('select_last_index', 0)):
+                raise NotImplementedError('ArgMax / ArgMin with select_last_index')
+            ext = self._reduce('MAX' if op == 'ArgMax' else 'MIN', x, [ax], True)
+            n = x.shape[ax]
+            iota = np.arange(n, dtype=np.float32).reshape([n if i == ax else 1 for i in range(x.dim())])
+            hit = self._binary('EQUAL', x, ext)
+            c, a, b = hit, self._dev(iota), self._dev(np.asarray([float(n)], np.float32))
+            cand = self._ew('WHERE', list(x.shape), c, self._strides(c.shape), a, self._bstrides(a.shape, list(x.shape)), b, self._bstrides(b.shape, list(x.shape)))
+            idx = self._reduce('MIN', cand, [ax], bool(at.get('keepdims', 1)))
+            return idx.detach().cpu().numpy().astype(np.int64)       # (an integer result is a host value)
+        if op == 'Split':
+            ax = int(at.get('axis', 0)) % x.dim()
+            sizes = [int(t) for t in (v[1] if len(v) > 1 and v[1] is not None else at.get('split', []))]
+            if not sizes:
+                k = len(node.outputs)
+                sizes = [-(-x.shape[ax] // k)] * k
+                sizes[-1] = x.shape[ax] - sum(sizes[:-1])
+            outs, o, st = [], 0, self._strides(x.shape)
+            for n in sizes:
+                shape = list(x.shape)
+                shape[ax] = n
+                outs.append(self._ew('COPY', shape, x, st, a_off=o * st[ax]))
+                o += n
+            return outs
         if op == 'Gelu':
             h = self._binary('MUL', x, np.asarray([0.7071067811865476], np.float32))
             return self._binary('MUL', self._binary('MUL', x, np.asarray([0.5], np.float32)), self._binary('ADD', self._unary('ERF', h), np.asarray([1.0], np.float32)))

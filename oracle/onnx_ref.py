@@ -86,6 +86,11 @@ def _node(node, v, opset):
         return (np.trunc(v[0]) if np.issubdtype(to, np.integer) and np.issubdtype(v[0].dtype, np.floating) else v[0]).astype(to)
     two = {'Add': np.add, 'Sub': np.subtract, 'Mul': np.multiply, 'Pow': np.power, 'Max': np.maximum, 'Min': np.minimum, 'Equal': np.equal,
            'Less': np.less, 'Greater': np.greater, 'And': np.logical_and, 'Or': np.logical_or}
+    if op in ('Max', 'Min') and len(v) != 2:
+        out = v[0]
+        for t in v[1:]:
+            out = two[op](out, t)
+        return out
     if op in two:
         return two[op](v[0], v[1])
     if op == 'Div':
@@ -98,6 +103,36 @@ def _node(node, v, opset):
            'Not': np.logical_not}
     if op in one:
         return one[op](v[0])
+    if op == 'Xor':
+        return np.logical_xor(v[0], v[1])
+    if op in ('Sum', 'Mean'):
+        acc = sum(x.astype(np.float64) for x in v)
+        return (acc / len(v) if op == 'Mean' else acc).astype(np.float32)
+    if op == 'PRelu':
+        return np.where(v[0] > 0, v[0], v[0] * v[1]).astype(np.float32)
+    if op == 'Elu':
+        return np.where(v[0] > 0, v[0], np.float32(at.get('alpha', 1.0)) * (np.exp(np.minimum(v[0], 0)) - 1)).astype(np.float32)
+    if op == 'HardSigmoid':
+        return np.clip(np.float32(at.get('alpha', 0.2)) * v[0] + np.float32(at.get('beta', 0.5)), 0, 1).astype(np.float32)
+    if op == 'Sign':
+        return np.sign(v[0])
+    if op == 'LogSoftmax':
+        x = v[0].astype(np.float64)
+        ax = int(at.get('axis', -1))
+        z = x - x.max(ax, keepdims=True)
+        return (z - np.log(np.exp(z).sum(ax, keepdims=True))).astype(np.float32)
+    if op in ('ArgMax', 'ArgMin'):
+        fn = np.argmax if op == 'ArgMax' else np.argmin
+        r = fn(v[0], axis=int(at.get('axis', 0)))
+        return (np.expand_dims(r, int(at.get('axis', 0))) if int(at.get('keepdims', 1)) else r).astype(np.int64)
+    if op == 'Split':
+        ax = int(at.get('axis', 0))
+        sizes = [int(t) for t in (v[1] if len(v) > 1 and v[1] is not None else at.get('split', []))]
+        if not sizes:
+            k = len(node.outputs)
+            sizes = [-(-v[0].shape[ax] // k)] * k
+            sizes[-1] = v[0].shape[ax] - sum(sizes[:-1])
+        return list(np.split(v[0], np.cumsum(sizes)[:-1], axis=ax))
     if op == 'Gelu':
         return (0.5 * v[0] * (1.0 + _erf(v[0] / np.float32(math.sqrt(2.0))))).astype(np.float32)
     if op == 'Clip':

@@ -534,6 +534,24 @@ def test_nd_elementwise_broadcast_strided_and_reductions():
     nd = og.Node('Conv', ['x', 'w', 'b'], ['y'], dict(kernel_shape=[3, 3], strides=[2, 1], pads=[1, 1, 1, 1]))
     want = F.conv2d(torch.from_numpy(x4), torch.from_numpy(w4), torch.from_numpy(b4), stride=(2, 1), padding=1).numpy()
     np.testing.assert_allclose(r._node(nd, [r._up(x4), w4, b4]).cpu().numpy(), want, rtol=1e-5, atol=1e-5)
+    # composite operators against the oracle's single-formula forms
+    from oracle import onnx_ref
+    xs = rng.standard_normal((3, 5, 17)).astype(np.float32)
+    slope = rng.standard_normal((5, 1)).astype(np.float32)
+    for opn, ins, attrs in (('PRelu', [xs, slope], {}), ('Elu', [xs], {'alpha': 0.7}), ('HardSigmoid', [xs], {'alpha': 0.3, 'beta': 0.4}), ('Sign', [xs], {}),
+                            ('LogSoftmax', [xs], {'axis': 1}), ('Sum', [xs, slope, xs], {}), ('Mean', [xs, slope], {}), ('Max', [xs, slope, -xs], {}),
+                            ('ArgMax', [xs], {'axis': 2, 'keepdims': 0}), ('ArgMin', [xs], {'axis': 1, 'keepdims': 1}),
+                            ('And', [(xs > 0), (xs < 0.5)], {}), ('Or', [(xs > 0.5), (xs < -0.5)], {}), ('Xor', [(xs > 0), (xs > 0.5)], {})):
+        nd = og.Node(opn, ['i%d' % i for i in range(len(ins))], ['o'], attrs)
+        dev_ins = [r._up(a) if a.dtype == np.float32 else r._up(a.astype(np.float32)) for a in ins]
+        got = r._node(nd, dev_ins)
+        got = got.cpu().numpy() if torch.is_tensor(got) else got
+        want = onnx_ref._node(nd, ins, 17)
+        np.testing.assert_allclose(got.astype(np.float64), np.asarray(want).astype(np.float64), rtol=1e-5, atol=2e-6, err_msg=opn)
+    nd = og.Node('Split', ['x', 's'], ['a', 'b', 'c'], {'axis': 2})
+    got = r._node(nd, [r._up(xs), np.asarray([4, 6, 7])])
+    for gpart, wpart in zip(got, np.split(xs, [4, 10], axis=2)):
+        np.testing.assert_array_equal(gpart.cpu().numpy(), wpart)
     x1, w1, b1 = rng.standard_normal((2, 6, 37)).astype(np.float32), rng.standard_normal((8, 3, 5)).astype(np.float32), rng.standard_normal(8).astype(np.float32)
     nd = og.Node('Conv', ['x', 'w', 'b'], ['y'], dict(kernel_shape=[5], strides=[2], dilations=[3], pads=[4, 7], group=2))
     want = F.conv1d(F.pad(torch.from_numpy(x1), (4, 7)), torch.from_numpy(w1), torch.from_numpy(b1), stride=2, dilation=3, groups=2).numpy()
