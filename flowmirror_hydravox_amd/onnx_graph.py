@@ -393,6 +393,14 @@ _EW = dict(COPY=0, RELU=1, SIGMOID=2, TANH=3, ERF=4, SQRT=5, EXP=6, LOG=7, NEG=8
 _RED = dict(SUM=0, MEAN=1, MAX=2, MIN=3, SUMSQ=4)
 
 
+# every operator the executor accepts (default ONNX domain); anything else raises NotImplementedError naming the operator
+OPERATORS = ('Constant Shape Size Reshape Flatten Unsqueeze Squeeze Dropout Cast Identity Transpose Slice Expand Tile Concat Pad Gather Split '
+             'Relu Sigmoid Tanh Erf Sqrt Exp Log Neg Abs Round Floor Ceil Reciprocal Softplus Sin Cos Add Sub Mul Div Pow Max Min Equal Less Greater '
+             'Clip LeakyRelu Not And Or Xor Sum Mean PRelu Elu HardSigmoid Sign LogSoftmax ArgMax ArgMin Gelu Where '
+             'ReduceMean ReduceSum ReduceMax ReduceMin ReduceL2 ReduceSumSquare GlobalAveragePool Softmax LayerNormalization BatchNormalization AveragePool '
+             'MatMul Gemm Conv Range ConstantOfShape ReduceProd Mod').split()
+
+
 class OnnxRunner:
     """run(feeds) -> {output name: numpy array}.  Floating-point tensors live on the device (fp32, contiguous), integer tensors on the host."""
 
