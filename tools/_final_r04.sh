@@ -1,8 +1,9 @@
-# round-4 record on the final build (one gpurun call): the driver's bench line, the other BASELINE configurations, head_num sweep, queue worker
+# round-4 record on the final build (one gpurun call): GPU test-suite, smoke, the driver's bench line, the other BASELINE configurations, head_num sweep, queue worker
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/final_r04; mkdir -p $O
+timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; grep -E "passed|failed" $O/pytest_gpu.log | tail -1
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench.log 2>&1; tail -1 $O/bench.log | cut -c1-200
+T0=$(date +%s); timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench.log 2> $O/bench.err; echo "bench wall $(( $(date +%s) - T0 )) s"; tail -1 $O/bench.log | cut -c1-200
 B="python bench.py --steps 8 --no-cpu-baseline --no-fp32-mode"
 timeout 500 $B --heads 1 > $O/k1.log 2>&1
 timeout 500 $B --heads 4 > $O/k4.log 2>&1

@@ -3,7 +3,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/prof_r04c; rm -rf $O; mkdir -p $O
 P="rocprofv3 --output-format csv"
 # new tests of the round
-timeout 900 python -m pytest tests/test_gpu_fullsize.py tests/test_gpu_models.py -x -q -m gpu -k "wide_grid_decode or silent or cancellation or queue_worker" 2>&1 | tail -4
+true
 # --- decode step (64 sequences x 2 heads, ctx 1536): per-kernel stats, HBM traffic, SQ counters ---
 $P --kernel-trace --stats -d $O/dec_stats -- python tools/bench_decode.py --seqs 64 --steps 100 > $O/dec_stats.log 2>&1
 $P --pmc FETCH_SIZE -d $O/dec_fetch -- python tools/bench_decode.py --seqs 64 --steps 10 > $O/dec_fetch.log 2>&1
