@@ -86,7 +86,9 @@ def campplus_like(seed=0, emb=24):
     return b.graph(['fbank'], ['embedding'])
 
 
-def tokenizer_like(seed=1, n_mels=16, d=32, heads=4):
+def tokenizer_like(seed=1, n_mels=16, d=32, heads=4, with_length=False):
+    """with_length: a second input `mel_len` (int32 [1], as `speech_tokenizer_session.get_inputs()[1]` of the reference) masks the attention keys past
+    ceil(mel_len / 2) — Range / Less / Where on the host-resident integer side of the graph"""
     b = _B(seed)
     hd = d // heads
 
@@ -116,6 +118,13 @@ def tokenizer_like(seed=1, n_mels=16, d=32, heads=4):
         k = b.op('Transpose', [proj(n)], perm=[0, 2, 3, 1])
         v = b.op('Transpose', [proj(n)], perm=[0, 2, 1, 3])
         sc = b.op('Mul', [b.op('MatMul', [q, k]), b.const(np.asarray(1.0 / math.sqrt(hd), np.float32))])
+        if with_length:
+            if blk == 0:
+                half = b.op('Div', [b.op('Add', [b.op('Cast', ['mel_len'], to=7), b.i64(1)]), b.i64(2)])            # ceil(len / 2) frames after the stride-2 stem
+                frames = b.op('Squeeze', [b.op('Slice', [b.op('Shape', [x]), b.i64(1), b.i64(2), b.i64(0)]), b.i64(0)])
+                pos = b.op('Range', [b.const(np.asarray(0, np.int64), 'i'), frames, b.const(np.asarray(1, np.int64), 'i')])
+                keymask = b.op('Unsqueeze', [b.op('Less', [pos, half]), b.i64(0, 1, 2)])                              # [1][1][1][T2] bool, on the host
+            sc = b.op('Where', [keymask, sc, b.const(np.asarray(-1e9, np.float32))])
         a = b.op('MatMul', [b.op('Softmax', [sc], axis=-1), v])                        # [1][heads][T2][hd]
         a = b.op('Reshape', [b.op('Transpose', [a], perm=[0, 2, 1, 3]), b.i64(1, -1, d)])
         x = b.op('Add', [x, b.op('Add', [b.op('MatMul', [a, b.w(d, d)]), b.w(d, scale=0.1)])])
@@ -129,4 +138,4 @@ def tokenizer_like(seed=1, n_mels=16, d=32, heads=4):
     ids = b.op('Squeeze', [b.op('Cast', [ids], to=7), b.i64(-1)])
     b.nodes.append(Node('Identity', [ids], ['tokens'], {}))
     b.nodes.append(Node('Identity', [z], ['latent'], {}))
-    return b.graph(['mel'], ['tokens', 'latent'])
+    return b.graph(['mel', 'mel_len'] if with_length else ['mel'], ['tokens', 'latent'])

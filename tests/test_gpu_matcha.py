@@ -205,6 +205,19 @@ def test_zero_shot_frontend_graphs_run_on_the_device():
     assert safe.mean() > 0.9 and np.array_equal(tok.cpu().numpy()[safe], ref['tokens'][safe])
     with pytest.raises(AssertionError):
         tk(torch.zeros(1, 16000 * 30 + 1))                                      # (frontend.py:94)
+    # the reference's two-input form: (features, their length as int32 [1]) by position; keys past the length are masked inside the graph
+    len_model = og.save_onnx(onnx_synth.tokenizer_like(n_mels=128, with_length=True))
+    tk2 = HvxSpeechTokenizer(len_model)
+    assert tk2.runner.g.inputs == ['mel', 'mel_len']
+    tok2, _ = tk2(speech)
+    feat = tk2.feat(speech).cpu().numpy()
+    ref2 = onnx_ref.run(og.load_onnx(len_model), {'mel': feat, 'mel_len': np.array([feat.shape[2]], np.int32)})
+    safe2 = (np.abs(np.abs(ref2['latent'] * 0.999) - 0.5) > 1e-3).all(-1)
+    assert np.array_equal(tok2.cpu().numpy()[safe2], ref2['tokens'][safe2])
+    short = onnx_ref.run(og.load_onnx(len_model), {'mel': feat, 'mel_len': np.array([feat.shape[2] // 2], np.int32)})
+    assert not np.array_equal(short['tokens'], ref2['tokens'])                  # (the mask is live: a shorter length changes the ids)
+    got_short = tk2.runner.run({'mel': feat, 'mel_len': np.array([feat.shape[2] // 2], np.int32)})
+    assert np.abs(got_short['latent'] - short['latent']).max() < 2e-4
     spk_model = og.save_onnx(onnx_synth.campplus_like(emb=192))
     enc = HvxSpeakerEncoder(spk_model)
     emb = enc(speech)
