@@ -20,7 +20,8 @@
 //     epilogue loads / stores issued in between only make the wait stronger (memory operations complete in order).
 //
 // Measured at 128 rows (us per launch, eager back-to-back; the 64-row-chunk skinny / mid forms of gemm_skinny.hip on row-major rows in
-// brackets): QKV + RoPE 3.9 [11.1], o_proj + residual 3.9 [10.0], gate/up + SwiGLU 9.1 [15.2], down_proj partials 5.7 [12.8].
+// brackets): QKV + RoPE 3.9 [11.1], o_proj + residual 3.9 [10.0], gate/up + SwiGLU 9.1 [15.2], down_proj partials 5.7 [12.8]; as kernel durations
+// inside the decode step's graph (rocprofv3): 6.3 [11.1], 5.2 [10.0], 8.4 [15.2], 5.9 [12.8] — DESIGN.md §4.1.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dec_kernel(SkinnyArgs a, int n_gr
     const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
     const int chunk = jj % mch, j2 = jj / mch;
     // eight K slices (down_proj): slice = XCD, so every slice of the activation matrix is fetched into ONE L2 instead of all eight (FETCH_SIZE of the
-    // launch 18.7 -> MB: the 1.2 MB of MLP rows used to arrive 8 x)
+    // launch 18.7 -> 10.0 MB: the 1.2 MB of MLP rows used to arrive 8 x)
     const int ksplit = a.split_k == 8 ? xcd : j2 % a.split_k, cg = a.split_k == 8 ? j2 : (j2 / a.split_k) * 8 + xcd;
     if (cg >= n_cg) return;
     const int g0 = cg * gpw;
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dec_kernel(SkinnyArgs a, int n_gr
     if constexpr (ANORM) {
         // sum of squares of the 16 rows ON THE MATRIX CORES: frag x frag^T accumulates sum_k x[i][k] x[j][k]; its diagonal (tile row i == tile column
         // i: lane 20 g + r holds row 4 g + r in accumulator element r) is what is wanted.  28 MFMAs on a pipe that has nothing else to do yet,
-        // against ~450 VALU instructions per wave for the convert-and-fma form (QKV 7.8 -> us per launch at 128 rows).
+        // against ~450 VALU instructions per wave for the convert-and-fma form (gate/up 9.5 -> 8.4 us per launch at 128 rows).
         f32x4 ssq = {0, 0, 0, 0};
 #pragma unroll
         for (int ks = 0; ks < KT; ++ks) mma32(ssq, af[ks], af[ks]);
