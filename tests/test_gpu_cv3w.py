@@ -328,3 +328,33 @@ def test_llm_continuous_batching_fp32_vs_reference(cfg, llm_setup):
     for r in k2:
         assert got[r] == g['r%d_tokens' % r].tolist(), r
     assert llm.last_stats['requests'] == 8
+
+
+def test_llm_wide_grid_bf16_is_batch_invariant_and_deterministic(cfg, llm_setup):
+    """The production (bf16) decode path of a WIDE grid — 40 slots x 2 heads = 80 rows: the A-stationary GEMM form over fragment-order activations, the
+    fragment-order KV cache, 512-key attention splits — through the continuous engine with joins and leaves.  A request's arithmetic never leaves its own
+    rows (no K split inside a workgroup, no cross-row reduction anywhere), so its ids must not depend on what shares the grid with it: the 8 golden
+    utterances alone in the 40-slot grid == the same 8 among 44 fillers, and a second run of the crowded job repeats the first bit for bit."""
+    g, sd, sampling = llm_setup
+    llm = _make_llm(cfg, sd, sampling, torch.bfloat16, max_batch=40, max_ctx=1024)
+    llm.inference_head_num = 2
+    k2 = [r for r in range(int(g['n_runs'])) if int(g['r%d_K' % r]) == 2]
+
+    def req(r, tag):
+        return dict(text=torch.from_numpy(g['r%d_text' % r]), prompt_text=torch.from_numpy(g['r%d_ptext' % r]), prompt_speech_token=torch.from_numpy(g['r%d_pspeech' % r]),
+                    seed=int(g['r%d_seed' % r]), tag=tag, max_token_text_ratio=float(g['r%d_ratios' % r][0]), min_token_text_ratio=float(g['r%d_ratios' % r][1]))
+    gen = torch.Generator().manual_seed(77)
+    fillers = [dict(text=torch.randint(0, cfg.llm.text_vocab, (int(torch.randint(5, 40, (1,), generator=gen)),), generator=gen, dtype=torch.int32), seed=5000 + i,
+                    tag=('f', i), max_token_text_ratio=4, min_token_text_ratio=2) for i in range(44)]
+    alone = dict(llm.generate_stream(iter([req(r, r) for r in k2]), n_slots=40))
+    crowded_job = []
+    for i, f in enumerate(fillers):
+        crowded_job.append(f)
+        if i % 5 == 0 and i // 5 < len(k2):
+            crowded_job.append(req(k2[i // 5], k2[i // 5]))
+    crowded = dict(llm.generate_stream(iter([dict(d) for d in crowded_job]), n_slots=40))
+    again = dict(llm.generate_stream(iter([dict(d) for d in crowded_job]), n_slots=40))
+    assert len(crowded) == len(crowded_job) and all(len(v) > 0 for v in crowded.values())
+    for r in k2:
+        assert alone[r] == crowded[r], r
+    assert crowded == again
