@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dec_kernel(SkinnyArgs a, int n_gr
                 e_sn[j][r] = 0.0f;
             }
         }
-        if constexpr (EPI == SK_RESID || EPI == SK_QKV_ROPE) {
+        if constexpr (EPI == SK_RESID || EPI == SK_QKV_ROPE || EPI == SK_STORE) {
             if (a.bias) {
 #pragma unroll
                 for (int j = 0; j < NTG; ++j) e_bias[j] = a.bias[(tile0 + j) * 16 + fr];
@@ -238,6 +238,21 @@ __global__ __launch_bounds__(256, 2) void gemm_dec_kernel(SkinnyArgs a, int n_gr
                     const int row = m0 + fg * 4 + r;
                     if (row < a.M) part[(long long)row * a.N + (tile0 + j) * 16 + fr] = acc[j][r];
                 }
+        } else if constexpr (EPI == SK_STORE) {
+            // fp32 rows of the stacked (head z, sequence s) grid, row = z * kn + s, stored where the per-head launches put them: out[s][z][col]
+            float* out = reinterpret_cast<float*>(a.out);
+            const int nv = a.n_valid > 0 ? a.n_valid : a.N;
+#pragma unroll
+            for (int j = 0; j < NTG; ++j) {
+                const int col = (tile0 + j) * 16 + fr;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = m0 + fg * 4 + r;
+                    if (row >= a.M || col >= nv) continue;
+                    const int z = row / a.kn, si = row - z * a.kn;
+                    out[(long long)si * a.ldo + (long long)z * a.out_zs + col] = acc[j][r] + e_bias[j];
+                }
+            }
         } else if constexpr (EPI == SK_RESID) {
             // residual stream update in place: x[row][col] += acc + bias, one writer per element; the 16-bit copy feeds the next fused-norm GEMM
             float* xo = reinterpret_cast<float*>(a.out);
@@ -329,13 +344,22 @@ bool dec_gemm_shape_ok(int M, int N, int K, int epi, int split_k) {
     switch (epi) {
         case SK_QKV_ROPE: return kt == 28 && split_k == 1;
         case SK_RESID: return kt == 28 && split_k == 1;
+        case SK_STORE: return kt == 28 && split_k == 1;
         case SK_SWIGLU: return kt == 28 && split_k == 1 && (N & 31) == 0;
         case SK_PARTIAL: return split_k > 1 && kt == split_k * 19 && (N & 31) == 0;
     }
     return false;
 }
 
-int launch_dec_gemm(const SkinnyArgs& a, hipStream_t s) {
+int launch_dec_gemm(const SkinnyArgs& a_in, hipStream_t s) {
+    SkinnyArgs a = a_in;
+    if (a.epi == SK_STORE && a.nz >= 1 && a.w_zs == 0 && a.out_f32 && (!a.bias || a.bias_zs == 0)) {
+        // the shared output projection over the K heads' last rows (hvx_llm.hip): the per-head row blocks [z][s] are ONE stacked activation
+        // matrix in fragment order; rows go back to out[s][z][:] in the epilogue
+        a.kn = a.M;
+        a.M = a.M * a.nz;
+        a.nz = 1;
+    }
     if (a.dtype != DT_BF16 || !a.a_frag || a.nz > 1 || a.w_narrow || !dec_gemm_shape_ok(a.M, a.N, a.K, a.epi, a.split_k)) return 0;
     if (a.epi != SK_PARTIAL && a.split_k != 1) return 0;
     if ((long long)a.N * a.K * 2 >= (1LL << 31)) return 0;            // (32-bit buffer offsets)
@@ -343,12 +367,13 @@ int launch_dec_gemm(const SkinnyArgs& a, hipStream_t s) {
     // (gate, up) pairs for the MLP (102 x 2 workgroups: the activation re-reads of more, smaller workgroups cost more than the idle CUs), two
     // pairs of tiles per K slice for the down projection (14 x 8 x 2)
     static const int gpw_qkv = env_int("HVX_DEC_GPW_QKV", 1), gpw_res = env_int("HVX_DEC_GPW_RES", 1), gpw_mlp = env_int("HVX_DEC_GPW_MLP", 3),
-                     gpw_down = env_int("HVX_DEC_GPW_DOWN", 2);
+                     gpw_down = env_int("HVX_DEC_GPW_DOWN", 2), gpw_out = env_int("HVX_DEC_GPW_OUT", 3);
     switch (a.epi) {
         case SK_QKV_ROPE:
             if (a.N != (a.q_heads + 2 * a.kv_heads) * 64) return set_error("launch_dec_gemm: QKV width %d != (q+2kv)*64", a.N), -1;
             return a.a_norm ? launch_form<1, SK_QKV_ROPE, 1, 28, 4, 7>(a, gpw_qkv, s) : launch_form<1, SK_QKV_ROPE, 0, 28, 4, 7>(a, gpw_qkv, s);
         case SK_RESID: return launch_form<1, SK_RESID, 0, 28, 4, 7>(a, gpw_res, s);
+        case SK_STORE: return launch_form<1, SK_STORE, 0, 28, 4, 7>(a, gpw_out, s);      // (423 vocabulary tiles: 141 x 2 workgroups)
         case SK_SWIGLU: return a.a_norm ? launch_form<2, SK_SWIGLU, 1, 28, 7, 4>(a, gpw_mlp, s) : launch_form<2, SK_SWIGLU, 0, 28, 7, 4>(a, gpw_mlp, s);
         case SK_PARTIAL: return launch_form<2, SK_PARTIAL, 0, 19, 10, 3>(a, gpw_down, s);
     }

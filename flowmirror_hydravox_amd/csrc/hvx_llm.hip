@@ -134,7 +134,7 @@ size_t carve(hvx_llm* h, char* base, int S, int R, int max_ctx) {
     h->att_ml = cv.take<float>((size_t)S * c.kv_heads * h->att_splits * h->att_rows_pad * 2 * 4);
     h->ylast = cv.take<float>((size_t)S * H * 4);
     h->hx = cv.take<float>((size_t)hn * S * H * 4);
-    h->ha = cv.take<void>((size_t)hn * S * H * es);
+    h->ha = cv.take<void>((((size_t)hn * S + 15) / 16 * 16) * H * es);     // (+ tile padding: the output projection of a wide grid reads it in fragment order)
     h->hv = cv.take<void>((size_t)hn * S * A * es);
     h->hm = cv.take<void>((size_t)hn * S * c.mtp_inter * es);
     h->logits = cv.take<float>((size_t)S * hn * c.vocab_pad * 4);
@@ -489,6 +489,9 @@ static int forward_impl(hvx_llm* h, hipStream_t s, int32_t n_seq, int32_t kn, co
     }
     if (launch_skinny(g, s)) return -1;
     hn.part = h->part; hn.split_k = g.split_k; hn.part_stride = (long long)S * H; hn.part_zs = g.part_zs; hn.gain = nullptr; hn.do_norm = 0;   // plain cast
+    // wide bf16 grids: the K heads' rows are one stacked fragment-order matrix for the weight-ring form of the output projection (gemm_dec.hip)
+    const bool dec_out = dt == DT_BF16 && dec_gemm_shape_ok(K * S, c.vocab_pad, H, SK_STORE, 1);
+    hn.y_frag = dec_out;
     if (launch_reduce_rmsnorm(hn, s)) return -1;
     // logits = llm_decoder(h) (shared weights) ; log_softmax
     memset(&g, 0, sizeof(g));
@@ -497,7 +500,12 @@ static int forward_impl(hvx_llm* h, hipStream_t s, int32_t n_seq, int32_t kn, co
     float* dst = logp ? logp : h->logits;
     const int ld = logp ? c.vocab : c.vocab_pad;
     g.split_k = 1; g.nz = K; g.epi = SK_STORE; g.out = dst; g.out_f32 = 1; g.ldo = K * ld; g.out_zs = ld; g.n_valid = c.vocab;
-    if (launch_skinny(g, s)) return -1;
+    if (dec_out) {
+        g.a_frag = 1;
+        const int rc = launch_dec_gemm(g, s);
+        if (rc < 0) return -1;
+        if (rc == 0) return set_error("hvx_llm_forward: output projection shape left the decode form"), -1;
+    } else if (launch_skinny(g, s)) return -1;
     if (launch_log_softmax(dst, ld, S * K, c.vocab, s)) return -1;
     return 0;
 }
