@@ -31,6 +31,7 @@ __global__ __launch_bounds__(256) void reduce_rmsnorm_kernel(ReduceNormArgs a) {
     __shared__ float red[4];
     const int m = blockIdx.x, H = a.H;
     const int z = m / a.rows_per_z, mz = m - z * a.rows_per_z;
+    const int mf = a.y_frag_zrows > 0 ? z * a.y_frag_zrows + mz : m;          // row of the fragment-order output
     float* xr = a.x + (long long)m * a.ldx;
     const float* part = a.part ? a.part + (long long)z * a.part_zs + (long long)mz * H : nullptr;
     const float* bias = a.bias ? a.bias + (long long)z * a.bias_zs : nullptr;
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(256) void reduce_rmsnorm_kernel(ReduceNormArgs a) {
             *reinterpret_cast<f32x4*>(xr + c) = v;
             if (y_inline) {
                 // (fragment order keeps 4 consecutive columns of a row contiguous: c % 4 == 0)
-                if constexpr (sizeof(T) == 2) *reinterpret_cast<bf16x4*>(yr + (a.y_frag ? frag_index(m, c, KTy) : (long long)c)) = bf16x4{f32_to_bf16(v[0]), f32_to_bf16(v[1]), f32_to_bf16(v[2]), f32_to_bf16(v[3])};
+                if constexpr (sizeof(T) == 2) *reinterpret_cast<bf16x4*>(yr + (a.y_frag ? frag_index(mf, c, KTy) : (long long)c)) = bf16x4{f32_to_bf16(v[0]), f32_to_bf16(v[1]), f32_to_bf16(v[2]), f32_to_bf16(v[3])};
                 else *reinterpret_cast<f32x4*>(yr + c) = v;
             }
             ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(256) void reduce_rmsnorm_kernel(ReduceNormArgs a) {
     T* y = reinterpret_cast<T*>(a.y) + (long long)m * a.ldy;
     if (!a.do_norm) {
         if (a.y_frag) {
-            for (int c = threadIdx.x; c < H; c += 256) reinterpret_cast<T*>(a.y)[frag_index(m, c, H >> 5)] = from_f32<T>(xr[c]);
+            for (int c = threadIdx.x; c < H; c += 256) reinterpret_cast<T*>(a.y)[frag_index(mf, c, H >> 5)] = from_f32<T>(xr[c]);
             return;
         }
         for (int c = threadIdx.x; c < H; c += 256) y[c] = from_f32<T>(xr[c]);
@@ -96,7 +97,9 @@ __global__ __launch_bounds__(256) void reduce_rmsnorm_kernel(ReduceNormArgs a) {
     const float inv = rsqrtf(ss / (float)H + a.eps);
     for (int c = threadIdx.x; c < H; c += 256) {
         const float v = xr[c] * inv;
-        y[c] = from_f32<T>(gain ? gain[c] * to_f32(from_f32<T>(v)) : v);
+        const T o = from_f32<T>(gain ? gain[c] * to_f32(from_f32<T>(v)) : v);
+        if (a.y_frag) reinterpret_cast<T*>(a.y)[frag_index(mf, c, H >> 5)] = o;
+        else y[c] = o;
     }
 }
 
@@ -104,7 +107,7 @@ int launch_reduce_rmsnorm(const ReduceNormArgs& a_in, hipStream_t s) {
     ReduceNormArgs a = a_in;
     if (a.M <= 0) return 0;
     if (a.rows_per_z <= 0) a.rows_per_z = a.M;
-    if (a.y_frag && (a.do_norm || a.dtype == DT_F32 || (a.H & 31))) return set_error("reduce_rmsnorm: fragment-order output is a plain 16-bit cast with H %% 32 == 0"), -1;
+    if (a.y_frag && (a.dtype == DT_F32 || (a.H & 31) || (a.y_frag_zrows & 15))) return set_error("reduce_rmsnorm: fragment-order output is 16-bit with H %% 32 == 0"), -1;
     if (a.dtype == DT_BF16) hipLaunchKernelGGL(reduce_rmsnorm_kernel<bf16_t>, dim3(a.M), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(reduce_rmsnorm_kernel<float>, dim3(a.M), dim3(256), 0, s, a);
     return hipGetLastError() == hipSuccess ? 0 : (set_error("reduce_rmsnorm launch failed"), -1);

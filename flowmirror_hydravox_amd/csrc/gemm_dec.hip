@@ -1,4 +1,6 @@
-// gemm_dec.hip — the four backbone GEMMs of the AR decode step on a WIDE grid (33..128 rows = 17..64 sequences x K heads), bf16.
+// gemm_dec.hip — the four backbone GEMMs of the AR decode step on a WIDE grid (33..256 rows = 17..128 sequences x K heads), bf16, and the two
+// largest GEMMs of its MTP heads: gate / up (K heads stacked over blockIdx.y, each with its own weights and its own fragment-order rows) and the
+// shared output projection (the K heads' rows as one stacked matrix).
 //
 // What bounds these launches (tools/dec_lab.hip, MI355X): a compute unit ingests ~45 GB/s whatever the source (HBM or L2) and however
 // many waves ask, so a launch takes  floor + max over CUs of (weight bytes + activation bytes that CU reads) / 45 GB/s.  At 128 rows the
@@ -21,7 +23,8 @@
 //
 // Measured at 128 rows (us per launch, eager back-to-back; the 64-row-chunk skinny / mid forms of gemm_skinny.hip on row-major rows in
 // brackets): QKV + RoPE 3.9 [11.1], o_proj + residual 3.9 [10.0], gate/up + SwiGLU 9.1 [15.2], down_proj partials 5.7 [12.8]; as kernel durations
-// inside the decode step's graph (rocprofv3): 6.3 [11.1], 5.2 [10.0], 8.4 [15.2], 5.9 [12.8] — DESIGN.md §4.1.
+// inside the decode step's graph (rocprofv3): 6.3 [11.1], 5.2 [10.0], 8.4 [15.2], 5.9 [12.8]; heads at 64 sequences x 2: gate / up 33 [48],
+// output projection 9.5 [~25] — DESIGN.md §4.1.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -77,20 +80,22 @@ __global__ __launch_bounds__(256, 2) void gemm_dec_kernel(SkinnyArgs a, int n_gr
     if (ng <= 0) return;
     const int KTT = a.K >> 5;
     const int ks0 = ksplit * KT;
+    const int zz = blockIdx.y;                                // stacked launch (the MTP heads' MLP): head z has its own weights, activation rows and output rows
     const int m0 = chunk * 64 + wave * 16;                    // this wave's 16 rows
 
     // ---- activation fragments of this wave's rows over the workgroup's K range (fragment order: 1 KiB per load) -----------------------------------
     bf16x8 af[KT];
     {
         const int mt = min(m0 >> 4, (a.M - 1) >> 4);          // (a wave past the last row tile re-reads it; none of its rows is ever stored)
-        const bf16_t* ap = reinterpret_cast<const bf16_t*>(a.A) + ((long long)mt * KTT + ks0) * 512 + lane * 8;
+        const bf16_t* ap = reinterpret_cast<const bf16_t*>(a.A) + (long long)zz * a.a_zs + ((long long)mt * KTT + ks0) * 512 + lane * 8;
 #pragma unroll
         for (int ks = 0; ks < KT; ++ks) af[ks] = load8(ap + ks * 512);
     }
 
     // ---- weight stream: group gi starts at byte ((g0 + gi) * NTG * KTT + ks0) * 1024; within a stage, DMA instruction li of wave w moves
     // fragment q = 4 li + w = (k-step q / NTG, tile q % NTG)
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.W), 0, a.N * a.K * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t*>(reinterpret_cast<const bf16_t*>(a.W) + (long long)zz * a.w_zs), 0, a.N * a.K * 2, 0x00020000);
     const int GS = NTG * KTT * 1024;
     int wg_cur = (g0 * NTG * KTT + ks0) * 1024;
     int foff[LPS];
@@ -272,7 +277,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dec_kernel(SkinnyArgs a, int n_gr
             }
         } else if constexpr (EPI == SK_SWIGLU) {
             static_assert(EPI != SK_SWIGLU || NTG == 2, "SwiGLU works on (gate, up) tile pairs");
-            bf16_t* out = reinterpret_cast<bf16_t*>(a.out);
+            bf16_t* out = reinterpret_cast<bf16_t*>(a.out) + (long long)zz * a.out_zs;
             const int col = (tile0 >> 1) * 16 + fr;
             const int KTo = a.N >> 6;
 #pragma unroll
@@ -321,7 +326,7 @@ int launch_form(const SkinnyArgs& a, int gpw, hipStream_t s) {
     const int grid = a.split_k == 8 ? 8 * mch * n_cg : 8 * mch * a.split_k * ((n_cg + 7) / 8);
     const double bytes = (double)a.N * a.K * 2 + (double)a.M * a.K * 2 + (double)a.M * a.N * (EPI == SK_PARTIAL ? 4.0 * a.split_k : 2.0);
     const int slot = prof_begin(PK_SKINNY, bytes, s);
-    hipLaunchKernelGGL((gemm_dec_kernel<NTG, EPI, ANORM, KT, SF, D>), dim3(grid), dim3(256), 0, s, a, n_groups, gpw, n_cg, mch);
+    hipLaunchKernelGGL((gemm_dec_kernel<NTG, EPI, ANORM, KT, SF, D>), dim3(grid, a.nz > 1 ? a.nz : 1), dim3(256), 0, s, a, n_groups, gpw, n_cg, mch);
     prof_end(slot, s);
     return hipGetLastError() == hipSuccess ? 1 : (set_error("decode gemm launch failed"), -1);
 }
@@ -360,21 +365,27 @@ int launch_dec_gemm(const SkinnyArgs& a_in, hipStream_t s) {
         a.M = a.M * a.nz;
         a.nz = 1;
     }
-    if (a.dtype != DT_BF16 || !a.a_frag || a.nz > 1 || a.w_narrow || !dec_gemm_shape_ok(a.M, a.N, a.K, a.epi, a.split_k)) return 0;
+    // (nz > 1: only the SwiGLU form carries the per-head strides — the MTP heads' MLP, every head its own fragment-order matrix of a.M rows)
+    if (a.dtype != DT_BF16 || !a.a_frag || (a.nz > 1 && a.epi != SK_SWIGLU) || a.w_narrow || !dec_gemm_shape_ok(a.M, a.N, a.K, a.epi, a.split_k)) return 0;
     if (a.epi != SK_PARTIAL && a.split_k != 1) return 0;
     if ((long long)a.N * a.K * 2 >= (1LL << 31)) return 0;            // (32-bit buffer offsets)
     // column groups per workgroup (tools/dec_lab.hip, 128 rows): one tile for the two narrow projections (72 / 56 tiles x 2 row chunks), three
     // (gate, up) pairs for the MLP (102 x 2 workgroups: the activation re-reads of more, smaller workgroups cost more than the idle CUs), two
     // pairs of tiles per K slice for the down projection (14 x 8 x 2)
     static const int gpw_qkv = env_int("HVX_DEC_GPW_QKV", 1), gpw_res = env_int("HVX_DEC_GPW_RES", 1), gpw_mlp = env_int("HVX_DEC_GPW_MLP", 3),
-                     gpw_down = env_int("HVX_DEC_GPW_DOWN", 2), gpw_out = env_int("HVX_DEC_GPW_OUT", 3);
+                     gpw_down = env_int("HVX_DEC_GPW_DOWN", 2), gpw_out = env_int("HVX_DEC_GPW_OUT", 3),
+                     gpw_hmlp = env_int("HVX_DEC_GPW_HMLP", 11);
     switch (a.epi) {
         case SK_QKV_ROPE:
             if (a.N != (a.q_heads + 2 * a.kv_heads) * 64) return set_error("launch_dec_gemm: QKV width %d != (q+2kv)*64", a.N), -1;
             return a.a_norm ? launch_form<1, SK_QKV_ROPE, 1, 28, 4, 7>(a, gpw_qkv, s) : launch_form<1, SK_QKV_ROPE, 0, 28, 4, 7>(a, gpw_qkv, s);
         case SK_RESID: return launch_form<1, SK_RESID, 0, 28, 4, 7>(a, gpw_res, s);
         case SK_STORE: return launch_form<1, SK_STORE, 0, 28, 4, 7>(a, gpw_out, s);      // (423 vocabulary tiles: 141 x 2 workgroups)
-        case SK_SWIGLU: return a.a_norm ? launch_form<2, SK_SWIGLU, 1, 28, 7, 4>(a, gpw_mlp, s) : launch_form<2, SK_SWIGLU, 0, 28, 7, 4>(a, gpw_mlp, s);
+        case SK_SWIGLU:
+            // (the heads' MLP is 1376 (gate, up) pairs per head: 11 per workgroup = 126 workgroups x K heads, 616 KB of weights behind one 115 KB activation chunk)
+            // (deeper rings — 6, 8, 10 stages — and 3 .. 22 pairs per workgroup measured within 1 % of this: the launch runs at ~4.8 TB/s, 33 us for 158 MB)
+            if (a.nz > 1 || a.N > 16384) return a.a_norm ? launch_form<2, SK_SWIGLU, 1, 28, 7, 4>(a, gpw_hmlp, s) : launch_form<2, SK_SWIGLU, 0, 28, 7, 4>(a, gpw_hmlp, s);
+            return a.a_norm ? launch_form<2, SK_SWIGLU, 1, 28, 7, 4>(a, gpw_mlp, s) : launch_form<2, SK_SWIGLU, 0, 28, 7, 4>(a, gpw_mlp, s);
         case SK_PARTIAL: return launch_form<2, SK_PARTIAL, 0, 19, 10, 3>(a, gpw_down, s);
     }
     return 0;

@@ -166,7 +166,8 @@ struct ReduceNormArgs {
     const float* gain; long long gain_zs; float eps; int do_norm;
     void* y; int ldy; int dtype;
     int M, H, rows_per_z;
-    int y_frag;                   // y (16-bit) is written in fragment order (hvx_device.h: frag_index, KT = H / 32); plain cast only
+    int y_frag;                   // y (16-bit) is written in fragment order (hvx_device.h: frag_index, KT = H / 32)
+    int y_frag_zrows;             // > 0: every z block is its own fragment-order matrix of this many (multiple of 16) rows: row = z * y_frag_zrows + m % rows_per_z
 };
 int launch_reduce_rmsnorm(const ReduceNormArgs& a, hipStream_t s);
 // y[r, c] = dtype(act(x[r, c])) for a [rows][cols] f32 matrix (per-column alpha for Snake)

@@ -134,7 +134,7 @@ size_t carve(hvx_llm* h, char* base, int S, int R, int max_ctx) {
     h->att_ml = cv.take<float>((size_t)S * c.kv_heads * h->att_splits * h->att_rows_pad * 2 * 4);
     h->ylast = cv.take<float>((size_t)S * H * 4);
     h->hx = cv.take<float>((size_t)hn * S * H * 4);
-    h->ha = cv.take<void>((((size_t)hn * S + 15) / 16 * 16) * H * es);     // (+ tile padding: the output projection of a wide grid reads it in fragment order)
+    h->ha = cv.take<void>((size_t)hn * (((size_t)S + 15) / 16 * 16) * H * es);     // (+ tile padding per head: wide grids read it in fragment order)
     h->hv = cv.take<void>((size_t)hn * S * A * es);
     h->hm = cv.take<void>((size_t)hn * S * c.mtp_inter * es);
     h->logits = cv.take<float>((size_t)S * hn * c.vocab_pad * 4);
@@ -470,12 +470,24 @@ static int forward_impl(hvx_llm* h, hipStream_t s, int32_t n_seq, int32_t kn, co
     g.split_k = pick_split(H, A, K); g.nz = K; g.epi = SK_PARTIAL; g.part = h->part; g.part_zs = (long long)g.split_k * S * H;
     if (launch_skinny(g, s)) return -1;
     hn.part = h->part; hn.split_k = g.split_k; hn.part_stride = (long long)S * H; hn.part_zs = g.part_zs; hn.gain = (const float*)mw[4];
+    // wide bf16 grids (33..256 sequences): the heads' gate / up projection takes the weight-ring form (gemm_dec.hip), every head its own fragment-order
+    // matrix of S16 rows written by this reduce
+    const int S16 = (S + 15) / 16 * 16;
+    static const int heads_dec = [] { const char* e = getenv("HVX_DEC_HEADS"); return e ? atoi(e) : 3; }();      // A / B switch: bit 0 = MLP, bit 1 = output projection
+    const bool dec_mlp = (heads_dec & 1) && dt == DT_BF16 && dec_gemm_shape_ok(S, 2 * I, H, SK_SWIGLU, 1);
+    hn.y_frag = dec_mlp; hn.y_frag_zrows = dec_mlp ? S16 : 0;
     if (launch_reduce_rmsnorm(hn, s)) return -1;
+    hn.y_frag = 0; hn.y_frag_zrows = 0;
     // SwiGLU MLP
     memset(&g, 0, sizeof(g));
     g.dtype = dt; g.M = S; g.N = 2 * I; g.K = H; g.A = h->ha; g.lda = H; g.a_zs = (long long)S * H; g.W = mw[5]; g.w_zs = (long long)2 * I * H;
     g.split_k = 1; g.nz = K; g.epi = SK_SWIGLU; g.out = h->hm; g.ldo = I; g.out_zs = (long long)S * I;
-    if (launch_skinny(g, s)) return -1;
+    if (dec_mlp) {
+        g.a_frag = 1; g.a_zs = (long long)S16 * H;
+        const int rc = launch_dec_gemm(g, s);
+        if (rc < 0) return -1;
+        if (rc == 0) return set_error("hvx_llm_forward: head MLP shape left the decode form"), -1;
+    } else if (launch_skinny(g, s)) return -1;
     memset(&g, 0, sizeof(g));
     g.dtype = dt; g.M = S; g.N = H; g.K = I; g.A = h->hm; g.lda = I; g.a_zs = (long long)S * I; g.W = mw[6]; g.w_zs = (long long)H * I;
     g.split_k = pick_split(H, I, K); g.nz = K; g.epi = SK_PARTIAL; g.part = h->part; g.part_zs = (long long)g.split_k * S * H;
@@ -490,7 +502,7 @@ static int forward_impl(hvx_llm* h, hipStream_t s, int32_t n_seq, int32_t kn, co
     if (launch_skinny(g, s)) return -1;
     hn.part = h->part; hn.split_k = g.split_k; hn.part_stride = (long long)S * H; hn.part_zs = g.part_zs; hn.gain = nullptr; hn.do_norm = 0;   // plain cast
     // wide bf16 grids: the K heads' rows are one stacked fragment-order matrix for the weight-ring form of the output projection (gemm_dec.hip)
-    const bool dec_out = dt == DT_BF16 && dec_gemm_shape_ok(K * S, c.vocab_pad, H, SK_STORE, 1);
+    const bool dec_out = (heads_dec & 2) && dt == DT_BF16 && dec_gemm_shape_ok(K * S, c.vocab_pad, H, SK_STORE, 1);
     hn.y_frag = dec_out;
     if (launch_reduce_rmsnorm(hn, s)) return -1;
     // logits = llm_decoder(h) (shared weights) ; log_softmax

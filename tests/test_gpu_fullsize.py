@@ -180,11 +180,13 @@ def test_llm_decode_grid_at_full_depth_vs_teacher_forced_prefill(S):
     assert worst[0] < 0.1 and worst[1] < 0.2, worst
 
 
-@pytest.mark.parametrize('S,K', [(20, 2), (64, 2), (25, 4), (100, 2)])
+@pytest.mark.parametrize('S,K', [(20, 2), (64, 2), (25, 4), (100, 2), (40, 4), (50, 1)])
 def test_wide_grid_decode_gemm_form_agrees_with_the_generic_kernels(S, K):
     """gemm_dec.hip (A-stationary / weight-ring GEMMs over fragment-order activations, 33..256 rows) against the generic skinny kernels on
     row-major activations (HVX_DEC_GEMM=0): one decode step of a 2-layer CV3-width LM over a random KV cache, ragged positions and row counts
-    (40 rows: a partial last row tile; 128: two 64-row chunks; 100 and 200: partial chunks, three and four chunks).  The two differ in the fp32
+    (40 rows: a partial last row tile; 128: two 64-row chunks; 100 and 200: partial chunks, three and four chunks).  The MTP heads take the form
+    too from 33 sequences on — gate / up with every head's rows as its own fragment-order matrix (40 sequences: padded to 48 rows per head), the
+    shared output projection over the stacked rows of all heads (from 33 ROWS on: 20 sequences x 2 heads already).  The two differ in the fp32
     summation order of every GEMM (K is not split inside a workgroup any more) and in where bf16 roundings fall after it: log-probs of the
     sampler's candidates within 3e-2 (measured 1.2e-2), appended K / V rows within 2e-2."""
     import os

@@ -284,11 +284,12 @@ int main(int argc, char** argv) {
     const std::string which = argc > 1 ? argv[1] : "swiglu";
     const int reps = argc > 2 ? atoi(argv[2]) : 20;
     const int M = argc > 3 ? atoi(argv[3]) : 128;
-    const Shape shapes[] = {{"swiglu", 9728, 896, EP_SWIGLU, 1}, {"qkv", 1152, 896, EP_STORE, 1}, {"oproj", 896, 896, EP_STORE, 1}, {"down", 896, 4864, EP_STORE, 8}};
+    const Shape shapes[] = {{"swiglu", 9728, 896, EP_SWIGLU, 1}, {"qkv", 1152, 896, EP_STORE, 1}, {"oproj", 896, 896, EP_STORE, 1}, {"down", 896, 4864, EP_STORE, 8},
+                            {"hmlp", 44032, 896, EP_SWIGLU, 1}};
     Shape sh = shapes[0];
     for (const Shape& s : shapes)
         if (which == s.name) sh = s;
-    const int NB = 24;
+    const int NB = which == "hmlp" ? 8 : 24;
     const int KT = sh.K / 32;
     srand(7);
     std::vector<bf16_t> hA((size_t)M * sh.K), hW((size_t)sh.N * sh.K);
@@ -365,7 +366,12 @@ int main(int argc, char** argv) {
     }
 #define RING(MTW, NTG, EPI, KT_, SF, D, AUX, GPW) run_ring<MTW, NTG, EPI, KT_, SF, D, AUX>("ring<" #MTW "," #NTG "," #KT_ "," #SF "," #D "," #AUX ">", sh, M, dA, dW, dOut, dPart, GPW, reps, ref, ldo)
 #define RINGF(MTW, NTG, EPI, KT_, SF, D, AUX, GPW) run_ring<MTW, NTG, EPI, KT_, SF, D, AUX>("ring<" #MTW "," #NTG "," #KT_ "," #SF "," #D "," #AUX ">", sh, M, dAf, dW, dOut, dPart, GPW, reps, ref, ldo, 1)
-    if (which == "swiglu") {
+    if (which == "hmlp") {                  // one MTP head's gate / up projection (79 MB of weights), M = 64 rows
+        for (int gpw : {6, 11, 22}) RINGF(1, 2, EP_SWIGLU, 28, 7, 4, 0, gpw);
+        for (int gpw : {6, 11}) RINGF(1, 2, EP_SWIGLU, 28, 7, 8, 0, gpw);
+        for (int gpw : {6, 11}) RINGF(1, 2, EP_SWIGLU, 28, 4, 10, 0, gpw);
+        for (int gpw : {11}) RINGF(1, 2, EP_SWIGLU, 28, 14, 3, 0, gpw);
+    } else if (which == "swiglu") {
         for (int gpw : {2, 3}) RING(1, 2, EP_SWIGLU, 28, 7, 4, 0, gpw);
         for (int gpw : {2, 3}) RINGF(1, 2, EP_SWIGLU, 28, 7, 4, 0, gpw);
         for (int gpw : {2, 3}) RINGF(1, 2, EP_SWIGLU, 28, 7, 6, 0, gpw);
