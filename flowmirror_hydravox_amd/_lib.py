@@ -123,6 +123,7 @@ SYMBOLS = {
     'hvx_llm_decode_steps': (c_i32, [c_vp, c_vp, C.POINTER(DecodeArgs), c_i32]),
     'hvx_llm_decode_join': (c_i32, [c_vp, c_vp, C.POINTER(DecodeArgs), c_i32, c_i32, c_i32, c_i32, c_i32]),
     'hvx_llm_use_graph': (c_i32, [c_vp, c_i32]),
+    'hvx_llm_set_head_mlp_fp8': (c_i32, [c_vp, c_vp, c_vp]),
     'hvx_llm_last_hidden': (c_i32, [c_vp, c_vp, c_i32, c_vp]),
     'hvx_flow_create': (c_i32, [C.POINTER(FlowConfig), C.POINTER(c_vp), c_i32, C.POINTER(c_vp)]),
     'hvx_flow_destroy': (None, [c_vp]),

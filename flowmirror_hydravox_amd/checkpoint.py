@@ -82,7 +82,7 @@ def graft_checkpoint_file(src, dst, **kw):
 
 # ---- packed-weight cache ----------------------------------------------------------------------------------------------------
 def _model_tag(model):
-    extra = {k: getattr(model, k) for k in ('max_ctx', 'max_t') if hasattr(model, k)}
+    extra = {k: getattr(model, k) for k in ('max_ctx', 'max_t', 'head_mlp_fp8') if hasattr(model, k)}
     return dict(kind=type(model).__name__, dtype=str(getattr(model, 'dtype', torch.float32)), layout=PACK_LAYOUT,
                 cfg=json.dumps(dataclasses.asdict(model.cfg), sort_keys=True), extra=json.dumps(extra, sort_keys=True))
 
@@ -105,6 +105,8 @@ def save_packed(model, path, source=''):
     ws = getattr(model, '_weights', None)
     if not ws:
         raise ValueError('model has no packed weights: load a checkpoint first')
+    if hasattr(model, '_cache_tensors'):
+        ws = model._cache_tensors()                       # (HvxLLM with fp8 head weights: the codes stand in for the bf16 tensor they expand to)
     meta = _model_tag(model)
     meta.update(n=str(len(ws)), source=source)
     tmp = path + '.tmp'

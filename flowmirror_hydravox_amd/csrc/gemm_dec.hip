@@ -47,6 +47,23 @@ template <int OFF> __device__ __forceinline__ i32x4 lds_read16(unsigned addr) {
 template <int CNT> __device__ __forceinline__ void lds_wait(i32x4& v) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(CNT)); }
 template <int CNT> __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT) : "memory"); }
 
+// 16 e4m3 codes (OCP) -> two bf16 fragments: codes 0..7 = the lane's 8 k of the even k-step, 8..15 = of the odd one.  gfx950's
+// v_cvt_scalef32_pk_bf16_fp8 turns two codes into two bf16 in one instruction (scale 1.0: the conversion is exact) — 8 per fragment pair
+// instead of 16 with the f32 detour, which would make the vector ALU (not the matrix pipe or the ring) the pace of the stream.
+__device__ __forceinline__ void fp8x16_to_bf16(const i32x4& v, bf16x8& lo, bf16x8& hi) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const bf16x2_t p01 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(v[w], 1.0f, false), p23 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(v[w], 1.0f, true);
+        bf16x8& o = w < 2 ? lo : hi;
+        const int e = (w & 1) * 4;
+        o[e + 0] = p01[0];
+        o[e + 1] = p01[1];
+        o[e + 2] = p23[0];
+        o[e + 3] = p23[1];
+    }
+}
+
 template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (I < N) {
         f(std::integral_constant<int, I>{});
@@ -58,10 +75,16 @@ template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& 
 // Grid (1-D, XCD-aware): id -> xcd = id & 7, j = id >> 3, row chunk = j % mch, K split = (j / mch) % split_k, column group =
 // (j / mch / split_k) * 8 + xcd — the row chunks of one column group land on the same XCD (same L2: the second chunk finds the weights there);
 // with exactly 8 K splits: K split = xcd, column group = j / mch.
-template <int NTG, int EPI, int ANORM, int KT, int SF, int D>
+// W8: the weights are e4m3 codes (SkinnyArgs.w_fp8): a 1 KiB ring fragment then holds TWO k-steps of a tile (lane: 8 codes of k-step 2j, 8 of 2j + 1;
+// packing.pack_frag_fp8) — the ring walks KT / 2 double steps (SF counts those), every fragment is converted to two bf16 operands (e4m3 -> bf16 is
+// exact) and feeds two MFMAs in k order, and the per-column power-of-two scale multiplies the accumulator in the epilogue: the products and their
+// order are those of the bf16 stream of the dequantised weights, bit for bit.
+template <int NTG, int EPI, int ANORM, int KT, int SF, int D, int W8 = 0>
 __global__ __launch_bounds__(256, 2) void gemm_dec_kernel(SkinnyArgs a, int n_groups, int gpw, int n_cg, int mch) {
 #if defined(__HIP_DEVICE_COMPILE__)      // (the host pass has no __amdgpu_buffer_rsrc_t and drops the stub of a kernel whose body it cannot build)
-    constexpr int NST = (KT + SF - 1) / SF;
+    static_assert(!W8 || (EPI == SK_SWIGLU && KT % 2 == 0), "fp8 weights: the SwiGLU form, whole double steps");
+    constexpr int KTR = W8 ? KT / 2 : KT;                     // ring steps of the workgroup's K range
+    constexpr int NST = (KTR + SF - 1) / SF;
     constexpr int SFN = SF * NTG;
     constexpr int LPS = (SFN + 3) / 4;
     static_assert(LPS * (D - 2) <= 63 && D >= 2, "vmcnt range");
@@ -79,6 +102,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dec_kernel(SkinnyArgs a, int n_gr
     const int ng = min(n_groups - g0, gpw);
     if (ng <= 0) return;
     const int KTT = a.K >> 5;
+    const int KTTR = W8 ? KTT >> 1 : KTT;                     // ring steps of a whole weight row
     const int ks0 = ksplit * KT;
     const int zz = blockIdx.y;                                // stacked launch (the MTP heads' MLP): head z has its own weights, activation rows and output rows
     const int m0 = chunk * 64 + wave * 16;                    // this wave's 16 rows
@@ -95,21 +119,21 @@ __global__ __launch_bounds__(256, 2) void gemm_dec_kernel(SkinnyArgs a, int n_gr
     // ---- weight stream: group gi starts at byte ((g0 + gi) * NTG * KTT + ks0) * 1024; within a stage, DMA instruction li of wave w moves
     // fragment q = 4 li + w = (k-step q / NTG, tile q % NTG)
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<bf16_t*>(reinterpret_cast<const bf16_t*>(a.W) + (long long)zz * a.w_zs), 0, a.N * a.K * 2, 0x00020000);
-    const int GS = NTG * KTT * 1024;
-    int wg_cur = (g0 * NTG * KTT + ks0) * 1024;
+        const_cast<char*>(reinterpret_cast<const char*>(a.W) + (long long)zz * a.w_zs * (W8 ? 1 : 2)), 0, a.N * a.K * (W8 ? 1 : 2), 0x00020000);
+    const int GS = NTG * KTTR * 1024;
+    int wg_cur = (g0 * NTG * KTTR + (W8 ? 0 : ks0)) * 1024;
     int foff[LPS];
 #pragma unroll
     for (int li = 0; li < LPS; ++li) {
         const int q = li * 4 + wave;
-        foff[li] = ((q % NTG) * KTT + q / NTG) * 1024;
+        foff[li] = ((q % NTG) * KTTR + q / NTG) * 1024;
     }
     char* const dummy = ring + (D * SFN + wave) * 1024;
     // stage (group gi + carry, st) -> ring slot `slot`; past the last group the loads still happen (uniform vmcnt accounting) but re-read
     // the current group into the dummy slot
     auto issue = [&](int gi, auto CARRY, auto ST, int slot) __attribute__((always_inline)) {
         constexpr int st = decltype(ST)::value, carry = decltype(CARRY)::value;
-        constexpr int nf = (KT - st * SF < SF ? KT - st * SF : SF) * NTG;
+        constexpr int nf = (KTR - st * SF < SF ? KTR - st * SF : SF) * NTG;
         const bool live = gi + carry < ng;
         const int src = wg_cur + (live ? carry * GS : 0) + st * SF * 1024;
         char* const dst = ring + (slot * SFN + wave) * 1024;
@@ -176,6 +200,11 @@ __global__ __launch_bounds__(256, 2) void gemm_dec_kernel(SkinnyArgs a, int n_gr
                 e_sn[j][r] = 0.0f;
             }
         }
+        if constexpr (W8) {                                  // (the per-column scale rides in the bias slot of the epilogue operands)
+            const float* sc = a.w_scale + (long long)zz * a.w_scale_zs;
+#pragma unroll
+            for (int j = 0; j < NTG; ++j) e_bias[j] = sc[(tile0 + j) * 16 + fr];
+        }
         if constexpr (EPI == SK_RESID || EPI == SK_QKV_ROPE || EPI == SK_STORE) {
             if (a.bias) {
 #pragma unroll
@@ -213,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dec_kernel(SkinnyArgs a, int n_gr
         for (int j = 0; j < NTG; ++j) acc[j] = f32x4{0, 0, 0, 0};
         static_for<0, NST>([&](auto ST) {
             constexpr int st = decltype(ST)::value;
-            constexpr int nf = (KT - st * SF < SF ? KT - st * SF : SF) * NTG;
+            constexpr int nf = (KTR - st * SF < SF ? KTR - st * SF : SF) * NTG;
             vm_wait<LPS*(D - 2)>();                             // this wave's DMA of the stage has landed ...
             __builtin_amdgcn_s_barrier();                      // ... and so has everybody's; everybody has read the previous stage
             {
@@ -227,7 +256,14 @@ __global__ __launch_bounds__(256, 2) void gemm_dec_kernel(SkinnyArgs a, int n_gr
             static_for<0, nf>([&](auto Q) {
                 constexpr int q = decltype(Q)::value;
                 lds_wait<(nf - 1 - q < 15 ? nf - 1 - q : 15)>(b[q]);
-                mma32(acc[q % NTG], af[st * SF + q / NTG], __builtin_bit_cast(bf16x8, b[q]));
+                if constexpr (W8) {
+                    bf16x8 w0, w1;
+                    fp8x16_to_bf16(b[q], w0, w1);
+                    mma32(acc[q % NTG], af[2 * (st * SF + q / NTG)], w0);
+                    mma32(acc[q % NTG], af[2 * (st * SF + q / NTG) + 1], w1);
+                } else {
+                    mma32(acc[q % NTG], af[st * SF + q / NTG], __builtin_bit_cast(bf16x8, b[q]));
+                }
             });
             slot = slot + 1 == D ? 0 : slot + 1;
         });
@@ -284,7 +320,11 @@ __global__ __launch_bounds__(256, 2) void gemm_dec_kernel(SkinnyArgs a, int n_gr
             for (int r = 0; r < 4; ++r) {
                 const int row = m0 + fg * 4 + r;
                 if (row >= a.M) continue;
-                const float gte = acc[0][r] * inv[r], up = acc[NTG - 1][r] * inv[r];
+                float gte = acc[0][r] * inv[r], up = acc[NTG - 1][r] * inv[r];
+                if constexpr (W8) {
+                    gte *= e_bias[0];
+                    up *= e_bias[NTG - 1];
+                }
                 const float v = gte * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * gte)) * up;   // silu(gate) * up
                 out[a.out_frag ? frag_index(row, col, KTo) : (long long)row * a.ldo + col] = f32_to_bf16(v);
             }
@@ -318,15 +358,15 @@ __global__ __launch_bounds__(256, 2) void gemm_dec_kernel(SkinnyArgs a, int n_gr
 #endif
 }
 
-template <int NTG, int EPI, int ANORM, int KT, int SF, int D>
+template <int NTG, int EPI, int ANORM, int KT, int SF, int D, int W8 = 0>
 int launch_form(const SkinnyArgs& a, int gpw, hipStream_t s) {
     const int n_groups = a.N / 16 / NTG;
     const int n_cg = (n_groups + gpw - 1) / gpw;
     const int mch = (a.M + 63) / 64;
     const int grid = a.split_k == 8 ? 8 * mch * n_cg : 8 * mch * a.split_k * ((n_cg + 7) / 8);
-    const double bytes = (double)a.N * a.K * 2 + (double)a.M * a.K * 2 + (double)a.M * a.N * (EPI == SK_PARTIAL ? 4.0 * a.split_k : 2.0);
+    const double bytes = (double)a.N * a.K * (W8 ? 1 : 2) + (double)a.M * a.K * 2 + (double)a.M * a.N * (EPI == SK_PARTIAL ? 4.0 * a.split_k : 2.0);
     const int slot = prof_begin(PK_SKINNY, bytes, s);
-    hipLaunchKernelGGL((gemm_dec_kernel<NTG, EPI, ANORM, KT, SF, D>), dim3(grid, a.nz > 1 ? a.nz : 1), dim3(256), 0, s, a, n_groups, gpw, n_cg, mch);
+    hipLaunchKernelGGL((gemm_dec_kernel<NTG, EPI, ANORM, KT, SF, D, W8>), dim3(grid, a.nz > 1 ? a.nz : 1), dim3(256), 0, s, a, n_groups, gpw, n_cg, mch);
     prof_end(slot, s);
     return hipGetLastError() == hipSuccess ? 1 : (set_error("decode gemm launch failed"), -1);
 }
@@ -369,6 +409,7 @@ int launch_dec_gemm(const SkinnyArgs& a_in, hipStream_t s) {
     if (a.dtype != DT_BF16 || !a.a_frag || (a.nz > 1 && a.epi != SK_SWIGLU) || a.w_narrow || !dec_gemm_shape_ok(a.M, a.N, a.K, a.epi, a.split_k)) return 0;
     if (a.epi != SK_PARTIAL && a.split_k != 1) return 0;
     if ((long long)a.N * a.K * 2 >= (1LL << 31)) return 0;            // (32-bit buffer offsets)
+    if (a.w_fp8 && a.epi != SK_SWIGLU) return set_error("launch_dec_gemm: fp8 weights on epilogue %d", a.epi), -1;
     // column groups per workgroup (tools/dec_lab.hip, 128 rows): one tile for the two narrow projections (72 / 56 tiles x 2 row chunks), three
     // (gate, up) pairs for the MLP (102 x 2 workgroups: the activation re-reads of more, smaller workgroups cost more than the idle CUs), two
     // pairs of tiles per K slice for the down projection (14 x 8 x 2)
@@ -384,6 +425,10 @@ int launch_dec_gemm(const SkinnyArgs& a_in, hipStream_t s) {
         case SK_SWIGLU:
             // (the heads' MLP is 1376 (gate, up) pairs per head: 11 per workgroup = 126 workgroups x K heads, 616 KB of weights behind one 115 KB activation chunk)
             // (deeper rings — 6, 8, 10 stages — and 3 .. 22 pairs per workgroup measured within 1 % of this: the launch runs at ~4.8 TB/s, 33 us for 158 MB)
+            if (a.w_fp8) {
+                if (a.a_norm || !a.w_scale) return set_error("launch_dec_gemm: fp8 weights serve the un-normalised SwiGLU form with per-column scales"), -1;
+                return launch_form<2, SK_SWIGLU, 0, 28, 7, 4, 1>(a, gpw_hmlp, s);          // (7 double steps x 2 tiles per stage: the bf16 form's 14 KB)
+            }
             if (a.nz > 1 || a.N > 16384) return a.a_norm ? launch_form<2, SK_SWIGLU, 1, 28, 7, 4>(a, gpw_hmlp, s) : launch_form<2, SK_SWIGLU, 0, 28, 7, 4>(a, gpw_hmlp, s);
             return a.a_norm ? launch_form<2, SK_SWIGLU, 1, 28, 7, 4>(a, gpw_mlp, s) : launch_form<2, SK_SWIGLU, 0, 28, 7, 4>(a, gpw_mlp, s);
         case SK_PARTIAL: return launch_form<2, SK_PARTIAL, 0, 19, 10, 3>(a, gpw_down, s);

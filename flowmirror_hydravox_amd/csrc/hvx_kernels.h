@@ -114,6 +114,9 @@ struct SkinnyArgs {
     // ---- wide decode grids (33..128 rows, bf16): activations in fragment order (hvx_device.h: frag_index) -----------------------
     int a_frag;                   // A is [ceil(M/16)][K/32][64][8] instead of row-major (launch_dec_gemm only)
     int out_frag;                 // SK_SWIGLU: out, SK_RESID: out2 are written in fragment order (their consumer is another launch_dec_gemm)
+    // launch_dec_gemm, SK_SWIGLU: W holds e4m3 codes in double-step fragment order (packing.pack_frag_fp8; w_zs in codes) and w_scale the
+    // power-of-two scale of every output column (row of W), [nz][N] with stride w_scale_zs
+    int w_fp8; const float* w_scale; long long w_scale_zs;
 };
 int launch_skinny(const SkinnyArgs& a, hipStream_t s);
 // The same GEMMs for 33..128 rows in the A-stationary / weight-ring form (gemm_dec.hip).  Returns 1 when the launch was taken, 0 when the

@@ -36,6 +36,8 @@ struct hvx_llm {
     hvx_llm_config c;
     std::vector<const void*> w;
     bool use_graph = false;
+    const void* head_mlp_codes = nullptr;    // hvx_llm_set_head_mlp_fp8: e4m3 copy of the heads' gate / up projection + per-column scales
+    const float* head_mlp_scales = nullptr;
     std::map<GraphKey, hipGraphExec_t> graphs;
     struct StepGraph {
         hvx_decode_args a;
@@ -336,6 +338,17 @@ int hvx_llm_use_graph(hvx_llm* h, int32_t enable) {
     return 0;
 }
 
+int hvx_llm_set_head_mlp_fp8(hvx_llm* h, const void* codes, const float* scales) {
+    if (!h) return set_error("hvx_llm_set_head_mlp_fp8: null handle"), -1;
+    if (codes && !scales) return set_error("hvx_llm_set_head_mlp_fp8: codes without scales"), -1;
+    if (codes && h->c.dtype != DT_BF16) return set_error("hvx_llm_set_head_mlp_fp8: the fp8 stream feeds the bf16 decode forms only"), -1;
+    if (codes && (h->c.hidden != 896 || (h->c.mtp_inter & 15))) return set_error("hvx_llm_set_head_mlp_fp8: hidden %d is not the ring form's 28 k-steps", h->c.hidden), -1;
+    h->head_mlp_codes = codes;
+    h->head_mlp_scales = codes ? scales : nullptr;
+    h->drop_graphs();                       // (captured launches hold the weight pointers)
+    return 0;
+}
+
 static int forward_impl(hvx_llm* h, hipStream_t s, int32_t n_seq, int32_t kn, const int32_t* tok, const int32_t* ctrl, int32_t head_k,
                         float* logp) {
     const hvx_llm_config& c = h->c;
@@ -484,6 +497,9 @@ static int forward_impl(hvx_llm* h, hipStream_t s, int32_t n_seq, int32_t kn, co
     g.split_k = 1; g.nz = K; g.epi = SK_SWIGLU; g.out = h->hm; g.ldo = I; g.out_zs = (long long)S * I;
     if (dec_mlp) {
         g.a_frag = 1; g.a_zs = (long long)S16 * H;
+        if (h->head_mlp_codes) {                              // the same weights as e4m3 codes x power-of-two column scales: half the bytes, the same products
+            g.W = h->head_mlp_codes; g.w_fp8 = 1; g.w_scale = h->head_mlp_scales; g.w_scale_zs = 2 * I;
+        }
         const int rc = launch_dec_gemm(g, s);
         if (rc < 0) return -1;
         if (rc == 0) return set_error("hvx_llm_forward: head MLP shape left the decode form"), -1;

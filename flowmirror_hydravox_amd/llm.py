@@ -19,7 +19,8 @@ import torch
 from . import _lib, ops
 from ._lib import check, ptr, stream_ptr
 from .config import LLMConfig
-from .packing import pack_frag, pack_gate_up, pack_narrow4, qkv_row_perm
+from .packing import (frag_fp8_to_frag, interleave_gate_up, pack_frag, pack_frag_fp8, pack_gate_up, pack_narrow4, qkv_row_perm,
+                      quantize_e4m3_pow2)
 from .sampling import NoiseStream, rep_threshold, sampling_params
 from .weights import llm_spec, check_state, DROP_KEYS
 
@@ -51,11 +52,19 @@ class _Request:
 
 class HvxLLM:
     def __init__(self, cfg: LLMConfig, state_dict=None, dtype=torch.bfloat16, device='cuda', sampling=None,
-                 inference_head_num=5, max_batch=8, max_ctx=4096, noise_cap=1 << 16, use_graph=True):
+                 inference_head_num=5, max_batch=8, max_ctx=4096, noise_cap=1 << 16, use_graph=True, head_mlp_fp8=False):
+        """head_mlp_fp8: quantise the MTP heads' gate / up projections (65 % of a head's weights) to e4m3 codes x one power-of-two scale per
+        output column at load (packing.quantize_e4m3_pow2).  Every kernel then computes with those quantised weights — the bf16 tensor holds
+        code x scale exactly — and wide bf16 decode grids stream the codes instead (hvx_llm_set_head_mlp_fp8: half the bytes, bit-identical
+        log-probabilities); the packed cache keeps the codes only.  A second numerical contract for the heads (tests/test_gpu_cv3w.py states the
+        id agreement with the bf16 heads), hence off by default."""
         _lib.require_gpu()
         self.lib = _lib.load()
         self.cfg = cfg
         self.dtype = dtype
+        self.head_mlp_fp8 = bool(head_mlp_fp8)
+        if self.head_mlp_fp8 and dtype != torch.bfloat16:
+            raise ValueError('head_mlp_fp8 belongs to the bf16 mode (the fp32 mode is the bit-exact parity mode)')
         self.device = torch.device(device)
         # reference attribute names
         self.llm_input_size = cfg.hidden
@@ -124,14 +133,32 @@ class HvxLLM:
         def stack(fn):
             return torch.stack([fn('mtp_block.%d.' % j) for j in range(hn)], 0).contiguous()
 
+        extra = []
+        if self.head_mlp_fp8:
+            q = [quantize_e4m3_pow2(interleave_gate_up(W('mtp_block.%d.mlp.gate_proj.weight' % j), W('mtp_block.%d.mlp.up_proj.weight' % j)).cpu()) for j in range(hn)]       # (host cast: one rounding rule)
+            gate_up = mat(torch.stack([pack_frag(deq) for _, _, deq in q], 0).contiguous().to(dev))            # code x scale, exact in bf16
+            extra = [torch.stack([pack_frag_fp8(codes) for codes, _, _ in q], 0).contiguous().to(dev), torch.stack([sc for _, sc, _ in q], 0).contiguous().to(dev)]
+        else:
+            gate_up = mat(stack(lambda p: pack_gate_up(W(p + 'mlp.gate_proj.weight'), W(p + 'mlp.up_proj.weight'))))
         ws += [vec(stack(lambda p: W(p + 'input_layernorm.weight'))),
                mat(stack(lambda p: pack_frag(W(p + 'self_attn.v_proj.weight')))),
                vec(stack(lambda p: W(p + 'self_attn.v_proj.bias'))),
                mat(stack(lambda p: pack_frag(W(p + 'self_attn.o_proj.weight')))),
                vec(stack(lambda p: W(p + 'post_attention_layernorm.weight'))),
-               mat(stack(lambda p: pack_gate_up(W(p + 'mlp.gate_proj.weight'), W(p + 'mlp.up_proj.weight')))),
+               gate_up,
                mat(stack(lambda p: pack_frag(W(p + 'mlp.down_proj.weight'))))]
+        return ws + extra                 # (+ [e4m3 codes, column scales] of the heads' gate / up with head_mlp_fp8)
+
+    def _cache_tensors(self):
+        """what checkpoint.save_packed writes: with head_mlp_fp8 the bf16 gate / up tensor is left out (an empty placeholder) — load_packed rebuilds
+        it from the codes, which are half its size"""
+        ws = list(self._weights)
+        if self.head_mlp_fp8:
+            ws[self._n_base() - 2] = ws[self._n_base() - 2].new_zeros(0)
         return ws
+
+    def _n_base(self):
+        return 6 + 9 * self.cfg.layers + 7
 
     def load_packed(self, ws):
         """create the native handle from already packed tensors (pack_state_dict, or checkpoint.load_packed)"""
@@ -139,7 +166,15 @@ class HvxLLM:
         hn = c.head_num
         vpad = (c.vocab + 15) // 16 * 16
         ws = [w.to(self.device) for w in ws]
+        nb = self._n_base()
+        if (len(ws) == nb + 2) != self.head_mlp_fp8:
+            raise ValueError('packed LLM weights: %d tensors, head_mlp_fp8=%s expects %d' % (len(ws), self.head_mlp_fp8, nb + 2 * self.head_mlp_fp8))
+        fp8 = ws[nb:]
+        if fp8 and ws[nb - 2].numel() == 0:                  # a packed cache holds the codes only
+            codes, scales = fp8
+            ws[nb - 2] = torch.stack([frag_fp8_to_frag(codes[j], scales[j], dt) for j in range(hn)], 0).contiguous()
         self._weights = ws                                   # keep device tensors alive
+        ws = ws[:nb]
         cc = _lib.LLMConfig(dtype=_lib.dtype_code(dt), hidden=c.hidden, layers=c.layers, q_heads=c.q_heads, kv_heads=c.kv_heads,
                             inter=c.inter, vocab=c.vocab, vocab_pad=vpad, speech_tokens=c.speech_tokens, text_vocab=c.text_vocab,
                             head_num=hn, mtp_attn_dim=c.mtp_attn_dim, mtp_inter=c.mtp_inter, rms_eps=c.rms_eps,
@@ -155,6 +190,8 @@ class HvxLLM:
         self._h = h
         self._bound = None
         check(self.lib.hvx_llm_use_graph(self._h, int(self.use_graph)), 'hvx_llm_use_graph')
+        if fp8:
+            check(self.lib.hvx_llm_set_head_mlp_fp8(self._h, ptr(fp8[0]), ptr(fp8[1])), 'hvx_llm_set_head_mlp_fp8')
         return self
 
     def eval(self):

@@ -46,13 +46,54 @@ def qkv_row_perm(n_heads, head_dim=64):
     return torch.tensor(idx, dtype=torch.long)
 
 
-def pack_gate_up(wg, wu):
-    """Interleave gate / up projections as alternating 16-row tiles, then pack (SwiGLU epilogue pairs tile 2p with 2p+1)."""
+def interleave_gate_up(wg, wu):
+    """[I][H] gate and up projections -> [2 I][H] with alternating 16-row tiles (the SwiGLU epilogue pairs tile 2p with 2p + 1)"""
     I, H = wg.shape
     assert I % 16 == 0 and wu.shape == wg.shape
-    g = wg.view(I // 16, 1, 16, H)
-    u = wu.view(I // 16, 1, 16, H)
-    return pack_frag(torch.cat([g, u], dim=1).reshape(2 * I, H))
+    g = wg.reshape(I // 16, 1, 16, H)
+    u = wu.reshape(I // 16, 1, 16, H)
+    return torch.cat([g, u], dim=1).reshape(2 * I, H)
+
+
+def pack_gate_up(wg, wu):
+    """Interleave gate / up projections as alternating 16-row tiles, then pack (SwiGLU epilogue pairs tile 2p with 2p+1)."""
+    return pack_frag(interleave_gate_up(wg, wu))
+
+
+def frag_fp8_to_frag(codes_packed, scale, dtype):
+    """pack_frag_fp8 codes [N][K] + row scales [N] -> the pack_frag tensor of the dequantised matrix (what a bf16 kernel streams): the two
+    fragment orders are permutations of each other, so a packed cache can hold the codes alone (checkpoint.save_packed)."""
+    N, K = codes_packed.shape
+    v = codes_packed.view(torch.float8_e4m3fn).float().view(N // 16, K // 64, 4, 16, 2, 8)        # [t][ds][g][r][half][8]
+    v = v * scale.view(N // 16, 1, 1, 16, 1, 1)
+    return v.permute(0, 1, 4, 2, 3, 5).contiguous().view(N, K).to(dtype)
+
+
+E4M3_MAX = 448.0
+
+
+def quantize_e4m3_pow2(w):
+    """[N][K] float -> (codes uint8 [N][K], scale fp32 [N], dequantised fp32 [N][K]): every row of W (one output column of the GEMM) as OCP e4m3
+    codes times ONE power-of-two scale, the smallest that brings the row's largest magnitude inside +-448.  A power of two makes code * scale exact
+    in bf16 (3 mantissa bits scaled by an exponent shift) and lets the scale commute with fp32 accumulation: the bf16 tensor `dequantised` and the
+    (codes, scale) pair describe the same GEMM bit for bit (csrc/gemm_dec.hip, W8).  Rounding is torch's float8_e4m3fn cast (nearest even)."""
+    assert w.dim() == 2
+    w = w.float()
+    amax = w.abs().amax(dim=1).clamp_min(2.0 ** -100)
+    scale = torch.exp2(torch.ceil(torch.log2(amax / E4M3_MAX)))
+    scale = torch.where(amax / scale > E4M3_MAX, scale * 2, scale)          # (log2 rounding at exact powers of two)
+    q8 = (w / scale[:, None]).to(torch.float8_e4m3fn)
+    deq = q8.float() * scale[:, None]
+    return q8.view(torch.uint8), scale.contiguous(), deq
+
+
+def pack_frag_fp8(codes):
+    """uint8 codes [N][K] (N % 16 == 0, K % 64 == 0) -> flat [N/16][K/64][64 lanes][16]: lane (r, g) of a fragment holds the 8 codes
+    k = 64 j + 8 g .. + 8 of row 16 t + r followed by those of k + 32 — the two k-steps one 1 KiB ring fragment of the fp8 stream carries
+    (csrc/gemm_dec.hip, W8), in the lane order of pack_frag."""
+    assert codes.dim() == 2 and codes.dtype == torch.uint8 and codes.shape[0] % 16 == 0 and codes.shape[1] % 64 == 0, (codes.shape, codes.dtype)
+    N, K = codes.shape
+    return codes.view(N // 16, 16, K // 64, 2, 4, 8).permute(0, 2, 4, 1, 3, 5).contiguous().view(N, K)
 
 
 def conv_weight(w, cin_pad=None):

@@ -151,6 +151,13 @@ int hvx_llm_forward(hvx_llm* h, hvx_stream s, int32_t n_seq, int32_t kn, const i
                     int32_t head_k, float* logp);
 /* replay the decode-step launches (head_k > 0) as one cached hipGraph per (grid, control/logp addresses, stream) */
 int hvx_llm_use_graph(hvx_llm* h, int32_t enable);
+/* fp8 copy of the MTP heads' gate / up projection (fp8 head weights; the largest weight stream of a decode step, 79 MB per head in
+ * bf16).  codes: [head_num][2 * mtp_inter * hidden] e4m3 (OCP) codes in the double-step fragment order of packing.pack_frag_fp8 over the same
+ * interleaved (gate, up) tile order as weights[mtp gate/up]; scales: [head_num][2 * mtp_inter] fp32 powers of two, one per output column.  The bf16
+ * tensor passed to hvx_llm_create must hold exactly code * scale (packing.quantize_e4m3_pow2 makes both): wide bf16 decode grids (33..256
+ * sequences) then stream the codes — half the bytes, the same products in the same order, bit-identical log-probabilities — and every other
+ * grid keeps reading the bf16 tensor.  NULL codes switch it off.  Device pointers; the caller keeps them alive.  Cached decode graphs are dropped. */
+int hvx_llm_set_head_mlp_fp8(hvx_llm* h, const void* codes, const float* scales);
 /* Device-resident decode loop — replaces the per-step host logic of CosyVoice3LM.inference_wrapper (llm_multi_head_v3.py:871-905):
  * one call enqueues `n_steps` repetitions of { forward over the [n_seq][head_k] grid, RAS sampling of the K heads, advance }, where
  * `advance` does on the device what the reference's Python loop does between two steps: feed the accepted tokens back (tok / ctrl

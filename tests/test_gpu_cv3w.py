@@ -358,3 +358,91 @@ def test_llm_wide_grid_bf16_is_batch_invariant_and_deterministic(cfg, llm_setup)
     for r in k2:
         assert alone[r] == crowded[r], r
     assert crowded == again
+
+
+def _one_wide_step(llm, cfg, S, K, seed=3, ctx=300):
+    """one decode step of an S x K grid over a random KV cache and ragged positions -> log-probs [S][K][vocab] (cpu)"""
+    llm.inference_head_num = K
+    llm._bind(S, S * K)
+    gen = torch.Generator().manual_seed(seed)
+    kvv = llm._kv.view(torch.bfloat16)
+    kvv.copy_((torch.randn(kvv.numel(), generator=gen) * 0.5).to(torch.bfloat16))
+    dev = llm.device
+    tok = torch.randint(0, cfg.llm.speech_tokens, (S * K,), generator=gen, dtype=torch.int32).to(dev)
+    pos = [ctx - K - (i * 7) % 50 for i in range(S)]
+    nnew = [K if i % 5 else max(1, K - 1) for i in range(S)]
+    ctrl = torch.tensor([list(range(S)), pos, nnew, [p + n for p, n in zip(pos, nnew)], [i * K + n - 1 for i, n in enumerate(nnew)]], dtype=torch.int32).reshape(-1).to(dev)
+    logp = torch.empty(S, K, cfg.llm.vocab, dtype=torch.float32, device=dev)
+    llm._forward(S, K, tok, ctrl, K, logp)
+    torch.cuda.synchronize()
+    return logp.cpu()
+
+
+def test_llm_fp8_head_gate_up_is_the_bf16_path_on_the_quantised_weights(cfg, llm_setup, tmp_path):
+    """SURVEY §8(f) N4, fp8 head weights (`HvxLLM(head_mlp_fp8=True)`, hvx_llm_set_head_mlp_fp8): the MTP heads' gate / up projections as e4m3
+    codes x one power-of-two scale per output column.
+    (1) The mode IS the bf16 mode of a checkpoint that holds code x scale: log-probs of a wide-grid step (40 x 2 and 48 x 4 rows: the codes are
+        streamed) and of a narrow one (8 x 2: the bf16 tensor is read) are BIT-IDENTICAL to a plain bf16 model built from the dequantised state
+        dict, and so are the ids of the golden requests through the continuous engine — the fp8 stream adds no arithmetic of its own to what the
+        bf16 tests pin to the oracle; switching the codes off on the same handle changes nothing either.
+    (2) What the quantisation itself costs against the unquantised heads is stated: log-probs of the 25 likeliest tokens, argmax agreement.
+    (3) The packed cache keeps the codes instead of the bf16 tensor (smaller file) and reloads to the same model."""
+    import os
+    from flowmirror_hydravox_amd import checkpoint
+    from flowmirror_hydravox_amd.llm import HvxLLM
+    from flowmirror_hydravox_amd.packing import interleave_gate_up, quantize_e4m3_pow2
+    g, sd, sampling = llm_setup
+    c = cfg.llm
+    sdq = dict(sd)
+    for j in range(c.head_num):
+        pg, pu = 'mtp_block.%d.mlp.gate_proj.weight' % j, 'mtp_block.%d.mlp.up_proj.weight' % j
+        codes, scale, deq = quantize_e4m3_pow2(interleave_gate_up(sd[pg].float(), sd[pu].float()))
+        assert torch.equal(torch.log2(scale), torch.log2(scale).round()) and torch.equal(deq.to(torch.bfloat16).float(), deq)
+        t = deq.view(-1, 2, 16, c.hidden)
+        sdq[pg], sdq[pu] = t[:, 0].reshape(-1, c.hidden).contiguous(), t[:, 1].reshape(-1, c.hidden).contiguous()
+    plain_q = _make_llm(cfg, sdq, sampling, torch.bfloat16, max_batch=48, max_ctx=1024)
+    from functools import partial
+    from flowmirror_hydravox_amd.sampling import ras_sampling
+    fp8 = HvxLLM(c, sd, dtype=torch.bfloat16, max_batch=48, max_ctx=1024, sampling=partial(ras_sampling, **sampling), head_mlp_fp8=True)
+    for S, K in ((40, 2), (48, 4), (8, 2)):
+        a, b = _one_wide_step(plain_q, cfg, S, K), _one_wide_step(fp8, cfg, S, K)
+        assert torch.isfinite(a).all() and torch.equal(a, b), (S, K, float((a - b).abs().max()))
+    # the same handle without the codes: wide grids read the bf16 tensor again
+    from flowmirror_hydravox_amd._lib import check
+    b_codes = _one_wide_step(fp8, cfg, 40, 2)
+    check(fp8.lib.hvx_llm_set_head_mlp_fp8(fp8._h, None, None), 'off')
+    assert torch.equal(_one_wide_step(fp8, cfg, 40, 2), b_codes)
+    check(fp8.lib.hvx_llm_set_head_mlp_fp8(fp8._h, fp8._weights[-2].data_ptr(), fp8._weights[-1].data_ptr()), 'on')
+    # ids through the continuous engine (40-slot grid, graphs)
+    k2 = [r for r in range(int(g['n_runs'])) if int(g['r%d_K' % r]) == 2]
+
+    def reqs():
+        return iter([dict(text=torch.from_numpy(g['r%d_text' % r]), prompt_text=torch.from_numpy(g['r%d_ptext' % r]), prompt_speech_token=torch.from_numpy(g['r%d_pspeech' % r]),
+                          seed=int(g['r%d_seed' % r]), tag=r, max_token_text_ratio=float(g['r%d_ratios' % r][0]), min_token_text_ratio=float(g['r%d_ratios' % r][1]))
+                     for r in k2 * 5])
+    for m in (plain_q, fp8):
+        m.inference_head_num = 2
+    ids_q = list(plain_q.generate_stream(reqs(), n_slots=40))
+    ids_8 = list(fp8.generate_stream(reqs(), n_slots=40))
+    assert len(ids_q) == 40 and ids_q == ids_8
+    # (2) against the unquantised heads
+    plain = _make_llm(cfg, sd, sampling, torch.bfloat16, max_batch=48, max_ctx=1024)
+    ref, q = _one_wide_step(plain, cfg, 48, 4), _one_wide_step(fp8, cfg, 48, 4)
+    top = ref.argsort(-1, descending=True)[..., :25]
+    d = (ref.gather(-1, top) - q.gather(-1, top)).abs()
+    agree = float((ref.argmax(-1) == q.argmax(-1)).float().mean())
+    print('fp8 gate / up vs bf16 heads: |dlogp| over the top-25 tokens max %.3f mean %.4f, argmax agreement %.3f (head 0 is the backbone\'s own: %.3f)'
+          % (float(d.max()), float(d.mean()), agree, float((ref[:, 0].argmax(-1) == q[:, 0].argmax(-1)).float().mean())))
+    assert float(d.mean()) < 0.05 and agree > 0.8, (float(d.max()), float(d.mean()), agree)
+    # (3) packed cache
+    p8, pq = str(tmp_path / 'fp8.hvxpack'), str(tmp_path / 'plain.hvxpack')
+    checkpoint.save_packed(fp8, p8)
+    checkpoint.save_packed(plain_q, pq)
+    saved = os.path.getsize(pq) - os.path.getsize(p8)
+    assert saved > 0.9 * c.head_num * 2 * c.mtp_inter * c.hidden, saved            # bf16 tensor out, codes (half its size) + scales in
+    again = HvxLLM(c, None, dtype=torch.bfloat16, max_batch=48, max_ctx=1024, head_mlp_fp8=True)
+    checkpoint.load_packed(again, p8)
+    assert torch.equal(again._weights[again._n_base() - 2], fp8._weights[fp8._n_base() - 2])
+    assert torch.equal(_one_wide_step(again, cfg, 40, 2), b_codes)
+    with pytest.raises(ValueError):
+        checkpoint.load_packed(HvxLLM(c, None, dtype=torch.bfloat16, max_batch=8, max_ctx=1024), p8)

@@ -767,3 +767,41 @@ def test_frontend_gemm_bases_reproduce_the_oracle_features():
     # the kaldi mel banks: 80 triangles, unit peak, zero outside [20 Hz, Nyquist)
     banks = R.kaldi_mel_banks()
     assert banks.shape == (80, 256) and float(banks.max()) <= 1.0 and float(banks[:, 0].max()) == 0.0 and (banks.sum(1) > 0).all()
+
+
+def test_e4m3_power_of_two_quantiser_and_fragment_orders():
+    """packing.quantize_e4m3_pow2 (fp8 head weights): codes decode by the OCP e4m3 definition (restated here: bias 7, subnormals at
+    exponent 0, no infinities, 0x7f / 0xff = NaN) to what the cast produced, one power-of-two scale per row, |code| <= 448 reached on the row's
+    largest element, code x scale exact in bf16, rounding error within half an e4m3 step; pack_frag_fp8 holds the two k-steps of pack_frag's
+    fragments lane by lane, and frag_fp8_to_frag rebuilds the bf16 tensor a packed cache leaves out."""
+    import torch
+    from flowmirror_hydravox_amd.packing import frag_fp8_to_frag, pack_frag, pack_frag_fp8, quantize_e4m3_pow2
+
+    def decode(code):
+        s, e, m = -1.0 if code & 0x80 else 1.0, (code >> 3) & 0xf, code & 7
+        if e == 0xf and m == 7:
+            return float('nan')
+        return s * (m / 8.0) * 2.0 ** -6 if e == 0 else s * (1 + m / 8.0) * 2.0 ** (e - 7)
+    table = torch.tensor([decode(c) for c in range(256)], dtype=torch.float32)
+    assert float(table[0x7e]) == 448.0 and float(table[0x01]) == 2.0 ** -9
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(64, 256, generator=g) * torch.logspace(-4, 1, 64)[:, None]
+    w[5] = 0
+    codes, scale, deq = quantize_e4m3_pow2(w)
+    assert codes.dtype == torch.uint8 and codes.shape == w.shape and scale.shape == (64,)
+    assert torch.equal(table[codes.long()] * scale[:, None], deq)
+    assert torch.equal(torch.log2(scale), torch.log2(scale).round())
+    assert torch.equal(deq.to(torch.bfloat16).float(), deq)
+    amax_code = table[codes.long()].abs().amax(1)
+    live = w.abs().amax(1) > 0
+    assert bool((amax_code[live] >= 224).all()) and bool((amax_code <= 448).all())             # the smallest power of two that fits (224.x rounds to 224)
+    step = torch.where(w.abs() / scale[:, None] >= 2.0 ** -6, 2.0 ** (torch.floor(torch.log2(w.abs() / scale[:, None]).clamp_min(-6)) - 3), torch.tensor(2.0 ** -9))
+    assert bool(((deq - w).abs() <= 0.5 * step * scale[:, None] * (1 + 1e-6)).all())
+    assert torch.equal(deq[5], torch.zeros(256))
+    # fragment orders
+    pf = pack_frag(deq).view(4, 8, 4, 16, 8)                                                   # [tile][k-step][g][r][8]
+    p8 = pack_frag_fp8(codes)
+    v8 = table[p8.long()].view(4, 4, 4, 16, 2, 8) * scale.view(4, 1, 1, 16, 1, 1)              # [tile][double step][g][r][half][8]
+    for half in range(2):
+        assert torch.equal(v8[..., half, :], pf[:, half::2])
+    assert torch.equal(frag_fp8_to_frag(p8, scale, torch.bfloat16), pack_frag(deq).to(torch.bfloat16))
