@@ -76,7 +76,9 @@ class HvxModelManager:
         self.device = 'cuda'
         # precision policy of the reference (:101-118): llm bf16 / flow half / hift fp32.  fp16 requests run in bf16 as well:
         # libhvx computes in bf16 (or fp32), with fp32 accumulation and an fp32 residual stream.
-        llm = HvxLLM(cfg.llm, None, dtype=torch.bfloat16)
+        # optional fp8 head weights (llm.HvxLLM: head_mlp_fp8): args.head_fp8 or $HVX_HEAD_FP8=1
+        head_fp8 = bool(getattr(args, 'head_fp8', False)) or os.environ.get('HVX_HEAD_FP8', '').strip().lower() in ('1', 'true', 'yes', 'on')
+        llm = HvxLLM(cfg.llm, None, dtype=torch.bfloat16, head_mlp_fp8=head_fp8)
         if extras.get('sampling'):                           # the yaml's `sampling: !name:...ras_sampling` keyword defaults
             from functools import partial
             from .sampling import ras_sampling
