@@ -33,8 +33,10 @@ __device__ __forceinline__ float fmax3(float a, float b, float c) { return __bui
 
 // KVF: K / V^T are the LLM's fragment-order caches — every operand fragment is ONE contiguous load (1 KiB per wave instruction at bf16) instead of
 // 16 key rows x 64 B (K) or 64 channel rows x 8 B twice (V^T)
-template <class T, int QT, bool MERGE, bool KVF>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+// NWV: waves per workgroup of the decode (MERGE) form — 4, or 8 on wide grids (one 64-key trip per wave over a 512-key split: every load of the
+// split is in flight at once, and the eight partial states still merge in LDS into ONE partial per workgroup)
+template <class T, int QT, bool MERGE, bool KVF, int NWV = 4>
+__global__ __launch_bounds__(64 * NWV) void attn_fwd_kernel(AttnArgs a) {
     typedef typename Vec8<T>::type V8;
     typedef typename Vec4<T>::type V4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -207,10 +209,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 
     // ---- finish -------------------------------------------------------------------------------------
     if constexpr (MERGE) {
-        // merge the four waves' partial softmax states in LDS (fixed wave order) and write ONE partial per workgroup
+        // merge the waves' partial softmax states in LDS (fixed wave order) and write ONE partial per workgroup
         constexpr int RW = 16 * QT;
-        __shared__ float mo[4][RW][64];
-        __shared__ float mml[4][RW][2];
+        __shared__ float mo[NWV][RW][64];
+        __shared__ float mml[NWV][RW][2];
 #pragma unroll
         for (int i = 0; i < QT; ++i) {
             float l = l_run[i];
@@ -228,16 +230,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         __syncthreads();
 #pragma unroll
         for (int pass = 0; pass < QT; ++pass) {
-            const int row = pass * 16 + (threadIdx.x >> 4), d0 = (threadIdx.x & 15) * 4;
+            const int row = pass * 16 + ((threadIdx.x & 255) >> 4), d0 = (threadIdx.x & 15) * 4;
             const int rh = row / a.kn, rl = row - rh * a.kn;
-            if (row < a.n_rows && rl < n_valid_lo) {
+            if (threadIdx.x < 256 && row < a.n_rows && rl < n_valid_lo) {
                 float m = -INFINITY;
 #pragma unroll
-                for (int ww = 0; ww < 4; ++ww) m = fmaxf(m, mml[ww][row][0]);
+                for (int ww = 0; ww < NWV; ++ww) m = fmaxf(m, mml[ww][row][0]);
                 f32x4 acc = {0, 0, 0, 0};
                 float ls = 0.0f;
 #pragma unroll
-                for (int ww = 0; ww < 4; ++ww) {
+                for (int ww = 0; ww < NWV; ++ww) {
                     const float mw = mml[ww][row][0];
                     const float wgt = (mw == -INFINITY) ? 0.0f : expf(mw - m);
                     acc += wgt * *reinterpret_cast<const f32x4*>(&mo[ww][row][d0]);
@@ -761,6 +763,7 @@ static int launch_t(const AttnArgs& a_in, hipStream_t s) {
     const int slot = prof_begin(a.kv_len ? PK_ATTN_LLM : PK_ATTN, flops, s);
     if (a.kv_frag) {
         if (merge && a.n_rows > 16) hipLaunchKernelGGL((attn_fwd_kernel<T, 2, true, true>), grid, dim3(256), 0, s, a);      // decode, 17..32 rows (K = 3, 4)
+        else if (merge && a.n_sub == 8) hipLaunchKernelGGL((attn_fwd_kernel<T, 1, true, true, 8>), grid, dim3(512), 0, s, a);
         else if (merge) hipLaunchKernelGGL((attn_fwd_kernel<T, 1, true, true>), grid, dim3(256), 0, s, a);
         else if (big) hipLaunchKernelGGL((attn_fwd_kernel<T, 2, false, true>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((attn_fwd_kernel<T, 1, false, true>), grid, dim3(256), 0, s, a);
@@ -782,7 +785,8 @@ int launch_attention(const AttnArgs& a_in, hipStream_t s) {
     if (a.n_splits < 1) a.n_splits = 1;
 
     if (a.kn < 1) a.kn = a.n_rows;
-    if (a.n_splits == 1 || a.n_rows > 32 || a.sub_chunk * 4 != a.split_chunk || (a.sub_chunk & 31)) a.sub_chunk = 0;
+    if (a.n_sub != 8 || !a.kv_frag || a.n_rows > 16 || a.dtype != DT_BF16) a.n_sub = 4;       // (the 8-wave form exists for the one-tile bf16 decode over fragment-order caches)
+    if (a.n_splits == 1 || a.n_rows > 32 || a.sub_chunk * a.n_sub != a.split_chunk || (a.sub_chunk & 31)) a.sub_chunk = 0;
     if (a.kv_frag && (a.chunk > 0 || !a.causal)) return set_error("launch_attention: fragment-order caches serve the causal LLM calls only"), -1;
     if (a.o_frag_kt > 0 && a.dtype == DT_F32) return set_error("launch_attention: fragment-order output is 16-bit only"), -1;
     if ((a.v_ld & 31) || (a.n_splits > 1 && ((a.split_chunk & 31) || !a.part_o || !a.part_ml || a.n_rows_pad < a.n_rows))) {

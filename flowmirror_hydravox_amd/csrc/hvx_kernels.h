@@ -145,7 +145,8 @@ struct AttnArgs {
     int q_log2;                   // q already multiplied by scale * log2(e) (fused QKV epilogue, GemmArgs.q_scale): scale is ignored
     void* out; long long o_bs, o_hs, o_hi, o_lo;      // dtype
     int n_splits; int split_chunk;                    // keys per split (multiple of 32) when n_splits > 1
-    int sub_chunk;                                    // > 0 (needs n_rows <= 32): one workgroup per split, its 4 waves take sub_chunk keys
+    int n_sub;                                        // waves per workgroup of that form: 4 (0 = 4), or 8 (bf16, fragment-order caches, n_rows <= 16)
+    int sub_chunk;                                    // > 0 (needs n_rows <= 32): one workgroup per split, its n_sub waves take sub_chunk keys
                                                       // each and merge their (m, l, o) in LDS, so the combine reads 4x fewer partials
     float* part_o; float* part_ml;                    // [batch][heads][n_splits][n_rows_pad][64], [...][n_rows_pad][2]
     int n_rows_pad;

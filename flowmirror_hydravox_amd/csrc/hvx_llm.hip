@@ -424,7 +424,10 @@ static int forward_impl(hvx_llm* h, hipStream_t s, int32_t n_seq, int32_t kn, co
             // the fragment-order cache two 64-key trips per wave cost less than twice the workgroups (64 sequences: 1.346 -> 1.335 ms per step at
             // context 1536, 1.517 -> 1.473 at 2560, and -2 % beside the acoustic stage); narrow grids lose with it (8 sequences: 0.977 -> 1.009 ms)
             const int chunk = (n_seq >= 32 && !att_chunk_from_env()) ? 2 * h->att_chunk : h->att_chunk;
-            at.n_splits = (h->max_ctx + chunk - 1) / chunk; at.split_chunk = chunk; at.sub_chunk = chunk / 4; at.part_o = h->att_o; at.part_ml = h->att_ml; at.n_rows_pad = h->att_rows_pad;
+            // ... and eight waves per split there (bf16, one query tile): one 64-key trip per wave, every load of the split in flight at once
+            static const int att_waves = [] { const char* e = getenv("HVX_ATT_WAVES"); return e ? atoi(e) : 8; }();
+            const int nsub = (n_seq >= 32 && dt == DT_BF16 && G * kn <= 16 && att_waves == 8 && chunk % 256 == 0) ? 8 : 4;
+            at.n_splits = (h->max_ctx + chunk - 1) / chunk; at.split_chunk = chunk; at.n_sub = nsub; at.sub_chunk = chunk / nsub; at.part_o = h->att_o; at.part_ml = h->att_ml; at.n_rows_pad = h->att_rows_pad;
         } else {
             at.n_splits = 1;
         }
