@@ -41,12 +41,23 @@ __global__ __launch_bounds__(64 * NWV) void attn_fwd_kernel(AttnArgs a) {
     typedef typename Vec4<T>::type V4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fr = lane & 15, fg = lane >> 4;
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int n_qt = (a.n_rows + 16 * QT - 1) / (16 * QT);
     constexpr bool merge = MERGE;                             // decode form: workgroup = one split, waves = its four quarters
-    const int w = merge ? blockIdx.x : blockIdx.x * 4 + wave;
+    int b = blockIdx.z, h = blockIdx.y, sp_m = blockIdx.x;
+    if constexpr (merge) {
+        // Workgroups go to the 8 XCDs round-robin in LAUNCH order (x fastest).  With (split, head, sequence) = (x, y, z) and 8 splits — capacity 4096,
+        // 512-key splits — split s would run on XCD s only, and a grid whose sequences are 1536 keys long would use 3 of the 8 XCDs (measured: the
+        // 64-sequence decode step 1.29 -> 1.46 ms).  The launch order is re-read as split-major: consecutive workgroups are the (head, sequence) pairs of one
+        // split, so every split is spread over all XCDs, and the live (low) splits are dispatched first.
+        const int L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), HB = gridDim.y * gridDim.z;
+        sp_m = L / HB;
+        const int rem = L - sp_m * HB;
+        b = rem / (int)gridDim.y;
+        h = rem - b * (int)gridDim.y;
+    }
+    const int n_qt = (a.n_rows + 16 * QT - 1) / (16 * QT);
+    const int w = merge ? sp_m : blockIdx.x * 4 + wave;
     if (!merge && w >= n_qt * a.n_splits) return;
-    const int qt = merge ? 0 : w / a.n_splits, sp = merge ? blockIdx.x : w - qt * a.n_splits;
+    const int qt = merge ? 0 : w / a.n_splits, sp = merge ? sp_m : w - qt * a.n_splits;
 
     const int kv_len = a.kv_len ? a.kv_len[b] : a.kv_len_const;
     const int pos0 = (a.causal && a.pos0) ? a.pos0[b] : 0;
@@ -54,6 +65,11 @@ __global__ __launch_bounds__(64 * NWV) void attn_fwd_kernel(AttnArgs a) {
     int key_begin = 0, key_end = kv_len;
     if (a.n_splits > 1) {
         key_begin = sp * a.split_chunk;
+        // The grid is sized by the cache CAPACITY (a captured launch cannot know the live lengths): a split that starts beyond every row's visible keys
+        // leaves at once — before the query loads, the LDS merge and the partial stores.  attn_combine_kernel reads only the first
+        // ceil(visible / split_chunk) splits of a row, so nothing of a dead split is ever looked at.  (At capacity 4096 and context 1536 five of
+        // eight workgroups are dead; running their epilogues cost the 64-sequence decode step 190 us.)
+        if (merge && key_begin >= (a.causal ? min(kv_len, pos0 + a.kn) : kv_len)) return;
         key_end = min(kv_len, key_begin + a.split_chunk);
         if (merge) {
             key_begin += wave * a.sub_chunk;

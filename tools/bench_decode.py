@@ -24,6 +24,7 @@ def main():
     ap.add_argument('--steps', type=int, default=300)
     ap.add_argument('--fp32', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--max-ctx', type=int, default=0, help='capacity of the KV cache (default: --ctx + 64); the engine of the bench runs with 4096: the attention grid is sized by it')
     ap.add_argument('--head-fp8', action='store_true', help="the MTP heads' gate / up projections as e4m3 codes (HvxLLM(head_mlp_fp8=True))")
     ap.add_argument('--cus', type=int, default=0, help='confine the stream to this many compute units (hvx_stream_create_cu_range)')
     args = ap.parse_args()
@@ -34,7 +35,7 @@ def main():
     cfg = cv3_config().llm
     S, K = args.seqs, args.heads
     dt = torch.float32 if args.fp32 else torch.bfloat16
-    llm = HvxLLM(cfg, make_llm_state(cfg, seed=1986), dtype=dt, inference_head_num=K, max_batch=S, max_ctx=args.ctx + 64,
+    llm = HvxLLM(cfg, make_llm_state(cfg, seed=1986), dtype=dt, inference_head_num=K, max_batch=S, max_ctx=args.max_ctx or args.ctx + 64,
                  use_graph=not args.no_graph, head_mlp_fp8=args.head_fp8)
     dev = llm.device
     stream = _lib.cu_range_stream(0, args.cus, device=dev) if args.cus > 0 else torch.cuda.Stream(device=dev)
