@@ -45,6 +45,56 @@ __global__ __launch_bounds__(256) void ingest_kernel(const char* src, long long 
     if (buf[0][threadIdx.x] == 77 && buf[1][threadIdx.x] == 78) sink[0] = 1;
 }
 
+// The DMA stream of gemm_x3p_kernel<128,128> on a k-tap convolution over C = 128 channels and nothing else: per K-step (32 channels of one tap) a
+// workgroup brings 128 activation rows x 64 B x 2 planes and 128 weight rows x 64 B x 2 planes into a double buffer, one barrier per step; consecutive
+// steps walk along the rows (4 per tap), the next tap is the tile shifted by `dil` rows.  `pitch` = bytes between activation rows (256 = dense C = 128).
+__global__ __launch_bounds__(256) void conv_walk_kernel(const char* act, long long plane, int pitch, const char* w, int taps, int dil, int rows, int* sink) {
+    __shared__ __attribute__((aligned(1024))) char buf[2][32768];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lrow = lane >> 2, lcol = (lane & 3) * 16;
+    const long long m0 = (long long)blockIdx.x * 128;
+    const int kbytes = taps * 256;                          // a weight row: taps x 128 channels x 2 B
+    int s = 0;
+    for (int tap = 0; tap < taps; ++tap)
+        for (int ci = 0; ci < 4; ++ci, ++s) {
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int r16 = (wave * 2 + q) * 16;
+                long long m = m0 + r16 + lrow + (long long)tap * dil;
+                m = m < rows ? m : rows - 1;
+                const char* gp = act + m * pitch + ci * 64 + lcol;
+                __builtin_amdgcn_global_load_lds((glb_ptr)gp, (lds_ptr)(buf[s & 1] + r16 * 64), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_ptr)(gp + plane), (lds_ptr)(buf[s & 1] + 8192 + r16 * 64), 16, 0, 0);
+                const char* wp = w + (long long)(r16 + lrow) * kbytes + tap * 256 + ci * 64 + lcol;
+                __builtin_amdgcn_global_load_lds((glb_ptr)wp, (lds_ptr)(buf[s & 1] + 16384 + r16 * 64), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_ptr)(wp + 128 * kbytes), (lds_ptr)(buf[s & 1] + 24576 + r16 * 64), 16, 0, 0);
+            }
+        }
+    __syncthreads();
+    if (buf[0][threadIdx.x] == 77 && buf[1][threadIdx.x] == 78) sink[0] = 1;
+}
+
+void run_conv(int pitch, int taps, int dil, int* sink) {
+    const int rows = 225280;                                // the C = 128 stage of a 5632-frame utterance
+    const long long plane = (long long)rows * pitch;
+    char *act, *w;
+    CK(hipMalloc(&act, 2 * plane)); CK(hipMemset(act, 1, 2 * plane));
+    CK(hipMalloc(&w, 2LL * 128 * taps * 256)); CK(hipMemset(w, 1, 2LL * 128 * taps * 256));
+    const int wgs = rows / 128;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(conv_walk_kernel, dim3(wgs), dim3(256), 0, 0, act, plane, pitch, w, taps, dil, rows, sink);
+    CK(hipEventRecord(e0));
+    const int reps = 5;
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(conv_walk_kernel, dim3(wgs), dim3(256), 0, 0, act, plane, pitch, w, taps, dil, rows, sink);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double us = ms * 1e3 / reps, total = (double)wgs * taps * 4 * 32768;
+    printf("conv walk C=128 taps %2d dil %d  act pitch %4d B  %4d wgs  %8.1f us  %6.2f TB/s into LDS  %6.1f GB/s per CU\n", taps, dil, pitch, wgs, us, total / us / 1e6, total / us / 1e3 / 256);
+    CK(hipFree(act)); CK(hipFree(w));
+}
+
 template <int PIECE, int PLAIN = 0>
 void run(const char* src, long long bytes, int stride, int wgs, int* sink, const char* what) {
     const int steps = 64;
@@ -62,6 +112,8 @@ void run(const char* src, long long bytes, int stride, int wgs, int* sink, const
 
 int main() {
     int* sink; CK(hipMalloc(&sink, 4));
+    for (int taps : {3, 7, 11})
+        for (int pitch : {256, 320, 512, 1024}) run_conv(pitch, taps, taps == 3 ? 1 : 3, sink);
     for (long long mb : {24LL, 512LL}) {
         char* src; CK(hipMalloc(&src, mb << 20)); CK(hipMemset(src, 1, mb << 20));
         char what[64]; snprintf(what, sizeof what, "source %lld MB", mb);
