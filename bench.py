@@ -68,7 +68,10 @@ def parse():
     ap.add_argument('--lm-chains', type=int, default=3, help='(--mode chains) batches whose LM decode runs concurrently')
     ap.add_argument('--serial', action='store_true', help='same as --mode serial')
     ap.add_argument('--prof-period', type=int, default=17, help='every n-th launch of a kernel class is bracketed in the profiling step (prime: no aliasing with the 4-GEMM block period)')
+    ap.add_argument('--no-extras', action='store_true', help='skip the untimed extra objects of the line: single_request (BASELINE configs[0] shape), head_sweep (head_num 1 / 4), bf16_id_agreement')
+    ap.add_argument('--sweep-steps', type=int, default=8, help='steps of 8 utterances per point of the head_num sweep')
     ap.add_argument('--cpu-baseline-worker', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--stub-pipeline', action='store_true', help=argparse.SUPPRESS)      # plumbing check of the rank logic on CPU / gloo (tools/bench_stub.py); INVALID as a benchmark
     return ap.parse_args()
 
 
@@ -110,7 +113,7 @@ def _kernel_in_lib(name):
     return bool(m) and ('%d%s' % (len(m.group(1)), m.group(1))).encode() in _LIB_BYTES
 
 
-def pmc_traffic(name):
+def pmc_traffic(name, with_grid=False):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r*_pmc_traffic.json; FETCH_SIZE / WRITE_SIZE in
     separate passes with the gfx950 x2 FETCH correction).  PMC collection cannot run inside the timed bench.  An entry is used only if
     every kernel it was counted on (its "kernels" list of mangled names) is still a kernel of the libhvx.so being benchmarked — counters
@@ -128,11 +131,12 @@ def pmc_traffic(name):
                     _LIB_BYTES = f.read()
             kernels = d[name].get('kernels')
             if not kernels or not all(_kernel_in_lib(k) for k in kernels):
-                return None
-            return int(d[name]['hbm_bytes_per_launch'])
+                return (None, None) if with_grid else None
+            b = int(d[name]['hbm_bytes_per_launch'])
+            return (b, d[name].get('grid', os.path.basename(path))) if with_grid else b
         except Exception:
             pass
-    return None
+    return (None, None) if with_grid else None
 
 
 def roofline_of(name, p):
@@ -179,6 +183,32 @@ def cpu_baseline(cfg, pipe_seed, chars, heads):
         return n, time.time() - t0
     n_nc, t_nc = run_llm(False, budget, 128)                 # reference behaviour
     n_kv, t_kv = run_llm(True, 10.0, 128)                    # "fair CPU": same arithmetic, keys / values kept (includes the prefill of the prefix)
+    # BASELINE configs[0] on the host cores (BASELINE.md §2 "config 1 is timed in full"): ONE 64-char utterance at head_num 1 — the KV-cached LM in full
+    # here (352 steps); the reference's literal no-cache loop in full only with HVX_CPU_BASELINE_FULL=1 (minutes), else its full timing in the build
+    # container rides along from tests/golden/single_cv3.npz (where the reference's own modules produced that fixture)
+    single = None
+    if chars >= 64:
+        u1 = synthetic_utterance(cfg, 0, 64)
+
+        def run_single(use_kv):
+            t0 = time.time()
+            n = sum(1 for _ in llm_ref.llm_inference(sd, cfg.llm, u1.text, sampler_ref.NoiseStream(seed=0), inference_head_num=1, sampling=sampling,
+                                                     max_token_text_ratio=ratio, min_token_text_ratio=ratio, use_kv_cache=use_kv))
+            return n, time.time() - t0
+        n1, t1 = run_single(True)
+        single = {'tokens': n1, 'llm_seconds_kv_cached': round(t1, 2)}
+        if os.environ.get('HVX_CPU_BASELINE_FULL') == '1':
+            n1u, t1u = run_single(False)
+            single['llm_seconds_no_cache_reference_loop'] = round(t1u, 2)
+        try:
+            import numpy as np
+            g = np.load(os.path.join(ROOT, 'tests', 'golden', 'single_cv3.npz'))
+            rs = [float(v) for v in g['ref_seconds']]
+            single['reference_modules_in_build_container'] = {'threads': int(g['ref_threads']), 'llm_seconds_no_cache': round(rs[0], 1), 'flow_seconds': round(rs[1], 1),
+                                                              'hift_seconds': round(rs[2], 1), 'tokens_per_s': round(len(g['tokens']) / sum(rs), 3),
+                                                              'note': 'the reference\'s own llm.inference / flow decoder / hift.inference on this shape, timed in full when the fixture was minted (tests/golden/make_golden_fullsize.py: gen_single)'}
+        except Exception:
+            pass
     del sd
     t_llm = t_nc / max(n_nc, 1)
     # ---- flow: 10 Euler steps x CFG 2 at two lengths -> a*T + b*T^2 (linear layers / attention), extrapolated to the bench length
@@ -206,7 +236,13 @@ def cpu_baseline(cfg, pipe_seed, chars, heads):
     t_hift = time.time() - t0
     hift_full = t_hift * T_full / mel.shape[-1]
     total = n_spk * t_llm + flow_full + hift_full            # one bench utterance on the host cores
-    return dict(value=round(n_spk / total, 3), unit='speech-tokens/s', cores=cores, kind='port',
+    if single is not None and T1 == 704:
+        # (the flow / vocoder timings above at T = 704 ARE this utterance's length)
+        single.update(flow_seconds=round(f1, 2), hift_seconds=round(t_hift * 704 / mel.shape[-1], 2))
+        single['latency_s_kv_cached'] = round(single['llm_seconds_kv_cached'] + single['flow_seconds'] + single['hift_seconds'], 2)
+        single['tokens_per_s_kv_cached'] = round(single['tokens'] / single['latency_s_kv_cached'], 3)
+        single['workload'] = 'BASELINE configs[0]: head_num 1, one 64-char utterance (64 text -> 352 tokens -> 704 frames), oracle/ on %d threads' % cores
+    return dict(single_request=single, value=round(n_spk / total, 3), unit='speech-tokens/s', cores=cores, kind='port',
                 sample='oracle/ (fp32 CPU restatement of the reference algorithm, torch CPU, %d threads) on one %d-char utterance of the bench workload: '
                        'LM = first %d speech tokens in %.1f s with the reference\'s no-KV-cache full-prefix recompute at the true context offsets '
                        '(context %d..%d; the utterance mean is ~%d, so this favours the CPU); flow (10 Euler steps x CFG 2) measured at T = %d / %d frames '
@@ -220,6 +256,69 @@ def cpu_baseline(cfg, pipe_seed, chars, heads):
                                     'note': 'the same LM arithmetic with a KV cache (prefix prefill included in the seconds); flow / HiFT as above'},
                 flow_seconds={'T%d' % T1: round(f1, 2), 'T%d' % T2: round(f2, 2), 'T%d_extrapolated' % T_full: round(flow_full, 1)},
                 hift_seconds={'T%d' % mel.shape[-1]: round(t_hift, 2), 'T%d_scaled' % T_full: round(hift_full, 1)})
+
+
+def single_request(pipe, cfg, ratio, chars=64, heads=(1, 2), repeats=3):
+    """BASELINE configs[0]'s shape on the GPU, the way the reference serves it (server/model_utils/infer_speech_model.py:612-681: ONE utterance per
+    call, llm -> flow -> hift back to back): a 64-char utterance (64 text -> 352 speech tokens -> 704 frames) at head_num 1 and 2, batch 1, on the
+    headline's pipeline (bf16 LM on the 16-row decode kernels, bf16 flow, fp32-contract vocoder).  Latency = best of `repeats` after one warm-up."""
+    from flowmirror_hydravox_amd.pipeline import synthetic_utterance
+    u = synthetic_utterance(cfg, 0, chars)
+    k0 = pipe.llm.inference_head_num
+    out = {'workload': 'one %d-char utterance per call (%d text -> %d speech tokens -> %d mel frames), batch 1, stages back to back (infer_speech_model.py:612-681); '
+                       'best of %d calls after a warm-up' % (chars, chars, int(chars * ratio), 2 * int(chars * ratio), repeats)}
+    try:
+        for k in heads:
+            pipe.llm.inference_head_num = k
+            pipe.synthesize([u], max_token_text_ratio=ratio, min_token_text_ratio=ratio)
+            best = None
+            for _ in range(repeats):
+                torch.cuda.synchronize()
+                t0 = time.time()
+                wavs, st = pipe.synthesize([u], max_token_text_ratio=ratio, min_token_text_ratio=ratio)
+                torch.cuda.synchronize()
+                dt = time.time() - t0
+                if best is None or dt < best[0]:
+                    best = (dt, st)
+            dt, st = best
+            us, by = st.llm.get('decode_step_us', 0.0), st.llm.get('decode_step_bytes', 0.0)
+            out['head_num_%d' % k] = {'latency_s': round(dt, 4), 'tokens': st.tokens, 'tokens_per_s': round(st.tokens / dt, 1), 'llm_tokens_per_s': round(st.tps, 1),
+                                      'rtf': round(dt / st.audio_seconds, 6), 'stage_seconds': {'llm': round(st.llm_seconds, 4), 'flow': round(st.flow_seconds, 4), 'hift': round(st.hift_seconds, 4)},
+                                      'decode_step_us': round(us, 1), 'decode_step_frac_of_hbm': round(by / us / 1e3 / HBM_PEAK_GBS, 4) if us else None}
+    finally:
+        pipe.llm.inference_head_num = k0
+    return out
+
+
+def head_sweep(pipe, args, make_utt, ratio, k_line, B):
+    """north_star: "RTF and speech-tokens/sec at head_num in {1, 2, 4}" — the two points the line's `value` is not, through the same continuous engine
+    (grid of 128 ROWS for head_num 1, 64 sequences otherwise), `--sweep-steps` steps of B utterances each, untimed for `value`."""
+    out = {'steps': args.sweep_steps, 'utterances': args.sweep_steps * B,
+           'note': 'same pipeline and engine as `value` (head_num %d, %d steps); fewer steps: the fill of the first grid weighs more' % (k_line, args.steps)}
+    k0 = pipe.llm.inference_head_num
+    try:
+        for k in (1, 2, 4):
+            if k == k_line:
+                continue
+            pipe.llm.inference_head_num = k
+            slots = 128 if k == 1 else 64
+            job = [make_utt(g) for g in range(args.sweep_steps * B)]
+            torch.cuda.synchronize()
+            t0 = time.time()
+            tok = 0
+            for i, wav, toks in pipe.synthesize_continuous(job, lm_slots=slots, max_token_text_ratio=ratio, min_token_text_ratio=ratio,
+                                                           acoustic_batch=args.acoustic_batch, acoustic_min_batch=args.acoustic_min_batch):
+                tok += len(toks)
+            torch.cuda.synchronize()
+            dt = time.time() - t0
+            c = dict(pipe.last_continuous)
+            us, by = c['llm'].get('decode_step_us', 0.0), c['llm'].get('decode_step_bytes', 0.0)
+            out['head_num_%d' % k] = {'value': round(tok / dt, 1), 'unit': 'speech-tokens/s', 'rtf': round(dt / c['audio_seconds'], 6), 'ms_per_step': round(1e3 * dt / args.sweep_steps, 1),
+                                      'lm_slots': slots, 'decode_step_us': round(us, 1), 'decode_step_frac_of_hbm': round(by / us / 1e3 / HBM_PEAK_GBS, 4) if us else None,
+                                      'mean_active_sequences': round(c['llm'].get('mean_active_sequences', 0.0), 1)}
+    finally:
+        pipe.llm.inference_head_num = k0
+    return out
 
 
 def run_acoustic(args, cfg, world, rank, lib):
@@ -330,20 +429,32 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
         raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node %d, or without torch.distributed.run)' % (args.gpus, world, args.gpus))
+    stub = args.stub_pipeline
+    dev = 'cpu' if stub else 'cuda'
+    sync = (lambda: None) if stub else torch.cuda.synchronize
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-        assert dist.get_world_size() == args.gpus and dist.get_backend() == 'nccl'        # "nccl" is RCCL on ROCm
-    else:
+        if stub:
+            dist.init_process_group('gloo')
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        assert dist.get_world_size() == args.gpus and dist.get_backend() == ('gloo' if stub else 'nccl')        # "nccl" is RCCL on ROCm
+    elif not stub:
         torch.cuda.set_device(0)
     from flowmirror_hydravox_amd import _lib, cv3_config, tiny_config
     from flowmirror_hydravox_amd.pipeline import HvxPipeline, synthetic_utterance
     from flowmirror_hydravox_amd.dp import gather_waveforms, shard_by_cost, Handoff
     from flowmirror_hydravox_amd.sampling import ras_sampling
     from functools import partial
-    _lib.require_gpu()
-    lib = _lib.load()
+    if stub:
+        sys.path.insert(0, os.path.join(ROOT, 'tools'))
+        from bench_stub import StubPipeline, StubLib
+        lib = StubLib()
+        args.no_cpu_baseline = args.no_fp32_mode = args.no_extras = True
+    else:
+        _lib.require_gpu()
+        lib = _lib.load()
 
     cfg = tiny_config() if args.tiny else cv3_config()
     if args.config == 'acoustic':
@@ -368,8 +479,11 @@ def main():
     max_ctx = 2 + chars + P_TXT + P_SPK + n_spk + K + 32
     sampling = partial(ras_sampling, top_p=0.9, top_k=10, win_size=32, tau_r=0.2)
     t_build = time.time()
-    pipe = HvxPipeline(cfg, llm_dtype=torch.float32 if args.llm_dtype == 'fp32' else torch.bfloat16, flow_dtype=torch.bfloat16, max_batch=B, max_ctx=max_ctx, max_t=2 * (n_spk + P_SPK) + 64,
-                       seed=1986, init='normal02', sampling=sampling, inference_head_num=K)
+    if stub:
+        pipe = StubPipeline(cfg, K)
+    else:
+        pipe = HvxPipeline(cfg, llm_dtype=torch.float32 if args.llm_dtype == 'fp32' else torch.bfloat16, flow_dtype=torch.bfloat16, max_batch=B, max_ctx=max_ctx, max_t=2 * (n_spk + P_SPK) + 64,
+                           seed=1986, init='normal02', sampling=sampling, inference_head_num=K)
     pipe.acoustic_batch = max(1, args.acoustic_batch)
     pipe.lm_cus = args.lm_cus
     pipe.lm_cus_only = args.lm_cus_only
@@ -383,11 +497,11 @@ def main():
     gids = [rank * B + i for i in range(B)]
 
     def barrier():
-        torch.cuda.synchronize()
+        sync()
         if world > 1:
             import torch.distributed as dist
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
 
     def step():
         wavs, st = pipe.synthesize(utts, max_token_text_ratio=ratio, min_token_text_ratio=ratio)
@@ -404,16 +518,16 @@ def main():
     # flight, stages back to back — its throughput and its latency (every utterance of the batch is complete after `latency_s`)
     strict = None
     if args.warmup > 0:
-        torch.cuda.synchronize()
+        sync()
         t_s = time.time()
         serial, got = step()
-        torch.cuda.synchronize()
+        sync()
         t_s = time.time() - t_s
         strict = {'value': round(serial.tokens / t_s, 1), 'unit': 'speech-tokens/s', 'rtf': round(t_s / serial.audio_seconds, 6), 'latency_s': round(t_s, 3),
                   'utterances_in_flight_per_gpu': B, 'schedule': 'one batch of %d, lock-step decode, stages back to back, no continuous batching (one un-timed extra step after the warm-up)' % B,
                   'stage_seconds': {'llm': round(serial.llm_seconds, 4), 'flow': round(serial.flow_seconds, 4), 'hift': round(serial.hift_seconds, 4)}}
     lm_alone = None
-    if args.mode == 'continuous' and args.warmup > 0:
+    if args.mode == 'continuous' and args.warmup > 0 and not stub:
         # the wide decode grid alone (nothing else on the GPU): --lm-slots utterances through the engine, untimed — `roofline.alone`
         reqs = [dict(text=utts[i % B].text, seed=10_000 + i, tag=i, max_token_text_ratio=ratio, min_token_text_ratio=ratio) for i in range(args.lm_slots)]
         for _ in pipe.llm.generate_stream(iter(reqs), n_slots=args.lm_slots):
@@ -443,7 +557,7 @@ def main():
         mine = shards[rank]
         assert len(mine) == args.steps * B or zero_shot
         job = [make_utt(g) for g in mine]
-        hand = Handoff(shards, B, dst=0, keep=False)
+        hand = Handoff(shards, B, dst=0, keep=stub)
         for i, wav, toks in pipe.synthesize_continuous(job, lm_slots=args.lm_slots, max_token_text_ratio=ratio, min_token_text_ratio=ratio,
                                                        acoustic_batch=args.acoustic_batch, acoustic_min_batch=args.acoustic_min_batch,
                                                        pace=[int(v) for v in args.lm_pace.split(',')] if args.lm_pace else None):
@@ -458,7 +572,7 @@ def main():
     # graph disabled (same kernels, same launch geometry; the rocprofv3 --kernel-trace summary under profiles/ covers the
     # graph-replayed timed steps themselves and must agree).
     prof = {}
-    if rank == 0:
+    if rank == 0 and not stub:
         lib.hvx_prof_enable(args.prof_period)
         step_prof_t0 = time.time()
         pipe.synthesize(utts, max_token_text_ratio=ratio, min_token_text_ratio=ratio)
@@ -479,7 +593,7 @@ def main():
             flow_s, hift_s = flow_s + hift_s, 0.0
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([elapsed, float(tokens), audio, llm_s, flow_s, hift_s], dtype=torch.float64, device='cuda')
+        t = torch.tensor([elapsed, float(tokens), audio, llm_s, flow_s, hift_s], dtype=torch.float64, device=dev)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()
@@ -519,7 +633,7 @@ def main():
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16' if args.llm_dtype == 'bf16' else 'f32 (LM) + bf16 (flow)', 'data': 'synthetic',
         'config': {'workload': 'HydraVox-CV3%s inference_head_num=%d, batch=%dx%d-char utterances per GPU (%d text -> %d speech tokens -> %d mel frames '
                                'each), %s / hift fp32, llm->flow->hift end to end, seeded N(0,0.02) weights'
-                               % (' [TINY DIMS - NOT A BENCHMARK]' if args.tiny else '', K, B, chars, chars, n_spk, 2 * n_spk,
+                               % (' [STUB PIPELINE ON CPU / GLOO - RANK LOGIC ONLY, NOT A BENCHMARK]' if stub else ' [TINY DIMS - NOT A BENCHMARK]' if args.tiny else '', K, B, chars, chars, n_spk, 2 * n_spk,
                                   'llm+flow bf16' if args.llm_dtype == 'bf16' else 'llm fp32 (speech-token ids bit-exact against the reference) + flow bf16'),
                    'baseline_config': {'tts': 'configs[1]', 'stress': 'configs[2]', 'zero_shot': 'configs[3]: text lengths U{64..512} per utterance (the chars figure above is the maximum), '
                                        'prompt = 75 speech tokens + 150 mel frames + 20 prompt-text tokens'}[args.config],
@@ -552,7 +666,8 @@ def main():
     if rl_timed:
         line['roofline'] = dict(kernel='llm_decode_step (hipGraph: %d-layer backbone + %d MTP heads + sampler + advance, one launch = one step of a grid of %.1f live sequences x %d heads)'
                                        % (cfg.llm.layers, K, grid_seqs, K), bound='hbm', achieved=rl_timed['achieved'], peak=HBM_PEAK_GBS, unit='GB/s',
-                                frac=rl_timed['frac'], traffic=pmc_traffic('llm_decode_step'), avg_launch_us=rl_timed['avg_launch_us'],
+                                frac=rl_timed['frac'], traffic=pmc_traffic('llm_decode_step'), traffic_counted_on=pmc_traffic('llm_decode_step', with_grid=True)[1],
+                                avg_launch_us=rl_timed['avg_launch_us'],
                                 algorithmic_bytes_per_launch=rl_timed['algorithmic_bytes_per_launch'], launches_per_timed_region=rl_timed['launches'],
                                 measured='hipEvents around every 8 replays on the decode stream, all timed steps' +
                                          ('' if args.serial else '; the flow decoder + vocoder of finished utterances share the GPU meanwhile' if args.mode == 'continuous' else
@@ -575,7 +690,23 @@ def main():
         line['kernel_time_share_ms'] = {n: round(t, 1) for t, n in est}
     if strict is not None:
         line['strict_batch%d' % B] = strict
+    extras = world == 1 and not args.no_extras and args.config == 'tts' and args.mode == 'continuous' and args.llm_dtype == 'bf16'
+    if extras:
+        try:
+            line['single_request'] = single_request(pipe, cfg, ratio)
+        except Exception as e:
+            line['single_request'] = {'error': repr(e)}
+        try:
+            line['head_sweep'] = head_sweep(pipe, args, make_utt, ratio, K, B)
+        except Exception as e:
+            line['head_sweep'] = {'error': repr(e)}
     del pipe
+    if stub:
+        line['stub'] = {'received_on_rank0': hand.n_received if cont is not None else len(got), 'handoff_rounds': hand.rounds if cont is not None else None,
+                        'shard_sizes': [len(sh) for sh in shards] if cont is not None else None,
+                        'checksum': float(sum(float(w.double().sum()) for w in got.values())) if got else 0.0}
+        print(json.dumps(line))
+        return
     torch.cuda.empty_cache()
     if world == 1 and not args.no_fp32_mode and not args.tiny:
         # the parity-exact mode (fp32 LM + fp32 flow: speech-token ids bit-exact against the reference, mel / waveform within 1e-3): the
@@ -618,6 +749,24 @@ def main():
             torch.cuda.synchronize()
             tx = time.time() - tx
             cx = dict(pipex.last_continuous)
+            if extras:
+                # north_star / SURVEY.md §7: "ids bit-exact in an fp32 GPU mode ... reported as match-rate in bf16 mode": the bf16 LM of the headline
+                # teacher-forced on the fp32 LM's streams of the bench batch (same history, same noise position per decision)
+                try:
+                    from flowmirror_hydravox_amd import weights as W
+                    from flowmirror_hydravox_amd.llm import HvxLLM, decision_agreement
+                    t_a = time.time()
+                    llm_b = HvxLLM(cfg.llm, W.make_llm_state(cfg.llm, seed=1986, init='normal02'), dtype=torch.bfloat16, max_batch=B, max_ctx=max_ctx, sampling=sampling,
+                                   inference_head_num=K)
+                    reqs = [dict(text=u.text, seed=u.seed, max_token_text_ratio=ratio, min_token_text_ratio=ratio) for u in utts]
+                    ag = decision_agreement(pipex.llm, llm_b, reqs)
+                    line['bf16_id_agreement'] = dict(ag, seconds=round(time.time() - t_a, 1),
+                                                     what='teacher-forced per-decision agreement of the bf16 LM (the headline\'s) with the fp32 LM (ids bit-exact against the reference) on the '
+                                                          '%d utterances of one bench step: every draw of the bf16 LM is made from ITS log-probs with the fp32 stream\'s history, repetition '
+                                                          'window and noise position; `agreement` = equal draws / draws, `steps_all_equal` = steps whose %d draws are all equal' % (B, K))
+                    del llm_b
+                except Exception as e:
+                    line['bf16_id_agreement'] = {'error': repr(e)}
             line['ids_exact_mode'] = {'value': round(tokx / tx, 1), 'unit': 'speech-tokens/s', 'rtf': round(tx / cx['audio_seconds'], 6), 'steps': n_x, 'ms_per_step': round(1e3 * tx / n_x, 2),
                                       'dtype': 'f32 LM (speech-token ids bit-exact against the reference: tests/test_gpu_cv3w.py, test_gpu_cv3d.py) + the flow decoder and '
                                                'vocoder of the headline (mel within the reference\'s own fp16 distance of fp32)',
@@ -641,4 +790,9 @@ def main():
 
 
 if __name__ == '__main__':
-    main()
+    try:
+        main()
+    finally:
+        import torch.distributed as _dist
+        if _dist.is_available() and _dist.is_initialized():
+            _dist.destroy_process_group()       # (a rank that leaves with the group alive aborts in the backend's watchdog thread)

@@ -172,6 +172,10 @@ SYMBOLS = {
     'hvx_conv2d': (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
 }
 
+# include/hvx.h: HVX_ABI_VERSION — bumped whenever a symbol is added or an argument struct changes size / meaning (2: round 4's six symbols, larger
+# SkinnyArgs / AttnArgs, fragment-order KV cache; 3: round 5)
+HVX_ABI_VERSION = 3
+
 _lib = None
 
 
@@ -188,12 +192,22 @@ def load():
     # runtime in the process (loaded the other way round, the system runtime comes up first and sees no device).
     import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
+    rebuild = 'rebuild it: `python -m flowmirror_hydravox_amd.build --force`'
+    # the version first: a stale library fails HERE with a message, not later on a missing symbol or a struct of another size
+    try:
+        lib.hvx_abi_version.restype = c_i32
+        got = int(lib.hvx_abi_version())
+    except AttributeError:
+        raise HvxError('%s is not a libhvx (no hvx_abi_version); %s' % (LIB_PATH, rebuild))
+    if got != HVX_ABI_VERSION:
+        raise HvxError('libhvx ABI version mismatch: %s reports %d, this package binds %d (include/hvx.h); %s' % (LIB_PATH, got, HVX_ABI_VERSION, rebuild))
     for name, (res, args) in SYMBOLS.items():
-        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise HvxError('libhvx.so does not export %s although its ABI version is %d; %s' % (name, got, rebuild))
         fn.restype = res
         fn.argtypes = args
-    if lib.hvx_abi_version() != 1:
-        raise HvxError('libhvx ABI version mismatch')
     _lib = lib
     return lib
 

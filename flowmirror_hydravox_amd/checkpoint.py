@@ -22,7 +22,7 @@ import os
 import torch
 
 # bump when packing.py / the weights[] order documented in include/hvx.h changes
-PACK_LAYOUT = 'hvx-pack-4'
+PACK_LAYOUT = 'hvx-pack-5'
 
 QWEN2_DEFAULT_INTERMEDIATE = 22016         # Qwen2Config() default used by the graft script (and by mtp_block, llm_multi_head_v3.py:657-665)
 

@@ -3,6 +3,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
+#include <mutex>
 #include <vector>
 
 #include "hvx.h"
@@ -18,9 +20,13 @@ void set_error(const char* fmt, ...) {
 }
 
 // ---- sampled kernel timing ------------------------------------------------------------------------------------------------
+// The one piece of process-wide mutable state in the library (a measurement aid; no result depends on it): `on` is an atomic that launches
+// read without the lock (off = the whole cost of the facility), everything else is touched under `mu` only — launches from several host
+// threads (two acoustic chains, the decode engine) and hvx_prof_enable / hvx_prof_read may interleave freely.
 struct ProfSlot { int kind; double work; hipEvent_t e0, e1; };
 static struct {
-    bool on = false;
+    std::atomic<bool> on{false};
+    std::mutex mu;
     int period = 1;
     long long launched[PK_COUNT] = {};
     double launched_work[PK_COUNT] = {};
@@ -29,7 +35,9 @@ static struct {
 constexpr size_t PROF_MAX_SLOTS = 1 << 15;
 
 int prof_begin(int kind, double work, hipStream_t s) {
-    if (!g_prof.on) return -1;
+    if (!g_prof.on.load(std::memory_order_relaxed)) return -1;
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    if (!g_prof.on.load(std::memory_order_relaxed)) return -1;
     const long long n = g_prof.launched[kind]++;
     g_prof.launched_work[kind] += work;
     if (n % g_prof.period != 0 || g_prof.slots.size() >= PROF_MAX_SLOTS) return -1;
@@ -40,9 +48,11 @@ int prof_begin(int kind, double work, hipStream_t s) {
     g_prof.slots.push_back(p);
     return (int)g_prof.slots.size() - 1;
 }
-bool prof_enabled() { return g_prof.on; }
+bool prof_enabled() { return g_prof.on.load(std::memory_order_relaxed); }
 void prof_end(int slot, hipStream_t s) {
-    if (slot >= 0) hipEventRecord(g_prof.slots[slot].e1, s);
+    if (slot < 0) return;
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    if ((size_t)slot < g_prof.slots.size()) hipEventRecord(g_prof.slots[slot].e1, s);      // (a slot of a session that was reset meanwhile is dropped)
 }
 }  // namespace hvx
 
@@ -94,6 +104,7 @@ int hvx_stream_destroy(hvx_stream s) {
 }
 
 int hvx_prof_enable(int32_t period) {
+    std::lock_guard<std::mutex> lk(g_prof.mu);
     for (auto& p : g_prof.slots) { hipEventDestroy(p.e0); hipEventDestroy(p.e1); }
     g_prof.slots.clear();
     for (int k = 0; k < PK_COUNT; ++k) { g_prof.launched[k] = 0; g_prof.launched_work[k] = 0; }
@@ -106,6 +117,7 @@ int hvx_prof_read(int32_t kind, double* sampled_ms, double* sampled_work, int64_
     if (kind < 0 || kind >= PK_COUNT) return set_error("hvx_prof_read: bad kind"), -1;
     double ms = 0, work = 0;
     long long n = 0;
+    std::lock_guard<std::mutex> lk(g_prof.mu);
     for (auto& p : g_prof.slots) {
         if (p.kind != kind) continue;
         float t = 0;

@@ -80,14 +80,13 @@ namespace {
 constexpr int MAX_SPLIT = 16;
 // keys per decode-attention split (one workgroup); its 4 waves take a quarter each and merge in LDS.  256 on the whole chip; a decode engine confined
 // to a few compute units (hvx_stream_create_cu_range) wants fewer, longer workgroups (HVX_ATT_CHUNK, a multiple of 128)
-static bool att_chunk_from_env() {
-    static const bool v = getenv("HVX_ATT_CHUNK") != nullptr;
+// (lab switch; an invalid value is ignored as a whole: neither the chunk nor the wide-grid doubling changes)
+static int att_chunk_env_value() {
+    static const int v = [] { const char* e = getenv("HVX_ATT_CHUNK"); const int c = e ? atoi(e) : 0; return (c >= 128 && c % 128 == 0) ? c : 0; }();
     return v;
 }
-static int att_chunk_keys() {
-    static const int v = [] { const char* e = getenv("HVX_ATT_CHUNK"); const int c = e ? atoi(e) : 256; return (c >= 128 && c % 128 == 0) ? c : 256; }();
-    return v;
-}
+static bool att_chunk_from_env() { return att_chunk_env_value() != 0; }
+static int att_chunk_keys() { return att_chunk_from_env() ? att_chunk_env_value() : 256; }
 
 size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
@@ -423,7 +422,8 @@ static int forward_impl(hvx_llm* h, hipStream_t s, int32_t n_seq, int32_t kn, co
             // keys per split: the partial buffers are carved for h->att_chunk (256); a wide grid (>= 32 sequences) takes splits of twice that — with
             // the fragment-order cache two 64-key trips per wave cost less than twice the workgroups (64 sequences: 1.346 -> 1.335 ms per step at
             // context 1536, 1.517 -> 1.473 at 2560, and -2 % beside the acoustic stage); narrow grids lose with it (8 sequences: 0.977 -> 1.009 ms)
-            const int chunk = (n_seq >= 32 && !att_chunk_from_env()) ? 2 * h->att_chunk : h->att_chunk;
+            // bf16 only: the fp32 parity mode keeps ONE summation order (256-key splits) at every grid width, like the heads' down projection below
+            const int chunk = (n_seq >= 32 && dt == DT_BF16 && !att_chunk_from_env()) ? 2 * h->att_chunk : h->att_chunk;
             // ... and eight waves per split there (bf16, one query tile): one 64-key trip per wave, every load of the split in flight at once
             static const int att_waves = [] { const char* e = getenv("HVX_ATT_WAVES"); return e ? atoi(e) : 8; }();
             const int nsub = (n_seq >= 32 && dt == DT_BF16 && G * kn <= 16 && att_waves == 8 && chunk % 256 == 0) ? 8 : 4;
@@ -514,7 +514,7 @@ static int forward_impl(hvx_llm* h, hipStream_t s, int32_t n_seq, int32_t kn, co
         // 39 MB per head (57 us for two heads); 8 slices of ~43 K-tiles: 30 us (decode step 1.314 -> 1.287 ms at 64 sequences; 6 / 12 / 16 slices
         // 1.293 / 1.292 / 1.292).  bf16 only: the fp32 parity mode keeps its summation order.
         static const int force = [] { const char* e = getenv("HVX_HEAD_DOWN_SPLIT"); return e ? atoi(e) : 0; }();
-        int want = force > 0 ? force : ((dt == DT_BF16 && I / 64 / 12 >= 8) ? 8 : 0);
+        int want = dt != DT_BF16 ? 0 : (force > 0 ? force : (I / 64 / 12 >= 8 ? 8 : 0));          // (the lab override too: never in the fp32 mode)
         if (want > MAX_SPLIT) want = MAX_SPLIT;
         if (want > g.split_k && S > 32 && S <= 128) { g.split_k = want; g.part_zs = (long long)g.split_k * S * H; }
     }

@@ -778,3 +778,72 @@ class _DecodeEngine:
                               device_idle_ms_between_blocks=sum(gaps), idle_gaps_over_1ms=[(i, round(g, 1)) for i, g in enumerate(gaps) if g > 1.0][:24], decode_step_us=1e3 * step_ms, decode_steps_timed=n_blk * sync_every,
                               mean_active_sequences=seqs, mean_ctx=ctx_sum / seqs if seqs else 0.0,
                               decode_step_bytes=llm.decode_step_bytes(1, K, ctx_sum), clean=finished_clean)
+
+
+@torch.inference_mode()
+def decision_agreement(teacher, student, requests, max_steps=None, refill_every=32):
+    """Teacher-forced per-DECISION agreement of two LMs over the same weights in different arithmetic (student = the bf16 production forms,
+    teacher = the exact-fp32 forms whose ids are bit-exact against the reference): the requests decode in lock-step on the TEACHER's engine
+    (forward + RAS sampler + advance, hvx_llm_decode_steps); before every step the STUDENT evaluates the same rows (the teacher's token / control
+    arrays, its own KV cache, filled with the teacher's history) and draws from ITS log-probs with the teacher's repetition window and the teacher's
+    noise position.  Sampling is discontinuous in the logits, so a free-running bf16 stream leaves the fp32 one at its first flipped draw; what is
+    well defined — SURVEY.md §7, "reported as match-rate in bf16 mode" — is the fraction of draws that come out equal given the same past.
+    requests: dicts like HvxLLM.generate_stream's (text, seed, min / max ratio).  Returns dict(decisions, equal, steps, steps_all_equal)."""
+    S = len(requests)
+    K = teacher.head_k()
+    if student.head_k() != K or student.cfg.vocab != teacher.cfg.vocab:
+        raise ValueError('decision_agreement: teacher and student must run the same heads over the same vocabulary')
+    reqs = []
+    for d in requests:
+        text = torch.as_tensor(d['text'])
+        n_text = int(text.numel())
+        reqs.append(_Request(teacher._encode_prefix(text, d.get('prompt_text'), d.get('prompt_speech_token')), n_text,
+                             int(n_text * d.get('min_token_text_ratio', 2)), int(n_text * d.get('max_token_text_ratio', 20)), NoiseStream(seed=d.get('seed'))))
+    max_out = max(r.max_len for r in reqs)
+    eng = _DecodeEngine(teacher, n_slots=S, max_out=max_out, max_prefix=max(len(r.prefix) for r in reqs))
+    stream, dev, lib = eng.stream, teacher.device, teacher.lib
+    n_steps = -(-max_out // K)
+    if max_steps is not None:
+        n_steps = min(n_steps, int(max_steps))
+    W = eng.W
+    with torch.cuda.stream(stream):
+        for i, r in enumerate(reqs):
+            eng._join(i, r, 0)
+        eng._publish_limits()
+        student._bind(S, max(max(len(r.prefix) for r in reqs), S * K))
+        for i, r in enumerate(reqs):                               # the student's own KV cache of every prefix (all rows but the last, like a join)
+            n = len(r.prefix) - 1
+            if n > 0:
+                student._forward(1, n, torch.tensor(r.prefix[:n], dtype=torch.int32, device=dev), torch.tensor([i, 0, n, n, n - 1], dtype=torch.int32, device=dev), 0, None)
+        ctl = eng.ctl_dev
+        tok, ctrl = ctl[eng.o_tok:eng.o_tok + S * K], ctl[eng.o_ctrl:eng.o_ctrl + 5 * S]
+        hist, hlen = ctl[eng.o_hist:eng.o_hist + S * W].view(S, W), ctl[eng.o_hlen:eng.o_hlen + S]
+        madj, act = ctl[eng.o_min:eng.o_min + S], ctl[eng.o_act:eng.o_act + S]
+        ids_t = ctl[eng.o_ids:eng.o_ids + S * K].view(S, K)
+        logp_s = torch.empty(S, K, teacher.cfg.vocab, dtype=torch.float32, device=dev)
+        equal = torch.zeros((), dtype=torch.int64, device=dev)
+        total = torch.zeros((), dtype=torch.int64, device=dev)
+        steps_eq = torch.zeros((), dtype=torch.int64, device=dev)
+        steps_n = torch.zeros((), dtype=torch.int64, device=dev)
+        sp = eng.sp
+        for step in range(n_steps):
+            if step and step % refill_every == 0:                   # top the noise rings up behind the device cursors
+                cur = eng.cur_dev.cpu().tolist()
+                for i in range(S):
+                    eng._fill_ring(i, int(cur[i]) + eng.ncap)
+                eng._publish_limits()
+            cur0 = eng.cur_dev.clone()
+            live = act.clone()
+            student._forward(S, K, tok, ctrl, K, logp_s)
+            ids_s = ops.ras_sample(logp_s, hist, hlen, madj, eng.noise_dev, cur0, speech_tokens=teacher.cfg.speech_tokens, top_k=sp['top_k'], top_p=sp['top_p'],
+                                   win_size=sp['win_size'], rep_thresh=eng.thr, active=act, max_trials=eng.max_trials)
+            check(lib.hvx_llm_decode_steps(teacher._h, C.c_void_p(stream.cuda_stream), C.byref(eng.args), 1), 'hvx_llm_decode_steps')
+            on = (live != 0)[:, None]
+            same = (ids_s == ids_t) & on
+            equal += same.sum()
+            total += on.sum() * K
+            steps_eq += (same.all(dim=1) & on[:, 0]).sum()
+            steps_n += on.sum()
+        stream.synchronize()
+    return dict(decisions=int(total), equal=int(equal), steps=int(steps_n), steps_all_equal=int(steps_eq), sequences=S, head_k=K,
+                agreement=(float(equal) / float(total)) if int(total) else None)

@@ -313,6 +313,28 @@ def _slice_args(node, vals, rank):
     return [int(s) for s in starts], [int(e) for e in ends], [int(a) % rank for a in axes], [int(s) for s in steps]
 
 
+def _resolve_pads(at, sizes, kernel, strides, dilations):
+    """ONNX `pads` ([begin..., end...]) of a Conv / pooling node after `auto_pad` (NOTSET: the attribute; VALID: none; SAME_UPPER / SAME_LOWER: output
+    = ceil(input / stride), the odd element at the end / at the beginning)"""
+    n = len(kernel)
+    mode = at.get('auto_pad', 'NOTSET')
+    mode = mode.decode() if isinstance(mode, (bytes, bytearray)) else str(mode)
+    if mode in ('', 'NOTSET'):
+        return [int(p) for p in at.get('pads', [0] * (2 * n))]
+    if mode == 'VALID':
+        return [0] * (2 * n)
+    if mode not in ('SAME_UPPER', 'SAME_LOWER'):
+        raise NotImplementedError('auto_pad=%s' % mode)
+    begin, end = [], []
+    for size, k, st, d in zip(sizes, kernel, strides, dilations):
+        out = -(-int(size) // int(st))
+        total = max((out - 1) * int(st) + (int(k) - 1) * int(d) + 1 - int(size), 0)
+        small, big = total // 2, total - total // 2
+        begin.append(small if mode == 'SAME_UPPER' else big)
+        end.append(big if mode == 'SAME_UPPER' else small)
+    return begin + end
+
+
 def _host_eval(node, v):
     """numpy evaluation of a node whose inputs are all host arrays (shape arithmetic and constants)"""
     op, at = node.op, node.attrs
@@ -540,7 +562,8 @@ class OnnxRunner:
         x = self._dev(x)
         group = int(at.get('group', 1))
         if x.dim() == 4:
-            dil, strides, pads = at.get('dilations', [1, 1]), at.get('strides', [1, 1]), at.get('pads', [0, 0, 0, 0])
+            dil, strides = at.get('dilations', [1, 1]), at.get('strides', [1, 1])
+            pads = _resolve_pads(at, x.shape[2:], w.shape[2:], strides, dil)
             if group != 1 or list(dil) != [1, 1] or pads[0] != pads[2] or pads[1] != pads[3]:
                 raise NotImplementedError('2-D Conv with groups / dilation / asymmetric padding')
             B, Cin, H, W = x.shape
@@ -556,7 +579,8 @@ class OnnxRunner:
         torch = self.torch
         B, Cin, T = x.shape
         Cout, cg, k = w.shape
-        dil, stride, pads = int(at.get('dilations', [1])[0]), int(at.get('strides', [1])[0]), at.get('pads', [0, 0])
+        dil, stride = int(at.get('dilations', [1])[0]), int(at.get('strides', [1])[0])
+        pads = _resolve_pads(at, [T], [k], [stride], [dil])
         T_out = (T + pads[0] + pads[1] - dil * (k - 1) - 1) // stride + 1
         key = ('conv', w_name)
         packed = self._wcache.get(key) if w_name in self.consts else None
@@ -635,6 +659,8 @@ class OnnxRunner:
             return x
         if op == 'Cast':
             to = _DTYPES[int(at['to'])]
+            if to == np.float16:                                 # device values stay fp32 STORAGE, but a Cast to fp16 rounds (and saturates to inf) like the graph says
+                return x.to(self.torch.float16).to(self.torch.float32)
             return x if np.issubdtype(to, np.floating) else x.detach().cpu().numpy().astype(to)   # (an integer result is a host value from here on)
         # ---- data movement ----------------------------------------------------------------------------------------------------------------
         if op == 'Transpose':
@@ -728,7 +754,7 @@ class OnnxRunner:
         if op == 'Sign':
             return self._binary('SUB', self._binary('GREATER', x, zero), self._binary('LESS', x, zero))
         if op == 'LogSoftmax':
-            sm = self._node(Node('Softmax', node.inputs, node.outputs, {'axis': at.get('axis', -1)}), v)
+            sm = self._node(Node('Softmax', node.inputs, node.outputs, {'axis': at.get('axis', 1 if self.g.opset < 13 else -1)}), v)
             return self._unary('LOG', sm)
         if op in ('ArgMax', 'ArgMin'):
             # first index of the extremum: min over where(x == extremum, index, n) — three elementwise passes and two reductions, no dedicated kernel
@@ -773,7 +799,7 @@ class OnnxRunner:
         if op == 'GlobalAveragePool':
             return self._reduce('MEAN', x, list(range(2, x.dim())), True)
         if op == 'Softmax':
-            ax = int(at.get('axis', -1)) % x.dim()
+            ax = int(at.get('axis', 1 if self.g.opset < 13 else -1)) % x.dim()      # (the default axis is 1 before opset 13, the last one from 13 on)
             if self.g.opset < 13 and ax != x.dim() - 1:            # (older opsets flatten from `axis`)
                 rows, cols = int(np.prod(x.shape[:ax])), int(np.prod(x.shape[ax:]))
                 xp, back = x, None
@@ -801,7 +827,7 @@ class OnnxRunner:
             return self._binary('ADD', self._binary('MUL', x, a.astype(np.float32).reshape(shp)), (bi - mu * a).astype(np.float32).reshape(shp))
         if op == 'AveragePool':
             k, st = at['kernel_shape'], at.get('strides', [1] * len(at['kernel_shape']))
-            pads = at.get('pads', [0] * (2 * len(k)))
+            pads = _resolve_pads(at, x.shape[2:], k, st, [1] * len(k))
             if len(k) != 1 or pads[0] != pads[1]:
                 raise NotImplementedError('AveragePool beyond 1-D with symmetric padding')
             T = x.shape[-1]

@@ -295,7 +295,10 @@ class HvxPipeline:
         utterances still in flight, in padded solves of up to `acoustic_batch` utterances of similar length.  `acoustic_min_batch` > 1 trades
         latency for throughput: the acoustic stage then waits until that many finished utterances are queued (or the LM is idle / done).
         A request that cannot run (context budget) comes back as (utterance, exception, []) without disturbing the others.  If the consumer
-        stops iterating, the LM thread is cancelled: it stops taking requests and abandons the decode of those in flight.
+        stops iterating, the LM thread is cancelled: it stops taking requests and abandons the decode of those in flight; every utterance that was
+        fetched from the source and got no result is listed in `self.last_continuous['abandoned']`.  Source protocol: `poll(block)` as above and,
+        optionally, `unpoll(utterance)` — an utterance fetched in the instant of a cancellation is handed back through it (the queue worker's
+        sources implement it and re-serve the request); without `unpoll` it joins the abandoned list.
         `pace` = (first, every_steps, more): admission pacing of the decode grid (see _DecodeEngine.run)."""
         acoustic_batch = acoustic_batch or self.acoustic_batch
         acoustic_min_batch = max(1, min(int(acoustic_min_batch), acoustic_batch))
@@ -332,6 +335,7 @@ class HvxPipeline:
         lm_info = {}
         seen = {}                                          # running id -> utterance in flight; an entry goes when its result is handed out
         n_seen = [0]
+        abandoned = []                                     # fetched from a source without `unpoll` while the engine was being cancelled
 
         class _Requests:
             @staticmethod
@@ -347,6 +351,8 @@ class HvxPipeline:
                 if cancel.is_set():                        # fetched while the engine was being cancelled: hand it back rather than fail it
                     if hasattr(source, 'unpoll'):
                         source.unpoll(u)
+                    else:                                  # (a source without `unpoll`: it is reported with the abandoned ones, never silently lost)
+                        abandoned.append(u)
                     raise StopIteration
                 tag = n_seen[0]
                 n_seen[0] += 1
@@ -432,7 +438,8 @@ class HvxPipeline:
                     pass
                 th.join(timeout=0.05)
             self.last_continuous = dict(tokens=tokens, audio_seconds=audio, acoustic_seconds=acoustic, total_seconds=time.time() - t_begin,
-                                        llm_seconds=lm_info.get('seconds', 0.0), llm=lm_info.get('stats', {}), lm_slots=lm_slots)
+                                        llm_seconds=lm_info.get('seconds', 0.0), llm=lm_info.get('stats', {}), lm_slots=lm_slots,
+                                        abandoned=abandoned + list(seen.values()))
 
     @torch.inference_mode()
     def synthesize_pipelined(self, batches, max_token_text_ratio=20, min_token_text_ratio=2, lm_chains=3, acoustic_chains=1):

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define HVX_ABI_VERSION 1
+#define HVX_ABI_VERSION 3
 #define HVX_F32 0
 #define HVX_BF16 1
 

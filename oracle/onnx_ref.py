@@ -204,7 +204,7 @@ def _node(node, v, opset):
         return v[0].mean(axis=tuple(range(2, v[0].ndim)), keepdims=True, dtype=np.float64).astype(np.float32)
     if op == 'Softmax':
         x = v[0].astype(np.float64)
-        ax = int(at.get('axis', -1)) % x.ndim
+        ax = int(at.get('axis', 1 if opset < 13 else -1)) % x.ndim          # (ONNX: the default axis is 1 before opset 13)
         if opset < 13 and ax != x.ndim - 1:
             shp = x.shape
             x2 = x.reshape(int(np.prod(shp[:ax])), -1)
@@ -226,7 +226,7 @@ def _node(node, v, opset):
         return ((x - mu) / np.sqrt(var + float(at.get('epsilon', 1e-5))) * sc + bi).astype(np.float32)
     if op == 'AveragePool':
         k, st = at['kernel_shape'], at.get('strides', [1])
-        pads = at.get('pads', [0, 0])
+        pads = _pads(at, v[0].shape[2:], k, st, [1])
         return _avgpool1d(v[0], int(k[0]), int(st[0]), int(pads[0]), int(at.get('ceil_mode', 0)), int(at.get('count_include_pad', 0)))
     if op == 'MatMul':
         return np.matmul(v[0].astype(np.float64), v[1].astype(np.float64)).astype(np.float32)
@@ -239,9 +239,27 @@ def _node(node, v, opset):
         return y.astype(np.float32)
     if op == 'Conv':
         nd = v[0].ndim - 2
-        return _conv(v[0], v[1], v[2] if len(v) > 2 else None, at.get('strides', [1] * nd), at.get('pads', [0] * (2 * nd)), at.get('dilations', [1] * nd),
-                     int(at.get('group', 1)))
+        st, dil = at.get('strides', [1] * nd), at.get('dilations', [1] * nd)
+        return _conv(v[0], v[1], v[2] if len(v) > 2 else None, st, _pads(at, v[0].shape[2:], v[1].shape[2:], st, dil), dil, int(at.get('group', 1)))
     raise NotImplementedError('oracle: ONNX operator %s' % op)
+
+
+def _pads(at, sizes, kernel, strides, dilations):
+    """ONNX auto_pad (operator spec: Conv / AveragePool): NOTSET -> `pads`; VALID -> 0; SAME_*: out = ceil(in / stride), odd element at the end (UPPER) / start (LOWER)"""
+    mode = at.get('auto_pad', b'NOTSET')
+    mode = mode.decode() if isinstance(mode, (bytes, bytearray)) else str(mode)
+    n = len(kernel)
+    if mode in ('', 'NOTSET'):
+        return list(at.get('pads', [0] * (2 * n)))
+    if mode == 'VALID':
+        return [0] * (2 * n)
+    lo, hi = [], []
+    for size, k, st, d in zip(sizes, kernel, strides, dilations):
+        total = max((-(-size // st) - 1) * st + (k - 1) * d + 1 - size, 0)
+        a, b = total // 2, total - total // 2
+        lo.append(a if mode == 'SAME_UPPER' else b)
+        hi.append(b if mode == 'SAME_UPPER' else a)
+    return lo + hi
 
 
 def run(graph, feeds):

@@ -548,6 +548,29 @@ def test_nd_elementwise_broadcast_strided_and_reductions():
         got = got.cpu().numpy() if torch.is_tensor(got) else got
         want = onnx_ref._node(nd, ins, 17)
         np.testing.assert_allclose(got.astype(np.float64), np.asarray(want).astype(np.float64), rtol=1e-5, atol=2e-6, err_msg=opn)
+    # attributes the real exports use: auto_pad on Conv / AveragePool, the opset < 13 default Softmax axis, Cast to fp16
+    xa1, wa1 = rng.standard_normal((2, 4, 23)).astype(np.float32), rng.standard_normal((6, 4, 4)).astype(np.float32)
+    for mode, (lo, hi) in ((b'SAME_UPPER', (1, 2)), (b'SAME_LOWER', (2, 1)), (b'VALID', (0, 0))):          # T = 23, k = 4, stride 2 -> out 12: total pad 3
+        nd = og.Node('Conv', ['x', 'w'], ['y'], dict(kernel_shape=[4], strides=[2], auto_pad=mode))
+        want = F.conv1d(F.pad(torch.from_numpy(xa1), (lo, hi)), torch.from_numpy(wa1), stride=2).numpy()
+        np.testing.assert_allclose(r._node(nd, [r._up(xa1), wa1, None]).cpu().numpy(), want, rtol=1e-4, atol=1e-4, err_msg=str(mode))
+        np.testing.assert_allclose(onnx_ref._node(nd, [xa1, wa1], 17), want, rtol=1e-4, atol=1e-4, err_msg=str(mode))
+    nd = og.Node('Conv', ['x', 'w', 'b'], ['y'], dict(kernel_shape=[3, 3], strides=[1, 1], auto_pad=b'SAME_UPPER'))
+    want = F.conv2d(torch.from_numpy(x4), torch.from_numpy(w4), torch.from_numpy(b4), padding=1).numpy()
+    np.testing.assert_allclose(r._node(nd, [r._up(x4), w4, b4]).cpu().numpy(), want, rtol=1e-5, atol=1e-5)
+    nd = og.Node('AveragePool', ['x'], ['y'], dict(kernel_shape=[3], strides=[1], auto_pad=b'SAME_UPPER', count_include_pad=0))
+    want = F.avg_pool1d(torch.from_numpy(xa1), 3, 1, 1, count_include_pad=False).numpy()
+    np.testing.assert_allclose(r._node(nd, [r._up(xa1)]).cpu().numpy(), want, rtol=1e-5, atol=1e-6)
+    with pytest.raises(NotImplementedError):
+        r._node(og.Node('Conv', ['x', 'w'], ['y'], dict(kernel_shape=[4], auto_pad=b'SAME_SOMETHING')), [r._up(xa1), wa1, None])
+    r11 = og.OnnxRunner(og.Graph([], {}, [], [], opset=11))
+    sm11 = r11._node(og.Node('Softmax', ['x'], ['y'], {}), [r11._up(xs)])                   # opset 11, no axis: axis 1, flattened [3][5 * 17]
+    want = torch.softmax(torch.from_numpy(xs).reshape(3, -1), 1).reshape(xs.shape).numpy()
+    np.testing.assert_allclose(sm11.cpu().numpy(), want, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(onnx_ref._node(og.Node('Softmax', ['x'], ['y'], {}), [xs], 11), want, rtol=1e-5, atol=1e-7)
+    big = (xs * 3000.0).astype(np.float32)
+    c16 = r._node(og.Node('Cast', ['x'], ['y'], {'to': 10}), [r._up(big)]).cpu().numpy()
+    np.testing.assert_array_equal(c16, big.astype(np.float16).astype(np.float32))
     nd = og.Node('Split', ['x', 's'], ['a', 'b', 'c'], {'axis': 2})
     got = r._node(nd, [r._up(xs), np.asarray([4, 6, 7])])
     for gpart, wpart in zip(got, np.split(xs, [4, 10], axis=2)):

@@ -32,7 +32,7 @@ def test_library_builds_and_exports_every_declared_symbol():
         assert hasattr(lib, name), 'libhvx.so does not export %s' % name
     # the ctypes binding covers exactly the header
     assert sorted(_lib.SYMBOLS.keys()) == declared
-    assert _lib.load().hvx_abi_version() == 1
+    assert _lib.load().hvx_abi_version() == _lib.HVX_ABI_VERSION == 3
 
 
 def test_libhvx_holds_no_packed_fp32_instruction(tmp_path):
@@ -805,3 +805,77 @@ def test_e4m3_power_of_two_quantiser_and_fragment_orders():
     for half in range(2):
         assert torch.equal(v8[..., half, :], pf[:, half::2])
     assert torch.equal(frag_fp8_to_frag(p8, scale, torch.bfloat16), pack_frag(deq).to(torch.bfloat16))
+
+
+def test_onnx_auto_pad_and_opset_defaults_are_honoured_not_ignored():
+    """a Conv / AveragePool exported with auto_pad = SAME_UPPER / SAME_LOWER / VALID must get those pads (host logic of the executor and of
+    the oracle, against torch), an unknown mode is refused, and Softmax without an axis means axis 1 before opset 13."""
+    import numpy as np
+    import torch
+    import torch.nn.functional as F
+    from flowmirror_hydravox_amd import onnx_graph as og
+    from oracle import onnx_ref
+    assert og._resolve_pads({'auto_pad': b'SAME_UPPER'}, [23], [4], [2], [1]) == [1, 2]
+    assert og._resolve_pads({'auto_pad': b'SAME_LOWER'}, [23], [4], [2], [1]) == [2, 1]
+    assert og._resolve_pads({'auto_pad': 'VALID', 'pads': [3, 3]}, [23], [4], [2], [1]) == [0, 0]
+    assert og._resolve_pads({'auto_pad': b'NOTSET', 'pads': [3, 5]}, [23], [4], [2], [1]) == [3, 5]
+    assert og._resolve_pads({}, [11, 9], [3, 3], [1, 1], [1, 1]) == [0, 0, 0, 0]
+    assert og._resolve_pads({'auto_pad': b'SAME_UPPER'}, [11, 9], [3, 5], [2, 1], [1, 2]) == [1, 4, 1, 4]
+    with pytest.raises(NotImplementedError):
+        og._resolve_pads({'auto_pad': b'SAME'}, [23], [4], [2], [1])
+    rng = np.random.default_rng(2)
+    x, w = rng.standard_normal((2, 4, 23)).astype(np.float32), rng.standard_normal((6, 4, 4)).astype(np.float32)
+    for mode, pad in ((b'SAME_UPPER', (1, 2)), (b'SAME_LOWER', (2, 1)), (b'VALID', (0, 0))):
+        nd = og.Node('Conv', ['x', 'w'], ['y'], dict(kernel_shape=[4], strides=[2], auto_pad=mode))
+        want = F.conv1d(F.pad(torch.from_numpy(x), pad), torch.from_numpy(w), stride=2).numpy()
+        np.testing.assert_allclose(onnx_ref._node(nd, [x, w], 17), want, rtol=1e-4, atol=1e-4)
+    xs = rng.standard_normal((3, 5, 7)).astype(np.float32)
+    want = torch.softmax(torch.from_numpy(xs).reshape(3, -1), 1).reshape(xs.shape).numpy()
+    np.testing.assert_allclose(onnx_ref._node(og.Node('Softmax', ['x'], ['y'], {}), [xs], 11), want, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(onnx_ref._node(og.Node('Softmax', ['x'], ['y'], {}), [xs], 13), torch.softmax(torch.from_numpy(xs), -1).numpy(), rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize('config', ['tts', 'zero_shot'])
+def test_bench_rank_logic_world_size_2_gloo_with_a_stub_pipeline(config):
+    """everything `bench.py --gpus 2` does AROUND the pipeline — WORLD_SIZE / RANK from the environment, the longest-first deal of the
+    global utterance list (uneven with mixed lengths), one continuous job per rank, Handoff rounds of one step's worth of waveforms to rank 0 inside the
+    timed region, barrier + max-over-ranks of the wall time, sum of the token counts, ONE JSON line from rank 0 — at world size 2 on gloo, with
+    tools/bench_stub.py standing in for the GPU pipeline.  Rank 0 must have received every global utterance, bit-equal to what one rank alone makes."""
+    import json
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    from bench_stub import stub_wave
+    steps, B, world = 3, 4, 2
+    port = {'tts': '29641', 'zero_shot': '29643'}[config]
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=port, WORLD_SIZE=str(world), HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='')
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(world), '--steps', str(steps), '--warmup', '1', '--batch', str(B), '--tiny', '--stub-pipeline', '--config', config]
+    procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-2000:] for o in outs]
+    assert not [ln for ln in outs[1][0].splitlines() if ln.startswith('{')]          # only rank 0 prints a line
+    lines = [ln for ln in outs[0][0].splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    n_global = steps * B * world
+    assert d['n_gpus'] == world and d['steps'] == steps and d['scaling'] == 'weak' and d['config']['parallelism'] == 'utterance-dp2' and d['config']['global_batch'] == B * world
+    assert 'STUB' in d['config']['workload'] and d['value'] > 0 and d['ms_per_step'] > 0
+    st = d['stub']
+    assert st['received_on_rank0'] == n_global and sum(st['shard_sizes']) == n_global
+    assert st['handoff_rounds'] == -(-max(st['shard_sizes']) // B)
+    if config == 'zero_shot':
+        assert st['shard_sizes'][0] != st['shard_sizes'][1] or True             # (mixed lengths: the deal balances text length, not counts)
+    # the checksum of everything rank 0 holds == what a single rank produces for those global ids (seed = global index)
+    import torch
+    from flowmirror_hydravox_amd.config import tiny_config
+    from flowmirror_hydravox_amd.pipeline import synthetic_utterance
+
+    def n_text_of(g):
+        return 512 if config == 'tts' else int(torch.randint(64, 513, (1,), generator=torch.Generator().manual_seed(7_000_003 + g)))
+    want = 0.0
+    tokens = 0
+    for gidx in range(n_global):
+        u = synthetic_utterance(tiny_config(), gidx, n_text_of(gidx)) if config == 'tts' else synthetic_utterance(tiny_config(), gidx, n_text_of(gidx), n_prompt_speech=75, n_prompt_text=20)
+        n = int(int(u.text.numel()) * 5.5) // 16
+        tokens += n
+        want += float(stub_wave(u.seed, n).double().sum())
+    assert abs(st['checksum'] - want) < 1e-6 * max(1.0, abs(want)), (st['checksum'], want)
+    assert abs(d['value'] * d['ms_per_step'] * steps / 1e3 - tokens) < 0.01 * tokens      # value = ALL ranks' tokens / max-over-ranks wall time

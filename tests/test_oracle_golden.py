@@ -570,3 +570,46 @@ def test_onnx_container_round_trip_and_oracle_operators_vs_torch():
                                0.5 * xs[0] @ g_.reshape(1, 16).repeat(3, 0).T + 2.0 * b_[:3], rtol=1e-5, atol=1e-5)
     assert np.array_equal(one('Round', [np.asarray([0.5, 1.5, 2.5, -0.5, -1.5], np.float32)]), np.asarray([0, 2, 2, -0, -2], np.float32))
     assert np.array_equal(one('Slice', [np.arange(10), np.asarray([8]), np.asarray([-11]), np.asarray([0]), np.asarray([-3])]), np.asarray([8, 5, 2]))
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[0] and the benchmarked shapes (tests/golden/make_golden_fullsize.py)
+# ------------------------------------------------------------------------------------------------------------------------------
+def test_configs0_single_utterance_oracle_vs_reference_end_to_end():
+    """BASELINE configs[0] on the CPU: head_num 1, ONE 64-char utterance at full CV3 depth — the oracle's three stages back to back (KV-cached LM:
+    the reference's own uncached loop took minutes when the fixture was minted and was asserted equal there) against the reference's ids, mel, f0,
+    source and waveform.  This is the configuration whose "CPU path" the north star names as the parity target."""
+    import torch.nn.functional as F
+    from flowmirror_hydravox_amd.config import cv3_config
+    g = load_golden('single_cv3.npz')
+    cfg = cv3_config()
+    top_p, top_k, win, tau = g['sampling']
+    sampling = dict(top_p=float(top_p), top_k=int(top_k), win_size=int(win), tau_r=float(tau))
+    sd = W.make_llm_state(cfg.llm, seed=1986, init='fan_in', with_lm_head=True)
+    assert state_checksum(sd) == str(g['llm_sha'])
+    text = torch.from_numpy(g['text'])
+    toks = list(llm_ref.llm_inference(sd, cfg.llm, text, sampler_ref.NoiseStream(seed=int(g['seed'])), inference_head_num=1, sampling=sampling,
+                                      max_token_text_ratio=5.5, min_token_text_ratio=5.5, use_kv_cache=True))
+    assert toks == g['tokens'].tolist() and len(toks) == 352
+    del sd
+    fsd = W.make_flow_state(cfg.flow, seed=1987, init='fan_in')
+    assert state_checksum(fsd) == str(g['flow_sha'])
+    mel = flow_ref.flow_inference(torch.tensor(toks)[None], torch.from_numpy(g['emb']), fsd, cfg.flow)
+    d_mel = (mel - torch.from_numpy(g['mel'])).abs().max().item() / float(np.abs(g['mel']).max())
+    assert tuple(mel.shape) == (1, 80, 704) and d_mel < 1e-4, d_mel
+    del fsd
+    hsd = W.make_hift_state(cfg.hift, seed=1988, init='fan_in')
+    assert state_checksum(hsd) == str(g['hift_sha'])
+    tables = hift_ref.make_tables(cfg.hift, seed=9, n_samples=704 * cfg.hift.upsample_total + 480)
+    mel_ref = torch.from_numpy(g['mel'])
+    f0 = hift_ref.f0_predictor(mel_ref, hsd)
+    assert (f0 - torch.from_numpy(g['f0'])).abs().max().item() < 2e-3
+    # source from the REFERENCE's f0 (an f0 difference of 1e-5 Hz is a phase difference after 14 s: the stages are held one at a time), decode with it
+    s = hift_ref.source_module(F.interpolate(torch.from_numpy(g['f0'])[:, None], scale_factor=float(cfg.hift.upsample_total), mode='nearest').transpose(1, 2),
+                               hsd, cfg.hift, tables).transpose(1, 2)
+    wav = hift_ref.decode(mel_ref, s, hsd, cfg.hift)
+    w, s = wav.reshape(-1).numpy(), s.reshape(-1).numpy()
+    assert np.abs(s[::16] - g['src_s16']).max() < 1e-5 and np.abs(s[:32768] - g['src_head']).max() < 1e-5
+    d_w = max(np.abs(w[::16] - g['wav_s16']).max(), np.abs(w[:32768] - g['wav_head']).max(), np.abs(w[-32768:] - g['wav_tail']).max())
+    print('configs[0], oracle vs the reference: ids equal, mel %.1e of its scale, waveform max |d| %.1e' % (d_mel, d_w))
+    assert d_w < 5e-4 and np.abs(w - g['wav_f16'].astype(np.float32)).max() < 1.5e-3, d_w
