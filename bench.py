@@ -457,6 +457,10 @@ def main():
         lib = _lib.load()
 
     cfg = tiny_config() if args.tiny else cv3_config()
+    if args.tiny:
+        # tiny_config's speech vocabulary (96 codes + 200 stop ids) makes an all-EOS nucleus a 2 % event per draw; with the generation length pinned
+        # (EOS refused 100 times = error, llm_multi_head_v3.py:158-166) a toy job dies on it.  Same toy widths, a CV3-like share of stop ids:
+        cfg.llm.speech_tokens = cfg.flow.vocab = 4096
     if args.config == 'acoustic':
         return run_acoustic(args, cfg, world, rank, lib)
     if args.config == 'stress' and '--heads' not in sys.argv and '--batch' not in sys.argv:

@@ -37,8 +37,9 @@ def test_dit_estimator_at_the_bench_shape_bf16_forms_vs_fp32_forms():
     assert torch.isfinite(outs[torch.float32]).all() and torch.isfinite(outs[torch.bfloat16]).all()
     rels = [_rel(outs[torch.bfloat16][i, :, :n], outs[torch.float32][i, :, :n]) for i, n in enumerate(lens)]
     print('bf16 vs fp32 forms, 22 blocks, T = %d: relative error per batch entry %s' % (T, ['%.2e' % r for r in rels]))
-    # measured 4.8e-3..5.6e-3 per entry (operands rounded to bf16 in 22 blocks x 4 Linears + attention); a wrong tile, lane map or mask shows as O(1)
-    assert max(rels) < 2e-2, rels
+    # measured 1.7e-3 per entry in the default (reference-precision) bf16 mode — 4.8e-3..5.6e-3 with plain bf16 operands everywhere; bound = 2x measured.
+    # (The same shape against the REFERENCE itself: tests/test_gpu_refpin.py.)
+    assert max(rels) < 4e-3, rels
     # rows of the full-length entries do not depend on their neighbours in the batch: entry 0 alone (704 GEMM tiles -> 176, attention grid / 4)
     flow = HvxFlow(cfg, sd, dtype=torch.bfloat16, max_t=T + 64)
     alone = flow.estimator(x[:2], mask[:2], mu[:2], t[:2], spk[:2], cond[:2]).cpu()
@@ -70,8 +71,8 @@ def test_cfm_solve_of_four_512_char_utterances_bf16_vs_fp32_forms():
         assert tuple(a.shape) == (1, cfg.mel, 2 * n) == tuple(b.shape) and torch.isfinite(a).all() and torch.isfinite(b).all()
         rels.append(_rel(a, b))
     print('10-step CFG solve, bf16 vs fp32 forms: relative mel error per utterance %s' % ['%.2e' % r for r in rels])
-    # measured 3.2e-3 per utterance
-    assert max(rels) < 1e-2, rels
+    # measured 1.4e-3 per utterance in the default mode (3.2e-3 with plain bf16 operands); bound = 2x measured.  Against the REFERENCE: tests/test_gpu_refpin.py.
+    assert max(rels) < 3e-3, rels
 
 
 _HIFT_SNIPPET = r"""
