@@ -203,7 +203,7 @@ def test_hift_5632_frames_vs_reference(tmp_path):
 
 # measured on MI355X (round 5), bounds <= 2x: see DESIGN.md §3
 #   f0 5.3e-4 Hz; source (reference f0) 3.0e-8; decode(reference source): split-bf16 2.1e-4 max / 1.5e-4 L2 (fp16 copy 3.9e-4), exact fp32 4.6e-5 / 2.8e-5 (2.7e-4)
-_HIFT_BOUNDS = {'source': 1e-6, 'x3': (4.5e-4, 8e-4), 'x3_l2': 3e-4, 'exact': (1e-4, 6e-4), 'exact_l2': 6e-5, 'e2e_first_second': 5e-3}
+_HIFT_BOUNDS = {'source': 1e-6, 'x3': (4.5e-4, 8e-4), 'x3_l2': 3e-4, 'exact': (1e-4, 6e-4), 'exact_l2': 6e-5, 'e2e_first_second': 5.5e-3}       # (first second, own f0: measured 2.7e-3)
 
 
 # ---- LM on a 3300-row prefix -------------------------------------------------------------------------------------------------------------------
