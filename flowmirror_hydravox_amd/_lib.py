@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libhvx.so')
+# (HVX_LIB_PATH: lab builds only — A / B of compiler flags on the same box; the product always loads the in-tree libhvx.so)
+LIB_PATH = os.environ.get('HVX_LIB_PATH') or os.path.join(HERE, 'libhvx.so')
 
 F32, BF16 = 0, 1
 

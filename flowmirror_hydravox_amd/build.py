@@ -16,7 +16,7 @@ INCLUDE = os.path.join(os.path.dirname(HERE), 'include')
 OUT = os.path.join(HERE, 'libhvx.so')
 ARCH = 'gfx950'
 # No packed fp32 VALU instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) anywhere in libhvx.  Measured on MI355X (tools/mfma_interference.py,
-# DESIGN.md §8): a wave executing v_pk_*_f32 returns wrong low halves in lanes 48-63 now and then while ANOTHER wave on its SIMD streams bf16
+# docs/history/DESIGN_rounds1-4.md §8): a wave executing v_pk_*_f32 returns wrong low halves in lanes 48-63 now and then while ANOTHER wave on its SIMD streams bf16
 # MFMAs — e.g. hift_stft_kernel beside the split-bf16 vocoder convolutions of a second stream: 1941 of 3000 launches differ with the packed
 # forms, 0 of 3000 without.  hipcc's SLP vectoriser forms them from any two adjacent fp32 operations, so the feature is switched off for the
 # device pass (the host pass does not know the feature and says so; harmless).  Beside MFMAs the packed forms are slower than two scalar ops
@@ -51,7 +51,8 @@ def _headers_mtime():
 
 
 def _compile(src, obj, verbose):
-    cmd = [_hipcc()] + FLAGS + FILE_FLAGS.get(os.path.basename(src), []) + ['-c', src, '-o', obj]
+    # HVX_EXTRA_FLAGS: lab builds only (e.g. -DHVX_ATTN_LAB adds timing-only variants of the DiT attention loop); never set for the shipped library
+    cmd = [_hipcc()] + FLAGS + FILE_FLAGS.get(os.path.basename(src), []) + os.environ.get('HVX_EXTRA_FLAGS', '').split() + ['-c', src, '-o', obj]
     t0 = time.time()
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if verbose or r.returncode != 0:

@@ -384,8 +384,13 @@ __global__ void attn_combine_kernel(AttnArgs a) {
 // online-softmax loop below (FAST = false path; exercised by tests/test_gpu_ops.py::test_attention_dit_fallback_on_score_spike).
 // PRE: the query operand already carries scale * log2(e) (a.q_log2: written that way by the fused QKV epilogue, one rounding) — the MFMA
 // accumulator then starts at -m_ref and exp2 is the only arithmetic left per score.  Otherwise the scale is applied to the fp32 score.
-template <int QR, bool FAST, bool PRE>   // 16-row query tiles per wave: every K / V^T fragment read from LDS feeds QR MFMAs
-__global__ __launch_bounds__(256, 2) void attn_dit_kernel(AttnArgs a) {
+// LAB (tools/attn_probe.py with HVX_ATTN_LAB=n, library built with -DHVX_ATTN_LAB): timing-only variants that REMOVE one ingredient of the fast loop
+// each (results are garbage): 1 no global loads / LDS stash of the next tile, 2 no barrier, 4 K / V^T fragments from registers instead of LDS,
+// 8 no exp2 / bf16 conversion, 16 no MFMA.  0 = the product.
+// NW: waves per workgroup.  4: 64 QR rows per workgroup, two workgroups per CU.  8: 128 QR rows per workgroup, ONE per CU — the same two waves per SIMD,
+// but a K / V^T tile is staged once for twice the rows, so every thread moves half the bytes per tile (one 16-byte piece of K and one of V^T).
+template <int QR, bool FAST, bool PRE, int LAB = 0, int NW = 4>   // 16-row query tiles per wave: every K / V^T fragment read from LDS feeds QR MFMAs
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_dit_kernel(AttnArgs a) {
     typedef bf16_t T;
     constexpr int KT = 64;                 // keys per tile
     constexpr int LD = 72;                 // LDS row stride (elements): 144 B keeps the 16 rows of a lane group on distinct 16-B slots
@@ -410,13 +415,15 @@ __global__ __launch_bounds__(256, 2) void attn_dit_kernel(AttnArgs a) {
     }
     // with a chunk mask the work per workgroup grows with its row index: dispatch the long ones first
     const int bx = a.chunk > 0 ? gridDim.x - 1 - bx0 : bx0;
-    const int row0 = bx * (64 * QR) + wave * (16 * QR);
+    constexpr int WG_ROWS = 16 * QR * NW;
+    constexpr int NLD = 8 / NW;            // 16-byte pieces of K (and of V^T) a thread moves per tile
+    const int row0 = bx * WG_ROWS + wave * (16 * QR);
     const int kv_len = a.kv_len ? a.kv_len[b] : a.kv_len_const;
     const T* __restrict__ kb = reinterpret_cast<const T*>(a.k) + (long long)b * a.k_bs + (long long)h * a.k_hs;
     const T* __restrict__ vb = reinterpret_cast<const T*>(a.vT) + (long long)b * a.v_bs + (long long)h * a.v_hs;
     // Static chunk mask (streaming synthesis): row r sees the keys below the end of its chunk.  The workgroup walks the keys that
     // its last row sees; tiles below the limit of its first row need no mask, the rest take the masked form with per-row limits.
-    const int wg_row0 = bx * (64 * QR), wg_row1 = min(wg_row0 + 64 * QR, a.n_rows) - 1;
+    const int wg_row0 = bx * WG_ROWS, wg_row1 = min(wg_row0 + WG_ROWS, a.n_rows) - 1;
     const int lim_hi = a.chunk > 0 ? min(kv_len, (wg_row1 / a.chunk + 1) * a.chunk) : kv_len;
     const int lim_lo = a.chunk > 0 ? min(kv_len, (wg_row0 / a.chunk + 1) * a.chunk) : kv_len;
     int lim[QR];
@@ -436,12 +443,12 @@ __global__ __launch_bounds__(256, 2) void attn_dit_kernel(AttnArgs a) {
             qf[i][1] = zero8<T>();
         }
     }
-    // tile loader: thread t moves 2 x 16 B of K (rows t/8 and t/8+32, chunk t%8) and 2 x 16 B of V^T
+    // tile loader: thread t moves NLD x 16 B of K (rows t/8 [and t/8+32], chunk t%8) and NLD x 16 B of V^T
     const int lrow = tid >> 3, lchunk = (tid & 7) * 8;
-    bf16x8 rk[2], rv[2];
+    bf16x8 rk[NLD], rv[NLD];
     auto gload = [&](int key0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NLD; ++i) {
             int key = key0 + lrow + i * 32;
             key = key < kv_len ? key : kv_len - 1;                       // clamped rows are masked below
             rk[i] = load8(kb + (long long)key * 64 + lchunk);
@@ -455,7 +462,7 @@ __global__ __launch_bounds__(256, 2) void attn_dit_kernel(AttnArgs a) {
     const int vpos = (vc >> 2) * 32 + ((vc & 1) * 2) * 8 + ((vc >> 1) & 1) * 4;
     auto stash = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NLD; ++i) {
             store8(&Ks[buf][(lrow + i * 32) * LD + lchunk], rk[i]);
             bf16x4 lo, hi;
 #pragma unroll
@@ -576,20 +583,38 @@ __global__ __launch_bounds__(256, 2) void attn_dit_kernel(AttnArgs a) {
         bf16x8 kf[4][2], vf[4][2];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
-            kf[kt][0] = load8(&Ks[buf][(kt * 16 + fr) * LD + fg * 8]);
-            kf[kt][1] = load8(&Ks[buf][(kt * 16 + fr) * LD + 32 + fg * 8]);
+            if constexpr (LAB & 4) {
+                kf[kt][0] = qf[kt % QR][0];
+                kf[kt][1] = qf[kt % QR][1];
+            } else {
+                kf[kt][0] = load8(&Ks[buf][(kt * 16 + fr) * LD + fg * 8]);
+                kf[kt][1] = load8(&Ks[buf][(kt * 16 + fr) * LD + 32 + fg * 8]);
+            }
         }
         auto qk = [&](int i, f32x4 (&sv)[4]) {
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
                 // the accumulator starts at -m_ref (loop-invariant registers): the scores arrive shifted, exp2 is all that is left
-                if constexpr (PRE) sv[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt][0], qf[i][0], nm_ref[i], 0, 0, 0);
-                else sv[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt][0], qf[i][0], f32x4{0, 0, 0, 0}, 0, 0, 0);
-                mma32(sv[kt], kf[kt][1], qf[i][1]);
+                if constexpr (LAB & 16) {
+                    sv[kt] = nm_ref[i] + f32x4{(float)key0, 1.0f, 2.0f, (float)kt};
+                } else {
+                    if constexpr (PRE) sv[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt][0], qf[i][0], nm_ref[i], 0, 0, 0);
+                    else sv[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt][0], qf[i][0], f32x4{0, 0, 0, 0}, 0, 0, 0);
+                    mma32(sv[kt], kf[kt][1], qf[i][1]);
+                }
             }
         };
         auto sm = [&](int i, f32x4 (&sv)[4], bf16x8 (&pf)[2]) {
             if constexpr (TAIL) mask_tail(sv, key0, i);
+            if constexpr (LAB & 8) {                                      // (lab: the scores' raw bits as probabilities: no exp2, no conversion)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    union { f32x4 f; bf16x8 b; } u;
+                    u.f = sv[2 * m] + sv[2 * m + 1];
+                    pf[m] = u.b;
+                }
+                return;
+            }
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -599,6 +624,14 @@ __global__ __launch_bounds__(256, 2) void attn_dit_kernel(AttnArgs a) {
                         pf[m][4 * hh + r] = f32_to_bf16(__builtin_amdgcn_exp2f(PRE ? sv[2 * m + hh][r] : __builtin_fmaf(sv[2 * m + hh][r], c, nm_ref[i][0])));   // -inf -> 0
         };
         auto pv = [&](int i, const bf16x8 (&pf)[2]) {
+            if constexpr (LAB & 16) {                                     // (lab: keep the probabilities alive without the matrix cores)
+                union { bf16x8 b; f32x4 f; } u0, u1;
+                u0.b = pf[0];
+                u1.b = pf[1];
+                o_acc[i][0] += u0.f;
+                o_acc[i][1] += u1.f;
+                return;
+            }
             f32x4 lt = {0, 0, 0, 0};
             mma32(lt, ones, pf[0]);
             mma32(lt, ones, pf[1]);
@@ -624,7 +657,10 @@ __global__ __launch_bounds__(256, 2) void attn_dit_kernel(AttnArgs a) {
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-            for (int m = 0; m < 2; ++m) vf[dt][m] = load8(&Vs[buf][(dt * 16 + fr) * LD + m * 32 + fg * 8]);
+            for (int m = 0; m < 2; ++m) {
+                if constexpr (LAB & 4) vf[dt][m] = qf[dt % QR][m];
+                else vf[dt][m] = load8(&Vs[buf][(dt * 16 + fr) * LD + m * 32 + fg * 8]);
+            }
         // (Measured and dropped: __builtin_amdgcn_sched_barrier(0) between the pipeline steps.  The disassembly then shows the pinned
         // "MFMA, exp x 3" interleave with hardly any s_nop left, but 30 more scratch instructions (spills inside the loop) and the kernel is
         // SLOWER: T = 5632 generic form 369 vs 337 us, flow solve (pre-scaled form) 564 vs 431 ms.)
@@ -651,12 +687,12 @@ __global__ __launch_bounds__(256, 2) void attn_dit_kernel(AttnArgs a) {
     const int n_full = lim_lo / KT;                                    // the first loop holds unmasked tiles only
     auto run = [&](auto&& tf) {
         for (int it = 0; it < n_full; ++it) {
-            const int buf = it & 1, key0 = it * KT;
-            const bool more = (it + 1) < n_tiles;
+            const int buf = (LAB & 1) ? 0 : (it & 1), key0 = it * KT;
+            const bool more = (it + 1) < n_tiles && !(LAB & 1);
             if (more) gload(key0 + KT);
             tf(buf, key0, std::false_type{});
             if (more) stash(buf ^ 1);
-            __syncthreads();
+            if constexpr (!(LAB & 2)) __syncthreads();
         }
         // masked tiles: one (the ragged end) without a chunk mask, the tiles between the first and the last row's chunk end with one
         for (int it = n_full; it < n_tiles; ++it) {
@@ -708,6 +744,7 @@ __global__ __launch_bounds__(256, 2) void attn_dit_kernel(AttnArgs a) {
                 for (int r = 0; r < 4; ++r) bad |= ((__float_as_uint(o_acc[i][dt][r]) & 0x7f800000u) == 0x7f800000u);
         }
         classical = __syncthreads_or((int)bad) != 0;
+        if constexpr (LAB != 0) classical = false;
         if (classical) {
 #pragma unroll
             for (int i = 0; i < QR; ++i) {
@@ -757,6 +794,33 @@ static int launch_t(const AttnArgs& a_in, hipStream_t s) {
         // T = 5632, 704 workgroups: 364 vs 337 us; 2816 workgroups: flow solve 441 vs 431 ms.  The rounds are not uniform enough for the
         // tail to be worth a kernel boundary.)
         const dim3 g4((a.n_rows + 255) / 256, a.heads, a.batch), g2((a.n_rows + 127) / 128, a.heads, a.batch);
+#ifdef HVX_ATTN_LAB
+        // (NW = 8, measured on MI355X round 5: 1158 vs 1055 us at B = 8, 349 vs 275 us at B = 2 — the barrier over eight waves costs more than the halved
+        // staging saves; two independent 4-wave workgroups per CU drift apart and cover each other.  Lab builds only.)
+        static const int nw8 = [] { const char* e = getenv("HVX_ATTN_NW"); return e ? atoi(e) == 8 : 0; }();
+        if (nw8 && a.n_rows >= 2048 && a.chunk <= 0 && a.q_log2) {
+            const dim3 g8((a.n_rows + 511) / 512, a.heads, a.batch);
+            hipLaunchKernelGGL((attn_dit_kernel<4, true, true, 0, 8>), g8, dim3(512), 0, s, a);
+            prof_end(slot, s);
+            return hipGetLastError() == hipSuccess ? 0 : (set_error("attention launch failed"), -1);
+        }
+        static const int lab = [] { const char* e = getenv("HVX_ATTN_LAB"); return e ? atoi(e) : 0; }();
+        if (lab && a.n_rows >= 2048 && a.chunk <= 0 && a.q_log2) {
+            switch (lab) {
+                case 1: hipLaunchKernelGGL((attn_dit_kernel<4, true, true, 1>), g4, dim3(256), 0, s, a); break;
+                case 2: hipLaunchKernelGGL((attn_dit_kernel<4, true, true, 2>), g4, dim3(256), 0, s, a); break;
+                case 3: hipLaunchKernelGGL((attn_dit_kernel<4, true, true, 3>), g4, dim3(256), 0, s, a); break;
+                case 7: hipLaunchKernelGGL((attn_dit_kernel<4, true, true, 7>), g4, dim3(256), 0, s, a); break;
+                case 11: hipLaunchKernelGGL((attn_dit_kernel<4, true, true, 11>), g4, dim3(256), 0, s, a); break;
+                case 15: hipLaunchKernelGGL((attn_dit_kernel<4, true, true, 15>), g4, dim3(256), 0, s, a); break;
+                case 19: hipLaunchKernelGGL((attn_dit_kernel<4, true, true, 19>), g4, dim3(256), 0, s, a); break;
+                case 23: hipLaunchKernelGGL((attn_dit_kernel<4, true, true, 23>), g4, dim3(256), 0, s, a); break;
+                default: return set_error("HVX_ATTN_LAB=%d is not instantiated", lab), -1;
+            }
+            prof_end(slot, s);
+            return hipGetLastError() == hipSuccess ? 0 : (set_error("attention launch failed"), -1);
+        }
+#endif
         if (a.n_rows >= 2048 && a.chunk <= 0) {
             if (a.q_log2) hipLaunchKernelGGL((attn_dit_kernel<4, true, true>), g4, dim3(256), 0, s, a);
             else hipLaunchKernelGGL((attn_dit_kernel<4, true, false>), g4, dim3(256), 0, s, a);

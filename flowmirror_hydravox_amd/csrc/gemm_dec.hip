@@ -24,7 +24,7 @@
 // Measured at 128 rows (us per launch, eager back-to-back; the 64-row-chunk skinny / mid forms of gemm_skinny.hip on row-major rows in
 // brackets): QKV + RoPE 3.9 [11.1], o_proj + residual 3.9 [10.0], gate/up + SwiGLU 9.1 [15.2], down_proj partials 5.7 [12.8]; as kernel durations
 // inside the decode step's graph (rocprofv3): 6.3 [11.1], 5.2 [10.0], 8.4 [15.2], 5.9 [12.8]; heads at 64 sequences x 2: gate / up 33 [48],
-// output projection 9.5 [~25] — DESIGN.md §4.1.
+// output projection 9.5 [~25] — docs/history/DESIGN_rounds1-4.md §4.1.
 #include <stdlib.h>
 
 #include <type_traits>

@@ -307,7 +307,7 @@ class HvxPipeline:
         if getattr(self, '_bg_stream', None) is None:
             lm_cus = int(getattr(self, 'lm_cus', 0) or 0)
             if lm_cus > 0:
-                # CU partition: the decode engine on CUs [0, lm_cus), the acoustic stage on the rest — both ranges spread over all
+                # CU partition (docs/history/DESIGN_rounds1-4.md §5.0): the decode engine on CUs [0, lm_cus), the acoustic stage on the rest — both ranges spread over all
                 # 8 XCDs.  Must be set before the first decode engine of self.llm is built (the engine keeps its stream).
                 from . import _lib
                 n_cu = _lib.load().hvx_device_ok()

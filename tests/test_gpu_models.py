@@ -563,7 +563,7 @@ def test_pipelined_batches_equal_serial(tiny_cfg):
 
 
 def test_results_do_not_depend_on_a_concurrent_mfma_stream(tiny_cfg):
-    """The round-2 hazard, as a deterministic reproducer: the vocoder of ONE stream is repeated with fixed inputs while a second
+    """The round-2 hazard, as a deterministic reproducer (docs/history/DESIGN_rounds1-4.md §8): the vocoder of ONE stream is repeated with fixed inputs while a second
     stream runs split-bf16 convolutions (a dense bf16 MFMA stream) with nothing in common with it; every repeat must be bit-identical to the
     undisturbed result.  With packed fp32 VALU instructions in the library 5-7 % of the repeats differed (tools/platform_probe.py:
     158 / 211 of 3000; 2203 of 3000 beside a bare MFMA loop), i.e. this test failed with certainty; without them 0 of 3000."""

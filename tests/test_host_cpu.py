@@ -36,7 +36,7 @@ def test_library_builds_and_exports_every_declared_symbol():
 
 
 def test_libhvx_holds_no_packed_fp32_instruction(tmp_path):
-    """DESIGN.md §8 / build.py: on MI355X a wave's v_pk_{fma,mul,add}_f32 return wrong values in lanes 48-63 now and then while a wave of
+    """docs/history/DESIGN_rounds1-4.md §8 / build.py: on MI355X a wave's v_pk_{fma,mul,add}_f32 return wrong values in lanes 48-63 now and then while a wave of
     another queue streams MFMAs on the same SIMD (tools/mfma_interference.py), so the device code of the shipped library must not contain one."""
     import shutil
     from flowmirror_hydravox_amd import build as hvx_build

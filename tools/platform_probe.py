@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Which kernel has to run BESIDE a victim for the victim's result to change?  (concurrent-chain hazard.)
+"""Which kernel has to run BESIDE a victim for the victim's result to change?  (docs/history/DESIGN_rounds1-4.md §8, concurrent-chain hazard.)
 
 A victim stream repeats a deterministic piece of work and compares every result bit-for-bit with its own first (un-disturbed) result; an
 aggressor stream launches one kind of kernel in a loop at the same time.

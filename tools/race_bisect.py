@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Stage- and buffer-level bisect of the concurrent-acoustic-chain hazard, without the LM and without the pipeline object.
+"""Stage- and buffer-level bisect of the concurrent-acoustic-chain hazard (docs/history/DESIGN_rounds1-4.md §8), without the LM and without the pipeline object.
 
 Two host threads, each with its own flow / vocoder handles (own workspaces, same packed weights) and its own stream, run the acoustic stages
 of a fixed list of utterances (speech tokens decoded once, serially) over and over; every intermediate (mel, f0, source, waveform) and a

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Reproducer for the concurrent-acoustic-chain hazard: serial synthesis on one pipeline object, pipelined synthesis with the given
+"""Reproducer for the concurrent-acoustic-chain hazard (docs/history/DESIGN_rounds1-4.md §8): serial synthesis on one pipeline object, pipelined synthesis with the given
 numbers of LM / acoustic chains on ANOTHER (so the pipelined handles were never used on the default stream), repeated; counts utterances whose
 waveform differs.   python tools/race_probe.py --lm 1 --acoustic 2 --reps 10"""
 import argparse
