@@ -260,6 +260,111 @@ __global__ __launch_bounds__(256) void gemm_x3p_kernel(GemmArgs a) {
 }
 
 
+// ---- the plane-pair product on a 128 x 128 x 64 tile with EIGHT waves (round 5) -----------------------------------------------------------
+// gemm_x3p_kernel<128,128> above is bound by what its loop does between two barriers: a 32-wide K-step is 64-byte row pieces for the LDS-DMA (the
+// L2 -> LDS rate of 64-byte pieces is ~42 GB/s per CU, of 128-byte pieces 51-67: tools/ingest_lab.hip) and one barrier per 48 MFMAs of a wave.
+// Here a K-tile is 64 wide — 128-byte row pieces, half the barriers per k — which needs 64 KB per stage (4 planes x 128 rows x 128 B), i.e. ONE
+// workgroup per CU; eight waves (4 x 2, a wave owns 32 x 64 of the tile) keep two waves on every SIMD.  LDS image of a plane tile: [128 rows][64 bf16],
+// lane-linear as the DMA deposits it (a wave instruction = 8 rows of 128 B); bank spread by a swizzle on the SOURCE address, chunk ^ ((row >> 1) & 7),
+// undone by the fragment reads (gemm_big.hip's scheme: the 16 lanes of every ds_read_b128 group touch 16 distinct 16-byte slots).
+// Same (hi, lo) pairs, same k order, same three MFMAs per step: results are bit-identical to the 4-wave form.
+__global__ __launch_bounds__(512) void gemm_x3p8_kernel(GemmArgs a) {
+    constexpr int BM = 128, BN = 128, BK = 64;
+    constexpr int WM = 32, WN = 64, MT = WM / 16, NT = WN / 16, WAVES_N = BN / WN;
+    constexpr int SLD = WN + 4, ROWS_PASS = (64 / WN) * 16;
+    constexpr int PLANE = 128 * BK;                         // bf16 elements of one plane tile (A and W tiles are both 128 rows)
+    constexpr int STAGE = 4 * PLANE;                        // Ah | Al | Bh | Bl
+    static_assert(8 * ROWS_PASS * SLD * 4 <= 2 * STAGE * 2, "epilogue staging fits the tile memory");
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE * 2];
+    bf16_t* const tiles = reinterpret_cast<bf16_t*>(smem);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int bz = blockIdx.z / a.groups, g = blockIdx.z % a.groups;
+    const bf16_t* __restrict__ Ab = reinterpret_cast<const bf16_t*>(a.A) + (long long)bz * a.a_bs + (long long)g * a.a_gs;
+    const bf16_t* __restrict__ Wb = reinterpret_cast<const bf16_t*>(a.W) + (long long)g * a.w_gs;
+    const int nk = a.K / BK;
+    const long long in_span = (long long)a.rows_in * a.up;
+
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+    const int lrow = lane >> 3, lslot = lane & 7;           // a DMA instruction: 8 rows x 8 slots of 16 B
+    auto issue = [&](int kc, int buf) {
+        const int k0 = kc * BK;
+        const int tap = k0 / a.cin_pad;                      // (cin_pad is a multiple of 64: a K-tile never straddles two taps)
+        const int ci = k0 - tap * a.cin_pad;
+        bf16_t* const st = tiles + buf * STAGE;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int r8 = wave * 16 + q * 8;                // first tile row of this instruction
+            const int gchunk = lslot ^ ((q * 4 + (lrow >> 1)) & 7);       // ((r >> 1) & 7) with r = r8 + lrow, r8 a multiple of 8
+            {
+                const int m = m0 + r8 + lrow;
+                const long long idx = (long long)m * a.conv_stride + (long long)tap * a.conv_dil - a.pad_left;
+                const bool ok = m < a.M && idx >= 0 && idx < in_span;
+                const long long src = (a.up == 1) ? idx : idx / a.up;
+                const bf16_t* gp = Ab + src * a.lda + ci + gchunk * 8;
+                const void* ph = ok ? static_cast<const void*>(gp) : static_cast<const void*>(g_zero_row);
+                const void* pl = ok ? static_cast<const void*>(gp + a.a_plane) : static_cast<const void*>(g_zero_row);
+                __builtin_amdgcn_global_load_lds((glb_ptr)ph, (lds_ptr)(st + r8 * BK), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_ptr)pl, (lds_ptr)(st + PLANE + r8 * BK), 16, 0, 0);
+            }
+            {
+                const int n = n0 + r8 + lrow;
+                const bf16_t* gp = Wb + (long long)n * a.K + k0 + gchunk * 8;
+                const void* ph = n < a.N ? static_cast<const void*>(gp) : static_cast<const void*>(g_zero_row);
+                const void* pl = n < a.N ? static_cast<const void*>(gp + a.w_plane) : static_cast<const void*>(g_zero_row);
+                __builtin_amdgcn_global_load_lds((glb_ptr)ph, (lds_ptr)(st + 2 * PLANE + r8 * BK), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_ptr)pl, (lds_ptr)(st + 3 * PLANE + r8 * BK), 16, 0, 0);
+            }
+        }
+    };
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+    const int fr = lane & 15, fg = lane >> 4;
+    const int sw = (fr >> 1) & 7;                            // ((row >> 1) & 7) of every fragment row of this lane (rows = 16 i + fr)
+    auto compute = [&](int cur) {
+        const bf16_t* const st = tiles + cur * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int off = ((ks * 4 + fg) ^ sw) * 8;
+            bf16x8 ah[MT], al[MT], bh[NT], bl[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                ah[i] = load8(st + (wm0 + i * 16 + fr) * BK + off);
+                al[i] = load8(st + PLANE + (wm0 + i * 16 + fr) * BK + off);
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                bh[j] = load8(st + 2 * PLANE + (wn0 + j * 16 + fr) * BK + off);
+                bl[j] = load8(st + 3 * PLANE + (wn0 + j * 16 + fr) * BK + off);
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    mma32(acc[i][j], al[i], bh[j]);
+                    mma32(acc[i][j], ah[i], bl[j]);
+                    mma32(acc[i][j], ah[i], bh[j]);
+                }
+        }
+    };
+    issue(0, 0);
+    for (int kc = 0; kc < nk; ++kc) {
+        __syncthreads();                                 // tile kc has landed (the barrier drains the DMA queue); buffer (kc + 1) & 1 is free
+        if (kc + 1 < nk) issue(kc + 1, (kc + 1) & 1);
+        compute(kc & 1);
+    }
+    __syncthreads();                                     // the epilogue reuses the tile memory as staging
+    gemm_epilogue<float, MT, NT, WN, EPI_GENERIC, 2>(a, acc, reinterpret_cast<float*>(smem) + wave * ROWS_PASS * SLD, lane, m0 + wm0, n0 + wn0, bz, g);
+}
+
 // ---- plane-pair convolution with the INPUT ROWS RESIDENT IN LDS (64 channels in, <= 64 out, stride 1): the last vocoder stage -------------------
 // A k-tap convolution read through gemm_x3p_kernel fetches the same input rows k times (tap t is the tile shifted by t * dil rows) and passes
 // 2 k barriers with 24 MFMAs per wave between them; at 64 channels that, not the matrix cores or HBM, sets the time (252 us for 350-690 MB of
@@ -350,6 +455,11 @@ __global__ __launch_bounds__(256) void conv64_x3p_kernel(GemmArgs a) {
     gemm_epilogue<float, MT, NT, WN, EPI_GENERIC, 2>(a, acc, reinterpret_cast<float*>(Bs) + wave * ROWS_PASS * SLD, lane, m0 + wm0, 0, 0, 0);
 }
 
+// (Round 5, measured and removed: the resident-row form of conv64_x3p_kernel below for the 128-channel stage — 128 + halo input rows of both planes in LDS
+// once (94 KB), only the 32 KB weight tile of a (tap, 64-channel half) staged per step, 8 waves.  Bit-identical, and SLOWER: vocoder 17.5 vs 17.1 ms per
+// 5632-frame utterance.  At 158 KB a CU holds ONE workgroup, so the 94 KB prologue of every tile is exposed; the 64-channel form works because two
+// 81 KB workgroups cover each other's prologues.)
+
 template <int BM, int BN, int WM, int WN>
 int launch_cfg_p(const GemmArgs& a, hipStream_t s) {
     dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, a.batch * a.groups);
@@ -385,7 +495,16 @@ int launch_gemm_x3(const GemmArgs& a, hipStream_t s) {
             prof_end(slot, s);
             return hipGetLastError() == hipSuccess ? 1 : (set_error("conv (resident-row plane-pair form) launch failed"), -1);
         }
-        return a.N <= 64 ? launch_cfg_p<128, 64, 32, 64>(a, s) : launch_cfg_p<128, 128, 64, 64>(a, s);
+        if (a.N <= 64) return launch_cfg_p<128, 64, 32, 64>(a, s);
+        static const int x3p8 = getenv("HVX_X3P8") ? atoi(getenv("HVX_X3P8")) : 1;                                  // (A/B switch)
+        if (x3p8 && (a.K & 63) == 0 && (a.cin_pad & 63) == 0) {
+            dim3 grid((a.M + 127) / 128, (a.N + 127) / 128, a.batch * a.groups);
+            const int slot = prof_begin(PK_GEMM_F32, 2.0 * a.M * a.N * (double)a.K * a.batch * a.groups, s);
+            hipLaunchKernelGGL(gemm_x3p8_kernel, grid, dim3(512), 0, s, a);
+            prof_end(slot, s);
+            return hipGetLastError() == hipSuccess ? 1 : (set_error("gemm (plane-pair form, 8 waves) launch failed"), -1);
+        }
+        return launch_cfg_p<128, 128, 64, 64>(a, s);
     }
     if (!a.x3 || a.dtype != DT_F32 || a.epi != EPI_GENERIC) return 0;
     const long long blocks128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.batch * a.groups;

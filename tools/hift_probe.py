@@ -25,3 +25,5 @@ for _ in range(a.iters):
 torch.cuda.synchronize()
 dt = (time.time() - t0) / a.iters
 print('hift %d frames: %.1f ms per utterance, %.0f TF/s fp32-equivalent of 672 MF per frame' % (a.frames, dt * 1e3, 672e6 * a.frames / dt / 1e12))
+if os.environ.get('HVX_PROBE_SAVE'):
+    torch.save(hift.inference(speech_feat=mel)[0].cpu(), os.environ['HVX_PROBE_SAVE'])
