@@ -33,9 +33,11 @@ def read(path, counter):
 ap = argparse.ArgumentParser()
 ap.add_argument('--out', required=True)
 ap.add_argument('--how', default='')
+ap.add_argument('--grid', action='append', default=[], help='name=text: the workload the counters of class `name` were taken on (bench.py prints it as traffic_counted_on)')
 ap.add_argument('specs', nargs='+')
 a = ap.parse_args()
 out = {'_how': a.how}
+grids = dict(g.split('=', 1) for g in a.grid)
 for spec in a.specs:
     name, rest = spec.split('=', 1)
     rx = None
@@ -56,6 +58,8 @@ for spec in a.specs:
         w = sum(write[k][0] for k in sel if k in write) / max(nw, 1)
         entry = {'per': 'launch', 'launches_fetch_pass': nf, 'launches_write_pass': nw}
     entry.update(fetch_size_kib=round(f, 1), write_size_kib=round(w, 1), hbm_bytes_per_launch=int((2 * f + w) * 1024), kernels=sorted(sel))
+    if name in grids:
+        entry['grid'] = grids[name]
     entry['per_kernel'] = {k: {'dispatches': fetch[k][1], 'fetch_size_kib_mean': round(fetch[k][0] / fetch[k][1], 1),
                                'write_size_kib_mean': round(write[k][0] / write[k][1], 1) if k in write and write[k][1] else None} for k in sel}
     out[name] = entry
