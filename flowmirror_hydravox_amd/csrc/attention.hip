@@ -624,6 +624,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_dit_kernel(Attn
                         pf[m][4 * hh + r] = f32_to_bf16(__builtin_amdgcn_exp2f(PRE ? sv[2 * m + hh][r] : __builtin_fmaf(sv[2 * m + hh][r], c, nm_ref[i][0])));   // -inf -> 0
         };
         auto pv = [&](int i, const bf16x8 (&pf)[2]) {
+            if constexpr ((LAB & 64) != 0) __builtin_amdgcn_s_setprio(1);
             if constexpr (LAB & 16) {                                     // (lab: keep the probabilities alive without the matrix cores)
                 union { bf16x8 b; f32x4 f; } u0, u1;
                 u0.b = pf[0];
@@ -640,6 +641,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_dit_kernel(Attn
             for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
                 for (int m = 0; m < 2; ++m) mma32(o_acc[i][dt], vf[dt][m], pf[m]);
+            if constexpr ((LAB & 64) != 0) __builtin_amdgcn_s_setprio(0);
         };
         // MFMA : VALU interleave of one pipeline step (masks: 0x8 MFMA, 0x2 VALU; the transcendental ops count as VALU)
         auto pin = [&](auto NM, auto NV) {
@@ -709,6 +711,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_dit_kernel(Attn
         stash(0);
     }
     __syncthreads();
+    if constexpr ((LAB & 32) != 0) {                              // (lab: every other workgroup starts a fraction of a tile later)
+        if ((blockIdx.x + blockIdx.y + blockIdx.z) & 1) __builtin_amdgcn_s_sleep(24);
+    }
     bool classical = !FAST;
     if constexpr (FAST) {
         if (n_tiles > 0) {
@@ -815,6 +820,9 @@ static int launch_t(const AttnArgs& a_in, hipStream_t s) {
                 case 15: hipLaunchKernelGGL((attn_dit_kernel<4, true, true, 15>), g4, dim3(256), 0, s, a); break;
                 case 19: hipLaunchKernelGGL((attn_dit_kernel<4, true, true, 19>), g4, dim3(256), 0, s, a); break;
                 case 23: hipLaunchKernelGGL((attn_dit_kernel<4, true, true, 23>), g4, dim3(256), 0, s, a); break;
+                case 32: hipLaunchKernelGGL((attn_dit_kernel<4, true, true, 32>), g4, dim3(256), 0, s, a); break;
+                case 64: hipLaunchKernelGGL((attn_dit_kernel<4, true, true, 64>), g4, dim3(256), 0, s, a); break;
+                case 96: hipLaunchKernelGGL((attn_dit_kernel<4, true, true, 96>), g4, dim3(256), 0, s, a); break;
                 default: return set_error("HVX_ATTN_LAB=%d is not instantiated", lab), -1;
             }
             prof_end(slot, s);
