@@ -288,11 +288,14 @@ class HvxHifiGan:
 
 
 class HvxDenoiser:
-    """Denoiser(vocoder, filter_length, n_overlap) (denoiser.py:10-55): bias spectrum = |STFT| of the vocoder's answer to a zero mel."""
+    """Denoiser(vocoder, filter_length, n_overlap, mode) (denoiser.py:10-55): bias spectrum = |STFT| of the vocoder's answer to a probe mel of 88 frames —
+    all zeros (mode 'zeros', the default) or N(0, 1) (mode 'normal', denoiser.py:20-21).  The 'normal' probe is drawn the way the reference draws it when its
+    vocoder lives on the CPU — `torch.randn((1, 80, 88))` from the GLOBAL CPU generator (or from `generator` when one is passed) — so that a seeded run gives the
+    reference's bias spectrum; with the vocoder on a GPU the reference would draw from that device's generator, whose stream nothing else can reproduce."""
 
-    def __init__(self, vocoder: HvxHifiGan, filter_length=None, n_overlap=None, mode='zeros'):
-        if mode != 'zeros':
-            raise NotImplementedError("Denoiser mode 'normal' draws its probe mel from the global RNG; only 'zeros' is served")
+    def __init__(self, vocoder: HvxHifiGan, filter_length=None, n_overlap=None, mode='zeros', generator=None):
+        if mode not in ('zeros', 'normal'):
+            raise Exception(f"Mode {mode} if not supported")          # (the reference's own message, denoiser.py:23)
         self.lib = vocoder.lib
         self.device = vocoder.device
         c = vocoder.cfg
@@ -302,7 +305,8 @@ class HvxDenoiser:
         self._ana, self._syn, self._wsq = ana.to(self.device), syn.to(self.device), wsq.to(self.device)
         self._ws = None
         bins = self.n_fft // 2 + 1
-        probe = vocoder(torch.zeros(1, c.mel, 88, device=self.device)).reshape(-1)
+        mel_input = torch.zeros(1, c.mel, 88) if mode == 'zeros' else torch.randn((1, c.mel, 88), generator=generator)
+        probe = vocoder(mel_input.to(self.device)).reshape(-1)
         self.bias_spec = self._magnitude_first_frame(probe, bins)
 
     def _workspace(self, L):

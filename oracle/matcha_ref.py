@@ -188,9 +188,11 @@ def generator_forward(sd, c, mel):
     return torch.tanh(x)
 
 
-def denoiser_bias(sd, c):
-    """Denoiser.__init__ (denoiser.py:49-55): |STFT| of the vocoder's response to an all-zero mel (88 frames), first frame"""
-    audio = generator_forward(sd, c, torch.zeros(1, c.mel, 88)).float().squeeze(0)
+def denoiser_bias(sd, c, mode='zeros', generator=None):
+    """Denoiser.__init__ (denoiser.py:17-23, 49-55): |STFT| of the vocoder's response to the probe mel (88 frames: zeros, or N(0, 1) from the CPU generator
+    in mode 'normal'), first frame"""
+    mel_input = torch.zeros(1, c.mel, 88) if mode == 'zeros' else torch.randn((1, c.mel, 88), generator=generator)
+    audio = generator_forward(sd, c, mel_input).float().squeeze(0)
     hop = c.n_fft // c.n_overlap
     spec = torch.stft(audio, c.n_fft, hop, c.n_fft, torch.hann_window(c.n_fft), return_complex=True)
     return spec.abs()[:, :, 0][:, :, None]                       # (1, bins, 1)

@@ -243,9 +243,41 @@ def gen_single():
     np.savez_compressed(os.path.join(HERE, 'single_cv3.npz'), **out)
 
 
+def gen_denoiser_normal():
+    """matcha/hifigan/denoiser.py:20-21: Denoiser(mode="normal") — the probe mel is torch.randn((1, 80, 88)) from the global generator — on the tiny HiFi-GAN
+    of matcha_tiny.npz -> denoiser_normal.npz (seed, bias spectrum, denoised audio)"""
+    from matcha.hifigan.models import Generator
+    from matcha.hifigan.denoiser import Denoiser
+    from flowmirror_hydravox_amd.config import tiny_hifigan_config
+    from oracle import matcha_ref
+    hc = tiny_hifigan_config()
+    h = DictConfig(resblock='1', upsample_rates=list(hc.upsample_rates), upsample_kernel_sizes=list(hc.upsample_kernel_sizes),
+                   upsample_initial_channel=hc.initial_channel, resblock_kernel_sizes=list(hc.resblock_kernel_sizes),
+                   resblock_dilation_sizes=[list(d) for d in hc.resblock_dilations])
+    gen = Generator(h).eval()
+    sdg = W.make_hifigan_state(hc, seed=23, init='fan_in')
+    gen.load_state_dict(sdg)
+    g = torch.Generator().manual_seed(77)
+    mel = torch.randn(1, hc.mel, 30, generator=g)
+    seed = 4242
+    with torch.inference_mode():
+        wav = gen(mel)
+        torch.manual_seed(seed)
+        den = Denoiser(gen, filter_length=hc.n_fft, n_overlap=hc.n_overlap, win_length=hc.n_fft, mode='normal')
+        clean = den(wav.squeeze(1), strength=0.05)
+    torch.manual_seed(seed)
+    o_bias = matcha_ref.denoiser_bias(sdg, hc, mode='normal')
+    o_clean = matcha_ref.denoise(wav.squeeze(1), o_bias, hc, 0.05)
+    d = [(o_bias - den.bias_spec).abs().max().item(), (o_clean - clean).abs().max().item()]
+    assert max(d) < 1e-4, d
+    print('[denoiser-normal] oracle-reference max abs diff bias %.1e denoised %.1e (bias max %.3f)' % (d[0], d[1], den.bias_spec.max()))
+    np.savez_compressed(os.path.join(HERE, 'denoiser_normal.npz'), weight_seed=np.int64(23), weight_sha=np.array(MG.state_checksum(sdg)), seed=np.int64(seed),
+                        wav=wav.numpy(), bias=den.bias_spec.numpy(), clean=clean.numpy(), strength=np.float32(0.05))
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['flow_est', 'flow_solve', 'hift', 'llm', 'single']
+    which = sys.argv[1:] or ['flow_est', 'flow_solve', 'hift', 'llm', 'single', 'denoiser_normal']
     for w in which:
         t0 = time.time()
-        {'flow_est': gen_flow_est, 'flow_solve': gen_flow_solve, 'hift': gen_hift, 'llm': gen_llm, 'single': gen_single}[w]()
+        {'flow_est': gen_flow_est, 'flow_solve': gen_flow_solve, 'hift': gen_hift, 'llm': gen_llm, 'single': gen_single, 'denoiser_normal': gen_denoiser_normal}[w]()
         print('== %s done in %.0f s' % (w, time.time() - t0))

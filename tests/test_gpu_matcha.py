@@ -105,6 +105,28 @@ def test_hifigan_generator_and_denoiser_vs_reference(golden):
     assert _rel(clean, g['g_clean']) < 1e-3                      # Denoiser.forward (M5)
 
 
+def test_denoiser_mode_normal_vs_reference():
+    """matcha/hifigan/denoiser.py:20-21: mode="normal" — the bias spectrum comes from the vocoder's answer to an N(0, 1) probe mel drawn from the global CPU
+    generator; seeded like the reference run that minted the fixture, bias spectrum and denoised audio agree"""
+    from flowmirror_hydravox_amd import weights as W
+    from flowmirror_hydravox_amd.config import tiny_hifigan_config
+    from flowmirror_hydravox_amd.matcha import HvxDenoiser, HvxHifiGan
+    g = load_golden('denoiser_normal.npz')
+    hc = tiny_hifigan_config()
+    sd = W.make_hifigan_state(hc, seed=int(g['weight_seed']), init='fan_in')
+    assert state_checksum(sd) == str(g['weight_sha'])
+    voc = HvxHifiGan(hc, sd)
+    torch.manual_seed(int(g['seed']))
+    den = HvxDenoiser(voc, mode='normal')
+    assert _rel(den.bias_spec.cpu().numpy(), g['bias'][0, :, 0]) < 1e-3
+    clean = den(torch.from_numpy(g['wav']).squeeze(1), strength=float(g['strength'])).cpu().numpy()
+    assert clean.shape == g['clean'].shape and _rel(clean, g['clean']) < 1e-3
+    zeros = HvxDenoiser(voc)
+    assert _rel(zeros.bias_spec.cpu().numpy(), g['bias'][0, :, 0]) > 1e-2          # (it is a different spectrum than the default mode's)
+    with pytest.raises(Exception):
+        HvxDenoiser(voc, mode='uniform')
+
+
 def test_hifigan_accepts_checkpoints_with_weight_norm_removed(golden):
     from flowmirror_hydravox_amd import weights as W
     from flowmirror_hydravox_amd.config import tiny_hifigan_config

@@ -613,3 +613,18 @@ def test_configs0_single_utterance_oracle_vs_reference_end_to_end():
     d_w = max(np.abs(w[::16] - g['wav_s16']).max(), np.abs(w[:32768] - g['wav_head']).max(), np.abs(w[-32768:] - g['wav_tail']).max())
     print('configs[0], oracle vs the reference: ids equal, mel %.1e of its scale, waveform max |d| %.1e' % (d_mel, d_w))
     assert d_w < 5e-4 and np.abs(w - g['wav_f16'].astype(np.float32)).max() < 1.5e-3, d_w
+
+
+def test_denoiser_mode_normal_oracle_vs_reference():
+    """matcha/hifigan/denoiser.py:20-21 (mode "normal": N(0, 1) probe mel from the global generator): the oracle, seeded like the reference run"""
+    from flowmirror_hydravox_amd.config import tiny_hifigan_config
+    from oracle import matcha_ref
+    g = load_golden('denoiser_normal.npz')
+    hc = tiny_hifigan_config()
+    sd = W.make_hifigan_state(hc, seed=int(g['weight_seed']), init='fan_in')
+    assert state_checksum(sd) == str(g['weight_sha'])
+    torch.manual_seed(int(g['seed']))
+    bias = matcha_ref.denoiser_bias(sd, hc, mode='normal')
+    assert (bias - torch.from_numpy(g['bias'])).abs().max().item() < 1e-4
+    clean = matcha_ref.denoise(torch.from_numpy(g['wav']).squeeze(1), bias, hc, float(g['strength']))
+    assert (clean - torch.from_numpy(g['clean'])).abs().max().item() < 1e-4
