@@ -491,6 +491,8 @@ int launch_gemm_x3(const GemmArgs& a, hipStream_t s) {
         if (resident && a.N <= 64 && a.cin_pad == 64 && a.conv_stride == 1 && a.up == 1 && a.groups == 1 && a.batch == 1 && a.M >= 4096 &&
             128 + (a.K / 64 - 1) * a.conv_dil <= 192) {
             const int slot = prof_begin(PK_GEMM_F32, 2.0 * a.M * a.N * (double)a.K, s);
+            // (Round 5, measured: 160 resident rows instead of 192 — 73 728 B of LDS, every convolution of the stage but (k = 11, dilation 5) — 213.9 vs
+            // 214.7 us per launch, and a start offset for the second workgroup of a CU changes nothing either: the two workgroups of a CU already overlap.)
             hipLaunchKernelGGL((conv64_x3p_kernel<192>), dim3((a.M + 127) / 128), dim3(256), 0, s, a);
             prof_end(slot, s);
             return hipGetLastError() == hipSuccess ? 1 : (set_error("conv (resident-row plane-pair form) launch failed"), -1);
