@@ -148,6 +148,24 @@ __global__ __launch_bounds__(NWAVE * 64, 2) void gemm_big_kernel(GemmArgs a, int
     iter(nk - 1, std::false_type{}, std::false_type{});
     __syncthreads();                                     // the epilogue reuses the tile memory as staging
 
+#if defined(HVX_LAB_GEMM_EPI) && HVX_LAB_GEMM_EPI == 1
+    {   // (lab: the K-loop alone — every accumulator stays observable through one value per lane)
+        f32x4 t = {0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) t += acc[i][j];
+        if (t[0] + t[1] + t[2] + t[3] == 123.456f) reinterpret_cast<float*>(smem)[lane] = t[0];
+        return;
+    }
+#elif defined(HVX_LAB_GEMM_EPI) && HVX_LAB_GEMM_EPI == 2
+    {   // (lab: the whole epilogue's instructions, but only row 0 is stored and every residual row read is row 0: no memory traffic to speak of)
+        GemmArgs a2 = a;
+        a2.M = 1;
+        gemm_epilogue<T, MT, NT, WN, EPI, 1, bf16_t>(a2, acc, reinterpret_cast<float*>(smem) + wave * SCR_FLOATS, lane, m0 + wm0, n0 + wn0, bz, 0);
+        return;
+    }
+#endif
     gemm_epilogue<T, MT, NT, WN, EPI, 1, bf16_t>(a, acc, reinterpret_cast<float*>(smem) + wave * SCR_FLOATS, lane, m0 + wm0, n0 + wn0, bz, 0);
 }
 
