@@ -201,8 +201,10 @@ int hvx_llm_bind(hvx_llm* h, void* workspace, size_t ws_bytes, int32_t max_seq, 
 // 16-column / 64-row form with the weights in MFMA fragment order reads them once per 64 rows; when that leaves too few workgroups K is
 // split across workgroups (fp32 partials) and the split reduce — fixed order, one writer per element — does the residual add and
 // the operand-type copy.
-static int resid_wide(hvx_llm* h, SkinnyArgs g, const void* w_frag, void* xcopy, hipStream_t s) {
-    const int groups = (g.N / 16) * ((g.M + 63) / 64);
+// m_split: the row count the split-K choice is made for.  A grouped prefill (several prefixes of kn rows each in one forward, llm.py: _prefill_group) passes kn, so
+// that every row is summed exactly as in a prefill of its sequence alone: a request's KV cache must not depend on what joined the grid with it.
+static int resid_wide(hvx_llm* h, SkinnyArgs g, const void* w_frag, void* xcopy, hipStream_t s, int m_split = 0) {
+    const int groups = (g.N / 16) * (((m_split > 0 ? m_split : g.M) + 63) / 64);
     int split = (512 + groups - 1) / groups;
     const int kt = g.K / 32;
     if (split > kt / 8) split = kt / 8;
@@ -390,6 +392,8 @@ static int forward_impl(hvx_llm* h, hipStream_t s, int32_t n_seq, int32_t kn, co
     // more than two 16-row tiles (prefill; decode of >= 17 sequences x 2 heads): the 4-column form would re-read its activation rows per
     // tile, see resid_wide
     const bool wide = R > 32;
+    // a grouped prefill (n_seq prefixes of kn > 256 rows): the residual projections choose their K split as for ONE prefix, whatever the group size
+    const int m_split = (n_seq > 1 && kn > 256) ? kn : 0;
     for (int l = 0; l < c.layers; ++l) {
         const void* const* lw = w + 6 + 9 * l;
         // 1. QKV + bias + RoPE + KV append
@@ -439,7 +443,7 @@ static int forward_impl(hvx_llm* h, hipStream_t s, int32_t n_seq, int32_t kn, co
         if (dec) {
             g.W = lw[7]; g.w_narrow = 0; g.a_frag = 1; g.out_frag = 1;                          // (fragment-packed copy of the weights)
             if (gemm(g)) return -1;
-        } else if (R > 256 ? resid_wide(h, g, lw[7], xcopy, s) : launch_skinny(g, s)) return -1;      // K = q*64 is short: the 4-column form holds up to 16 row tiles
+        } else if (R > 256 ? resid_wide(h, g, lw[7], xcopy, s, m_split) : launch_skinny(g, s)) return -1;      // K = q*64 is short: the 4-column form holds up to 16 row tiles
         // 4. hmlp = SwiGLU(RMSNorm(x) * ln2)
         memset(&g, 0, sizeof(g));
         g.dtype = dt; g.M = R; g.N = 2 * c.inter; g.K = H; g.A = xa; g.lda = H; g.W = lw[5]; g.split_k = 1; g.nz = 1;
@@ -459,7 +463,7 @@ static int forward_impl(hvx_llm* h, hipStream_t s, int32_t n_seq, int32_t kn, co
             r.x = h->x; r.ldx = H; r.part = h->part; r.split_k = down_split; r.part_stride = (long long)R * H; r.do_norm = 0;
             r.y = xcopy; r.ldy = H; r.dtype = dt; r.M = R; r.H = H; r.rows_per_z = R; r.y_frag = 1;
             if (launch_reduce_rmsnorm(r, s)) return -1;
-        } else if (wide ? resid_wide(h, g, lw[8], xcopy, s) : launch_skinny(g, s)) return -1;
+        } else if (wide ? resid_wide(h, g, lw[8], xcopy, s, m_split) : launch_skinny(g, s)) return -1;
     }
     if (head_k <= 0) return 0;
 

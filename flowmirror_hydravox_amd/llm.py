@@ -392,6 +392,7 @@ class _DecodeEngine:
     sequence, its tokens are copied out and the next waiting request takes the slot over: prefill of its prefix into the slot's KV cache,
     hvx_llm_decode_join, noise at position 0 of the slot's ring — all ordered on the decode stream behind the blocks already enqueued."""
     NS = 8
+    PREFILL_GROUP = int(os.environ.get('HVX_PREFILL_GROUP', '8'))     # prefixes per grouped prefill forward (8 x 514 rows = the GEMMs' efficient range; the workspace grows with it; 1: every prefix alone — A / B)
 
     def __init__(self, llm, n_slots, max_out, max_prefix, stream_first=False, sync_every=None, pace=None):
         import time
@@ -420,7 +421,9 @@ class _DecodeEngine:
         self.W = max(self.sp['win_size'] if self.sp['win_size'] > 0 else self.max_out, 1)
         W = self.W
         with torch.cuda.stream(self.stream):
-            llm._bind(S, max(int(max_prefix), S * K))
+            # (rows for a grouped prefill: up to PREFILL_GROUP prefixes of equal length go through the backbone in ONE forward — see _prefill_group)
+            self.prefill_group = max(1, min(self.PREFILL_GROUP, S))
+            llm._bind(S, max(self.max_prefix * self.prefill_group, S * K))
             # ---- decode state (fixed device addresses: the step graph is captured once and replayed); every slot starts empty ------------
             self.o_tok, self.o_ctrl, self.o_hist = 0, S * K, S * K + 5 * S
             self.o_hlen, self.o_min, self.o_act = self.o_hist + S * W, self.o_hist + S * W + S, self.o_hist + S * W + 2 * S
@@ -508,14 +511,28 @@ class _DecodeEngine:
             return ValueError("prefix of %d rows exceeds the engine's max_prefix=%d" % (len(r.prefix), self.max_prefix))
         return None
 
-    def _join(self, i, r, launched):
+    def _prefill_group(self, pairs):
+        """KV caches of several joining requests in ONE backbone forward: pairs = [(slot, request), ...] whose prefixes have the same length.  A 514-row prefill
+        alone runs the GEMMs at ~100 TF/s (3.7 ms); eight of them together are one 4112-row pass.  Same rows, same arithmetic per row: every row of the
+        backbone depends on its own sequence only (per-sequence slot / position / length in the control block), so the caches are what single prefills write."""
+        llm = self.llm
+        n = len(pairs[0][1].prefix) - 1
+        S = len(pairs)
+        toks = []
+        for _, r in pairs:
+            toks += r.prefix[:n]
+        tok = self._h2d(toks, torch.int32)
+        ctrl = self._h2d([i for i, _ in pairs] + [0] * S + [n] * S + [n] * S + [s * n + n - 1 for s in range(S)], torch.int32)
+        llm._forward(S, n, tok, ctrl, 0, None)
+
+    def _join(self, i, r, launched, prefilled=False):
         """request r takes slot i (stream-ordered behind every block enqueued so far)"""
         llm = self.llm
         n = len(r.prefix) - 1
         err = self._refuse(r)
         if err is not None:
             raise err
-        if n > 0:
+        if n > 0 and not prefilled:
             tok = self._h2d(r.prefix[:n], torch.int32)
             ctrl = self._h2d([i, 0, n, n, n - 1], torch.int32)
             llm._forward(1, n, tok, ctrl, 0, None)
@@ -626,8 +643,21 @@ class _DecodeEngine:
                 from concurrent.futures import ThreadPoolExecutor
                 with ThreadPoolExecutor(max_workers=min(8, len(batch))) as pool:
                     list(pool.map(lambda ir: ir[1].noise.window(0, self.ncap), batch))
+            # several joins at once (the first occupants of a grid, a burst of requests): prefixes of equal length share a prefill forward
+            done = set()
+            if self.prefill_group > 1 and len(batch) > 1:
+                by_len = {}
+                for i, r in batch:
+                    if self._refuse(r) is None and len(r.prefix) - 1 > 256:         # (short prefixes: a single prefill is cheap, and the K-split rule of hvx_llm.hip covers kn > 256)
+                        by_len.setdefault(len(r.prefix), []).append((i, r))
+                for group in by_len.values():
+                    for a in range(0, len(group), self.prefill_group):
+                        part = group[a:a + self.prefill_group]
+                        if len(part) > 1:
+                            self._prefill_group(part)
+                            done.update(i for i, _ in part)
             for i, r in batch:
-                self._join(i, r, launched)
+                self._join(i, r, launched, prefilled=i in done)
             return bool(batch)
 
         try:

@@ -446,3 +446,23 @@ def test_llm_fp8_head_gate_up_is_the_bf16_path_on_the_quantised_weights(cfg, llm
     assert torch.equal(_one_wide_step(again, cfg, 40, 2), b_codes)
     with pytest.raises(ValueError):
         checkpoint.load_packed(HvxLLM(c, None, dtype=torch.bfloat16, max_batch=8, max_ctx=1024), p8)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_llm_grouped_prefill_is_the_single_prefill(cfg, llm_setup, dtype):
+    """Requests that join a grid together and have prefixes of equal length (> 256 rows) share ONE prefill forward (llm.py: _prefill_group, up to 8 per pass; the
+    bench's first 64 occupants all have 514 rows).  Every row's arithmetic is that of a prefill of its sequence alone — the K split of the residual projections is
+    chosen per prefix, not per pass — so the ids are those of the same requests served one by one, in the exact mode AND in bf16."""
+    g, sd, sampling = llm_setup
+    llm = _make_llm(cfg, sd, sampling, dtype, max_batch=6, max_ctx=1024)
+    llm.inference_head_num = 2
+    gen = torch.Generator().manual_seed(91)
+    reqs = [dict(text=torch.randint(0, cfg.llm.text_vocab, (20,), generator=gen, dtype=torch.int32),
+                 prompt_speech_token=torch.randint(0, cfg.llm.speech_tokens, (300,), generator=gen, dtype=torch.int32), seed=8100 + i, tag=i,
+                 max_token_text_ratio=3, min_token_text_ratio=2) for i in range(6)]
+    together = dict(llm.generate_stream(iter(reqs), n_slots=6))
+    assert llm.last_stats['requests'] == 6
+    for r in reqs:
+        alone = dict(llm.generate_stream(iter([r]), n_slots=1))
+        assert alone[r['tag']] == together[r['tag']], r['tag']
+        assert len(alone[r['tag']]) >= 40
