@@ -362,6 +362,24 @@ __global__ __launch_bounds__(512) void gemm_x3p8_kernel(GemmArgs a) {
         compute(kc & 1);
     }
     __syncthreads();                                     // the epilogue reuses the tile memory as staging
+#if defined(HVX_LAB_X3_EPI) && HVX_LAB_X3_EPI == 1
+    {   // (lab: the K-loop alone — every accumulator stays observable through one value per lane)
+        f32x4 t = {0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) t += acc[i][j];
+        if (t[0] + t[1] + t[2] + t[3] == 123.456f) reinterpret_cast<float*>(a.out)[lane] = t[0];
+        return;
+    }
+#elif defined(HVX_LAB_X3_EPI) && HVX_LAB_X3_EPI == 2
+    {   // (lab: the epilogue's instructions without its memory traffic: only row 0 is stored / read)
+        GemmArgs a2 = a;
+        a2.M = 1;
+        gemm_epilogue<float, MT, NT, WN, EPI_GENERIC, 2>(a2, acc, reinterpret_cast<float*>(smem) + wave * ROWS_PASS * SLD, lane, m0 + wm0, n0 + wn0, bz, g);
+        return;
+    }
+#endif
     gemm_epilogue<float, MT, NT, WN, EPI_GENERIC, 2>(a, acc, reinterpret_cast<float*>(smem) + wave * ROWS_PASS * SLD, lane, m0 + wm0, n0 + wn0, bz, g);
 }
 
@@ -452,6 +470,24 @@ __global__ __launch_bounds__(256) void conv64_x3p_kernel(GemmArgs a) {
         }
     }
     __syncthreads();                                     // the epilogue stages through the weight buffers
+#if defined(HVX_LAB_X3_EPI) && HVX_LAB_X3_EPI == 1
+    {   // (lab: the K-loop alone — every accumulator stays observable through one value per lane)
+        f32x4 t = {0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) t += acc[i][j];
+        if (t[0] + t[1] + t[2] + t[3] == 123.456f) reinterpret_cast<float*>(a.out)[lane] = t[0];
+        return;
+    }
+#elif defined(HVX_LAB_X3_EPI) && HVX_LAB_X3_EPI == 2
+    {   // (lab: the epilogue's instructions without its memory traffic: only row 0 is stored / read)
+        GemmArgs a2 = a;
+        a2.M = 1;
+        gemm_epilogue<float, MT, NT, WN, EPI_GENERIC, 2>(a2, acc, reinterpret_cast<float*>(Bs) + wave * ROWS_PASS * SLD, lane, m0 + wm0, 0, 0, 0);
+        return;
+    }
+#endif
     gemm_epilogue<float, MT, NT, WN, EPI_GENERIC, 2>(a, acc, reinterpret_cast<float*>(Bs) + wave * ROWS_PASS * SLD, lane, m0 + wm0, 0, 0, 0);
 }
 
