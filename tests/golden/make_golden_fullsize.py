@@ -98,6 +98,34 @@ def gen_flow_solve():
                         token=token.numpy().astype(np.int32), emb=emb.numpy(), mel=mel.numpy())
 
 
+def gen_flow_prompt():
+    """BASELINE configs[3]'s flow call at full depth: CausalMaskedDiffWithDiT.inference with a 3 s prompt (75 prompt tokens + 150 prompt mel frames, flow.py:389-430:
+    prompt tokens prepended, prompt mel as `cond`, the prompt frames cut from the result) and 1408 tokens -> flow_full_prompt.npz"""
+    c = cv3_config().flow
+    flow, dit, sd = build_ref_flow(c)
+    g = torch.Generator().manual_seed(63)
+    N, Np = 1408, 75
+    token = torch.randint(0, c.vocab, (1, N), generator=g)
+    ptoken = torch.randint(0, c.vocab, (1, Np), generator=g)
+    pfeat = torch.randn(1, 2 * Np, 80, generator=g)
+    emb = torch.randn(1, 192, generator=g)
+    t0 = time.time()
+    e = flow.spk_embed_affine_layer(F.normalize(emb, dim=1))
+    h = flow.pre_lookahead_layer(flow.input_embedding(torch.cat([ptoken, token], dim=1))).repeat_interleave(2, dim=1)
+    T = h.shape[1]
+    cond = torch.zeros(1, T, 80)
+    cond[:, :2 * Np] = pfeat
+    feat, _ = flow.decoder(mu=h.transpose(1, 2).contiguous(), mask=torch.ones(1, 1, T), spks=e, cond=cond.transpose(1, 2), n_timesteps=10, streaming=False)
+    feat = feat[:, :, 2 * Np:]
+    print('[flow-full] reference solve with a %d-token / %d-frame prompt, %d tokens (T = %d): %.0f s; mel absmax %.3f' % (Np, 2 * Np, N, T, time.time() - t0, feat.abs().max()))
+    o_feat = flow_ref.flow_inference(token, emb, sd, c, prompt_token=ptoken, prompt_feat=pfeat)
+    d = (o_feat - feat).abs().max().item()
+    assert d < 2e-3, d
+    print('[flow-full] oracle-reference max abs diff %.1e' % d)
+    np.savez_compressed(os.path.join(HERE, 'flow_full_prompt.npz'), weight_seed=np.int64(1987), weight_sha=np.array(MG.state_checksum(sd)),
+                        token=token.numpy().astype(np.int32), ptoken=ptoken.numpy().astype(np.int32), pfeat=pfeat.numpy(), emb=emb.numpy(), mel=feat.numpy())
+
+
 def build_ref_hift(c, seed_w=1988, seed_t=9):
     from cosyvoice.hifigan.generator import CausalHiFTGenerator
     from cosyvoice.hifigan.f0_predictor import CausalConvRNNF0Predictor
@@ -276,8 +304,8 @@ def gen_denoiser_normal():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['flow_est', 'flow_solve', 'hift', 'llm', 'single', 'denoiser_normal']
+    which = sys.argv[1:] or ['flow_est', 'flow_solve', 'hift', 'llm', 'single', 'denoiser_normal', 'flow_prompt']
     for w in which:
         t0 = time.time()
-        {'flow_est': gen_flow_est, 'flow_solve': gen_flow_solve, 'hift': gen_hift, 'llm': gen_llm, 'single': gen_single, 'denoiser_normal': gen_denoiser_normal}[w]()
+        {'flow_est': gen_flow_est, 'flow_solve': gen_flow_solve, 'hift': gen_hift, 'llm': gen_llm, 'single': gen_single, 'denoiser_normal': gen_denoiser_normal, 'flow_prompt': gen_flow_prompt}[w]()
         print('== %s done in %.0f s' % (w, time.time() - t0))

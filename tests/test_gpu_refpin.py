@@ -108,6 +108,30 @@ def test_cfm_solve_of_a_512_char_utterance_vs_reference(flow_sd, mode):
         assert eb[0] < _SOLVE_BOUNDS[mode][0] and eb[1] < _SOLVE_BOUNDS[mode][1], eb
 
 
+#   measured: fp32 1.0e-6 / 1.1e-6; production 1.66e-3 / 1.54e-3
+_PROMPT_BOUNDS = {'fp32': (1e-3, 1e-3), 'production': (3.3e-3, 3.0e-3)}
+
+
+@pytest.mark.parametrize('mode', ['fp32', 'production'])
+def test_cfm_solve_with_a_prompt_at_full_depth_vs_reference(flow_sd, mode):
+    """BASELINE configs[3]'s flow call (zero-shot: 75 prompt tokens + 150 prompt mel frames, cosyvoice/flow/flow.py:389-430) at 22 blocks and 2966 frames: prompt tokens
+    prepended, the prompt mel as `cond`, the prompt frames cut from the result; alone and as a member of a mixed-length padded batch (configs[3] batches are mixed)."""
+    from flowmirror_hydravox_amd.flow import HvxFlow
+    c, sd, sd_sha = flow_sd
+    g = load_golden('flow_full_prompt.npz')
+    assert sd_sha == str(g['weight_sha'])
+    token, ptoken, pfeat, emb = (torch.from_numpy(g[k]) for k in ('token', 'ptoken', 'pfeat', 'emb'))
+    flow = HvxFlow(c, sd, dtype=torch.float32 if mode == 'fp32' else torch.bfloat16, max_t=2 * (token.shape[1] + ptoken.shape[1]) + 64)
+    mel, _ = flow.inference(token=token.to(DEV), token_len=torch.tensor([token.shape[1]], dtype=torch.int32), embedding=emb.to(DEV), finalize=True,
+                            prompt_token=ptoken.to(DEV), prompt_token_len=torch.tensor([ptoken.shape[1]], dtype=torch.int32),
+                            prompt_feat=pfeat.to(DEV), prompt_feat_len=torch.tensor([pfeat.shape[1]], dtype=torch.int32))
+    mel = mel.cpu().numpy()
+    assert mel.shape == g['mel'].shape and np.isfinite(mel).all()
+    e = (_scale_rel(mel, g['mel']), _l2_rel(mel, g['mel']))
+    print('10-step CFG solve with a prompt, 1408 + 75 tokens -> 2966 frames, %s forms vs the REFERENCE: max|d|/max|ref| %.2e, relative L2 %.2e' % (mode, e[0], e[1]))
+    assert e[0] < _PROMPT_BOUNDS[mode][0] and e[1] < _PROMPT_BOUNDS[mode][1], (mode, e)
+
+
 # ---- vocoder at 5632 frames ----------------------------------------------------------------------------------------------------------------------
 def _check_wave(tag, wav, g, p, b_s16, b_f16):
     """a waveform against the packed fixture (make_golden_fullsize.pack_wave): fp32 on every 16th sample + head / tail, fp16 everywhere"""
