@@ -4,8 +4,10 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-# (HVX_LIB_PATH: lab builds only — A / B of compiler flags on the same box; the product always loads the in-tree libhvx.so)
+# (HVX_LIB_PATH: lab builds only — A / B of compiler flags on the same box, `python -m flowmirror_hydravox_amd.build --lab NAME` prints the path to put here; the
+# product always loads the in-tree libhvx.so, and load() refuses a library built with -DHVX_LAB unless it was named this way)
 LIB_PATH = os.environ.get('HVX_LIB_PATH') or os.path.join(HERE, 'libhvx.so')
+LIB_EXPLICIT = bool(os.environ.get('HVX_LIB_PATH'))
 
 F32, BF16 = 0, 1
 
@@ -84,7 +86,7 @@ class HiftConfig(C.Structure):
                 ('src_rb_kernels', c_i32 * 4), ('src_rb_dils', (c_i32 * 3) * 4),
                 ('n_fft', c_i32), ('hop', c_i32), ('conv_pre_kernel', c_i32), ('conv_post_kernel', c_i32),
                 ('sampling_rate', c_f32), ('nsf_alpha', c_f32), ('nsf_sigma', c_f32), ('voiced_threshold', c_f32),
-                ('lrelu_slope', c_f32), ('audio_limit', c_f32)]
+                ('lrelu_slope', c_f32), ('audio_limit', c_f32), ('exact_fp32', c_i32)]
 
 
 class MatchaConfig(C.Structure):
@@ -94,7 +96,7 @@ class MatchaConfig(C.Structure):
 
 class HifiGanConfig(C.Structure):
     _fields_ = [('mel', c_i32), ('initial_channel', c_i32), ('n_up', c_i32), ('up_rates', c_i32 * 4), ('up_kernels', c_i32 * 4),
-                ('n_rb', c_i32), ('rb_kernels', c_i32 * 4), ('rb_dils', (c_i32 * 3) * 4)]
+                ('n_rb', c_i32), ('rb_kernels', c_i32 * 4), ('rb_dils', (c_i32 * 3) * 4), ('exact_fp32', c_i32)]
 
 
 class NdDesc(C.Structure):
@@ -106,6 +108,11 @@ SYMBOLS = {
     'hvx_abi_version': (c_i32, []),
     'hvx_last_error': (C.c_char_p, []),
     'hvx_device_ok': (c_i32, []),
+    'hvx_set_option': (c_i32, [C.c_char_p, c_i64]),
+    'hvx_get_option': (c_i32, [C.c_char_p, C.POINTER(c_i64)]),
+    'hvx_option_name': (C.c_char_p, [c_i32, C.POINTER(c_i32), C.POINTER(c_i64)]),
+    'hvx_build_flags': (C.c_char_p, []),
+    'hvx_is_lab_build': (c_i32, []),
     'hvx_stream_create_cu_range': (c_i32, [c_i32, c_i32, C.POINTER(c_vp)]),
     'hvx_stream_destroy': (c_i32, [c_vp]),
     'hvx_prof_enable': (c_i32, [c_i32]),
@@ -174,8 +181,9 @@ SYMBOLS = {
 }
 
 # include/hvx.h: HVX_ABI_VERSION — bumped whenever a symbol is added or an argument struct changes size / meaning (2: round 4's six symbols, larger
-# SkinnyArgs / AttnArgs, fragment-order KV cache; 3: round 5)
-HVX_ABI_VERSION = 3
+# SkinnyArgs / AttnArgs, fragment-order KV cache; 3: round 5; 4: round 6 — hvx_set_option / hvx_get_option / hvx_option_name / hvx_build_flags / hvx_is_lab_build,
+# `exact_fp32` in hvx_hift_config and hvx_hifigan_config)
+HVX_ABI_VERSION = 4
 
 _lib = None
 
@@ -209,8 +217,53 @@ def load():
             raise HvxError('libhvx.so does not export %s although its ABI version is %d; %s' % (name, got, rebuild))
         fn.restype = res
         fn.argtypes = args
+    if int(lib.hvx_is_lab_build()) and not LIB_EXPLICIT:
+        # a library compiled with -DHVX_LAB can reach timing-only kernels that store no results: never by accident
+        raise HvxError('%s was built with -DHVX_LAB (flags: %s): a lab library is loaded only when HVX_LIB_PATH names it; %s'
+                       % (LIB_PATH, (lib.hvx_build_flags() or b'').decode(), rebuild))
     _lib = lib
     return lib
+
+
+def set_option(key, value):
+    """hvx_set_option (csrc/hvx_options.h): the library's one switchboard — there are no environment variables"""
+    check(load().hvx_set_option(key.encode(), int(value)), 'hvx_set_option(%s)' % key)
+
+
+def get_option(key):
+    v = c_i64()
+    check(load().hvx_get_option(key.encode(), C.byref(v)), 'hvx_get_option(%s)' % key)
+    return int(v.value)
+
+
+def options():
+    """{name: (value, default, lab_only)} of every run-time option of the loaded library"""
+    lib, out, i = load(), {}, 0
+    while True:
+        lab, dflt = c_i32(), c_i64()
+        name = lib.hvx_option_name(i, C.byref(lab), C.byref(dflt))
+        if not name:
+            return out
+        out[name.decode()] = (get_option(name.decode()), int(dflt.value), bool(lab.value))
+        i += 1
+
+
+class option_scope:
+    """with option_scope(dec_gemm=0): ...  — sets options for the block and restores the previous values (A / B inside one process)"""
+
+    def __init__(self, **kv):
+        self.kv, self.old = kv, {}
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            self.old[k] = get_option(k)
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            set_option(k, v)
+        return False
 
 
 def check(rc, what=''):

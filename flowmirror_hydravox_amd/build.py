@@ -1,8 +1,11 @@
 """Build libhvx.so (HIP kernels + C-ABI) for gfx950 with hipcc, in-tree.
 
     python -m flowmirror_hydravox_amd.build [--force] [-j N]
+    python -m flowmirror_hydravox_amd.build --lab NAME -- -DHVX_LAB [-DHVX_LAB_GEMM_EPI=1 ...]      # a LAB library, never the product's
 
-hipcc cross-compiles without a GPU.  Objects are cached by source mtime under csrc/_build/.
+hipcc cross-compiles without a GPU.  Objects are cached under csrc/_build/ by source mtime AND by a stamp of the exact compiler command: objects built with
+other flags are rebuilt, never reused.  A lab build (extra flags) goes to its own directory and its own file, csrc/_build/lab_NAME/libhvx_lab_NAME.so, and is
+loaded only through HVX_LIB_PATH (flowmirror_hydravox_amd._lib refuses a -DHVX_LAB library found at the product's path); it never touches libhvx.so.
 """
 import os
 import subprocess
@@ -50,45 +53,76 @@ def _headers_mtime():
     return m
 
 
-def _compile(src, obj, verbose):
-    # HVX_EXTRA_FLAGS: lab builds only (e.g. -DHVX_ATTN_LAB adds timing-only variants of the DiT attention loop); never set for the shipped library
-    cmd = [_hipcc()] + FLAGS + FILE_FLAGS.get(os.path.basename(src), []) + os.environ.get('HVX_EXTRA_FLAGS', '').split() + ['-c', src, '-o', obj]
+def _command(src, obj, extra):
+    flags_text = ' '.join(extra)
+    define = ['-DHVX_BUILD_FLAGS="%s"' % flags_text.replace('"', "'")] if extra else []
+    return [_hipcc()] + FLAGS + FILE_FLAGS.get(os.path.basename(src), []) + list(extra) + define + ['-c', src, '-o', obj]
+
+
+def _compile(src, obj, verbose, extra=()):
+    cmd = _command(src, obj, extra)
     t0 = time.time()
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if verbose or r.returncode != 0:
         sys.stderr.write('[hvx build] %s  (%.1fs)\n%s' % (os.path.basename(src), time.time() - t0, r.stdout))
     if r.returncode != 0:
         raise RuntimeError('hipcc failed on %s' % src)
+    with open(obj + '.cmd', 'w') as f:                 # the stamp: what this object was built with
+        f.write(' '.join(cmd))
     return obj
 
 
-def build(force=False, jobs=None, verbose=False):
-    bdir = os.path.join(CSRC, '_build')
+def _stale(src, obj, hm, extra):
+    if not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hm):
+        return True
+    try:
+        with open(obj + '.cmd') as f:
+            return f.read() != ' '.join(_command(src, obj, extra))
+    except OSError:
+        return True                                    # an object without a stamp (an older build, a lab build of unknown flags) is never trusted
+
+
+def build(force=False, jobs=None, verbose=False, lab=None, extra=()):
+    """lab = NAME + extra flags: a separate library under csrc/_build/lab_NAME/ (returned path -> HVX_LIB_PATH); the product build takes no extra flags"""
+    extra = tuple(extra)
+    if extra and not lab:
+        raise ValueError('extra compiler flags make a LAB library: pass lab=NAME (the in-tree libhvx.so is only ever built with the product flags)')
+    if os.environ.get('HVX_EXTRA_FLAGS'):
+        raise RuntimeError('HVX_EXTRA_FLAGS is gone (it rebuilt the product library in place): use `python -m flowmirror_hydravox_amd.build --lab NAME -- FLAGS`')
+    bdir = os.path.join(CSRC, '_build') if not lab else os.path.join(CSRC, '_build', 'lab_' + lab)
+    out = OUT if not lab else os.path.join(bdir, 'libhvx_lab_%s.so' % lab)
     os.makedirs(bdir, exist_ok=True)
     hm = _headers_mtime()
     todo, objs = [], []
     for src in sources():
         obj = os.path.join(bdir, os.path.basename(src)[:-4] + '.o')
         objs.append(obj)
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hm):
+        if force or _stale(src, obj, hm, extra):
             todo.append((src, obj))
     if todo:
         jobs = jobs or min(6, os.cpu_count() or 2)
         with ThreadPoolExecutor(max_workers=jobs) as ex:
-            list(ex.map(lambda so: _compile(so[0], so[1], verbose), todo))
-    if todo or not os.path.exists(OUT):
-        cmd = [_hipcc(), '-shared', '-fPIC', '--offload-arch=' + ARCH, '-o', OUT] + objs
+            list(ex.map(lambda so: _compile(so[0], so[1], verbose, extra), todo))
+    if todo or not os.path.exists(out):
+        cmd = [_hipcc(), '-shared', '-fPIC', '--offload-arch=' + ARCH, '-o', out] + objs
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode != 0:
             sys.stderr.write(r.stdout)
             raise RuntimeError('link failed')
-    return OUT
+    return out
 
 
 if __name__ == '__main__':
-    force = '--force' in sys.argv
-    jobs = None
-    if '-j' in sys.argv:
-        jobs = int(sys.argv[sys.argv.index('-j') + 1])
+    argv = sys.argv[1:]
+    extra = []
+    if '--' in argv:
+        extra = argv[argv.index('--') + 1:]
+        argv = argv[:argv.index('--')]
+    force = '--force' in argv
+    jobs = int(argv[argv.index('-j') + 1]) if '-j' in argv else None
+    lab = argv[argv.index('--lab') + 1] if '--lab' in argv else None
     t0 = time.time()
-    print(build(force=force, jobs=jobs, verbose=True), '(%.1fs)' % (time.time() - t0))
+    path = build(force=force, jobs=jobs, verbose=True, lab=lab, extra=extra)
+    print(path, '(%.1fs)' % (time.time() - t0))
+    if lab:
+        print('lab library: export HVX_LIB_PATH=%s' % path)

@@ -384,7 +384,7 @@ __global__ void attn_combine_kernel(AttnArgs a) {
 // online-softmax loop below (FAST = false path; exercised by tests/test_gpu_ops.py::test_attention_dit_fallback_on_score_spike).
 // PRE: the query operand already carries scale * log2(e) (a.q_log2: written that way by the fused QKV epilogue, one rounding) — the MFMA
 // accumulator then starts at -m_ref and exp2 is the only arithmetic left per score.  Otherwise the scale is applied to the fp32 score.
-// LAB (tools/attn_probe.py with HVX_ATTN_LAB=n, library built with -DHVX_ATTN_LAB): timing-only variants that REMOVE one ingredient of the fast loop
+// LAB (tools/attn_probe.py with option attn_lab = n, library built with -DHVX_LAB): timing-only variants that REMOVE one ingredient of the fast loop
 // each (results are garbage): 1 no global loads / LDS stash of the next tile, 2 no barrier, 4 K / V^T fragments from registers instead of LDS,
 // 8 no exp2 / bf16 conversion, 16 no MFMA.  0 = the product.
 // NW: waves per workgroup.  4: 64 QR rows per workgroup, two workgroups per CU.  8: 128 QR rows per workgroup, ONE per CU — the same two waves per SIMD,
@@ -799,17 +799,17 @@ static int launch_t(const AttnArgs& a_in, hipStream_t s) {
         // T = 5632, 704 workgroups: 364 vs 337 us; 2816 workgroups: flow solve 441 vs 431 ms.  The rounds are not uniform enough for the
         // tail to be worth a kernel boundary.)
         const dim3 g4((a.n_rows + 255) / 256, a.heads, a.batch), g2((a.n_rows + 127) / 128, a.heads, a.batch);
-#ifdef HVX_ATTN_LAB
+#ifdef HVX_LAB
         // (NW = 8, measured on MI355X round 5: 1158 vs 1055 us at B = 8, 349 vs 275 us at B = 2 — the barrier over eight waves costs more than the halved
         // staging saves; two independent 4-wave workgroups per CU drift apart and cover each other.  Lab builds only.)
-        static const int nw8 = [] { const char* e = getenv("HVX_ATTN_NW"); return e ? atoi(e) == 8 : 0; }();
+        const int nw8 = opt(OPT_ATTN_NW) == 8;
         if (nw8 && a.n_rows >= 2048 && a.chunk <= 0 && a.q_log2) {
             const dim3 g8((a.n_rows + 511) / 512, a.heads, a.batch);
             hipLaunchKernelGGL((attn_dit_kernel<4, true, true, 0, 8>), g8, dim3(512), 0, s, a);
             prof_end(slot, s);
             return hipGetLastError() == hipSuccess ? 0 : (set_error("attention launch failed"), -1);
         }
-        static const int lab = [] { const char* e = getenv("HVX_ATTN_LAB"); return e ? atoi(e) : 0; }();
+        const int lab = (int)opt(OPT_ATTN_LAB);
         if (lab && a.n_rows >= 2048 && a.chunk <= 0 && a.q_log2) {
             switch (lab) {
                 case 1: hipLaunchKernelGGL((attn_dit_kernel<4, true, true, 1>), g4, dim3(256), 0, s, a); break;
@@ -823,7 +823,7 @@ static int launch_t(const AttnArgs& a_in, hipStream_t s) {
                 case 32: hipLaunchKernelGGL((attn_dit_kernel<4, true, true, 32>), g4, dim3(256), 0, s, a); break;
                 case 64: hipLaunchKernelGGL((attn_dit_kernel<4, true, true, 64>), g4, dim3(256), 0, s, a); break;
                 case 96: hipLaunchKernelGGL((attn_dit_kernel<4, true, true, 96>), g4, dim3(256), 0, s, a); break;
-                default: return set_error("HVX_ATTN_LAB=%d is not instantiated", lab), -1;
+                default: return set_error("option attn_lab=%d is not instantiated", lab), -1;
             }
             prof_end(slot, s);
             return hipGetLastError() == hipSuccess ? 0 : (set_error("attention launch failed"), -1);

@@ -177,7 +177,7 @@ int launch_form(const GemmArgs& a, hipStream_t s, long long min_tiles) {
     // Column groups of 4 tiles: the W panels of a group (4 x 256 rows x K bf16 = 2-4 MiB at K = 1024-2048) fit the XCD's L2; with all 8-12 column
     // tiles in one sweep W (4-6 MiB) is re-fetched through the fabric for every row tile (FETCH_SIZE 530 MB per QKV launch for 98 MB of operands).
     // Measured at M = 45056: N = 3072 330 -> 302 us, N = 2048 214 -> 204 us; N = 1024 has four column tiles anyway.
-    static const int gw_env = getenv("HVX_GEMM_BIG_GW") ? atoi(getenv("HVX_GEMM_BIG_GW")) : 4;     // (tuning knob; 0 = all columns in one group)
+    const int gw_env = (int)opt(OPT_GEMM_BIG_GW);     // (tuning option; 0 = all columns in one group)
     int gw = tiles_n;
     if (gw_env > 0 && gw_env < tiles_n && tiles_n % gw_env == 0) gw = gw_env;
     const int slot = prof_begin(PK_GEMM, 2.0 * a.M * a.N * (double)a.K * a.batch, s);
@@ -208,7 +208,7 @@ int launch_gemm_big(const GemmArgs& a, hipStream_t s) {
     if (a.dtype != DT_BF16 || !shape_ok) return 0;
     // below half a round of the 256 CUs the 128 x 128 form (2-3 workgroups per CU, four times as many tiles) balances better (measured: M = 11264,
     // N = 1024: 176 tiles tie; M = 2816: 44 tiles lose 177 vs 267 TF/s)
-    static const long long min_tiles = [] { const char* e = getenv("HVX_GEMM_BIG_MIN_TILES"); return e ? atoll(e) : 128LL; }();   // (tuning knob)
+    const long long min_tiles = opt(OPT_GEMM_BIG_MIN_TILES);   // (tuning option)
     // (launch_form<128, 32, 4> — two workgroups per CU — measured 3-10 % slower on every DiT Linear at M = 45056: flow solve 450 vs 433 ms)
     return launch_form<256, 64, 8>(a, s, min_tiles);
 }

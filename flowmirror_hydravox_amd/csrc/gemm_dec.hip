@@ -371,17 +371,12 @@ int launch_form(const SkinnyArgs& a, int gpw, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? 1 : (set_error("decode gemm launch failed"), -1);
 }
 
-int env_int(const char* name, int dflt) {
-    const char* e = getenv(name);
-    return e ? atoi(e) : dflt;
-}
-
 }  // namespace
 
 // The instantiations cover the Qwen2-0.5B backbone of HydraVox-CV3 (hidden 896 = 28 k-steps, intermediate 4864 = 8 x 19 k-steps); any other
 // shape stays on the generic kernels of gemm_skinny.hip.
 bool dec_gemm_shape_ok(int M, int N, int K, int epi, int split_k) {
-    static const bool off = env_int("HVX_DEC_GEMM", 1) == 0;          // (A / B switch for tools/bench_decode.py and the parity tests)
+    const bool off = opt(OPT_DEC_GEMM) == 0;          // (option dec_gemm: A / B switch for tools/bench_decode.py and the parity tests)
     // (rows come in chunks of 64 per workgroup: 33..128 rows are the two-chunk geometry the lab tuned; up to 256 rows — 128 sequences x 2 heads — the
     // weights are read once per chunk from the XCD's L2)
     if (off || M <= 32 || M > 256 || (N & 15) || (K & 31)) return false;
@@ -413,9 +408,8 @@ int launch_dec_gemm(const SkinnyArgs& a_in, hipStream_t s) {
     // column groups per workgroup (tools/dec_lab.hip, 128 rows): one tile for the two narrow projections (72 / 56 tiles x 2 row chunks), three
     // (gate, up) pairs for the MLP (102 x 2 workgroups: the activation re-reads of more, smaller workgroups cost more than the idle CUs), two
     // pairs of tiles per K slice for the down projection (14 x 8 x 2)
-    static const int gpw_qkv = env_int("HVX_DEC_GPW_QKV", 1), gpw_res = env_int("HVX_DEC_GPW_RES", 1), gpw_mlp = env_int("HVX_DEC_GPW_MLP", 3),
-                     gpw_down = env_int("HVX_DEC_GPW_DOWN", 2), gpw_out = env_int("HVX_DEC_GPW_OUT", 3),
-                     gpw_hmlp = env_int("HVX_DEC_GPW_HMLP", 11);
+    const int gpw_qkv = (int)opt(OPT_DEC_GPW_QKV), gpw_res = (int)opt(OPT_DEC_GPW_RES), gpw_mlp = (int)opt(OPT_DEC_GPW_MLP),
+              gpw_down = (int)opt(OPT_DEC_GPW_DOWN), gpw_out = (int)opt(OPT_DEC_GPW_OUT), gpw_hmlp = (int)opt(OPT_DEC_GPW_HMLP);       // (lab options: the defaults are the tuned values)
     switch (a.epi) {
         case SK_QKV_ROPE:
             if (a.N != (a.q_heads + 2 * a.kv_heads) * 64) return set_error("launch_dec_gemm: QKV width %d != (q+2kv)*64", a.N), -1;

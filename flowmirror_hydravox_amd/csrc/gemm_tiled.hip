@@ -268,7 +268,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
     }
     const int x3 = launch_gemm_x3(a, s);                   // fp32 operands split into bf16 pairs (gemm_x3.hip), where the caller allows it
     if (x3) return x3 < 0 ? -1 : 0;
-    static const int resident = getenv("HVX_CONV_RESIDENT") ? atoi(getenv("HVX_CONV_RESIDENT")) : 1;      // (A/B switch)
+    const int resident = (int)opt(OPT_CONV_RESIDENT);      // (A/B option conv_resident)
     const int rc = resident ? launch_conv_resident(a, s) : 0;   // 64-channel-per-group bf16 convolutions with their input rows resident in LDS
     if (rc) return rc < 0 ? -1 : 0;
     const int big = launch_gemm_big(a, s);                 // the 256 x 256 tile form takes the large bf16 Linears (gemm_big.hip)

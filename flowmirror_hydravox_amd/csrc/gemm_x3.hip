@@ -523,7 +523,7 @@ int launch_gemm_x3(const GemmArgs& a, hipStream_t s) {
         // plane pairs cannot fall back to an fp32 kernel: every shape takes one of the two tile forms
         if (!a.a_planes || !a.w_planes || a.dtype != DT_F32 || a.epi != EPI_GENERIC) return set_error("gemm (plane-pair form): both operands must be plane pairs of an fp32 generic-epilogue GEMM"), -1;
         if ((a.lda & 7) || (a.a_plane & 7) || (a.w_plane & 7)) return set_error("gemm (plane-pair form): 16-byte alignment"), -1;
-        static const int resident = getenv("HVX_CONV64_RESIDENT") ? atoi(getenv("HVX_CONV64_RESIDENT")) : 1;      // (A/B switch)
+        const int resident = (int)opt(OPT_CONV64_RESIDENT);      // (A/B option conv64_resident)
         if (resident && a.N <= 64 && a.cin_pad == 64 && a.conv_stride == 1 && a.up == 1 && a.groups == 1 && a.batch == 1 && a.M >= 4096 &&
             128 + (a.K / 64 - 1) * a.conv_dil <= 192) {
             const int slot = prof_begin(PK_GEMM_F32, 2.0 * a.M * a.N * (double)a.K, s);
@@ -534,7 +534,7 @@ int launch_gemm_x3(const GemmArgs& a, hipStream_t s) {
             return hipGetLastError() == hipSuccess ? 1 : (set_error("conv (resident-row plane-pair form) launch failed"), -1);
         }
         if (a.N <= 64) return launch_cfg_p<128, 64, 32, 64>(a, s);
-        static const int x3p8 = getenv("HVX_X3P8") ? atoi(getenv("HVX_X3P8")) : 1;                                  // (A/B switch)
+        const int x3p8 = (int)opt(OPT_X3P8);                                  // (A/B option x3p8)
         if (x3p8 && (a.K & 63) == 0 && (a.cin_pad & 63) == 0) {
             dim3 grid((a.M + 127) / 128, (a.N + 127) / 128, a.batch * a.groups);
             const int slot = prof_begin(PK_GEMM_F32, 2.0 * a.M * a.N * (double)a.K * a.batch * a.groups, s);

@@ -9,6 +9,7 @@
 
 #include "hvx.h"
 #include "hvx_kernels.h"
+#include "hvx_options.h"
 
 namespace hvx {
 static thread_local char g_err[512] = "";
@@ -54,6 +55,34 @@ void prof_end(int slot, hipStream_t s) {
     std::lock_guard<std::mutex> lk(g_prof.mu);
     if ((size_t)slot < g_prof.slots.size()) hipEventRecord(g_prof.slots[slot].e1, s);      // (a slot of a session that was reset meanwhile is dropped)
 }
+
+// ---- run-time options (hvx_options.h) ---------------------------------------------------------------------------------------
+const OptDef g_opt_defs[OPT_COUNT] = {
+    {"att_chunk", 0, 0}, {"att_waves", 8, 0}, {"gemm_big_gw", 4, 0}, {"gemm_big_min_tiles", 128, 0}, {"dec_gemm", 1, 0}, {"dec_heads", 3, 0},
+    {"conv_resident", 1, 0}, {"conv64_resident", 1, 0}, {"x3p8", 1, 0}, {"rb_fused", 1, 0}, {"attn_dit_form", 0, 0},
+    {"head_down_split", 0, 1}, {"dec_gpw_qkv", 1, 1}, {"dec_gpw_res", 1, 1}, {"dec_gpw_mlp", 3, 1}, {"dec_gpw_down", 2, 1}, {"dec_gpw_out", 3, 1}, {"dec_gpw_hmlp", 11, 1},
+    {"attn_lab", 0, 1}, {"attn_nw", 4, 1},
+};
+static std::atomic<long long> g_opt_val[OPT_COUNT];
+static std::atomic<bool> g_opt_init{false};
+static std::mutex g_opt_mu;
+static void opt_init() {
+    if (g_opt_init.load(std::memory_order_acquire)) return;
+    std::lock_guard<std::mutex> lk(g_opt_mu);
+    if (g_opt_init.load(std::memory_order_relaxed)) return;
+    for (int i = 0; i < OPT_COUNT; ++i) g_opt_val[i].store(g_opt_defs[i].dflt, std::memory_order_relaxed);
+    g_opt_init.store(true, std::memory_order_release);
+}
+long long opt(OptId id) {
+    opt_init();
+    return g_opt_val[id].load(std::memory_order_relaxed);
+}
+static int opt_find(const char* key) {
+    if (key)
+        for (int i = 0; i < OPT_COUNT; ++i)
+            if (strcmp(key, g_opt_defs[i].name) == 0) return i;
+    return -1;
+}
 }  // namespace hvx
 
 using namespace hvx;
@@ -62,6 +91,46 @@ extern "C" {
 
 int hvx_abi_version(void) { return HVX_ABI_VERSION; }
 const char* hvx_last_error(void) { return g_err; }
+
+const char* hvx_build_flags(void) {
+#ifdef HVX_BUILD_FLAGS
+    return HVX_BUILD_FLAGS;
+#else
+    return "";
+#endif
+}
+int hvx_is_lab_build(void) {
+#ifdef HVX_LAB
+    return 1;
+#else
+    return 0;
+#endif
+}
+int hvx_set_option(const char* key, int64_t value) {
+    const int i = opt_find(key);
+    if (i < 0) return set_error("hvx_set_option: unknown option '%s'", key ? key : "(null)"), -1;
+#ifndef HVX_LAB
+    if (g_opt_defs[i].lab) return set_error("hvx_set_option: '%s' is a lab option; this library was built without -DHVX_LAB", key), -1;
+#endif
+    if (i == OPT_ATT_CHUNK && value != 0 && (value < 128 || value % 128)) return set_error("hvx_set_option: att_chunk must be 0 or a multiple of 128, got %lld", (long long)value), -1;
+    if (i == OPT_ATT_WAVES && value != 4 && value != 8) return set_error("hvx_set_option: att_waves must be 4 or 8, got %lld", (long long)value), -1;
+    if (i == OPT_ATTN_DIT_FORM && value != 0 && value != 16 && value != 32) return set_error("hvx_set_option: attn_dit_form must be 0, 16 or 32, got %lld", (long long)value), -1;
+    opt_init();
+    g_opt_val[i].store(value, std::memory_order_relaxed);
+    return 0;
+}
+int hvx_get_option(const char* key, int64_t* value) {
+    const int i = opt_find(key);
+    if (i < 0 || !value) return set_error("hvx_get_option: unknown option '%s'", key ? key : "(null)"), -1;
+    *value = opt((OptId)i);
+    return 0;
+}
+const char* hvx_option_name(int32_t index, int32_t* lab_only, int64_t* dflt) {
+    if (index < 0 || index >= OPT_COUNT) return nullptr;
+    if (lab_only) *lab_only = g_opt_defs[index].lab;
+    if (dflt) *dflt = g_opt_defs[index].dflt;
+    return g_opt_defs[index].name;
+}
 
 int hvx_device_ok(void) {
     int n = 0;

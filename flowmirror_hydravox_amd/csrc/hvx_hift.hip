@@ -85,12 +85,11 @@ GemmArgs conv(int M, int N, int taps, int cin_pad, const float* A, int lda, int 
     return g;
 }
 
-// decode-path convolutions: fp32 operands as bf16 pairs on the bf16 matrix cores (gemm_x3.hip, ~1e-6 relative; HVX_HIFT_FP32_MFMA=1 keeps the
-// exact fp32 MFMA form).  The F0 predictor (hvx_hift_f0) always stays exact: its output is integrated into the harmonic phase.
-GemmArgs conv3(int M, int N, int taps, int cin_pad, const float* A, int lda, int rows_in, const float* W, const float* bias) {
-    static const int allow = getenv("HVX_HIFT_FP32_MFMA") ? 0 : 1;
+// decode-path convolutions: fp32 operands as bf16 pairs on the bf16 matrix cores (gemm_x3.hip, ~1e-6 relative); hvx_hift_config.exact_fp32 keeps the
+// exact fp32 MFMA form (x3 = false).  The F0 predictor (hvx_hift_f0) always stays exact: its output is integrated into the harmonic phase.
+GemmArgs conv3(bool x3, int M, int N, int taps, int cin_pad, const float* A, int lda, int rows_in, const float* W, const float* bias) {
     GemmArgs g = conv(M, N, taps, cin_pad, A, lda, rows_in, W, bias);
-    g.x3 = allow;
+    g.x3 = x3 ? 1 : 0;
     return g;
 }
 
@@ -98,6 +97,7 @@ struct WCursor {
     const void* const* w;
     int n, i = 0;
     const void* const* wp = nullptr;        // plane pairs, parallel to w (or null)
+    bool x3 = true;                         // split-bf16 convolutions (false: hvx_hift_config.exact_fp32)
     const float* next() { return (const float*)(i < n ? w[i++] : (i++, nullptr)); }
     const void* planes_of_last() const { return (wp && i >= 1 && i <= n) ? wp[i - 1] : nullptr; }
 };
@@ -121,6 +121,7 @@ void out2_planes(GemmArgs& g, long long plane) { g.out2_planes = 1; g.out2_plane
 int resblock(hipStream_t s, WCursor& wc, bool pp, int L, int C, int k, const int* dils, const float* x_raw, const float* x_act, float* t1,
              float* curA, float* curB, float* actA, float* actB, float* out, const float* res2, float div, float* out2, int act2, float act2_param) {
     const int Cp = pad32(C);
+    const bool x3 = wc.x3;
     const long long plane = (long long)L * Cp;
     const float* w1[3]; const float* b1[3]; const float* w2[3]; const float* b2[3]; const float* a1[3]; const float* a2[3];
     const void* p1[3]; const void* p2[3];
@@ -134,13 +135,13 @@ int resblock(hipStream_t s, WCursor& wc, bool pp, int L, int C, int k, const int
     float* raw_bufs[2] = {curA, curB};
     float* act_bufs[2] = {actA, actB};
     for (int d = 0; d < 3; ++d) {
-        GemmArgs g = pp ? convp(L, C, k, Cp, cur_act, plane, Cp, L, p1[d], b1[d]) : conv3(L, C, k, Cp, cur_act, Cp, L, w1[d], b1[d]);
+        GemmArgs g = pp ? convp(L, C, k, Cp, cur_act, plane, Cp, L, p1[d], b1[d]) : conv3(x3, L, C, k, Cp, cur_act, Cp, L, w1[d], b1[d]);
         g.conv_dil = dils[d]; g.pad_left = (k - 1) * dils[d];
         g.act = ACT_SNAKE; g.act_alpha = a2[d];
         g.out = t1; g.out_f32 = 1; g.ldo = Cp; g.out_cols = Cp;
         if (pp) out_planes(g, plane);
         HVX_CHECK(launch_gemm(g, s));
-        g = pp ? convp(L, C, k, Cp, t1, plane, Cp, L, p2[d], b2[d]) : conv3(L, C, k, Cp, t1, Cp, L, w2[d], b2[d]);
+        g = pp ? convp(L, C, k, Cp, t1, plane, Cp, L, p2[d], b2[d]) : conv3(x3, L, C, k, Cp, t1, Cp, L, w2[d], b2[d]);
         g.pad_left = k - 1;
         g.res = cur; g.ldres = Cp;
         if (d < 2) {
@@ -256,8 +257,9 @@ static int decode_impl(hvx_hift* h, hvx_stream stream, void* ws, size_t ws_bytes
     wc.i = 14;                                           // skip f0 predictor (12) + source linear (2)
     wc.wp = h->wp.data();
     // plane-pair dataflow (see resblock): on when the caller handed over weight planes and the split-bf16 form is allowed
-    static const int allow_x3 = getenv("HVX_HIFT_FP32_MFMA") ? 0 : 1;
-    bool pp = allow_x3 != 0;
+    const bool x3 = c.exact_fp32 == 0;
+    wc.x3 = x3;
+    bool pp = x3;
     {
         bool any = false;
         for (const void* p : h->wp) any = any || p != nullptr;
@@ -277,7 +279,7 @@ static int decode_impl(hvx_hift* h, hvx_stream stream, void* ws, size_t ws_bytes
         const float* W = wc.next();
         const float* bias = wc.next();
         const int C0 = c.base_channels;
-        GemmArgs g = conv3(T, C0, c.conv_pre_kernel, melp, b.melT, melp, T_in, W, bias);
+        GemmArgs g = conv3(x3, T, C0, c.conv_pre_kernel, melp, b.melT, melp, T_in, W, bias);
         g.act = ACT_LRELU; g.act_param = c.lrelu_slope;
         g.out = xin; g.out_f32 = 1; g.ldo = pad32(C0); g.out_cols = pad32(C0);
         if (pp) out_planes(g, (long long)T * pad32(C0));
@@ -313,9 +315,9 @@ static int decode_impl(hvx_hift* h, hvx_stream stream, void* ws, size_t ws_bytes
             const int d = down[i];
             GemmArgs g;
             if (d == 1) {
-                g = conv3((int)L, C, 1, 32, b.spec, 32, frames, sdW, sdB);
+                g = conv3(x3, (int)L, C, 1, 32, b.spec, 32, frames, sdW, sdB);
             } else {
-                g = conv3((int)L, C, 2 * d, 32, b.spec, 32, frames, sdW, sdB);
+                g = conv3(x3, (int)L, C, 2 * d, 32, b.spec, 32, frames, sdW, sdB);
                 g.conv_stride = d; g.pad_left = d - 1;
             }
             g.out = sd_raw; g.out_f32 = 1; g.ldo = Cp; g.out_cols = Cp;
@@ -330,7 +332,7 @@ static int decode_impl(hvx_hift* h, hvx_stream stream, void* ws, size_t ws_bytes
         float* x_raw = P[2];
         {
             const int Cpp = pad32(Cprev);
-            GemmArgs g = pp ? convp((int)Lup, C, ku, Cpp, xin, Lprev * Cpp, Cpp, (int)Lprev, upP, upB) : conv3((int)Lup, C, ku, Cpp, xin, Cpp, (int)Lprev, upW, upB);
+            GemmArgs g = pp ? convp((int)Lup, C, ku, Cpp, xin, Lprev * Cpp, Cpp, (int)Lprev, upP, upB) : conv3(x3, (int)Lup, C, ku, Cpp, xin, Cpp, (int)Lprev, upW, upB);
             g.up = u; g.pad_left = ku - 1;
             g.res = si; g.ldres = Cp;
             g.out = x_raw; g.out_f32 = 1; g.ldo = Cp; g.out_cols = Cp;
@@ -368,7 +370,7 @@ static int decode_impl(hvx_hift* h, hvx_stream stream, void* ws, size_t ws_bytes
         const int Cpp = pad32(Cprev);
         if (pp && !Wp) return set_error("hvx_hift_decode: conv_post has no weight planes"), -1;
         GemmArgs g = pp ? convp((int)Lprev, c.n_fft + 2, c.conv_post_kernel, Cpp, xin, Lprev * Cpp, Cpp, (int)Lprev, Wp, bias)
-                        : conv3((int)Lprev, c.n_fft + 2, c.conv_post_kernel, Cpp, xin, Cpp, (int)Lprev, W, bias);
+                        : conv3(x3, (int)Lprev, c.n_fft + 2, c.conv_post_kernel, Cpp, xin, Cpp, (int)Lprev, W, bias);
         g.pad_left = c.conv_post_kernel - 1;
         g.out = b.post; g.out_f32 = 1; g.ldo = 32; g.out_cols = 32;
         HVX_CHECK(launch_gemm(g, s));

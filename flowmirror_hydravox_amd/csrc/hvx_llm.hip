@@ -79,10 +79,9 @@ namespace {
 
 constexpr int MAX_SPLIT = 16;
 // keys per decode-attention split (one workgroup); its 4 waves take a quarter each and merge in LDS.  256 on the whole chip; a decode engine confined
-// to a few compute units (hvx_stream_create_cu_range) wants fewer, longer workgroups (HVX_ATT_CHUNK, a multiple of 128)
-// (lab switch; an invalid value is ignored as a whole: neither the chunk nor the wide-grid doubling changes)
+// to a few compute units (hvx_stream_create_cu_range) wants fewer, longer workgroups (option att_chunk, a multiple of 128; hvx_set_option refuses anything else)
 static int att_chunk_env_value() {
-    static const int v = [] { const char* e = getenv("HVX_ATT_CHUNK"); const int c = e ? atoi(e) : 0; return (c >= 128 && c % 128 == 0) ? c : 0; }();
+    const int v = (int)opt(OPT_ATT_CHUNK);              // (validated by hvx_set_option: 0 or a multiple of 128)
     return v;
 }
 static bool att_chunk_from_env() { return att_chunk_env_value() != 0; }
@@ -429,7 +428,7 @@ static int forward_impl(hvx_llm* h, hipStream_t s, int32_t n_seq, int32_t kn, co
             // bf16 only: the fp32 parity mode keeps ONE summation order (256-key splits) at every grid width, like the heads' down projection below
             const int chunk = (n_seq >= 32 && dt == DT_BF16 && !att_chunk_from_env()) ? 2 * h->att_chunk : h->att_chunk;
             // ... and eight waves per split there (bf16, one query tile): one 64-key trip per wave, every load of the split in flight at once
-            static const int att_waves = [] { const char* e = getenv("HVX_ATT_WAVES"); return e ? atoi(e) : 8; }();
+            const int att_waves = (int)opt(OPT_ATT_WAVES);
             const int nsub = (n_seq >= 32 && dt == DT_BF16 && G * kn <= 16 && att_waves == 8 && chunk % 256 == 0) ? 8 : 4;
             at.n_splits = (h->max_ctx + chunk - 1) / chunk; at.split_chunk = chunk; at.n_sub = nsub; at.sub_chunk = chunk / nsub; at.part_o = h->att_o; at.part_ml = h->att_ml; at.n_rows_pad = h->att_rows_pad;
         } else {
@@ -493,7 +492,7 @@ static int forward_impl(hvx_llm* h, hipStream_t s, int32_t n_seq, int32_t kn, co
     // wide bf16 grids (33..256 sequences): the heads' gate / up projection takes the weight-ring form (gemm_dec.hip), every head its own fragment-order
     // matrix of S16 rows written by this reduce
     const int S16 = (S + 15) / 16 * 16;
-    static const int heads_dec = [] { const char* e = getenv("HVX_DEC_HEADS"); return e ? atoi(e) : 3; }();      // A / B switch: bit 0 = MLP, bit 1 = output projection
+    const int heads_dec = (int)opt(OPT_DEC_HEADS);      // A / B option dec_heads: bit 0 = MLP, bit 1 = output projection
     const bool dec_mlp = (heads_dec & 1) && dt == DT_BF16 && dec_gemm_shape_ok(S, 2 * I, H, SK_SWIGLU, 1);
     hn.y_frag = dec_mlp; hn.y_frag_zrows = dec_mlp ? S16 : 0;
     if (launch_reduce_rmsnorm(hn, s)) return -1;
@@ -517,7 +516,7 @@ static int forward_impl(hvx_llm* h, hipStream_t s, int32_t n_seq, int32_t kn, co
     {   // wide grids (the mid-M form, 33..128 rows): a workgroup walks its K slice serially, and pick_split's 3 slices leave 84 workgroups to pull
         // 39 MB per head (57 us for two heads); 8 slices of ~43 K-tiles: 30 us (decode step 1.314 -> 1.287 ms at 64 sequences; 6 / 12 / 16 slices
         // 1.293 / 1.292 / 1.292).  bf16 only: the fp32 parity mode keeps its summation order.
-        static const int force = [] { const char* e = getenv("HVX_HEAD_DOWN_SPLIT"); return e ? atoi(e) : 0; }();
+        const int force = (int)opt(OPT_HEAD_DOWN_SPLIT);        // (lab option)
         int want = dt != DT_BF16 ? 0 : (force > 0 ? force : (I / 64 / 12 >= 8 ? 8 : 0));          // (the lab override too: never in the fp32 mode)
         if (want > MAX_SPLIT) want = MAX_SPLIT;
         if (want > g.split_k && S > 32 && S <= 128) { g.split_k = want; g.part_zs = (long long)g.split_k * S * H; }

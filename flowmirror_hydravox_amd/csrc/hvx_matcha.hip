@@ -61,11 +61,10 @@ GemmArgs conv(int M, int N, int taps, int cin_pad, const void* A, int lda, int r
     return g;
 }
 // the HiFi-GAN v1 generator's convolutions: fp32 operands split into bf16 pairs on the bf16 matrix cores (gemm_x3.hip, ~4e-6 of the output scale,
-// the reference's contract here is 1e-3); HVX_HIFT_FP32_MFMA=1 keeps the exact fp32 MFMA form, as for the HiFT vocoder
-GemmArgs convx(int M, int N, int taps, int cin_pad, const void* A, int lda, int rows_in, const void* W, const float* bias) {
-    static const int allow = getenv("HVX_HIFT_FP32_MFMA") ? 0 : 1;
+// the reference's contract here is 1e-3); hvx_hifigan_config.exact_fp32 keeps the exact fp32 MFMA form (x3 = false), as for the HiFT vocoder
+GemmArgs convx(bool x3, int M, int N, int taps, int cin_pad, const void* A, int lda, int rows_in, const void* W, const float* bias) {
     GemmArgs g = conv(M, N, taps, cin_pad, A, lda, rows_in, W, bias);
-    g.x3 = allow;
+    g.x3 = x3 ? 1 : 0;
     return g;
 }
 void batched(GemmArgs& g, int B, long long a_bs, long long out_bs) {
@@ -372,6 +371,7 @@ int gen_expected_weights(const hvx_hifigan_config& c) { return 2 + c.n_up * (2 +
 
 int generator_core(const hvx_hifigan* h, hipStream_t s, GBufs& b, const float* mel, int T, float* wav) {
     const hvx_hifigan_config& c = h->c;
+    const bool x3 = c.exact_fp32 == 0;
     WCursor wc{h->w.data()};
     const int melp = pad32(c.mel);
     HIP_OK(hipMemsetAsync(b.melT, 0, (size_t)T * melp * 4, s));
@@ -379,7 +379,7 @@ int generator_core(const hvx_hifigan* h, hipStream_t s, GBufs& b, const float* m
     // conv_pre k7 p3; only lrelu(x, 0.1) is consumed (models.py:183-185)
     const void* w0 = wc.next(); const float* b0 = wc.nextf();
     int C = c.initial_channel;
-    GemmArgs g = convx(T, C, 7, melp, b.melT, melp, T, w0, b0);
+    GemmArgs g = convx(x3, T, C, 7, melp, b.melT, melp, T, w0, b0);
     g.pad_left = 3; g.act = ACT_LRELU; g.act_param = 0.1f;
     g.out = b.x_act; g.ldo = C; g.out_cols = C;
     HVX_CHECK(launch_gemm(g, s));
@@ -391,7 +391,7 @@ int generator_core(const hvx_hifigan* h, hipStream_t s, GBufs& b, const float* m
         const float* uw = wc.nextf(); const float* ub = wc.nextf();
         // ConvTranspose1d as `r` phase convolutions: output row t*r + p, taps over input rows t + c_p - (taps-1) .. t + c_p
         for (int p = 0; p < r; ++p) {
-            g = convx((int)L, Co, taps, Ci, b.x_act, Ci, (int)L, uw + (size_t)p * Co * taps * Ci, ub);
+            g = convx(x3, (int)L, Co, taps, Ci, b.x_act, Ci, (int)L, uw + (size_t)p * Co * taps * Ci, ub);
             g.pad_left = taps - 1 - (p + pd) / r;
             g.out = b.u + (size_t)p * Cop; g.ldo = r * Cop; g.out_cols = Cop;
             g.out2 = nullptr;
@@ -408,11 +408,11 @@ int generator_core(const hvx_hifigan* h, hipStream_t s, GBufs& b, const float* m
             for (int d = 0; d < 3; ++d) {
                 const int dil = c.rb_dils[j][d];
                 const void* w1 = wc.next(); const float* b1 = wc.nextf(); const void* w2 = wc.next(); const float* b2 = wc.nextf();
-                g = convx((int)L, Co, kk, Cop, xa, Cop, (int)L, w1, b1);
+                g = convx(x3, (int)L, Co, kk, Cop, xa, Cop, (int)L, w1, b1);
                 g.conv_dil = dil; g.pad_left = dil * (kk - 1) / 2; g.act = ACT_LRELU; g.act_param = 0.1f;
                 g.out = b.t1; g.ldo = Cop; g.out_cols = Cop;
                 HVX_CHECK(launch_gemm(g, s));
-                g = convx((int)L, Co, kk, Cop, b.t1, Cop, (int)L, w2, b2);
+                g = convx(x3, (int)L, Co, kk, Cop, b.t1, Cop, (int)L, w2, b2);
                 g.pad_left = (kk - 1) / 2;
                 g.res = xr; g.ldres = Cop;
                 if (d < 2) {
@@ -437,7 +437,7 @@ int generator_core(const hvx_hifigan* h, hipStream_t s, GBufs& b, const float* m
         C = Cop;                                           // the next stage reads rows of the padded width
     }
     const void* wp = wc.next(); const float* bp = wc.nextf();
-    g = convx((int)L, 1, 7, C, b.x_act, C, (int)L, wp, bp);
+    g = convx(x3, (int)L, 1, 7, C, b.x_act, C, (int)L, wp, bp);
     g.pad_left = 3; g.act = ACT_TANH;
     g.out = wav; g.ldo = 1; g.out_cols = 1;
     HVX_CHECK(launch_gemm(g, s));

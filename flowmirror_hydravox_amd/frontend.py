@@ -128,9 +128,9 @@ class HvxSpeechTokenizer:
     (`session.get_inputs()[0]` = the features [1][128][T], `[1]` = their length as int32 [1]); a graph with a single input gets the features only.
     `speech_tokenizer_v3.onnx` itself is an asset of the weights repository (not in the tree): parity with onnxruntime on it is unpinned."""
 
-    def __init__(self, onnx_model, device='cuda'):
+    def __init__(self, onnx_model, device='cuda', allow_uncovered=False):
         from .onnx_graph import OnnxRunner
-        self.runner = OnnxRunner(onnx_model, device=device)
+        self.runner = OnnxRunner(onnx_model, device=device, allow_uncovered=allow_uncovered)          # (refuses a graph outside onnx_graph.COVERED unless told otherwise)
         self.feat = HvxWhisperLogMel(128, device=device)
         self.device = torch.device(device)
 
@@ -155,9 +155,9 @@ class HvxSpeakerEncoder:
     mean subtraction (HvxKaldiFbank) -> the CAM++ ONNX graph through the device executor -> embedding float32 [1][D] (D = 192 for campplus.onnx, an
     asset that is not in the tree: parity with onnxruntime on it is unpinned)."""
 
-    def __init__(self, onnx_model, device='cuda'):
+    def __init__(self, onnx_model, device='cuda', allow_uncovered=False):
         from .onnx_graph import OnnxRunner
-        self.runner = OnnxRunner(onnx_model, device=device)
+        self.runner = OnnxRunner(onnx_model, device=device, allow_uncovered=allow_uncovered)
         self.feat = HvxKaldiFbank(80, 16000, subtract_mean=True, device=device)
         self.device = torch.device(device)
 

@@ -66,8 +66,11 @@ def pack_hift_weights(sd, cfg: HiftConfig, device):
 
 
 class HvxHift:
-    def __init__(self, cfg: HiftConfig, state_dict=None, device='cuda', tables=None, table_seed=0):
+    def __init__(self, cfg: HiftConfig, state_dict=None, device='cuda', tables=None, table_seed=0, exact_fp32=False):
+        """exact_fp32: the decode convolutions on the exact fp32 MFMA forms (hvx_hift_config.exact_fp32: the reference's fp32 vocoder arithmetic, 2.8e-5 of it at
+        5632 frames) instead of 3 bf16 MFMAs on (hi, lo) operand pairs (1.5e-4; the default, 2.2x faster).  The F0 predictor is exact fp32 either way."""
         _lib.require_gpu()
+        self.exact_fp32 = bool(exact_fp32)
         self.lib = _lib.load()
         self.cfg = cfg
         self.device = torch.device(device)
@@ -112,6 +115,7 @@ class HvxHift:
         cc.n_fft, cc.hop, cc.conv_pre_kernel, cc.conv_post_kernel = c.n_fft, c.hop, c.conv_pre_look_right + 1, 7
         cc.sampling_rate, cc.nsf_alpha, cc.nsf_sigma = c.sampling_rate, c.nsf_alpha, c.nsf_sigma
         cc.voiced_threshold, cc.lrelu_slope, cc.audio_limit = c.nsf_voiced_threshold, c.lrelu_slope, c.audio_limit
+        cc.exact_fp32 = 1 if self.exact_fp32 else 0
         assert hift_source_down_rates(c)[-1] == 1
         if self._h is not None:
             self.lib.hvx_hift_destroy(self._h)

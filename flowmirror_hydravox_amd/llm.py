@@ -392,7 +392,8 @@ class _DecodeEngine:
     sequence, its tokens are copied out and the next waiting request takes the slot over: prefill of its prefix into the slot's KV cache,
     hvx_llm_decode_join, noise at position 0 of the slot's ring — all ordered on the decode stream behind the blocks already enqueued."""
     NS = 8
-    PREFILL_GROUP = int(os.environ.get('HVX_PREFILL_GROUP', '8'))     # prefixes per grouped prefill forward (8 x 514 rows = the GEMMs' efficient range; the workspace grows with it; 1: every prefix alone — A / B)
+    PREFILL_GROUP = 8              # prefixes per grouped prefill forward, at most (8 x 514 rows = the GEMMs' efficient range; llm.prefill_group = 1: every prefix alone — A / B)
+    PREFILL_ROWS = 8 * 528         # row budget of one grouped forward: the workspace is bound for max(max_prefix, this), whatever max_prefix is — a group of n-row prefixes holds PREFILL_ROWS // n members
 
     def __init__(self, llm, n_slots, max_out, max_prefix, stream_first=False, sync_every=None, pace=None):
         import time
@@ -422,8 +423,9 @@ class _DecodeEngine:
         W = self.W
         with torch.cuda.stream(self.stream):
             # (rows for a grouped prefill: up to PREFILL_GROUP prefixes of equal length go through the backbone in ONE forward — see _prefill_group)
-            self.prefill_group = max(1, min(self.PREFILL_GROUP, S))
-            llm._bind(S, max(self.max_prefix * self.prefill_group, S * K))
+            self.prefill_group = max(1, min(int(getattr(llm, 'prefill_group', self.PREFILL_GROUP)), S))
+            self.prefill_rows = max(self.max_prefix, self.PREFILL_ROWS if self.prefill_group > 1 else 0)
+            llm._bind(S, max(self.prefill_rows, S * K))
             # ---- decode state (fixed device addresses: the step graph is captured once and replayed); every slot starts empty ------------
             self.o_tok, self.o_ctrl, self.o_hist = 0, S * K, S * K + 5 * S
             self.o_hlen, self.o_min, self.o_act = self.o_hist + S * W, self.o_hist + S * W + S, self.o_hist + S * W + 2 * S
@@ -650,9 +652,10 @@ class _DecodeEngine:
                 for i, r in batch:
                     if self._refuse(r) is None and len(r.prefix) - 1 > 256:         # (short prefixes: a single prefill is cheap, and the K-split rule of hvx_llm.hip covers kn > 256)
                         by_len.setdefault(len(r.prefix), []).append((i, r))
-                for group in by_len.values():
-                    for a in range(0, len(group), self.prefill_group):
-                        part = group[a:a + self.prefill_group]
+                for n_rows, group in by_len.items():
+                    per = max(1, min(self.prefill_group, self.prefill_rows // n_rows))     # members of one forward: the bound row budget over the prefix length
+                    for a in range(0, len(group), per):
+                        part = group[a:a + per]
                         if len(part) > 1:
                             self._prefill_group(part)
                             done.update(i for i, _ in part)

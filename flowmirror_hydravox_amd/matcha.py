@@ -212,8 +212,9 @@ class HvxMatchaCFM:
 
 
 class HvxHifiGan:
-    def __init__(self, cfg: HifiGanConfig, state_dict, device='cuda'):
+    def __init__(self, cfg: HifiGanConfig, state_dict, device='cuda', exact_fp32=False):
         _lib.require_gpu()
+        self.exact_fp32 = bool(exact_fp32)          # hvx_hifigan_config.exact_fp32: exact fp32 MFMA convolutions instead of split-bf16 pairs
         self.lib = _lib.load()
         self.cfg = cfg
         self.device = torch.device(device)
@@ -243,7 +244,7 @@ class HvxHifiGan:
                            f(conv_weight(_fold_wn_old(sd, p + 'convs2.%d' % d))), f(sd[p + 'convs2.%d.bias' % d])]
         ws += [f(conv_weight(_fold_wn_old(sd, 'conv_post'))), f(sd['conv_post.bias'])]
         self._weights = ws
-        cc = _lib.HifiGanConfig(mel=c.mel, initial_channel=c.initial_channel, n_up=len(c.upsample_rates), n_rb=nk)
+        cc = _lib.HifiGanConfig(mel=c.mel, initial_channel=c.initial_channel, n_up=len(c.upsample_rates), n_rb=nk, exact_fp32=1 if self.exact_fp32 else 0)
         for i, (u, k) in enumerate(zip(c.upsample_rates, c.upsample_kernel_sizes)):
             cc.up_rates[i], cc.up_kernels[i] = u, k
         for j, k in enumerate(c.resblock_kernel_sizes):

@@ -77,7 +77,7 @@ def _flow_prompt(u):
 class HvxPipeline:
     def __init__(self, cfg: HvxConfig, llm_sd=None, flow_sd=None, hift_sd=None, llm_dtype=torch.bfloat16, flow_dtype=torch.bfloat16,
                  device='cuda', max_batch=8, max_ctx=4096, max_t=None, seed=1986, init='normal02', hift_tables=None, sampling=None,
-                 inference_head_num=2):
+                 inference_head_num=2, hift_exact_fp32=False):
         self.cfg = cfg
         llm_sd = llm_sd if llm_sd is not None else W.make_llm_state(cfg.llm, seed=seed, init=init)
         self._llm_kw = dict(dtype=llm_dtype, device=device, max_batch=max_batch, max_ctx=max_ctx)
@@ -89,7 +89,7 @@ class HvxPipeline:
         self.flow = HvxFlow(cfg.flow, flow_sd, **self._flow_kw)
         del flow_sd
         hift_sd = hift_sd if hift_sd is not None else W.make_hift_state(cfg.hift, seed=seed + 2, init=init)
-        self._hift_kw = dict(device=device, tables=hift_tables)
+        self._hift_kw = dict(device=device, tables=hift_tables, exact_fp32=hift_exact_fp32)      # (exact_fp32: the reference's own fp32 vocoder arithmetic, hift.py)
         self.hift = HvxHift(cfg.hift, hift_sd, **self._hift_kw)
         self._acoustic = [(self.flow, self.hift)]
         # utterances of similar length that share one padded CFM solve (hvx_cfm_solve_batch): the DiT GEMMs and the attention reach their

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define HVX_ABI_VERSION 3
+#define HVX_ABI_VERSION 4
 #define HVX_F32 0
 #define HVX_BF16 1
 
@@ -42,6 +42,17 @@ int hvx_device_ok(void);
  * then never queue behind 200-900 us workgroups of the DiT GEMMs / attention.  Destroy with hvx_stream_destroy.  Returns 0 or -1. */
 int hvx_stream_create_cu_range(int32_t first_cu, int32_t n_cus, hvx_stream* out);
 int hvx_stream_destroy(hvx_stream s);
+
+/* Run-time options: the ONE switchboard of the library (csrc/hvx_options.h lists them; there are no environment variables).  An option picks between two forms of
+ * the same contract or tunes a launch geometry; it is read when a launch is decided (a captured step graph keeps what it was captured with).  Unknown key, a value
+ * out of range, or a lab option in a library built without -DHVX_LAB: -1 + hvx_last_error().  hvx_option_name enumerates them (NULL past the end).
+ * hvx_build_flags: the extra compiler flags this library was built with ("" for the shipped one); hvx_is_lab_build: 1 when built with -DHVX_LAB (timing-only
+ * kernels that do not store results may be reachable: flowmirror_hydravox_amd._lib refuses such a library unless it was named explicitly). */
+int hvx_set_option(const char* key, int64_t value);
+int hvx_get_option(const char* key, int64_t* value);
+const char* hvx_option_name(int32_t index, int32_t* lab_only, int64_t* dflt);
+const char* hvx_build_flags(void);
+int hvx_is_lab_build(void);
 
 int hvx_prof_enable(int32_t period);
 int hvx_prof_read(int32_t kind, double* sampled_ms, double* sampled_work, int64_t* n_sampled, int64_t* n_launched, double* launched_work);
@@ -284,6 +295,8 @@ typedef struct {
     int32_t src_rb_kernels[4]; int32_t src_rb_dils[4][3];
     int32_t n_fft, hop, conv_pre_kernel, conv_post_kernel;
     float sampling_rate, nsf_alpha, nsf_sigma, voiced_threshold, lrelu_slope, audio_limit;
+    int32_t exact_fp32;     /* 0: decode convolutions as 3 bf16 MFMAs on (hi, lo) operand pairs (~16 mantissa bits: 1.5e-4 of the reference at 5632 frames);
+                             * 1: on the exact fp32 MFMA forms (2.8e-5), the arithmetic of the reference's fp32 vocoder.  The F0 predictor is exact fp32 either way. */
 } hvx_hift_config;
 /* weights[]: f32, weight-norm folded, conv kernels as [Cout][tap][Cin_pad32]; consumed in the order documented in
  * flowmirror_hydravox_amd/hift.py::pack_hift_weights (f0 predictor, source linear, conv_pre, per stage: up, source_down,
@@ -350,6 +363,7 @@ typedef struct {
     int32_t mel, initial_channel;
     int32_t n_up; int32_t up_rates[4]; int32_t up_kernels[4];
     int32_t n_rb; int32_t rb_kernels[4]; int32_t rb_dils[4][3];
+    int32_t exact_fp32;     /* as hvx_hift_config.exact_fp32 */
 } hvx_hifigan_config;
 /* weights[] (f32, weight-norm folded): conv_pre W [C0][7][mel_pad32], b; per upsample: ConvTranspose phases [rate][C/2][k/rate][C], b,
  * then n_rb x 3 x (convs1 W, b, convs2 W, b); conv_post W [1][7][C], b */

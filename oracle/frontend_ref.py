@@ -15,6 +15,9 @@ from the published sources of those versions and anchored on the reference's cal
     spectrum, 80 triangular filters equally spaced on mel(f) = 1127 ln(1 + f / 700) between 20 Hz and Nyquist evaluated at the first 256
     FFT bin centres, log(max(., float32 eps)).
 
+The Slaney mel table itself (`slaney_mel_table` below) IS pinned, to the literal values librosa publishes in its own docstrings (see the function): it
+is what whisper ships as assets/mel_filters.npz and what matcha/utils/audio.py:53 builds for the prompt mel.
+
 Both are written with torch.stft / torch.fft directly — deliberately NOT in the folded-basis GEMM form the HIP path uses — so that a
 test of one against the other checks the framing, the folding and the filterbanks independently.
 """
@@ -22,6 +25,63 @@ import math
 
 import torch
 import torch.nn.functional as F
+
+
+# ---- librosa.filters.mel (htk=False, norm='slaney'): an independent float64 statement -------------------------------------------------------
+# librosa is absent from this image.  What follows is written from the formulas librosa documents (librosa.hz_to_mel / mel_to_hz / mel_frequencies /
+# filters.mel docstrings) in scalar Python floats, sharing no code with the product's vectorised flowmirror_hydravox_amd.packing.mel_filterbank, and
+# is pinned by `LIBROSA_PUBLISHED` — the literal numbers those docstrings print — in tests/test_oracle_golden.py.
+_F_SP = 200.0 / 3.0                 # Hz per mel below 1 kHz
+_MIN_LOG_HZ = 1000.0
+_MIN_LOG_MEL = _MIN_LOG_HZ / _F_SP  # = 15
+_LOGSTEP = math.log(6.4) / 27.0     # 27 log-spaced mels per factor of 6.4 above 1 kHz
+
+LIBROSA_PUBLISHED = dict(
+    hz_to_mel={60.0: 0.9, 110.0: 1.65, 220.0: 3.3, 440.0: 6.6},                                         # librosa.hz_to_mel docstring
+    mel_to_hz={1.0: 66.667, 2.0: 133.333, 3.0: 200.0, 4.0: 266.667, 5.0: 333.333},                      # librosa.mel_to_hz docstring
+    mel_frequencies_40=[0.0, 85.317, 170.635, 255.952, 341.269, 426.586, 511.904, 597.221, 682.538, 767.855, 853.173, 938.49, 1024.856, 1119.114,
+                        1222.042, 1334.436, 1457.167, 1591.187, 1737.532, 1897.337, 2071.84, 2262.393, 2470.47, 2697.686, 2945.799, 3216.731, 3512.582,
+                        3835.643, 4188.417, 4573.636, 4994.285, 5453.621, 5955.205, 6502.92, 7101.009, 7754.107, 8467.272, 9246.028, 10096.408, 11025.0],
+    #                                                                                                      librosa.mel_frequencies(n_mels=40) docstring (fmin 0, fmax 11025)
+    filters_mel_22050_2048_row0_col1=0.016,                                                             # librosa.filters.mel(sr=22050, n_fft=2048) docstring: melfb[0, 1]
+)
+
+
+def slaney_hz_to_mel(f):
+    return f / _F_SP if f < _MIN_LOG_HZ else _MIN_LOG_MEL + math.log(f / _MIN_LOG_HZ) / _LOGSTEP
+
+
+def slaney_mel_to_hz(m):
+    return _F_SP * m if m < _MIN_LOG_MEL else _MIN_LOG_HZ * math.exp(_LOGSTEP * (m - _MIN_LOG_MEL))
+
+
+def slaney_mel_frequencies(n_mels, fmin, fmax):
+    lo, hi = slaney_hz_to_mel(float(fmin)), slaney_hz_to_mel(float(fmax))
+    return [slaney_mel_to_hz(lo + (hi - lo) * i / (n_mels - 1)) for i in range(n_mels)]
+
+
+def slaney_mel_table(sr, n_fft, n_mels, fmin=0.0, fmax=None):
+    """librosa.filters.mel(sr=, n_fft=, n_mels=, fmin=, fmax=) with htk=False, norm='slaney' -> float64 tensor (n_mels, n_fft // 2 + 1): filter i is the
+    triangle over (edge[i], edge[i+1], edge[i+2]) of n_mels + 2 edges equally spaced on the Slaney mel scale, sampled at the FFT bin frequencies
+    k sr / n_fft, times 2 / (edge[i+2] - edge[i])."""
+    fmax = sr / 2.0 if fmax is None else float(fmax)
+    edges = slaney_mel_frequencies(n_mels + 2, fmin, fmax)
+    rows = []
+    for i in range(n_mels):
+        lo, ce, hi = edges[i], edges[i + 1], edges[i + 2]
+        area = 2.0 / (hi - lo)
+        row = []
+        for k in range(n_fft // 2 + 1):
+            f = k * float(sr) / n_fft
+            if lo < f <= ce:
+                w = (f - lo) / (ce - lo)
+            elif ce < f < hi:
+                w = (hi - f) / (hi - ce)
+            else:
+                w = 0.0
+            row.append(w * area)
+        rows.append(row)
+    return torch.tensor(rows, dtype=torch.float64)
 
 
 def whisper_log_mel(audio, mel_filters):

@@ -105,6 +105,8 @@ def _node(node, v, opset):
         return one[op](v[0])
     if op == 'Xor':
         return np.logical_xor(v[0], v[1])
+    if op == 'Mod':                                            # ONNX Mod, fmod = 0 (integer operands): the sign follows the divisor; fmod = 1: C fmod
+        return np.fmod(v[0], v[1]) if int(at.get('fmod', 0)) else np.mod(v[0], v[1])
     if op in ('Sum', 'Mean'):
         acc = sum(x.astype(np.float64) for x in v)
         return (acc / len(v) if op == 'Mean' else acc).astype(np.float32)

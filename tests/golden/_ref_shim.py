@@ -123,11 +123,13 @@ def install():
                 raise AttributeError(k)
     _mod('omegaconf', DictConfig=DictConfig)
 
-    # librosa (absent): matcha/utils/audio.py only needs filters.mel — the restated table of flowmirror_hydravox_amd.packing.mel_filterbank
+    # librosa (absent): matcha/utils/audio.py only needs filters.mel — the oracle's own float64 statement of the Slaney table (oracle/frontend_ref.py:
+    # scalar arithmetic pinned to the literal values of librosa's docstrings; it shares no code with the product's packing.mel_filterbank, which
+    # tests/test_oracle_golden.py::test_slaney_mel_table_is_pinned_and_the_product_table_equals_it holds to it at 1e-7)
     def _librosa_mel(sr, n_fft, n_mels, fmin, fmax):
         sys.path.insert(0, '/root/repo') if '/root/repo' not in sys.path else None
-        from flowmirror_hydravox_amd.packing import mel_filterbank
-        return mel_filterbank(sr, n_fft, n_mels, fmin, fmax).numpy()
+        from oracle.frontend_ref import slaney_mel_table
+        return slaney_mel_table(sr, n_fft, n_mels, fmin, fmax).float().numpy()
     _mod('librosa')
     _mod('librosa.filters', mel=_librosa_mel)
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Mint golden vectors AT THE BENCHMARKED SHAPES by running the REFERENCE implementation (build container only; minutes of CPU per part).
 
-    python tests/golden/make_golden_fullsize.py [flow_est] [flow_solve] [hift] [llm] [single]
+    python tests/golden/make_golden_fullsize.py [flow_est] [flow_solve] [hift] [hift_cond] [llm] [single]
 
 BASELINE.json configs[1] = 512-char utterances: 2816 speech tokens -> 5632 mel frames -> 2 703 360 samples, LM contexts 514 .. 3330 rows.  The small
 fixtures of make_golden.py stop at T = 256 (22 blocks), 160 vocoder frames and a 1100-row LM context; the kernels the benchmark actually runs
@@ -176,6 +176,80 @@ def gen_hift():
     return gen, sd, tables, mel, f0, wav, s
 
 
+def gen_hift_cond(which='full'):
+    """The REFERENCE's own conditioning number for the end-to-end vocoder output (generator.py:713-726; the ill-conditioned step is SineGen2's fp32
+    `cumsum(rad) * 2 pi`, scaled by 480, :254-260): the reference's m_source + decode are run again on the SAME mel with its f0 perturbed by what another
+    convolution summation order changes — uniform noise of +-5e-4 Hz (two draws), +-1 ulp, and the f0 predictor evaluated in fp64 — and the distance of
+    each waveform to the unperturbed one is recorded sample-wise (first second / every second / whole utterance) and under the phase-insensitive
+    distances of tests/wave_metrics.py.  A REAL error of known size (the mel perturbed by 1e-2 N(0,1); the source scaled by 1.01) is recorded under the
+    same distances, to show what they do detect.  which = 'full': the 5632-frame mel of hift_full.npz -> hift_full_cond.npz; 'single': the 704-frame mel of
+    single_cv3.npz (BASELINE configs[0]) -> single_cv3_cond.npz (scalars and per-second profiles only)."""
+    import copy
+    sys.path.insert(0, os.path.dirname(HERE))
+    import wave_metrics as WM
+    c = cv3_config().hift
+    gen, sd, tables = build_ref_hift(c)
+    if which == 'full':
+        g0 = np.load(os.path.join(HERE, 'hift_full.npz'))
+        T = int(g0['T'])
+        mel = torch.randn(1, c.mel, T, generator=torch.Generator().manual_seed(int(g0['mel_seed'])))
+        assert sha(mel) == str(g0['mel_sha'])
+        out_name = 'hift_full_cond.npz'
+    else:
+        g0 = np.load(os.path.join(HERE, 'single_cv3.npz'))
+        assert MG.state_checksum(sd) == str(g0['hift_sha'])
+        mel = torch.from_numpy(g0['mel'])
+        T = mel.shape[-1]
+        out_name = 'single_cv3_cond.npz'
+
+    def run(f0, mel_=None, gain=1.0):
+        with torch.inference_mode():
+            s = gen.f0_upsamp(f0[:, None]).transpose(1, 2)
+            s, _, _ = gen.m_source(s)
+            s = s.transpose(1, 2) * gain
+            return gen.decode(x=mel if mel_ is None else mel_, s=s, finalize=True).reshape(-1).numpy()
+
+    t0 = time.time()
+    with torch.inference_mode():
+        f0 = gen.f0_predictor(mel)
+        f0_64 = copy.deepcopy(gen.f0_predictor).double()(mel.double()).float()
+    assert np.array_equal(f0.numpy(), g0['f0'])
+    base = run(f0)
+    assert np.abs(base[::16] - g0['wav_s16']).max() == 0.0                      # the run of the fixture, reproduced bit for bit
+    print('[hift-cond %s] baseline reproduced in %.0f s; f0(fp64 predictor) - f0(fp32): max %.2e Hz' % (which, time.time() - t0, (f0_64 - f0).abs().max()))
+    gn = torch.Generator().manual_seed(4711)
+    cases = {
+        'noise_a': f0 + (torch.rand(f0.shape, generator=gn) * 2 - 1) * 5e-4,
+        'noise_b': f0 + (torch.rand(f0.shape, generator=gn) * 2 - 1) * 5e-4,
+        'ulp_up': torch.nextafter(f0, torch.full_like(f0, 1e9)),
+        'ulp_down': torch.nextafter(f0, torch.full_like(f0, -1e9)),
+        'f0_fp64': f0_64,
+    }
+    sec = 24000
+    out = dict(T=np.int32(T), f0_fp64_minus_fp32=np.float64((f0_64 - f0).abs().max()), peak=np.float64(np.abs(base).max()),
+               names=np.array(list(cases) + ['real_mel_1e-2', 'real_source_gain_1.01']))
+
+    def record(name, w):
+        d = np.abs(w - base)
+        n = (d.size // sec) * sec
+        prof = d[:n].reshape(-1, sec).max(axis=1)
+        m = WM.all_metrics(w, base)
+        out[name + '_first_second'] = np.float64(d[:sec].max())
+        out[name + '_max'] = np.float64(d.max())
+        out[name + '_l2'] = np.float64(np.linalg.norm(w - base) / np.linalg.norm(base))
+        out[name + '_per_second'] = prof.astype(np.float32)
+        for k, v in m.items():
+            out[name + '_' + k] = np.float64(v)
+        print('[hift-cond %s] %-22s sample-wise: first second %.2e, whole %.2e (L2 %.2e) | %s' %
+              (which, name, d[:sec].max(), d.max(), out[name + '_l2'], ' '.join('%s %.2e' % kv for kv in m.items())))
+
+    for name, f in cases.items():
+        record(name, run(f))
+    record('real_mel_1e-2', run(f0, mel_=mel + 1e-2 * torch.randn(mel.shape, generator=gn)))
+    record('real_source_gain_1.01', run(f0, gain=1.01))
+    np.savez_compressed(os.path.join(HERE, out_name), **out)
+
+
 def gen_llm():
     c = cv3_config().llm
     sd = W.make_llm_state(c, seed=1986, init='fan_in', with_lm_head=True)
@@ -307,5 +381,5 @@ if __name__ == '__main__':
     which = sys.argv[1:] or ['flow_est', 'flow_solve', 'hift', 'llm', 'single', 'denoiser_normal', 'flow_prompt']
     for w in which:
         t0 = time.time()
-        {'flow_est': gen_flow_est, 'flow_solve': gen_flow_solve, 'hift': gen_hift, 'llm': gen_llm, 'single': gen_single, 'denoiser_normal': gen_denoiser_normal, 'flow_prompt': gen_flow_prompt}[w]()
+        {'flow_est': gen_flow_est, 'flow_solve': gen_flow_solve, 'hift': gen_hift, 'llm': gen_llm, 'single': gen_single, 'denoiser_normal': gen_denoiser_normal, 'flow_prompt': gen_flow_prompt, 'hift_cond': gen_hift_cond, 'single_cond': lambda: gen_hift_cond('single')}[w]()
         print('== %s done in %.0f s' % (w, time.time() - t0))

@@ -139,3 +139,48 @@ def tokenizer_like(seed=1, n_mels=16, d=32, heads=4, with_length=False):
     b.nodes.append(Node('Identity', [ids], ['tokens'], {}))
     b.nodes.append(Node('Identity', [z], ['latent'], {}))
     return b.graph(['mel', 'mel_len'] if with_length else ['mel'], ['tokens', 'latent'])
+
+
+def per_operator_cases(seed=11):
+    """(operator, inputs, attributes) — one node each, evaluated on the device against oracle/onnx_ref.py by tests/test_gpu_ops.py::
+    test_onnx_per_operator_cases_vs_oracle: the operators / attributes the two synthetic graphs above do not reach.  float32 and bool inputs are device
+    values there, integer inputs stay host values (as shape arithmetic does in a real graph).  Together with the graphs this list IS the executor's covered
+    set (onnx_graph.COVERED; tests/test_host_cpu.py checks the two are equal): OnnxRunner refuses a graph that steps outside it."""
+    rng = np.random.default_rng(seed)
+    xs = rng.standard_normal((3, 5, 17)).astype(np.float32)
+    pos = (np.abs(xs) + 0.1).astype(np.float32)
+    slope = rng.standard_normal((5, 1)).astype(np.float32)
+    small = (1.0 + 0.1 * rng.standard_normal((2, 4, 3))).astype(np.float32)
+    i64 = lambda *v: np.asarray(v, np.int64)                                                                             # noqa: E731
+    x1, w1, b1 = rng.standard_normal((2, 6, 37)).astype(np.float32), rng.standard_normal((8, 3, 5)).astype(np.float32), rng.standard_normal(8).astype(np.float32)
+    x4, w4, b4 = rng.standard_normal((2, 3, 11, 9)).astype(np.float32), rng.standard_normal((4, 3, 3, 3)).astype(np.float32), rng.standard_normal(4).astype(np.float32)
+    xa1, wa1 = rng.standard_normal((2, 4, 23)).astype(np.float32), rng.standard_normal((6, 4, 4)).astype(np.float32)
+    return [
+        ('Exp', [xs], {}), ('Log', [pos], {}), ('Neg', [xs], {}), ('Abs', [xs], {}), ('Floor', [3 * xs], {}), ('Ceil', [3 * xs], {}), ('Reciprocal', [pos], {}),
+        ('Softplus', [xs], {}), ('Sin', [xs], {}), ('Cos', [xs], {}), ('Min', [xs, slope], {}), ('Max', [xs, slope, -xs], {}), ('Max', [xs, slope], {}),
+        ('Equal', [np.round(xs), np.round(slope)], {}), ('Greater', [xs, slope], {}), ('Not', [xs > 0], {}), ('And', [xs > 0, xs < 0.5], {}), ('Or', [xs > 0.5, xs < -0.5], {}),
+        ('Xor', [xs > 0, xs > 0.5], {}), ('LeakyRelu', [xs], {'alpha': 0.2}), ('Gelu', [xs], {}), ('PRelu', [xs, slope], {}), ('Elu', [xs], {'alpha': 0.7}),
+        ('HardSigmoid', [xs], {'alpha': 0.3, 'beta': 0.4}), ('Sign', [xs], {}), ('LogSoftmax', [xs], {'axis': 1}), ('Sum', [xs, slope, xs], {}), ('Mean', [xs, slope], {}),
+        ('ArgMax', [xs], {'axis': 2, 'keepdims': 0}), ('ArgMin', [xs], {'axis': 1, 'keepdims': 1}),
+        ('ReduceSum', [xs, i64(1)], {'keepdims': 0}), ('ReduceMax', [xs], {'axes': [2], 'keepdims': 1}), ('ReduceMin', [xs], {'axes': [0, 2], 'keepdims': 0}),
+        ('ReduceL2', [xs], {'axes': [1], 'keepdims': 1}), ('ReduceSumSquare', [xs], {'axes': [2], 'keepdims': 0}), ('ReduceProd', [small], {'axes': [1], 'keepdims': 1}),
+        ('GlobalAveragePool', [xs], {}), ('Flatten', [xs], {'axis': 2}), ('Tile', [xs, i64(2, 1, 3)], {}), ('Pad', [xs, i64(0, 1, 2, 0, 0, 3), np.asarray(0.5, np.float32)], {}),
+        ('Size', [xs], {}), ('Constant', [], {'value': small}), ('ConstantOfShape', [i64(2, 3)], {'value': np.asarray([1.5], np.float32)}), ('Dropout', [xs], {}),
+        ('Mod', [i64(7, -7, 9), i64(3, 3, 4)], {}), ('Split', [xs, i64(4, 6, 7)], {'axis': 2}), ('Cast', [3000.0 * xs], {'to': 10}),
+        ('Conv', [x1, w1, b1], dict(kernel_shape=[5], strides=[2], dilations=[3], pads=[4, 7], group=2)),
+        ('Conv', [x4, w4, b4], dict(kernel_shape=[3, 3], strides=[1, 1], auto_pad=b'SAME_UPPER')),
+        ('Conv', [xa1, wa1], dict(kernel_shape=[4], strides=[2], auto_pad=b'SAME_LOWER')),
+        ('AveragePool', [xa1], dict(kernel_shape=[3], strides=[1], auto_pad=b'SAME_UPPER', count_include_pad=0)),
+        ('AveragePool', [xa1], dict(kernel_shape=[4], strides=[3], pads=[1, 1], ceil_mode=1, count_include_pad=1)),
+    ]
+
+
+def covered_set():
+    """operator -> attribute names reached by the two synthetic graphs and per_operator_cases(): what the device executor is tested on against the oracle"""
+    cov = {}
+    for g in (campplus_like(), tokenizer_like(), tokenizer_like(with_length=True)):
+        for n in g.nodes:
+            cov.setdefault(n.op, set()).update(n.attrs.keys())
+    for op, _, attrs in per_operator_cases():
+        cov.setdefault(op, set()).update(attrs.keys())
+    return cov

@@ -81,8 +81,12 @@ sys.path.insert(0, sys.argv[2])
 from flowmirror_hydravox_amd import cv3_config
 from flowmirror_hydravox_amd import weights as W
 from flowmirror_hydravox_amd.hift import HvxHift
+from flowmirror_hydravox_amd import _lib
 c = cv3_config().hift
-hift = HvxHift(c, W.make_hift_state(c, seed=1988, init='fan_in'))
+mode = sys.argv[3]
+if mode == 'x3_tiled':
+    _lib.set_option('conv64_resident', 0)
+hift = HvxHift(c, W.make_hift_state(c, seed=1988, init='fan_in'), exact_fp32=(mode == 'exact'))
 g = torch.Generator().manual_seed(11)
 mel = (torch.randn(1, c.mel, 5632, generator=g) * 1.5 - 4.0).cuda()
 wav, _ = hift.inference(speech_feat=mel)
@@ -93,17 +97,16 @@ torch.save(wav.cpu(), sys.argv[1])
 def test_hift_of_a_512_char_utterance_split_bf16_convs_vs_exact_fp32_convs(tmp_path):
     """The vocoder at the bench length (5632 mel frames -> 112.6 s of audio, HiFT base 512): the production convolutions (fp32 operands as
     (hi, lo) bf16 pairs, gemm_x3.hip, with the ResBlock epilogue modes) against the exact fp32-MFMA convolutions of the same library
-    (HVX_HIFT_FP32_MFMA=1: the form the small-size tests pin to the reference).  The switch is read once per process, hence two processes."""
+    (HvxHift(exact_fp32=True) = hvx_hift_config.exact_fp32: the form the small-size tests pin to the reference), and the tiled form of the 64-channel convolutions
+    (option conv64_resident = 0).  One process per form: each holds ~6 GB of workspace."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     wavs = []
-    for name, extra in (('x3', {}), ('exact', {'HVX_HIFT_FP32_MFMA': '1'}), ('x3_tiled', {'HVX_CONV64_RESIDENT': '0'})):
+    for name in ('x3', 'exact', 'x3_tiled'):
         out = str(tmp_path / (name + '.pt'))
-        env = {k: v for k, v in os.environ.items() if k not in ('HVX_HIFT_FP32_MFMA', 'HVX_CONV64_RESIDENT')}
-        env.update(extra)
-        r = subprocess.run([sys.executable, '-c', _HIFT_SNIPPET, out, root], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+        r = subprocess.run([sys.executable, '-c', _HIFT_SNIPPET, out, root, name], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-2000:]
         wavs.append(torch.load(out))
     a, b, c = wavs
@@ -184,7 +187,7 @@ def test_llm_decode_grid_at_full_depth_vs_teacher_forced_prefill(S):
 @pytest.mark.parametrize('S,K', [(20, 2), (64, 2), (25, 4), (100, 2), (40, 4), (50, 1)])
 def test_wide_grid_decode_gemm_form_agrees_with_the_generic_kernels(S, K):
     """gemm_dec.hip (A-stationary / weight-ring GEMMs over fragment-order activations, 33..256 rows) against the generic skinny kernels on
-    row-major activations (HVX_DEC_GEMM=0): one decode step of a 2-layer CV3-width LM over a random KV cache, ragged positions and row counts
+    row-major activations (option dec_gemm = 0): one decode step of a 2-layer CV3-width LM over a random KV cache, ragged positions and row counts
     (40 rows: a partial last row tile; 128: two 64-row chunks; 100 and 200: partial chunks, three and four chunks).  The MTP heads take the form
     too from 33 sequences on — gate / up with every head's rows as its own fragment-order matrix (40 sequences: padded to 48 rows per head), the
     shared output projection over the stacked rows of all heads (from 33 ROWS on: 20 sequences x 2 heads already).  The two differ in the fp32

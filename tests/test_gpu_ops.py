@@ -581,6 +581,33 @@ def test_nd_elementwise_broadcast_strided_and_reductions():
     np.testing.assert_allclose(r._node(nd, [r._up(x1), w1, b1]).cpu().numpy(), want, rtol=1e-4, atol=1e-4)
 
 
+def test_onnx_per_operator_cases_vs_oracle():
+    """every one-node case of tests/onnx_synth.py::per_operator_cases on the device against oracle/onnx_ref.py (the operators / attributes the synthetic graphs do
+    not reach: with them these ARE onnx_graph.COVERED); and the refusal of a graph outside that set before anything runs"""
+    import onnx_synth
+    from flowmirror_hydravox_amd import onnx_graph as og
+    from oracle import onnx_ref
+    r = og.OnnxRunner(og.Graph([], {}, [], []))
+    for opn, ins, attrs in onnx_synth.per_operator_cases():
+        nd = og.Node(opn, ['i%d' % i for i in range(len(ins))], ['o%d' % i for i in range(3)] if opn == 'Split' else ['o'], attrs)
+        dev_ins = [a if np.issubdtype(a.dtype, np.integer) else r._up(a.astype(np.float32)) for a in ins]
+        got = r._node(nd, dev_ins)
+        want = onnx_ref._node(nd, ins, 17)
+        if not isinstance(got, (list, tuple)):
+            got, want = [got], [want]
+        assert len(got) == len(want), opn
+        for g1, w1 in zip(got, want):
+            g1 = g1.cpu().numpy() if torch.is_tensor(g1) else np.asarray(g1)
+            w1 = np.asarray(w1)
+            assert tuple(g1.shape) == tuple(w1.shape), (opn, g1.shape, w1.shape)
+            np.testing.assert_allclose(g1.astype(np.float64), w1.astype(np.float64), rtol=1e-4 if opn in ('Conv', 'ReduceProd') else 1e-5, atol=1e-4 if opn == 'Conv' else 2e-6,
+                                       err_msg='%s %r' % (opn, attrs))
+    bad = og.Graph([og.Node('Conv', ['x', 'w'], ['y'], {'kernel_shape': [3], 'storage_order': 1}, name='n1'), og.Node('LSTM', ['y'], ['z'], {}, name='n2')], {}, ['x'], ['z'])
+    with pytest.raises(NotImplementedError, match='Conv.storage_order, LSTM'):
+        og.OnnxRunner(bad)
+    og.OnnxRunner(bad, allow_uncovered=True)                       # (construction only: bring-up override)
+
+
 @pytest.mark.parametrize('T', [57, 200])
 def test_onnx_frontend_graphs_on_device_vs_oracle(T):
     """The two synthetic frontend graphs (tests/onnx_synth.py: the operator mix of campplus.onnx and speech_tokenizer_v3.onnx at toy widths) through the

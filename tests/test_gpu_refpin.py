@@ -152,11 +152,9 @@ def _hift_production_and_exact(snippet, tmp_path, extra_args=()):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = {}
-    for name, extra in (('x3', {}), ('exact', {'HVX_HIFT_FP32_MFMA': '1'})):
+    for name in ('x3', 'exact'):                  # (one process per form: each holds the full-size workspace; the form is hvx_hift_config.exact_fp32, no environment involved)
         out = str(tmp_path / (name + '.pt'))
-        env = {k: v for k, v in os.environ.items() if k not in ('HVX_HIFT_FP32_MFMA', 'HVX_CONV64_RESIDENT')}
-        env.update(extra)
-        r = subprocess.run([sys.executable, '-c', snippet, out, root] + list(extra_args), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+        r = subprocess.run([sys.executable, '-c', snippet, out, root, name] + list(extra_args), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-3000:]
         outs[name] = torch.load(out)
     return outs
@@ -175,7 +173,7 @@ g = np.load(sys.argv[2] + '/tests/golden/hift_full.npz')
 c = cv3_config().hift
 sd = W.make_hift_state(c, seed=int(g['weight_seed']), init='fan_in')
 tables = hift_ref.make_tables(c, seed=int(g['table_seed']))
-hift = HvxHift(c, sd, tables=tables)
+hift = HvxHift(c, sd, tables=tables, exact_fp32=(sys.argv[3] == 'exact'))
 gen = torch.Generator().manual_seed(int(g['mel_seed']))
 mel = torch.randn(1, c.mel, int(g['T']), generator=gen)
 f0_ref = torch.from_numpy(g['f0'])
@@ -185,7 +183,8 @@ f0 = hift.f0(mel[0]).cpu()
 s = hift.source(f0_ref[0]).cpu()
 wav = hift.decode(mel[0], s_ref).cpu()
 wav2, _ = hift.inference(speech_feat=mel.cuda())
-torch.save(dict(f0=f0, s=s, s_ref=s_ref, wav=wav, wav_e2e=wav2.cpu()), sys.argv[1])
+wav3 = hift.decode(mel[0], hift.source(f0_ref[0])).cpu()          # the reference's f0 -> OWN source -> OWN decode: two of the three stages chained
+torch.save(dict(f0=f0, s=s, s_ref=s_ref, wav=wav, wav_e2e=wav2.cpu(), wav_chain=wav3), sys.argv[1])
 """
 
 
@@ -212,22 +211,43 @@ def test_hift_5632_frames_vs_reference(tmp_path):
     assert l2 < _HIFT_BOUNDS['x3_l2'], l2
     l2e = _check_wave('   decode(reference source), exact fp32 convolutions vs the REFERENCE', outs['exact']['wav'], g, '', *_HIFT_BOUNDS['exact'])
     assert l2e < _HIFT_BOUNDS['exact_l2'], l2e
-    # End to end (own f0 -> own source -> decode).  The reference's phase is ILL-CONDITIONED in f0 at this length: SineGen2 accumulates rad = f0 k / 24000
-    # per frame with an fp32 cumsum and multiplies the sum by 2 pi 480 (generator.py:254-260); after n frames the sum is ~0.05 n, so ONE fp32 rounding of it
-    # is 2 pi 480 ulp(0.05 n) of phase — 7e-4 rad after 1 s, 0.09 rad after 100 s — and an f0 that differs in its last bits (5e-4 Hz of 375 here: another
-    # convolution summation order, as between two CPUs) takes a different rounding path.  So: the first second is held tightly, the rest is the same
-    # harmonics at a drifted phase (bounded by twice the signal's peak, printed); every STAGE is held tightly above with the reference's own inputs.
+    # Two stages chained: the reference's f0 -> OWN source -> OWN decode (no link of the chain is fed a reference intermediate except f0)
+    l2c = _check_wave('   decode(own source(reference f0)), split-bf16 convolutions vs the REFERENCE', o['wav_chain'], g, '', *_HIFT_BOUNDS['x3'])
+    assert l2c < _HIFT_BOUNDS['x3_l2'], l2c
+    # End to end (own f0 -> own source -> decode).  The reference's OUTPUT is ill-conditioned in its own f0 at this length: SineGen2 accumulates rad = f0 k / 24000
+    # per frame with an fp32 cumsum and multiplies the sum by 2 pi 480 (generator.py:254-260), so an f0 that differs in its LAST BIT takes another rounding path.
+    # That is a measurement, not an argument: hift_full_cond.npz (make_golden_fullsize.py hift_cond) holds the distance of the reference's waveform to ITSELF with its
+    # f0 moved by +-1 ulp, by +-5e-4 Hz of noise, and computed by its predictor in fp64 — sample-wise per second (1e-3 in the first second, > 1e-2 from second 5-10,
+    # > 0.1 from second 43-68, up to 0.37 of a 0.99 peak) and under the phase-insensitive distances of tests/wave_metrics.py (3-7e-2: with seeded weights the network
+    # is chaotic in the source phase, not merely phase-shifted).  The GPU path's own f0 differs from the reference's by 5e-4 Hz (asserted above), so its end-to-end
+    # output is held to THAT band: per second to 2x the running maximum of the reference's own self-distance (+ 1e-3: the fixture's fp16 copy), and overall to 1.5x it.
+    gc = load_golden('hift_full_cond.npz')
+    import wave_metrics as WM
+    cases = ['noise_a', 'noise_b', 'ulp_up', 'ulp_down', 'f0_fp64']
     w = o['wav_e2e'].numpy().reshape(-1)
+    ref16 = g['wav_f16'].astype(np.float32)
+    sec = 24000
+    n = (w.size // sec) * sec
+    prof = np.abs(w - ref16)[:n].reshape(-1, sec).max(axis=1)
+    env = np.maximum.accumulate(np.max([gc[c + '_per_second'] for c in cases], axis=0))
     d_first = np.abs(w[:24000] - g['wav_head'][:24000]).max()
-    d_e2e = np.abs(w[::16] - g['wav_s16']).max()
-    print('   end to end (own f0 and source): first second max |d| %.2e; whole utterance %.2e on every 16th sample (phase drift, see the comment; signal peak %.2f)'
-          % (d_first, d_e2e, np.abs(g['wav_s16']).max()))
-    assert d_first < _HIFT_BOUNDS['e2e_first_second'] and d_e2e < 2.0 * np.abs(g['wav_s16']).max(), (d_first, d_e2e)
+    l2 = _l2_rel(w[::16], g['wav_s16'])
+    m = WM.all_metrics(w, ref16)
+    worst = {k: max(float(gc[c + '_' + k]) for c in cases) for k in ('l2', 'envelope', 'stft2048_l2', 'band_energy', 'first_second', 'max')}
+    over = prof / (2.0 * env + 1e-3)
+    print('   end to end (own f0 and source): first second max |d| %.2e (the reference under its own f0 perturbations: up to %.2e); whole utterance max %.2e, L2 %.2e '
+          '(reference: %.2e, %.2e); per second at most %.2f of the bound 2 x the reference\'s own running maximum (worst second %d)'
+          % (d_first, worst['first_second'], prof.max(), l2, worst['max'], worst['l2'], over.max(), int(over.argmax())))
+    print('   phase-insensitive distances, GPU vs reference / the reference vs itself (worst of 5 perturbations): frame-RMS envelope %.2e / %.2e, |STFT 2048| L2 %.2e / %.2e, '
+          'band energies %.2e / %.2e' % (m['envelope'], worst['envelope'], m['stft2048_l2'], worst['stft2048_l2'], m['band_energy'], worst['band_energy']))
+    assert (prof <= 2.0 * env + 1e-3).all(), (int(over.argmax()), float(over.max()))
+    assert d_first < 2.0 * worst['first_second'] and l2 < 1.5 * worst['l2'], (d_first, l2)
+    assert m['envelope'] < 1.5 * worst['envelope'] and m['stft2048_l2'] < 1.5 * worst['stft2048_l2'] and m['band_energy'] < 1.5 * worst['band_energy'], m
 
 
 # measured on MI355X (round 5), bounds <= 2x: see DESIGN.md §3
 #   f0 5.3e-4 Hz; source (reference f0) 3.0e-8; decode(reference source): split-bf16 2.1e-4 max / 1.5e-4 L2 (fp16 copy 3.9e-4), exact fp32 4.6e-5 / 2.8e-5 (2.7e-4)
-_HIFT_BOUNDS = {'source': 1e-6, 'x3': (4.5e-4, 8e-4), 'x3_l2': 3e-4, 'exact': (1e-4, 6e-4), 'exact_l2': 6e-5, 'e2e_first_second': 5.5e-3}       # (first second, own f0: measured 2.7e-3)
+_HIFT_BOUNDS = {'source': 1e-6, 'x3': (4.5e-4, 8e-4), 'x3_l2': 3e-4, 'exact': (1e-4, 6e-4), 'exact_l2': 6e-5}
 
 
 # ---- LM on a 3300-row prefix -------------------------------------------------------------------------------------------------------------------
@@ -295,6 +315,58 @@ def test_llm_3300_row_prefix_fp32_vs_reference(llm_full):
         if len(got) >= len(want):
             break
     assert got == want, (got, want)
+
+
+def test_llm_fp32_64_slot_grid_ids_vs_reference_beside_63_live_sequences(llm_full):
+    """The geometry of bench.py's `ids_exact_mode` (fp32 LM, the continuous engine, 64 slots x 2 heads = 128 rows per step: gemm_dec.hip's A-stationary form on the
+    exact fp32 MFMAs, fp32 KV cache, 512-key attention splits), where the claim "speech-token ids bit-exact against the reference" is printed: the request of
+    llm_full.npz (3300-row prefix, the reference's own uncached K = 2 generation, llm_multi_head_v3.py:871-922) joins the grid as its 64th sequence, beside 63 live
+    sequences at contexts > 1024 (1042-row prefixes: eight of them per grouped prefill forward) that keep decoding for as long as it does."""
+    g, c, sd, sampling = llm_full
+    llm = _mk_llm(c, sd, sampling, torch.float32, max_batch=64, max_ctx=3392)
+    llm.inference_head_num = int(g['K'])
+    assert llm.inference_head_num == 2
+    text, ps = torch.from_numpy(g['text']), torch.from_numpy(g['pspeech'])
+    gen = torch.Generator().manual_seed(4100)
+    fillers = [dict(text=torch.randint(0, c.text_vocab, (1040,), generator=gen, dtype=torch.int32), seed=7000 + i, tag=('f', i),
+                    max_token_text_ratio=0.08, min_token_text_ratio=0.08) for i in range(63)]               # 83 tokens each: alive for all of the 38 steps of the pinned request
+    main = dict(text=text, prompt_text=torch.zeros(0, dtype=torch.int32), prompt_speech_token=ps, seed=int(g['seed']), tag='ref',
+                max_token_text_ratio=0.15, min_token_text_ratio=2)                                           # (max_len 76 fits max_ctx; min_len 1024 as minted: no EOS may be drawn)
+    got = dict(llm.generate_stream(iter(fillers + [main]), n_slots=64))
+    st = llm.last_stats
+    want = g['tokens'].tolist()
+    print('fp32 LM, 64-slot continuous grid, K = 2: %d requests, %d steps, mean live sequences %.1f, mean context %.0f rows; the pinned request emitted %d ids, the first %d == the REFERENCE\'s'
+          % (st['requests'], st['steps'], st['mean_active_sequences'], st['mean_ctx'], len(got['ref']), len(want)))
+    assert st['requests'] == 64 and all(len(got[('f', i)]) == 83 for i in range(63))
+    assert len(got['ref']) == 76 and got['ref'][:len(want)] == want, (got['ref'][:len(want)], want)
+    assert st['mean_active_sequences'] > 48 and st['mean_ctx'] > 1024, st
+    # ... and alone in the same 64-slot grid: the ids of a request do not depend on what shares the grid with it (all 76)
+    alone = dict(llm.generate_stream(iter([dict(main)]), n_slots=64))
+    assert alone['ref'] == got['ref']
+
+
+def test_llm_fp32_64_slot_grid_is_batch_invariant_over_a_whole_512_char_stream(llm_full):
+    """One 512-char utterance of the bench (512 text ids -> 2816 speech tokens, head_num 2: 1408 decode steps, contexts 514 -> 3330, crossing every 512-key split
+    boundary of the decode attention) through the fp32 64-slot grid ALONE and beside 63 other 512-char utterances (the `ids_exact_mode` job itself): the same 2816 ids.
+    Together with the test above (ids == the reference's inside the full grid) this carries the reference pin to every row of that job."""
+    g, c, sd, sampling = llm_full
+    llm = _mk_llm(c, sd, sampling, torch.float32, max_batch=64, max_ctx=2 + 512 + 2816 + 2 + 32)
+    llm.inference_head_num = 2
+
+    def req(i):
+        return dict(text=torch.randint(0, c.text_vocab, (512,), generator=torch.Generator().manual_seed(4200 + i), dtype=torch.int32), seed=9000 + i, tag=i,
+                    max_token_text_ratio=5.5, min_token_text_ratio=5.5)
+    alone = dict(llm.generate_stream(iter([req(0)]), n_slots=64))
+    assert len(alone[0]) == 2816
+    steps_alone = llm.last_stats['steps']
+    crowd = dict(llm.generate_stream(iter([req(i) for i in range(64)]), n_slots=64))
+    st = llm.last_stats
+    print('fp32 LM, one 512-char stream alone (%d steps) vs inside the full 64-slot grid (%d steps, mean live sequences %.1f, mean context %.0f): %d ids equal'
+          % (steps_alone, st['steps'], st['mean_active_sequences'], st['mean_ctx'], len(alone[0])))
+    assert st['steps'] >= 1024 and st['mean_active_sequences'] > 60
+    assert all(len(crowd[i]) == 2816 for i in range(64))
+    assert crowd[0] == alone[0]
+    assert len({tuple(v) for v in crowd.values()}) == 64                                                   # (64 different streams: nobody decoded somebody else's rows)
 
 
 def test_llm_3300_row_context_bf16_wide_grid_vs_reference(llm_full):

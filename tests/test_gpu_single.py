@@ -102,7 +102,18 @@ def test_configs0_one_64_char_utterance_head_num_1_fp32_vs_reference(single):
     assert e_mel < 1e-3, e_mel                                                          # measured 1.0e-6
     assert d_f0 < 1e-3 and d_or < 1e-6 and d_s < 1e-6, (d_f0, d_or, d_s)                # measured 4.8e-4 Hz, 3e-8, 3e-8
     assert rel_w < 3e-4 and d_w < 7e-4 and d_w16 < 1e-3, (rel_w, d_w, d_w16)            # measured 1.5e-4 / 3.3e-4 (split-bf16 convolutions)
-    assert d_first < 2.6e-2 and d_e2e < 2.0 * float(np.abs(g['wav_s16']).max()), (d_first, d_e2e)      # measured 1.3e-2 in the first second (own mel, own f0)
+    # End to end (own mel, own f0): held to the REFERENCE's own self-distance under last-bit perturbations of its f0 on this very mel (single_cv3_cond.npz,
+    # make_golden_fullsize.py single_cond; generator.py:254-260 is ill-conditioned in f0): per second <= 2x the running maximum of that band (+ 1e-3: the fp16 copy)
+    gc = load_golden('single_cv3_cond.npz')
+    cases = ['noise_a', 'noise_b', 'ulp_up', 'ulp_down', 'f0_fp64']
+    env = np.maximum.accumulate(np.max([gc[c + '_per_second'] for c in cases], axis=0))
+    n = (w_e2e.size // 24000) * 24000
+    prof = np.abs(w_e2e - g['wav_f16'].astype(np.float32))[:n].reshape(-1, 24000).max(axis=1)
+    l2_e2e = float(np.linalg.norm(w_e2e[::16] - g['wav_s16']) / np.linalg.norm(g['wav_s16']))
+    worst_l2 = max(float(gc[c + '_l2']) for c in cases)
+    print('   end to end per second / (2 x the reference\'s own band): at most %.2f; L2 %.2e (the reference against itself: up to %.2e)' % (float((prof / (2 * env + 1e-3)).max()), l2_e2e, worst_l2))
+    assert (prof <= 2.0 * env + 1e-3).all(), (prof / (2 * env + 1e-3)).max()
+    assert l2_e2e < 2.0 * worst_l2, (l2_e2e, worst_l2)
 
 
 def test_configs0_production_mode_teacher_forced_vs_reference(single):

@@ -32,7 +32,7 @@ def test_library_builds_and_exports_every_declared_symbol():
         assert hasattr(lib, name), 'libhvx.so does not export %s' % name
     # the ctypes binding covers exactly the header
     assert sorted(_lib.SYMBOLS.keys()) == declared
-    assert _lib.load().hvx_abi_version() == _lib.HVX_ABI_VERSION == 3
+    assert _lib.load().hvx_abi_version() == _lib.HVX_ABI_VERSION == 4
 
 
 def test_libhvx_holds_no_packed_fp32_instruction(tmp_path):
@@ -879,3 +879,62 @@ def test_bench_rank_logic_world_size_2_gloo_with_a_stub_pipeline(config):
         want += float(stub_wave(u.seed, n).double().sum())
     assert abs(st['checksum'] - want) < 1e-6 * max(1.0, abs(want)), (st['checksum'], want)
     assert abs(d['value'] * d['ms_per_step'] * steps / 1e3 - tokens) < 0.01 * tokens      # value = ALL ranks' tokens / max-over-ranks wall time
+
+
+def test_onnx_covered_set_is_what_the_tests_reach():
+    """N2: the device ONNX executor refuses what it was never compared on.  onnx_graph.COVERED must equal, operator by operator and attribute by attribute, what
+    the synthetic frontend graphs and the one-node cases of tests/onnx_synth.py reach (the GPU tests run exactly those against oracle/onnx_ref.py); every one-node
+    case is evaluable by the oracle; `uncovered` names operators and attributes outside the table (OnnxRunner raises on them before touching the device)."""
+    import onnx_synth
+    from flowmirror_hydravox_amd import onnx_graph as og
+    from oracle import onnx_ref
+    reach = {k: tuple(sorted(v)) for k, v in onnx_synth.covered_set().items()}
+    assert reach == {k: tuple(sorted(v)) for k, v in og.COVERED.items()}
+    assert set(og.COVERED) <= set(og.OPERATORS)
+    for op, ins, at in onnx_synth.per_operator_cases():
+        out = onnx_ref._node(og.Node(op, ['i%d' % i for i in range(len(ins))], ['o'], at), ins, 17)
+        assert out is not None, op
+    assert og.uncovered(onnx_synth.campplus_like()) == [] and og.uncovered(onnx_synth.tokenizer_like(with_length=True)) == []
+    g = og.Graph([og.Node('Conv', ['x', 'w'], ['y'], {'kernel_shape': [3], 'foo': 1}, name='n1'), og.Node('LSTM', ['y'], ['z'], {}, name='n2'),
+                  og.Node('Softmax', ['z'], ['o'], {'axis': -1}, name='n3')], {}, ['x'], ['o'])
+    assert og.uncovered(g) == [('n1', 'Conv', 'foo'), ('n2', 'LSTM', None)]
+    assert np.array_equal(onnx_ref._node(og.Node('Mod', ['a', 'b'], ['o'], {}), [np.asarray([7, -7, 9]), np.asarray([3, 3, 4])], 17), [1, 2, 1])
+
+
+def test_library_options_are_one_switchboard_and_lab_ones_are_refused():
+    """hvx_set_option / hvx_get_option / hvx_option_name (include/hvx.h; csrc/hvx_options.h): no environment variable is read anywhere in csrc/, unknown keys and
+    out-of-range values fail with a message, lab options cannot be set in the shipped library, and the shipped library is not a lab build."""
+    from flowmirror_hydravox_amd import _lib
+    lib = _lib.load()
+    assert int(lib.hvx_is_lab_build()) == 0 and lib.hvx_build_flags() == b''
+    opts = _lib.options()
+    assert {'dec_gemm', 'conv64_resident', 'x3p8', 'att_chunk', 'att_waves', 'gemm_big_gw', 'attn_lab'} <= set(opts)
+    assert all(v == d for v, d, _ in opts.values())                       # nothing has been switched in this process
+    assert opts['attn_lab'][2] and not opts['dec_gemm'][2]
+    with _lib.option_scope(dec_gemm=0, att_chunk=512):
+        assert _lib.get_option('dec_gemm') == 0 and _lib.get_option('att_chunk') == 512
+    assert _lib.get_option('dec_gemm') == 1 and _lib.get_option('att_chunk') == 0
+    for key, val, msg in (('no_such_option', 1, 'unknown option'), ('att_chunk', 100, 'multiple of 128'), ('att_waves', 5, '4 or 8'), ('attn_lab', 3, 'lab option')):
+        with pytest.raises(_lib.HvxError, match=msg):
+            _lib.set_option(key, val)
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'flowmirror_hydravox_amd', 'csrc')
+    for f in os.listdir(csrc):
+        if f.endswith(('.hip', '.h')):
+            assert 'getenv' not in open(os.path.join(csrc, f)).read(), f
+
+
+def test_build_never_reuses_objects_of_other_flags(tmp_path):
+    """objects carry a stamp of the exact compiler command; another flag set (a lab build) means rebuild, and extra flags never go into the product library"""
+    from flowmirror_hydravox_amd import build as B
+    src = tmp_path / 'k.hip'
+    src.write_text('// x')
+    obj = str(tmp_path / 'k.o')
+    assert B._stale(str(src), obj, 0.0, ())                                 # no object
+    open(obj, 'w').write('o')
+    assert B._stale(str(src), obj, 0.0, ())                                 # no stamp: never trusted
+    open(obj + '.cmd', 'w').write(' '.join(B._command(str(src), obj, ())))
+    assert not B._stale(str(src), obj, 0.0, ())
+    assert B._stale(str(src), obj, 0.0, ('-DHVX_LAB',))                     # other flags
+    assert '-DHVX_BUILD_FLAGS="-DHVX_LAB -DHVX_LAB_GEMM_EPI=1"' in B._command(str(src), obj, ('-DHVX_LAB', '-DHVX_LAB_GEMM_EPI=1'))
+    with pytest.raises(ValueError):
+        B.build(extra=('-DHVX_LAB',))                                       # extra flags without a lab name: refused before anything is compiled

@@ -251,6 +251,41 @@ def test_mel_spectrogram_oracle_vs_reference_vectors():
         assert (out - torch.from_numpy(g['mel_%s_out' % tag])).abs().max() < 1e-5
 
 
+def test_slaney_mel_table_is_pinned_and_the_product_table_equals_it():
+    """N2 / matcha/utils/audio.py:53, cosyvoice/cli/frontend.py:95 (whisper's mel_filters.npz = librosa.filters.mel(sr=16000, n_fft=400, n_mels=80 | 128)):
+    librosa is absent, so (1) the oracle's scalar float64 statement of the Slaney table is held to the LITERAL values librosa prints in its docstrings
+    (hz_to_mel, mel_to_hz, mel_frequencies(n_mels=40), filters.mel(sr=22050, n_fft=2048)[0, 1]) at their printed precision, and to the table's defining
+    properties; (2) the product's vectorised packing.mel_filterbank — separate code — must equal it to 1e-7 of the table's scale at every geometry the path uses."""
+    from flowmirror_hydravox_amd.packing import mel_filterbank
+    from oracle import frontend_ref as R
+    pub = R.LIBROSA_PUBLISHED
+    for f, m in pub['hz_to_mel'].items():
+        assert abs(R.slaney_hz_to_mel(f) - m) < 5e-3, (f, R.slaney_hz_to_mel(f))                      # printed to 2 decimals
+    for m, f in pub['mel_to_hz'].items():
+        assert abs(R.slaney_mel_to_hz(m) - f) < 5e-4, (m, R.slaney_mel_to_hz(m))                      # printed to 3 decimals
+    mf = R.slaney_mel_frequencies(40, 0.0, 11025.0)
+    assert len(mf) == 40 and max(abs(a - b) for a, b in zip(mf, pub['mel_frequencies_40'])) < 6e-4      # printed to 3 decimals
+    t = R.slaney_mel_table(22050, 2048, 128)
+    assert t.shape == (128, 1025) and abs(float(t[0, 1]) - pub['filters_mel_22050_2048_row0_col1']) < 5e-4 and float(t[0, 0]) == 0.0
+    for (sr, n_fft, n_mels, fmin, fmax) in ((24000, 1920, 80, 0.0, None), (24000, 1920, 80, 0.0, 8000.0), (22050, 1024, 80, 0.0, 8000.0), (22050, 2048, 128, 0.0, None),
+                                            (16000, 400, 80, 0.0, None), (16000, 400, 128, 0.0, None), (800, 64, 8, 0.0, 400.0)):
+        ref = R.slaney_mel_table(sr, n_fft, n_mels, fmin, fmax)
+        # defining properties: non-negative, zero outside (edge[i], edge[i+2]), and Slaney's normalisation: the continuous triangle has unit area, so the sampled
+        # one sums to ~ 1 / bin width wherever a filter spans several bins
+        edges = R.slaney_mel_frequencies(n_mels + 2, fmin, sr / 2.0 if fmax is None else fmax)
+        freqs = torch.arange(n_fft // 2 + 1, dtype=torch.float64) * sr / n_fft
+        assert float(ref.min()) >= 0.0
+        for i in (0, n_mels // 2, n_mels - 1):
+            outside = (freqs <= edges[i]) | (freqs >= edges[i + 2])
+            assert float(ref[i][outside].abs().max()) == 0.0
+            if edges[i + 2] - edges[i] > 8 * sr / n_fft:
+                assert abs(float(ref[i].sum()) * sr / n_fft - 1.0) < 0.05, (sr, n_fft, i, float(ref[i].sum()) * sr / n_fft)
+        mine = mel_filterbank(sr, n_fft, n_mels, fmin, fmax)
+        assert mine.dtype == torch.float32 and mine.shape == ref.shape
+        d = float((mine.double() - ref).abs().max() / ref.max())
+        assert d < 1e-7, (sr, n_fft, n_mels, fmin, fmax, d)
+
+
 # ------------------------------------------------------------------------------------------------------------------------
 # streaming synthesis (SURVEY.md §8(f) N3): static chunk mask, finalize=False in flow and HiFT
 # ------------------------------------------------------------------------------------------------------------------------
@@ -628,3 +663,30 @@ def test_denoiser_mode_normal_oracle_vs_reference():
     assert (bias - torch.from_numpy(g['bias'])).abs().max().item() < 1e-4
     clean = matcha_ref.denoise(torch.from_numpy(g['wav']).squeeze(1), bias, hc, float(g['strength']))
     assert (clean - torch.from_numpy(g['clean'])).abs().max().item() < 1e-4
+
+
+def test_wave_metrics_and_the_reference_conditioning_fixture():
+    """tests/wave_metrics.py on known inputs, and the shape of hift_full_cond.npz (make_golden_fullsize.py hift_cond: the REFERENCE's end-to-end vocoder output
+    against itself under last-bit perturbations of its own f0, generator.py:254-260) that tests/test_gpu_refpin.py holds the GPU path to."""
+    import wave_metrics as WM
+    rng = np.random.default_rng(3)
+    t = np.arange(48000) / 24000.0
+    a = (0.4 * np.sin(2 * np.pi * 220 * t) + 0.2 * np.sin(2 * np.pi * 660 * t + 1.0) + 0.01 * rng.standard_normal(t.size)).astype(np.float32)
+    m0 = WM.all_metrics(a, a)
+    assert all(v == 0.0 for v in m0.values()), m0
+    m1 = WM.all_metrics(1.01 * a, a)
+    assert abs(m1['envelope'] - 0.01) < 2e-3 and abs(m1['stft2048_l2'] - 0.01) < 1e-3 and abs(m1['band_energy'] - 0.0201) < 2e-3, m1
+    # a pure phase shift of both partials: large sample-wise, small in the envelope / long-window magnitude
+    b = (0.4 * np.sin(2 * np.pi * 220 * t + 0.7) + 0.2 * np.sin(2 * np.pi * 660 * t + 1.0 + 2.1)).astype(np.float32)
+    a0 = (0.4 * np.sin(2 * np.pi * 220 * t) + 0.2 * np.sin(2 * np.pi * 660 * t + 1.0)).astype(np.float32)
+    m2 = WM.all_metrics(b, a0)
+    assert np.abs(b - a0).max() > 0.3 and m2['stft2048_l2'] < 2e-2 and m2['band_energy'] < 2e-2, m2
+    g = load_golden('hift_full_cond.npz')
+    names = [str(n) for n in g['names']]
+    assert names[:5] == ['noise_a', 'noise_b', 'ulp_up', 'ulp_down', 'f0_fp64'] and int(g['T']) == 5632
+    for n in names:
+        p = g[n + '_per_second']
+        assert p.shape == (112,) and float(p.max()) == pytest.approx(float(g[n + '_max']), rel=1e-6) or float(g[n + '_max']) >= float(p.max())
+    # the measurement itself: one ulp of f0 moves the reference's own waveform by ~1e-3 within the first second and by > 0.2 of a 0.99 peak over the utterance
+    assert float(g['ulp_up_first_second']) < 5e-3 and float(g['ulp_up_max']) > 0.1 and float(g['ulp_down_max']) > 0.1 and 0.9 < float(g['peak']) <= 0.99 + 1e-6
+    assert float(g['f0_fp64_minus_fp32']) < 1e-3

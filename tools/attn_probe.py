@@ -10,6 +10,10 @@ from flowmirror_hydravox_amd import _lib, ops  # noqa: E402
 from bench_ops import timeit  # noqa: E402
 
 _lib.require_gpu()
+if os.environ.get('ATTN_LAB'):          # (lab library only: hvx_set_option refuses lab options in the product build)
+    _lib.set_option('attn_lab', int(os.environ['ATTN_LAB']))
+if os.environ.get('ATTN_FORM'):
+    _lib.set_option('attn_dit_form', int(os.environ['ATTN_FORM']))
 T, H = int(os.environ.get('T', 5632)), 16
 iters = int(os.environ.get('ITERS', 10))
 for B in [int(x) for x in sys.argv[1:]] or [2, 4, 8, 16]:

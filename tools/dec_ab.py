@@ -3,7 +3,7 @@
 
     python tools/dec_ab.py [--seqs 64] [--heads 2] [--ctx 300] [--layers 24]
 
-Runs one decode forward (random prefilled KV cache, random tokens) in two fresh processes (HVX_DEC_GEMM=1 / 0: the switch is read once per process)
+Runs one decode forward (random prefilled KV cache, random tokens) in two fresh processes (option dec_gemm = 1 / 0, set through hvx_set_option in the child)
 and compares the log-probabilities and the K / V rows the step appended."""
 import argparse
 import os
@@ -23,6 +23,7 @@ def child(args, out):
     from flowmirror_hydravox_amd.llm import HvxLLM
     from flowmirror_hydravox_amd.weights import make_llm_state
     _lib.require_gpu()
+    _lib.set_option('dec_gemm', args.dec_gemm)
     cfg = cv3_config().llm
     cfg.layers = args.layers
     S, K = args.seqs, args.heads
@@ -48,9 +49,8 @@ def compare(seqs=64, heads=2, ctx=300, layers=24):
     with tempfile.TemporaryDirectory() as td:
         for flag in ('1', '0'):
             out = os.path.join(td, 'r%s.npz' % flag)
-            env = dict(os.environ, HVX_DEC_GEMM=flag)
             subprocess.run([sys.executable, os.path.abspath(__file__), '--seqs', str(seqs), '--heads', str(heads), '--ctx', str(ctx),
-                            '--layers', str(layers), '--child', out], check=True, env=env)
+                            '--layers', str(layers), '--child', out, '--dec-gemm', flag], check=True)
             res[flag] = dict(np.load(out))
     a, b = res['1'], res['0']
     finite = bool(np.isfinite(a['logp']).all() and np.isfinite(b['logp']).all())
@@ -68,6 +68,7 @@ def main():
     ap.add_argument('--ctx', type=int, default=300)
     ap.add_argument('--layers', type=int, default=24)
     ap.add_argument('--child', default=None)
+    ap.add_argument('--dec-gemm', type=int, default=1)
     args = ap.parse_args()
     if args.child:
         return child(args, args.child)
