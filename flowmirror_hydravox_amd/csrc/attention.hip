@@ -592,6 +592,17 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_dit_kernel(Attn
             }
         }
         auto qk = [&](int i, f32x4 (&sv)[4]) {
+            if constexpr ((LAB & 128) != 0) {
+                // de-paired order: the four first halves, then the four second halves — no two neighbouring MFMAs share an accumulator (same sums, same order per accumulator)
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) {
+                    if constexpr (PRE) sv[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt][0], qf[i][0], nm_ref[i], 0, 0, 0);
+                    else sv[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt][0], qf[i][0], f32x4{0, 0, 0, 0}, 0, 0, 0);
+                }
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) mma32(sv[kt], kf[kt][1], qf[i][1]);
+                return;
+            }
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
                 // the accumulator starts at -m_ref (loop-invariant registers): the scores arrive shifted, exp2 is all that is left
@@ -637,10 +648,17 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_dit_kernel(Attn
             mma32(lt, ones, pf[0]);
             mma32(lt, ones, pf[1]);
             l_acc[i] += lt[0];
+            if constexpr ((LAB & 128) != 0) {
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
+                for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int m = 0; m < 2; ++m) mma32(o_acc[i][dt], vf[dt][m], pf[m]);
+                    for (int dt = 0; dt < 4; ++dt) mma32(o_acc[i][dt], vf[dt][m], pf[m]);
+            } else {
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) mma32(o_acc[i][dt], vf[dt][m], pf[m]);
+            }
             if constexpr ((LAB & 64) != 0) __builtin_amdgcn_s_setprio(0);
         };
         // MFMA : VALU interleave of one pipeline step (masks: 0x8 MFMA, 0x2 VALU; the transcendental ops count as VALU)
@@ -782,6 +800,368 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_dit_kernel(Attn
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// DiT attention on the 32x32x16 MFMA shape (round 6).  Same contract, same operand layouts and the same fixed-reference softmax as attn_dit_kernel above, another
+// tile: v_mfma_f32_32x32x16_bf16 holds the matrix pipe 32 cycles per instruction (8 issue slots) instead of 16, so the exponentials of one score tile fit
+// in the shadow of the MFMAs of its neighbours, and half as many MFMA instructions compete for issue slots (MI355X guide: <= 5 fillers per 32x32x16 gap).
+//   S^T[key, q] = K Q^T   A = K rows (lane: key = l & 31, 8 consecutive d at 16 kk + 8 (l >> 5)), B = Q^T (lane: q = l & 31, the same d) — 4 MFMAs per 32 x 32 tile;
+//                         C/D: lane (q = l & 31, hi = l >> 5), register r: key (r & 3) + 8 (r >> 2) + 4 hi — a lane holds 16 scores of ONE query.
+//   O^T[d, q] += V^T P^T  the k-slot (hi, j) of a 16-key step is DEFINED as the key the lane already holds in registers 8 s + j of its score tile
+//                         (keys {0-3, 8-11} + 4 hi of the step): P^T needs no cross-lane move at all, and V^T goes into LDS with the two middle 4-key groups of
+//                         every 16 swapped, so that its fragment is one 16-byte read.  Row sums: fp32 adds per lane (the two lanes of a query meet once, at the end).
+// A wave owns QT query tiles of 32 rows (QT = 4: 128 rows, ONE wave per SIMD and the whole 512-register file, every K / V^T fragment read from LDS feeds 4 MFMAs;
+// QT = 2: two waves per SIMD).  Within a 64-key tile the work is cut into units of (32 keys) x (two query tiles) — 8 score MFMAs on two alternating accumulators,
+// 32 exponentials + 16 conversions, 8 PV MFMAs on four accumulators — and software-pipelined: scores of unit u+1 | softmax of unit u | PV of unit u-1.
+// Consecutive MFMAs never share an accumulator, so vector instructions may sit between any two of them (MI355X guide: an extra issue slot between two MFMAs on the
+// SAME accumulator costs 43 cycles; that is what the 16x16x32 tile's dependent pairs ran into).
+// ---------------------------------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int QT, bool PRE, int SUMS = 1, int PIN = 0, int WPS = 2, int PIPE = 1, int REF = 1>     // REF 0: no per-row reference — p = exp2(s) as it is; a workgroup whose rows leave [2^-60, 2^127] takes the classical loop; PIPE 0: units one after the other (the other waves of the SIMD cover a wave's vector phases); QT query tiles of 32 rows per wave; SUMS: row sums by fp32 adds (0) or on the matrix cores (1);
+                                                                         // PIN: vector instructions pinned behind every MFMA of a unit (0: the compiler's order); WPS: waves per SIMD the register budget is cut for
+__global__ __launch_bounds__(256, WPS) void attn_dit32_kernel(AttnArgs a) {
+    typedef bf16_t T;
+    constexpr int KT = 64, LD = 72;            // keys per tile; LDS row stride (144 B: the 16 rows of a ds_read_b128 lane group fall on 16 distinct 16-byte slots)
+    __shared__ __attribute__((aligned(16))) T Ks[2][KT * LD];
+    __shared__ __attribute__((aligned(16))) T Vs[2][64 * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fq = lane & 31, hi = lane >> 5;
+    int b = blockIdx.z, h = blockIdx.y, bx = blockIdx.x;
+    {   // XCD-aware order (see attn_dit_kernel): XCD e walks the row blocks of heads e, e + 8, ... one head after the other
+        const int nx = gridDim.x, nh = gridDim.y * gridDim.z;
+        if ((nh & 7) == 0) {
+            const int L = blockIdx.x + nx * (blockIdx.y + gridDim.y * blockIdx.z);
+            const int j = L >> 3, hb = (j / nx) * 8 + (L & 7);
+            bx = j % nx;
+            h = hb % gridDim.y;
+            b = hb / gridDim.y;
+        }
+    }
+    constexpr int WG_ROWS = 4 * QT * 32;
+    const int row0 = bx * WG_ROWS + wave * (QT * 32);
+    const int kv_len = a.kv_len ? a.kv_len[b] : a.kv_len_const;
+    const T* __restrict__ kb = reinterpret_cast<const T*>(a.k) + (long long)b * a.k_bs + (long long)h * a.k_hs;
+    const T* __restrict__ vb = reinterpret_cast<const T*>(a.vT) + (long long)b * a.v_bs + (long long)h * a.v_hs;
+
+    bf16x8 qf[QT][4];
+#pragma unroll
+    for (int i = 0; i < QT; ++i) {
+        const int r = row0 + i * 32 + fq;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+            qf[i][kk] = r < a.n_rows ? load8(reinterpret_cast<const T*>(a.q) + (long long)b * a.q_bs + (long long)h * a.q_hs + (long long)r * a.q_lo + kk * 16 + hi * 8) : zero8<T>();
+    }
+    // tile loader (the 4 waves together): thread t moves 2 x 16 B of K (rows t / 8 and t / 8 + 32, chunk t % 8) and 2 x 16 B of V^T
+    const int lrow = tid >> 3, lchunk = (tid & 7) * 8;
+    bf16x8 rk[2], rv[2];
+    auto gload = [&](int key0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int key = key0 + lrow + i * 32;
+            key = key < kv_len ? key : kv_len - 1;                       // clamped rows are masked in the tail tile
+            rk[i] = load8(kb + (long long)key * 64 + lchunk);
+            rv[i] = load8(vb + (long long)(lrow + i * 32) * a.v_ld + key0 + lchunk);
+        }
+    };
+    // V^T in LDS: within every 16 keys the 4-key groups go in the order 0, 2, 1, 3 — the k-slots of a PV step as the score tile's registers define them
+    const int vc = tid & 7;                                              // the thread's 8-key chunk = groups 2 (vc & 1), 2 (vc & 1) + 1 of 16-key block vc / 2
+    const int vpos = (vc >> 1) * 16 + (vc & 1) * 4;
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            store8(&Ks[buf][(lrow + i * 32) * LD + lchunk], rk[i]);
+            bf16x4 lo, hv;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                lo[j] = rv[i][j];
+                hv[j] = rv[i][4 + j];
+            }
+            *reinterpret_cast<bf16x4*>(&Vs[buf][(lrow + i * 32) * LD + vpos]) = lo;
+            *reinterpret_cast<bf16x4*>(&Vs[buf][(lrow + i * 32) * LD + vpos + 8]) = hv;
+        }
+    };
+
+    f32x16 o_acc[QT][2];
+    float l_acc[QT];
+    auto zero16f = [] {                                                  // (a literal every time: a zero vector kept in registers across the key loop would cost 16 of them)
+        f32x16 z;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+        return z;
+    };
+#define zero16 zero16f()
+#pragma unroll
+    for (int i = 0; i < QT; ++i) {
+        l_acc[i] = 0.0f;
+        o_acc[i][0] = zero16;
+        o_acc[i][1] = zero16;
+    }
+    const float c = PRE ? 1.0f : a.scale * 1.4426950408889634f;
+    f32x16 nm_ref[QT];                                                   // -m_ref of the lane's query in every register: the score accumulators start there
+
+    auto kfrag = [&](int buf, int kh, bf16x8 (&kf)[4]) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) kf[kk] = load8(&Ks[buf][(kh * 32 + fq) * LD + kk * 16 + hi * 8]);
+    };
+    auto vfrag = [&](int buf, int kh, bf16x8 (&vf)[2][2]) {
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) vf[dt][s] = load8(&Vs[buf][(dt * 32 + fq) * LD + (kh * 2 + s) * 16 + hi * 8]);
+    };
+    auto qk0 = [&](int i, const bf16x8 (&kf)[4], f32x16& s) {           // scores of one query tile against 32 keys, from zero
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk], qf[i][kk], kk == 0 ? zero16 : s, 0, 0, 0);
+    };
+    auto mask = [&](f32x16& s, int key0) {                               // keys at or beyond the sequence end (tail tile only)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (key0 + (r & 3) + 8 * (r >> 2) + 4 * hi >= kv_len) s[r] = -INFINITY;
+    };
+    auto pv1 = [&](int i, const bf16x8 (&vf)[2][2], const bf16x8 (&pf)[2]) {
+#pragma unroll
+        for (int st = 0; st < 4; ++st) o_acc[i][st & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[st & 1][st >> 1], pf[st >> 1], o_acc[i][st & 1], 0, 0, 0);
+    };
+
+    // ---- the fast tile: units of (32 keys) x (ONE query tile), pipelined  QK(u + 1) | SM(u) | PV(u - 1); the 4 dependent score MFMAs of unit u + 1 alternate with
+    //      the 4 PV MFMAs of unit u - 1 (two accumulators, twice each), so no two neighbours share an accumulator ----------------------------------------------
+    bf16x8 ones_sel;                                                     // A operand of the row-sum MFMA (16x16x32): row 0 sums the k-groups 0 and 2 (the two lanes of query n), row 1 the groups 1 and 3 (query n + 16)
+    {
+        const bool on = ((lane & 15) == 0 && ((lane >> 4) & 1) == 0) || ((lane & 15) == 1 && ((lane >> 4) & 1) == 1);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ones_sel[e] = f32_to_bf16(on ? 1.0f : 0.0f);
+    }
+    f32x4 l_mm[QT];
+#pragma unroll
+    for (int i = 0; i < QT; ++i) l_mm[i] = f32x4{0, 0, 0, 0};
+    auto sm1 = [&](int i, f32x16& s, bf16x8 (&pf)[2], int key0, auto tail_tag) {
+        constexpr bool TAIL = decltype(tail_tag)::value;
+        if constexpr (TAIL) mask(s, key0);
+        float sum = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float e = __builtin_amdgcn_exp2f(PRE ? s[r] : (REF ? __builtin_fmaf(s[r], c, nm_ref[i][0]) : s[r] * c));      // -inf -> 0
+            if constexpr (SUMS == 0) sum += e;
+            pf[r >> 3][r & 7] = f32_to_bf16(e);
+        }
+        if constexpr (SUMS == 0) l_acc[i] += sum;
+    };
+    auto tile_fast = [&](int buf, int key0, auto tail_tag) {
+        constexpr int NU = 2 * QT;                                       // units: u = kh * QT + i
+        bf16x8 kf[4], vf[2][2];
+        f32x16 sa, sb;
+        bf16x8 pa[2], pb[2];
+        kfrag(buf, 0, kf);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk], qf[0][kk], kk == 0 ? ((PRE && REF) ? nm_ref[0] : zero16) : sa, 0, 0, 0);
+        vfrag(buf, 0, vf);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int kh = u / QT, i = u % QT;
+            f32x16& s_cur = (u & 1) ? sb : sa;
+            f32x16& s_nxt = (u & 1) ? sa : sb;
+            bf16x8 (&p_cur)[2] = (u & 1) ? pb : pa;
+            bf16x8 (&p_prv)[2] = (u & 1) ? pa : pb;
+            const bool has_qk = u + 1 < NU, has_pv = u > 0;
+            const int in = (u + 1) % QT, ip = (u + QT - 1) % QT;         // query tiles of units u + 1 / u - 1
+            if (has_qk && in == 0) kfrag(buf, (u + 1) / QT, kf);         // the next 32 keys
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                if (has_qk) s_nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[st], qf[in][st], st == 0 ? ((PRE && REF) ? nm_ref[in] : zero16) : s_nxt, 0, 0, 0);
+                if (has_pv) o_acc[ip][st & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[st & 1][st >> 1], p_prv[st >> 1], o_acc[ip][st & 1], 0, 0, 0);
+            }
+            if (has_pv && i == 0 && kh == 1) vfrag(buf, 1, vf);          // unit u - 1 was the last of key half 0: its PV (just issued) was the last reader of that half's V^T fragments
+            sm1(i, s_cur, p_cur, key0 + kh * 32, tail_tag);
+            if constexpr (SUMS == 1) {
+                l_mm[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones_sel, p_cur[0], l_mm[i], 0, 0, 0);
+                l_mm[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones_sel, p_cur[1], l_mm[i], 0, 0, 0);
+            }
+            if constexpr (PIN > 0) {
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x2, PIN, 0);
+                }
+            }
+            if constexpr (PIN < 0) __builtin_amdgcn_sched_barrier(0);    // units are scheduling regions: nothing moves across (keeps the fragments of later units out of the registers)
+        }
+        if (QT == 1) vfrag(buf, 1, vf);                                  // (QT = 1: unit 1 = key half 1 has no later slot that loads its fragments)
+        pv1(QT - 1, vf, ((NU - 1) & 1) ? pb : pa);                       // PV of the last unit
+    };
+    // ---- the same units one after the other (PIPE = 0): scores of all the wave's query tiles against 32 keys (independent accumulators alternate), their
+    //      probabilities, their PV — no second score / probability buffer, so three waves fit a SIMD at QT = 1 and cover each other's vector phases ------------------
+    auto tile_seq = [&](int buf, int key0, auto tail_tag) {
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+            bf16x8 kf[4], vf[2][2];
+            f32x16 s[QT];
+            bf16x8 pf[QT][2];
+            kfrag(buf, kh, kf);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int i = 0; i < QT; ++i) s[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk], qf[i][kk], kk == 0 ? ((PRE && REF) ? nm_ref[i] : zero16) : s[i], 0, 0, 0);
+            vfrag(buf, kh, vf);
+#pragma unroll
+            for (int i = 0; i < QT; ++i) sm1(i, s[i], pf[i], key0 + kh * 32, tail_tag);
+#pragma unroll
+            for (int st = 0; st < 4; ++st)
+#pragma unroll
+                for (int i = 0; i < QT; ++i) o_acc[i][st & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[st & 1][st >> 1], pf[i][st >> 1], o_acc[i][st & 1], 0, 0, 0);
+            if constexpr (SUMS == 1) {
+#pragma unroll
+                for (int i = 0; i < QT; ++i) {
+                    l_mm[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones_sel, pf[i][0], l_mm[i], 0, 0, 0);
+                    l_mm[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones_sel, pf[i][1], l_mm[i], 0, 0, 0);
+                }
+            }
+        }
+    };
+    // ---- classical online-softmax tile (the fall-back when a score outgrew its reference by 2^127), one query tile at a time ------------------------------
+    float m_run[QT];
+    auto tile_classical = [&](int buf, int key0, auto tail_tag) {
+        constexpr bool TAIL = decltype(tail_tag)::value;
+#pragma unroll
+        for (int i = 0; i < QT; ++i) {
+            bf16x8 kf[4], vf[2][2];
+            f32x16 s[2];                                                 // the two key halves
+            bf16x8 pf[2][2];
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) {
+                kfrag(buf, kh, kf);
+                qk0(i, kf, s[kh]);
+                if constexpr (TAIL) mask(s[kh], key0 + kh * 32);
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmax2(mx, s[kh][r]);
+            mx = fmax2(mx, __shfl_xor(mx, 32, 64));                      // the two lanes of a query
+            const float m_new = fmax2(m_run[i], mx * c);
+            const float alpha = m_new == -INFINITY ? 1.0f : __builtin_amdgcn_exp2f(m_run[i] - m_new);      // exp2(-inf) == 0 on the first tile
+            float sum = 0.0f;
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float e = m_new == -INFINITY ? 0.0f : __builtin_amdgcn_exp2f(__builtin_fmaf(s[kh][r], c, -m_new));
+                    sum += e;
+                    pf[kh][r >> 3][r & 7] = f32_to_bf16(e);
+                }
+            l_acc[i] = l_acc[i] * alpha + sum;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o_acc[i][dt][r] *= alpha;
+            m_run[i] = m_new;
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) {
+                vfrag(buf, kh, vf);
+                pv1(i, vf, pf[kh]);
+            }
+        }
+    };
+
+    const int n_tiles = (kv_len + KT - 1) / KT, n_full = kv_len / KT;
+    auto run = [&](auto&& tf) {
+        for (int it = 0; it < n_tiles; ++it) {
+            const int buf = it & 1, key0 = it * KT;
+            const bool more = (it + 1) < n_tiles;
+            if (more) gload(key0 + KT);
+            if (it < n_full) tf(buf, key0, std::false_type{});
+            else tf(buf, key0, std::true_type{});
+            if (more) stash(buf ^ 1);
+            __syncthreads();
+        }
+    };
+    if (n_tiles > 0) {
+        gload(0);
+        stash(0);
+    }
+    __syncthreads();
+    bool classical = false;
+    if (n_tiles > 0) {
+        // reference maximum of every row: its (masked) scores against the first key tile
+#pragma unroll
+        for (int i = 0; i < (REF ? QT : 0); ++i) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) {
+                bf16x8 kf[4];
+                f32x16 s;
+                kfrag(0, kh, kf);
+                qk0(i, kf, s);
+                mask(s, kh * 32);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmax2(mx, s[r]);
+            }
+            float m = fmax2(mx, __shfl_xor(mx, 32, 64));
+            m = -fmax2(m * c, -1e30f);                                       // a row without a visible key in the tile: finite reference, p = 0
+#pragma unroll
+            for (int r = 0; r < 16; ++r) nm_ref[i][r] = m;
+            if constexpr (PRE) asm volatile("" : "+v"(nm_ref[i]));          // 16 REGISTERS from here on: the compiler must not rebuild the splat in front of every score tile
+        }
+        if constexpr (PIPE == 1) run(tile_fast);
+        else run(tile_seq);
+        if constexpr (SUMS == 1) {
+            // row sums off the matrix cores: query n < 16 in lane n, register 0; query n + 16 in lane n, register 1 (both lanes of a query already added)
+#pragma unroll
+            for (int i = 0; i < QT; ++i) {
+                const float v0 = __shfl(l_mm[i][0], lane & 15, 64), v1 = __shfl(l_mm[i][1], lane & 15, 64);
+                l_acc[i] = 0.5f * ((fq & 16) ? v1 : v0);                      // (halved: the epilogue adds the lane pair)
+            }
+        }
+        // overflow vote: any non-finite row sum / output sends the whole workgroup to the classical loop
+        unsigned bad = 0;
+#pragma unroll
+        for (int i = 0; i < QT; ++i) {
+            bad |= ((__float_as_uint(l_acc[i]) & 0x7f800000u) == 0x7f800000u);
+            if constexpr (!REF) {
+                const float lq = l_acc[i] + __shfl_xor(l_acc[i], 32, 64);
+                bad |= (row0 + i * 32 + fq < a.n_rows) && !(lq >= 8.7e-19f);            // a row whose probabilities sank below 2^-60: not enough range left
+            }
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) bad |= ((__float_as_uint(o_acc[i][dt][r]) & 0x7f800000u) == 0x7f800000u);
+        }
+        classical = __syncthreads_or((int)bad) != 0;
+        if (classical) {
+#pragma unroll
+            for (int i = 0; i < QT; ++i) {
+                l_acc[i] = 0.0f;
+                o_acc[i][0] = zero16;
+                o_acc[i][1] = zero16;
+            }
+#pragma unroll
+            for (int i = 0; i < QT; ++i) m_run[i] = -INFINITY;
+            gload(0);
+            stash(0);
+            __syncthreads();
+            run(tile_classical);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < QT; ++i) {
+        const float l = l_acc[i] + __shfl_xor(l_acc[i], 32, 64);             // the two lanes of a query hold the sums of complementary key sets
+        const int r = row0 + i * 32 + fq;
+        if (r >= a.n_rows) continue;
+        const float inv = l > 0.0f ? 1.0f / l : 0.0f;
+        T* op = reinterpret_cast<T*>(a.out) + (long long)b * a.o_bs + (long long)h * a.o_hs + (long long)r * a.o_lo;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 o4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o4[e] = f32_to_bf16(o_acc[i][dt][4 * g + e] * inv);
+                *reinterpret_cast<bf16x4*>(op + dt * 32 + 8 * g + 4 * hi) = o4;
+            }
+    }
+}
+#undef zero16
+
 template <class T>
 static int launch_t(const AttnArgs& a_in, hipStream_t s) {
     AttnArgs a = a_in;
@@ -823,13 +1203,21 @@ static int launch_t(const AttnArgs& a_in, hipStream_t s) {
                 case 32: hipLaunchKernelGGL((attn_dit_kernel<4, true, true, 32>), g4, dim3(256), 0, s, a); break;
                 case 64: hipLaunchKernelGGL((attn_dit_kernel<4, true, true, 64>), g4, dim3(256), 0, s, a); break;
                 case 96: hipLaunchKernelGGL((attn_dit_kernel<4, true, true, 96>), g4, dim3(256), 0, s, a); break;
+                case 128: hipLaunchKernelGGL((attn_dit_kernel<4, true, true, 128>), g4, dim3(256), 0, s, a); break;     // de-paired MFMA order (bit-identical results; round 6: 1382 vs 958 us)
                 default: return set_error("option attn_lab=%d is not instantiated", lab), -1;
             }
             prof_end(slot, s);
             return hipGetLastError() == hipSuccess ? 0 : (set_error("attention launch failed"), -1);
         }
 #endif
-        if (a.n_rows >= 2048 && a.chunk <= 0) {
+        // attn_dit_form: 0 = per shape (below), 16 = the 16x16x32 tile whatever the shape says, 32 = the 32x32x16 tile (attn_dit32_kernel: measured SLOWER on MI355X,
+        // profiles/r06_attn_tile_ab.md — kept selectable, parity-tested, not the default)
+        const int form = (int)opt(OPT_ATTN_DIT_FORM);
+        if (form == 32 && a.chunk <= 0) {
+            const dim3 g1q((a.n_rows + 127) / 128, a.heads, a.batch);
+            if (a.q_log2) hipLaunchKernelGGL((attn_dit32_kernel<1, true>), g1q, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((attn_dit32_kernel<1, false>), g1q, dim3(256), 0, s, a);
+        } else if (a.n_rows >= 2048 && a.chunk <= 0) {
             if (a.q_log2) hipLaunchKernelGGL((attn_dit_kernel<4, true, true>), g4, dim3(256), 0, s, a);
             else hipLaunchKernelGGL((attn_dit_kernel<4, true, false>), g4, dim3(256), 0, s, a);
         } else {

@@ -434,7 +434,7 @@ COVERED = {'Abs': (), 'Add': (), 'And': (), 'ArgMax': ('axis', 'keepdims'), 'Arg
            'Gelu': (), 'Gemm': ('transB',), 'GlobalAveragePool': (), 'Greater': (), 'HardSigmoid': ('alpha', 'beta'), 'Identity': (), 'LayerNormalization': ('axis', 'epsilon'),
            'LeakyRelu': ('alpha',), 'Less': (), 'Log': (), 'LogSoftmax': ('axis',), 'MatMul': (), 'Max': (), 'Mean': (), 'Min': (), 'Mod': (), 'Mul': (), 'Neg': (), 'Not': (),
            'Or': (), 'PRelu': (), 'Pad': (), 'Pow': (), 'Range': (), 'Reciprocal': (), 'ReduceL2': ('axes', 'keepdims'), 'ReduceMax': ('axes', 'keepdims'),
-           'ReduceMean': ('axes', 'keepdims'), 'ReduceMin': ('axes', 'keepdims'), 'ReduceProd': ('axes', 'keepdims'), 'ReduceSum': ('keepdims',),
+           'ReduceMean': ('axes', 'keepdims'), 'ReduceMin': ('axes', 'keepdims'), 'ReduceProd': ('keepdims',), 'ReduceSum': ('keepdims',),
            'ReduceSumSquare': ('axes', 'keepdims'), 'Relu': (), 'Reshape': (), 'Round': (), 'Shape': (), 'Sigmoid': (), 'Sign': (), 'Sin': (), 'Size': (), 'Slice': (),
            'Softmax': ('axis',), 'Softplus': (), 'Split': ('axis',), 'Sqrt': (), 'Squeeze': (), 'Sub': (), 'Sum': (), 'Tanh': (), 'Tile': (), 'Transpose': ('perm',),
            'Unsqueeze': (), 'Where': (), 'Xor': ()}

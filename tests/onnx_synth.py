@@ -163,7 +163,7 @@ def per_operator_cases(seed=11):
         ('HardSigmoid', [xs], {'alpha': 0.3, 'beta': 0.4}), ('Sign', [xs], {}), ('LogSoftmax', [xs], {'axis': 1}), ('Sum', [xs, slope, xs], {}), ('Mean', [xs, slope], {}),
         ('ArgMax', [xs], {'axis': 2, 'keepdims': 0}), ('ArgMin', [xs], {'axis': 1, 'keepdims': 1}),
         ('ReduceSum', [xs, i64(1)], {'keepdims': 0}), ('ReduceMax', [xs], {'axes': [2], 'keepdims': 1}), ('ReduceMin', [xs], {'axes': [0, 2], 'keepdims': 0}),
-        ('ReduceL2', [xs], {'axes': [1], 'keepdims': 1}), ('ReduceSumSquare', [xs], {'axes': [2], 'keepdims': 0}), ('ReduceProd', [small], {'axes': [1], 'keepdims': 1}),
+        ('ReduceL2', [xs], {'axes': [1], 'keepdims': 1}), ('ReduceSumSquare', [xs], {'axes': [2], 'keepdims': 0}), ('ReduceProd', [i64(2, 3, 4)], {'keepdims': 0}),             # (shape arithmetic: an integer, host-resident operand)
         ('GlobalAveragePool', [xs], {}), ('Flatten', [xs], {'axis': 2}), ('Tile', [xs, i64(2, 1, 3)], {}), ('Pad', [xs, i64(0, 1, 2, 0, 0, 3), np.asarray(0.5, np.float32)], {}),
         ('Size', [xs], {}), ('Constant', [], {'value': small}), ('ConstantOfShape', [i64(2, 3)], {'value': np.asarray([1.5], np.float32)}), ('Dropout', [xs], {}),
         ('Mod', [i64(7, -7, 9), i64(3, 3, 4)], {}), ('Split', [xs, i64(4, 6, 7)], {'axis': 2}), ('Cast', [3000.0 * xs], {'to': 10}),

@@ -634,3 +634,52 @@ def test_onnx_frontend_graphs_on_device_vs_oracle(T):
     z = ref['latent'] * 0.999
     safe = (np.abs(np.abs(z) - 0.5) > 1e-3).all(-1)
     assert safe.mean() > 0.9 and np.array_equal(out['tokens'][safe], ref['tokens'][safe])
+
+
+def test_attention_dit_32x32x16_tile_vs_fp32_reference_and_the_product_tile():
+    """csrc/attention.hip: attn_dit32_kernel (option attn_dit_form = 32; the 32x32x16 MFMA tile, not the default: profiles/r06_attn_tile_ab.md) against an fp32 torch
+    reference and against the 16x16x32 product tile — ragged length (partial last tile, rows beyond n_rows), key padding per batch entry, both scale conventions, and the
+    classical fall-back when a score outgrows its row's reference by more than 2^127."""
+    from flowmirror_hydravox_amd import _lib, ops
+    g = torch.Generator().manual_seed(12)
+    B, H, T = 2, 8, 1000
+    Tp = 1024
+    q = (torch.randn(B, H, Tp, 64, generator=g) * 0.7).to(torch.bfloat16).to(DEV)
+    k = (torch.randn(B, H, Tp, 64, generator=g) * 0.7).to(torch.bfloat16).to(DEV)
+    vT = torch.randn(B, H, 64, Tp, generator=g).to(torch.bfloat16).to(DEV)
+    kv = torch.tensor([1000, 77], dtype=torch.int32, device=DEV)
+
+    def ref(b, h, n, log2):
+        s = q[b, h, :T].float() @ k[b, h, :n].float().t() * (0.6931471805599453 if log2 else 0.125)
+        return torch.softmax(s, dim=-1) @ vT[b, h, :, :n].float().t()
+    try:
+        for log2 in (True, False):
+            for kv_len in (None, kv):
+                outs = {}
+                for form in (16, 32):
+                    _lib.set_option('attn_dit_form', form)
+                    outs[form] = ops.attention(q, k, vT, T, q_log2=log2, kv_len=kv_len).float()
+                assert torch.isfinite(outs[32]).all()
+                assert float((outs[32] - outs[16]).abs().max()) < 2e-2
+                for b, h in ((0, 0), (1, 5)):
+                    n = T if kv_len is None else int(kv_len[b])
+                    r = ref(b, h, n, log2)
+                    e32 = float((outs[32][b, :, h * 64:(h + 1) * 64] - r).abs().max())
+                    e16 = float((outs[16][b, :, h * 64:(h + 1) * 64] - r).abs().max())
+                    assert e32 < 1.5e-2 and e32 < 2.0 * e16 + 1e-3, (log2, b, h, e32, e16)
+        # a key far from the first tile that beats a row's reference by > 2^127: the workgroup must redo its rows with the classical loop
+        q2, k2 = q.clone(), k.clone()
+        q2[0, 0, 5] = 0
+        q2[0, 0, 5, 0] = 16.0
+        k2[0, 0, :, 0] = 0
+        k2[0, 0, 900, 0] = 16.0                                        # score 256 (log2 units) at key 900 of row 5, ~0 elsewhere
+        _lib.set_option('attn_dit_form', 32)
+        o = ops.attention(q2, k2, vT, T, q_log2=True).float()
+        assert torch.isfinite(o).all()
+        want = vT[0, 0, :, 900].float()
+        assert float((o[0, 5, :64] - want).abs().max()) < 1e-2
+        s = q2[0, 0, :T].float() @ k2[0, 0, :T].float().t() * 0.6931471805599453
+        r = torch.softmax(s, dim=-1) @ vT[0, 0, :, :T].float().t()
+        assert float((o[0, :, :64] - r).abs().max()) < 2e-2
+    finally:
+        _lib.set_option('attn_dit_form', 0)
