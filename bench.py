@@ -70,6 +70,8 @@ def parse():
     ap.add_argument('--prof-period', type=int, default=17, help='every n-th launch of a kernel class is bracketed in the profiling step (prime: no aliasing with the 4-GEMM block period)')
     ap.add_argument('--no-extras', action='store_true', help='skip the untimed extra objects of the line: single_request (BASELINE configs[0] shape), head_sweep (head_num 1 / 4), bf16_id_agreement')
     ap.add_argument('--sweep-steps', type=int, default=8, help='steps of 8 utterances per point of the head_num sweep')
+    ap.add_argument('--hift-exact', action='store_true', help='the vocoder on the exact fp32 MFMA forms (hvx_hift_config.exact_fp32) instead of split-bf16 pairs')
+    ap.add_argument('--config-steps', type=int, default=4, help='steps of each of the other BASELINE configs (stress, zero_shot, acoustic) run behind the headline as the `configs` object; 0: skip')
     ap.add_argument('--cpu-baseline-worker', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--stub-pipeline', action='store_true', help=argparse.SUPPRESS)      # plumbing check of the rank logic on CPU / gloo (tools/bench_stub.py); INVALID as a benchmark
     return ap.parse_args()
@@ -144,12 +146,13 @@ def roofline_of(name, p):
         ach = p['rate'] / 1e9
         return dict(kernel=name, bound='hbm', achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(ach / HBM_PEAK_GBS, 4),
                     traffic=pmc_traffic(name), avg_launch_us=round(p['avg_us'], 2), algorithmic_bytes_per_launch=round(p['work_per_launch']),
-                    launches_per_timed_region=p['launches'], sampled_launches=p['sampled'])
+                    launches_per_step=p['launches'], launches_per_timed_region=p['launches'] * p.get('steps', 1), sampled_launches=p['sampled'])
     peak = MFMA_X3_PEAK_TF if name.endswith('f32') else MFMA_BF16_PEAK_TF
     ach = p['rate'] / 1e12
     d = dict(kernel=name, bound='mfma', achieved=round(ach, 2), peak=round(peak, 1), unit='TFLOP/s', frac=round(ach / peak, 4), traffic=pmc_traffic(name),
              avg_launch_us=round(p['avg_us'], 2), algorithmic_flops_per_launch=round(p['work_per_launch']),
-             launches_per_timed_region=p['launches'], sampled_launches=p['sampled'])
+             launches_per_step=p['launches'], launches_per_timed_region=p['launches'] * p.get('steps', 1), sampled_launches=p['sampled'],
+             measured='hipEvent brackets around every %d-th launch of the class in ONE extra profiling step (same kernels, same geometry as a timed step)' % p.get('period', 1))
     if name.endswith('f32'):
         d['peak_note'] = 'fp32-equivalent flops of the convolution; every step is 3 bf16 MFMAs on (hi, lo) operand pairs, so the peak is the dense bf16 peak / 3'
         d['includes'] = 'every split-bf16 GEMM launch of the timed region: the vocoder convolutions and, in the flow\'s reference-precision mode, the fp32 input projection of its estimator calls'
@@ -328,12 +331,16 @@ def run_acoustic(args, cfg, world, rank, lib):
     from flowmirror_hydravox_amd import weights as W
     from flowmirror_hydravox_amd.flow import HvxFlow
     from flowmirror_hydravox_amd.hift import HvxHift
-    from flowmirror_hydravox_amd.dp import gather_waveforms
+    from flowmirror_hydravox_amd.dp import gather_waveforms, shard_by_cost, acoustic_cost
     flow = HvxFlow(cfg.flow, W.make_flow_state(cfg.flow, seed=1987, init='normal02'), dtype=torch.bfloat16, max_t=2 * 2816 + 64)
-    hift = HvxHift(cfg.hift, W.make_hift_state(cfg.hift, seed=1988, init='normal02'))
-    n = args.streams
-    ids = [rank * n + i for i in range(n)]
-    lens = [int(torch.randint(352, 2817, (1,), generator=torch.Generator().manual_seed(9_000_011 + i))) for i in ids]
+    hift = HvxHift(cfg.hift, W.make_hift_state(cfg.hift, seed=1988, init='normal02'), exact_fp32=args.hift_exact)
+    # the GLOBAL list of streams x world streams (global index = seed) dealt longest-first by cost a T + b T^2 (dp.acoustic_cost): every rank gets the same
+    # amount of WORK, not the same count; one rank: all of them
+    n_global = args.streams * world
+    all_lens = [int(torch.randint(352, 2817, (1,), generator=torch.Generator().manual_seed(9_000_011 + i))) for i in range(n_global)]
+    ids = shard_by_cost([acoustic_cost(2.0 * m) for m in all_lens], world)[rank]
+    n = len(ids)
+    lens = [all_lens[i] for i in ids]
     toks = [torch.randint(0, cfg.flow.vocab, (m,), generator=torch.Generator().manual_seed(i), dtype=torch.int32).cuda() for i, m in zip(ids, lens)]
     embs = [torch.randn(cfg.flow.spk_embed_dim, generator=torch.Generator().manual_seed(i)).cuda() for i in ids]
     order = sorted(range(n), key=lambda i: -lens[i])
@@ -389,6 +396,7 @@ def run_acoustic(args, cfg, world, rank, lib):
     print(json.dumps({
         'metric': 'mel frames/sec, flow-matching (10 Euler steps x CFG 2) + HiFT vocoder only, pre-tokenised streams', 'value': round(frames / elapsed, 1),
         'unit': 'mel-frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 2),
+        'rccl_ranks': (torch.distributed.get_world_size() if world > 1 else 1), 'collective_backend': ((torch.distributed.get_backend() + ' (= RCCL on ROCm)') if world > 1 else None),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
         'config': {'workload': 'BASELINE configs[4] slice: %d speech-token streams per GPU and step, lengths U{352..2816} (mean %.0f), flow bf16 (DiT 22 x 1024) in padded '
                                'solves of up to %d streams of neighbouring length, HiFT fp32 contract (decode convolutions as split-bf16 MFMA), seeded N(0,0.02) weights'
@@ -487,7 +495,7 @@ def main():
         pipe = StubPipeline(cfg, K)
     else:
         pipe = HvxPipeline(cfg, llm_dtype=torch.float32 if args.llm_dtype == 'fp32' else torch.bfloat16, flow_dtype=torch.bfloat16, max_batch=B, max_ctx=max_ctx, max_t=2 * (n_spk + P_SPK) + 64,
-                           seed=1986, init='normal02', sampling=sampling, inference_head_num=K)
+                           seed=1986, init='normal02', sampling=sampling, inference_head_num=K, hift_exact_fp32=args.hift_exact)
     pipe.acoustic_batch = max(1, args.acoustic_batch)
     pipe.lm_cus = args.lm_cus
     pipe.lm_cus_only = args.lm_cus_only
@@ -634,9 +642,12 @@ def main():
         'metric': 'speech-tokens/sec + RTF, HydraVox-CV3 head_num=%d, %s' % (K, '%d-char batch' % chars if not zero_shot else 'zero-shot mixed-length batch'),
         'value': round(tokens / elapsed, 2), 'unit': 'speech-tokens/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 2),
+        # ranks that took part in the collective group of THIS run (torch.distributed over RCCL: backend "nccl"), so that a scaling record can be checked for N ranks
+        'rccl_ranks': (torch.distributed.get_world_size() if world > 1 else 1), 'collective_backend': ((torch.distributed.get_backend() + ('' if stub else ' (= RCCL on ROCm)')) if world > 1 else None),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16' if args.llm_dtype == 'bf16' else 'f32 (LM) + bf16 (flow)', 'data': 'synthetic',
         'config': {'workload': 'HydraVox-CV3%s inference_head_num=%d, batch=%dx%d-char utterances per GPU (%d text -> %d speech tokens -> %d mel frames '
-                               'each), %s / hift fp32, llm->flow->hift end to end, seeded N(0,0.02) weights'
+                               'each), %s / hift split-bf16 (fp32 operands as (hi, lo) bf16 pairs, 3 MFMAs per step: ~16 mantissa bits; `exact_vocoder` = the exact fp32 form), '
+                               'llm->flow->hift end to end, seeded N(0,0.02) weights'
                                % (' [STUB PIPELINE ON CPU / GLOO - RANK LOGIC ONLY, NOT A BENCHMARK]' if stub else ' [TINY DIMS - NOT A BENCHMARK]' if args.tiny else '', K, B, chars, chars, n_spk, 2 * n_spk,
                                   'llm+flow bf16' if args.llm_dtype == 'bf16' else 'llm fp32 (speech-token ids bit-exact against the reference) + flow bf16'),
                    'baseline_config': {'tts': 'configs[1]', 'stress': 'configs[2]', 'zero_shot': 'configs[3]: text lengths U{64..512} per utterance (the chars figure above is the maximum), '
@@ -690,6 +701,8 @@ def main():
                                              measured='the same grid of %d sequences with nothing else on the GPU (untimed run before the timed region)' % args.lm_slots
                                                       if lm_alone else 'same brackets in the warm-up step (stages back to back, nothing else on the GPU)')
     if est:
+        for n in prof:
+            prof[n]['steps'], prof[n]['period'] = args.steps, args.prof_period
         line['roofline_other'] = [roofline_of(n, prof[n]) for _, n in est if prof[n]['work_per_launch'] > 0]
         line['kernel_time_share_ms'] = {n: round(t, 1) for t, n in est}
     if strict is not None:
@@ -704,10 +717,22 @@ def main():
             line['head_sweep'] = head_sweep(pipe, args, make_utt, ratio, K, B)
         except Exception as e:
             line['head_sweep'] = {'error': repr(e)}
+        try:
+            # the decode step of a ONE-sequence grid (every single request; configs[1] read literally sits at 8 x 2 rows on the same launch floor): a roofline entry of its own
+            sr = line['single_request']['head_num_1']
+            by = pipe.llm.decode_step_bytes(1, 1, 2 + 64 + 176)                       # mean context of a 64-char request: prefix 66 + half of its 352 tokens
+            line.setdefault('roofline_other', []).append(dict(
+                kernel='llm_decode_small_grid (hipGraph step of ONE sequence x 1 head: 6 dependent launches x 24 layers + head + sampler)', bound='hbm',
+                achieved=round(by / sr['decode_step_us'] / 1e3, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(by / sr['decode_step_us'] / 1e3 / HBM_PEAK_GBS, 4), traffic=None,
+                avg_launch_us=sr['decode_step_us'], algorithmic_bytes_per_launch=round(by), launches_per_timed_region=0,
+                measured='hipEvents around blocks of decode-graph replays inside `single_request` (untimed extra): launch-latency-bound, DESIGN.md §8'))
+        except Exception as e:
+            line.setdefault('roofline_other', []).append({'kernel': 'llm_decode_small_grid', 'error': repr(e)})
     del pipe
     if stub:
         line['stub'] = {'received_on_rank0': hand.n_received if cont is not None else len(got), 'handoff_rounds': hand.rounds if cont is not None else None,
                         'shard_sizes': [len(sh) for sh in shards] if cont is not None else None,
+                        'shard_text': [sum(n_text_of(g) for g in sh) for sh in shards] if cont is not None else None,
                         'checksum': float(sum(float(w.double().sum()) for w in got.values())) if got else 0.0}
         print(json.dumps(line))
         return
@@ -780,6 +805,67 @@ def main():
             torch.cuda.empty_cache()
         except Exception as e:
             line['ids_exact_mode'] = {'value': None, 'error': repr(e)}
+    if world == 1 and not args.no_fp32_mode and not args.tiny and args.mode == 'continuous' and args.llm_dtype == 'bf16' and args.config == 'tts' and not args.hift_exact:
+        # the headline's job with the vocoder on the EXACT fp32 MFMA forms (hvx_hift_config.exact_fp32 = the reference's own fp32 vocoder arithmetic, 2.8e-5 of the
+        # reference's waveform at 5632 frames against 1.5e-4 for the split-bf16 default: tests/test_gpu_refpin.py), through the same engine, its own clock
+        try:
+            pipev = HvxPipeline(cfg, llm_dtype=torch.bfloat16, flow_dtype=torch.bfloat16, max_batch=B, max_ctx=max_ctx, max_t=2 * (n_spk + P_SPK) + 64,
+                                seed=1986, init='normal02', sampling=sampling, inference_head_num=K, hift_exact_fp32=True)
+            pipev.acoustic_batch = max(1, args.acoustic_batch)
+            _, stv = pipev.synthesize(utts, max_token_text_ratio=ratio, min_token_text_ratio=ratio)        # warm-up + the un-overlapped stage times
+            n_v = min(args.steps, 8)
+            jobv = [make_utt(g) for g in range(n_v * B)]
+            torch.cuda.synchronize()
+            tv = time.time()
+            tokv = 0
+            for i, wav, toks in pipev.synthesize_continuous(jobv, lm_slots=args.lm_slots, max_token_text_ratio=ratio, min_token_text_ratio=ratio,
+                                                            acoustic_batch=args.acoustic_batch, acoustic_min_batch=args.acoustic_min_batch):
+                tokv += len(toks)
+            torch.cuda.synchronize()
+            tv = time.time() - tv
+            line['exact_vocoder'] = {'value': round(tokv / tv, 1), 'unit': 'speech-tokens/s', 'steps': n_v, 'ms_per_step': round(1e3 * tv / n_v, 2),
+                                     'hift_seconds': round(stv.hift_seconds, 4), 'hift_seconds_split_bf16': None if serial is None else round(serial.hift_seconds, 4),
+                                     'what': 'the headline job with HvxHift(exact_fp32=True): every vocoder convolution on v_mfma_f32_16x16x4_f32 (the reference\'s fp32 arithmetic); '
+                                             'hift_seconds = the vocoder stage of one batch of %d utterances, stages back to back' % B}
+            del pipev
+            torch.cuda.empty_cache()
+        except Exception as e:
+            line['exact_vocoder'] = {'value': None, 'error': repr(e)}
+    if world == 1 and not args.tiny and args.config == 'tts' and args.mode == 'continuous' and args.llm_dtype == 'bf16':
+        # north_star's parity clause (ids bit-exact; mel / waveform 1e-3) against what each measured mode delivers, in ONE place.  The distances are what
+        # the GPU tests assert against the REFERENCE's own outputs at these shapes (tests/test_gpu_refpin.py, test_gpu_cv3d.py), not measured in this run.
+        def _v(k):
+            return (line.get(k) or {}).get('value')
+        line['parity_modes'] = {
+            'headline (bf16 LM, reference-fp16-precision flow, split-bf16 vocoder)': {
+                'speech_tokens_per_s': line['value'], 'ids_vs_reference': 'not bit-exact: teacher-forced per-decision agreement %s' % (
+                    (line.get('bf16_id_agreement') or {}).get('agreement')), 'mel_vs_reference': 1.5e-3, 'vocoder_stage_vs_reference': 1.5e-4},
+            'ids_exact_mode (fp32 LM, same flow / vocoder)': {
+                'speech_tokens_per_s': _v('ids_exact_mode'), 'ids_vs_reference': 'bit-exact (the 64-slot x 2-head grid of this mode beside 63 live sequences at contexts > 1024, and '
+                'batch-invariant over a whole 1408-step stream: tests/test_gpu_refpin.py)', 'mel_vs_reference': 1.5e-3, 'vocoder_stage_vs_reference': 1.5e-4},
+            'exact_vocoder (headline + exact fp32 vocoder)': {'speech_tokens_per_s': _v('exact_vocoder'), 'vocoder_stage_vs_reference': 2.8e-5},
+            'fp32_mode (fp32 LM + fp32 flow, strict batch of 8)': {
+                'speech_tokens_per_s': _v('fp32_mode'), 'ids_vs_reference': 'bit-exact', 'mel_vs_reference': 1.1e-6, 'vocoder_stage_vs_reference': 1.5e-4},
+            'note': 'the 19-20 k tokens/s of `value` and "ids bit-exact" never hold in the same run; end-to-end waveforms are held to the reference\'s own conditioning band '
+                    '(tests/golden/hift_full_cond.npz: the reference against itself under 1-ulp f0 perturbations), stage-wise numbers above'}
+    if world == 1 and not args.tiny and not stub and args.config == 'tts' and args.config_steps > 0 and not args.no_extras:
+        # the other BASELINE configs on this GPU, behind the headline: one fresh process each (their pipelines differ: 4 heads x 32 slots, prompts, no LM), compact summaries
+        import subprocess
+        line['configs'] = {}
+        for name, extra in (('stress', []), ('zero_shot', []), ('acoustic', [])):
+            try:
+                cmd = [sys.executable, os.path.abspath(__file__), '--config', name, '--steps', str(args.config_steps), '--warmup', '1', '--no-cpu-baseline', '--no-fp32-mode',
+                       '--no-extras', '--config-steps', '0'] + extra
+                t_c = time.time()
+                out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=420)
+                js = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+                d = json.loads(js[-1])
+                line['configs'][name] = {'baseline_config': {'stress': 'configs[2]', 'zero_shot': 'configs[3] (one GPU of its 8)', 'acoustic': 'configs[4] (one GPU of its 8)'}[name],
+                                         'metric': d.get('metric'), 'value': d.get('value'), 'unit': d.get('unit'), 'steps': d.get('steps'), 'ms_per_step': d.get('ms_per_step'),
+                                         'rtf': d.get('rtf'), 'workload': (d.get('config') or {}).get('workload'), 'seconds': round(time.time() - t_c, 1),
+                                         'roofline_frac': (d.get('roofline') or {}).get('frac')}
+            except Exception as e:
+                line['configs'][name] = {'value': None, 'error': repr(e)}
     if world == 1 and not args.no_cpu_baseline:
         try:
             # separate process with a hard wall-clock limit: the GPU line must be printed whatever the host cores do

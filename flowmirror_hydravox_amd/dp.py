@@ -25,6 +25,13 @@ def shard_by_cost(costs: Sequence[float], world: int) -> List[List[int]]:
     return [sorted(s) for s in shards]
 
 
+def acoustic_cost(frames: float) -> float:
+    """Work of the flow decoder + vocoder for one stream of `frames` mel frames, in flops: DiT Linears 7.56 GF and vocoder 0.672 GF per frame,
+    DiT attention 1.80 MF per frame squared — the shard cost of BASELINE configs[4] (mixed lengths: the quadratic term makes a long stream worth more than
+    its length)."""
+    return (7.56e9 + 0.672e9) * frames + 1.80e6 * frames * frames
+
+
 class Handoff:
     """Hands a rank's finished waveforms to rank `dst` in rounds of `per_round` utterances.  gather_waveforms is a collective, so every rank
     must enter it the same number of times although a longest-first deal gives the ranks different utterance counts: the number of rounds

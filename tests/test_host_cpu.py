@@ -835,34 +835,44 @@ def test_onnx_auto_pad_and_opset_defaults_are_honoured_not_ignored():
     np.testing.assert_allclose(onnx_ref._node(og.Node('Softmax', ['x'], ['y'], {}), [xs], 13), torch.softmax(torch.from_numpy(xs), -1).numpy(), rtol=1e-5, atol=1e-7)
 
 
-@pytest.mark.parametrize('config', ['tts', 'zero_shot'])
-def test_bench_rank_logic_world_size_2_gloo_with_a_stub_pipeline(config):
-    """everything `bench.py --gpus 2` does AROUND the pipeline — WORLD_SIZE / RANK from the environment, the longest-first deal of the
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        return str(sk.getsockname()[1])
+
+
+@pytest.mark.parametrize('config,world,steps,B', [('tts', 2, 3, 4), ('zero_shot', 2, 3, 4), ('zero_shot', 8, 1, 8)])
+def test_bench_rank_logic_world_size_2_gloo_with_a_stub_pipeline(config, world, steps, B):
+    """everything `bench.py --gpus N` does AROUND the pipeline — WORLD_SIZE / RANK from the environment, the longest-first deal of the
     global utterance list (uneven with mixed lengths), one continuous job per rank, Handoff rounds of one step's worth of waveforms to rank 0 inside the
-    timed region, barrier + max-over-ranks of the wall time, sum of the token counts, ONE JSON line from rank 0 — at world size 2 on gloo, with
-    tools/bench_stub.py standing in for the GPU pipeline.  Rank 0 must have received every global utterance, bit-equal to what one rank alone makes."""
+    timed region, barrier + max-over-ranks of the wall time, sum of the token counts, ONE JSON line from rank 0 — at world size 2 and, for BASELINE configs[3]'s
+    own geometry (64 mixed-length zero-shot utterances over 8 ranks, 8 per rank and step), at world size 8 on gloo, with tools/bench_stub.py standing in for the GPU
+    pipeline.  Rank 0 must have received every global utterance, bit-equal to what one rank alone makes; the deal balances TEXT, not counts."""
     import json
     sys.path.insert(0, os.path.join(ROOT, 'tools'))
     from bench_stub import stub_wave
-    steps, B, world = 3, 4, 2
-    port = {'tts': '29641', 'zero_shot': '29643'}[config]
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=port, WORLD_SIZE=str(world), HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='')
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=_free_port(), WORLD_SIZE=str(world), HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='', OMP_NUM_THREADS='1')
     cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(world), '--steps', str(steps), '--warmup', '1', '--batch', str(B), '--tiny', '--stub-pipeline', '--config', config]
     procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
-    outs = [p.communicate(timeout=300) for p in procs]
+    outs = [p.communicate(timeout=600) for p in procs]
     assert all(p.returncode == 0 for p in procs), [o[1][-2000:] for o in outs]
-    assert not [ln for ln in outs[1][0].splitlines() if ln.startswith('{')]          # only rank 0 prints a line
+    for r in range(1, world):
+        assert not [ln for ln in outs[r][0].splitlines() if ln.startswith('{')]      # only rank 0 prints a line
     lines = [ln for ln in outs[0][0].splitlines() if ln.startswith('{')]
     assert len(lines) == 1
     d = json.loads(lines[0])
     n_global = steps * B * world
-    assert d['n_gpus'] == world and d['steps'] == steps and d['scaling'] == 'weak' and d['config']['parallelism'] == 'utterance-dp2' and d['config']['global_batch'] == B * world
+    assert d['n_gpus'] == world and d['steps'] == steps and d['scaling'] == 'weak' and d['config']['parallelism'] == 'utterance-dp%d' % world and d['config']['global_batch'] == B * world
+    assert d['rccl_ranks'] == world and d['collective_backend'] == 'gloo'               # (the stub's group; on GPUs: "nccl (= RCCL on ROCm)")
     assert 'STUB' in d['config']['workload'] and d['value'] > 0 and d['ms_per_step'] > 0
     st = d['stub']
     assert st['received_on_rank0'] == n_global and sum(st['shard_sizes']) == n_global
     assert st['handoff_rounds'] == -(-max(st['shard_sizes']) // B)
     if config == 'zero_shot':
-        assert st['shard_sizes'][0] != st['shard_sizes'][1] or True             # (mixed lengths: the deal balances text length, not counts)
+        # mixed lengths: the longest-first deal balances the text the ranks decode (the spread of LPT is bounded by the largest item over the mean load)
+        lo, hi = min(st['shard_text']), max(st['shard_text'])
+        assert (hi - lo) / (sum(st['shard_text']) / world) < (0.03 if world == 8 else 0.06), st['shard_text']
     # the checksum of everything rank 0 holds == what a single rank produces for those global ids (seed = global index)
     import torch
     from flowmirror_hydravox_amd.config import tiny_config
@@ -938,3 +948,20 @@ def test_build_never_reuses_objects_of_other_flags(tmp_path):
     assert '-DHVX_BUILD_FLAGS="-DHVX_LAB -DHVX_LAB_GEMM_EPI=1"' in B._command(str(src), obj, ('-DHVX_LAB', '-DHVX_LAB_GEMM_EPI=1'))
     with pytest.raises(ValueError):
         B.build(extra=('-DHVX_LAB',))                                       # extra flags without a lab name: refused before anything is compiled
+
+
+def test_acoustic_config_deal_of_10000_streams_over_8_ranks():
+    """BASELINE configs[4] on 8 GPUs: 10 000 pre-tokenised streams of U{352..2816} tokens dealt longest-first by WORK a T + b T^2 (dp.acoustic_cost: the DiT attention
+    makes a long stream worth more than its length) — every rank's work within 0.1 % of the mean although the counts differ, every stream exactly once; and what
+    bench.py --config acoustic does with it at one rank (all streams, same ids as before the deal existed)."""
+    from flowmirror_hydravox_amd.dp import acoustic_cost, shard_by_cost
+    lens = [int(torch.randint(352, 2817, (1,), generator=torch.Generator().manual_seed(9_000_011 + i))) for i in range(10000)]
+    costs = [acoustic_cost(2.0 * m) for m in lens]
+    shards = shard_by_cost(costs, 8)
+    assert sorted(i for s in shards for i in s) == list(range(10000))
+    work = [sum(costs[i] for i in s) for s in shards]
+    assert (max(work) - min(work)) / (sum(work) / 8) < 1e-3, work
+    frames = [sum(2 * lens[i] for i in s) for s in shards]
+    assert (max(frames) - min(frames)) / (sum(frames) / 8) < 0.02            # frames follow the work closely but not exactly (quadratic term)
+    assert acoustic_cost(5632) / acoustic_cost(704) > 8.5                    # 8x the frames, ~8.9x the work
+    assert shard_by_cost(costs[:64], 1) == [list(range(64))]
