@@ -28,7 +28,14 @@ constexpr int BM = 256, WM = 128, WN = 64, MT = WM / 16, NT = WN / 16;
 // with or without a deliberate half-tile start offset between the two co-resident workgroups: 1.5x the L2 -> LDS bytes per flop)
 // T: the operand type — bf16, or IEEE fp16 for the DiT block Linears of a handle that runs them in the reference's deployed dtype (DT_F16); the QKV
 // epilogue writes q / k / V^T for the attention in bf16 either way
-template <int EPI, int BN, int BK, int NWAVE, class T>
+// MS: the MFMA shape of the K-loop — 16 (v_mfma_f32_16x16x32: 64 instructions of 16 cycles per K-tile and wave) or 32 (v_mfma_f32_32x32x16: 32 instructions of
+// 32 cycles, the shape the matrix pipe sustains 12-15 % faster and that leaves twice the issue slots per matrix cycle for the fragment reads and the DMA; the
+// accumulators are then 4 x 2 tiles of 32 x 32, the same 128 registers, and the epilogue stages them through acc_stage's second form).  Same sums per output
+// element, another order of the k index inside a K-tile: results differ in the last fp32 bits of the accumulation only.
+__device__ __forceinline__ f32x16_epi mfma32(const bf16x8& x, const bf16x8& y, const f32x16_epi& c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16_epi mfma32(const f16x8& x, const f16x8& y, const f32x16_epi& c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, c, 0, 0, 0); }
+
+template <int EPI, int BN, int BK, int NWAVE, class T, int MS = 16>
 __global__ __launch_bounds__(NWAVE * 64, 2) void gemm_big_kernel(GemmArgs a, int tiles_m, int tiles_n, int gw) {
     constexpr int TILE_ELEMS = (BM + BN) * BK;               // one K-tile of A and W (bf16 elements)
     constexpr int WAVES_N = BN / WN;
@@ -89,6 +96,73 @@ __global__ __launch_bounds__(NWAVE * 64, 2) void gemm_big_kernel(GemmArgs a, int
         for (int q = 0; q < QB; ++q) __builtin_amdgcn_global_load_lds((glb_ptr)(pw + offW[q]), (lds_ptr)(Bs + (wave * QB + q) * RPI * BK), 16, 0, 0);
     };
 
+    const int nk = a.K / BK;
+    if constexpr (MS == 32) {
+        // ---- K-loop on 32 x 32 x 16 MFMAs: four k-steps of 16 per K-tile, 4 A + 2 B fragments (one ds_read_b128 each) feed the 8 MFMAs of a step; the two fragment
+        // sets alternate, the barrier sits behind the third step: after it the first step of tile kc + 1 is read under the last step of tile kc -------------------
+        static_assert(BK == 64 && MT == 8 && NT == 4, "written for the 128 x 64 wave tile");
+        constexpr int MT2 = MT / 2, NT2 = NT / 2;
+        f32x16_epi acc[MT2][NT2];
+#pragma unroll
+        for (int i = 0; i < MT2; ++i)
+#pragma unroll
+            for (int j = 0; j < NT2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        typedef typename Vec8<T>::type frag_t;
+        const int c31 = lane & 31, hi = lane >> 5;
+        const int sw = (c31 >> 1) & (SLOTS - 1);                     // ((row >> 1) & 7) of every fragment row of this lane (rows = 32 i + c31)
+        frag_t a0[MT2], b0[NT2], a1[MT2], b1[NT2];
+        auto loadf = [&](int buf, int step, frag_t (&af)[MT2], frag_t (&bf)[NT2]) __attribute__((always_inline)) {
+            const int off = ((2 * step + hi) ^ sw) * 8;
+            const T* const As = lds + buf * TILE_ELEMS + (wm0 + c31) * BK + off;
+            const T* const Bs = lds + buf * TILE_ELEMS + BM * BK + (wn0 + c31) * BK + off;
+#pragma unroll
+            for (int j = 0; j < NT2; ++j) bf[j] = load8(Bs + j * 32 * BK);
+#pragma unroll
+            for (int i = 0; i < MT2; ++i) af[i] = load8(As + i * 32 * BK);
+        };
+        auto mfmas = [&](const frag_t (&af)[MT2], const frag_t (&bf)[NT2]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < MT2; ++i)
+#pragma unroll
+                for (int j = 0; j < NT2; ++j) acc[i][j] = mfma32(af[i], bf[j], acc[i][j]);
+        };
+        auto interleave = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int q = 0; q < MT2 + NT2; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);           // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);           // one LDS read
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, MT2 * NT2 - (MT2 + NT2), 0);
+        };
+        auto iter = [&](int kc, auto DMA, auto NEXT) __attribute__((always_inline)) {
+            loadf(kc & 1, 1, a1, b1);
+            mfmas(a0, b0);
+            interleave();
+            loadf(kc & 1, 2, a0, b0);
+            mfmas(a1, b1);
+            interleave();
+            loadf(kc & 1, 3, a1, b1);
+            mfmas(a0, b0);
+            interleave();
+            __syncthreads();                             // every wave has read all of tile kc (its buffer is free); tile kc + 1 has landed
+            if constexpr (decltype(DMA)::value) issue(kc + 2, kc & 1);
+            if constexpr (decltype(NEXT)::value) loadf((kc + 1) & 1, 0, a0, b0);
+            mfmas(a1, b1);
+            if constexpr (decltype(NEXT)::value) interleave();
+        };
+        issue(0, 0);
+        __syncthreads();
+        if (nk > 1) issue(1, 1);
+        loadf(0, 0, a0, b0);
+        for (int kc = 0; kc < nk - 2; ++kc) iter(kc, std::true_type{}, std::true_type{});
+        if (nk >= 2) iter(nk - 2, std::false_type{}, std::true_type{});
+        iter(nk - 1, std::false_type{}, std::false_type{});
+        __syncthreads();                                 // the epilogue reuses the tile memory as staging
+        gemm_epilogue<T, MT, NT, WN, EPI, 1, bf16_t>(a, acc, reinterpret_cast<float*>(smem) + wave * SCR_FLOATS, lane, m0 + wm0, n0 + wn0, bz, 0);
+        return;
+    }
     f32x4 acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -128,7 +202,6 @@ __global__ __launch_bounds__(NWAVE * 64, 2) void gemm_big_kernel(GemmArgs a, int
         }
         __builtin_amdgcn_sched_group_barrier(0x008, MT * NT - 2 * (MT + NT), 0);
     };
-    const int nk = a.K / BK;
     auto iter = [&](int kc, auto DMA, auto NEXT) __attribute__((always_inline)) {
         loadf(kc & 1, off1, a1, b1);
         mfmas(a0, b0);
@@ -182,13 +255,20 @@ int launch_form(const GemmArgs& a, hipStream_t s, long long min_tiles) {
     if (gw_env > 0 && gw_env < tiles_n && tiles_n % gw_env == 0) gw = gw_env;
     const int slot = prof_begin(PK_GEMM, 2.0 * a.M * a.N * (double)a.K * a.batch, s);
     const dim3 grid((unsigned)tiles), block(NWAVE * 64);
+    const bool m32 = opt(OPT_GEMM_BIG_MFMA) == 32;          // (A / B option gemm_big_mfma: 16 | 32)
+#define HVX_BIG(EPI_, T_)                                                                                                            \
+    do {                                                                                                                            \
+        if (m32) hipLaunchKernelGGL((gemm_big_kernel<EPI_, BN, BK, NWAVE, T_, 32>), grid, block, 0, s, a, tiles_m, tiles_n, gw);    \
+        else hipLaunchKernelGGL((gemm_big_kernel<EPI_, BN, BK, NWAVE, T_, 16>), grid, block, 0, s, a, tiles_m, tiles_n, gw);        \
+    } while (0)
     if (a.dtype == DT_F16) {
-        if (a.epi == EPI_GENERIC) hipLaunchKernelGGL((gemm_big_kernel<EPI_GENERIC, BN, BK, NWAVE, f16_t>), grid, block, 0, s, a, tiles_m, tiles_n, gw);
-        else hipLaunchKernelGGL((gemm_big_kernel<EPI_QKV_DIT, BN, BK, NWAVE, f16_t>), grid, block, 0, s, a, tiles_m, tiles_n, gw);
+        if (a.epi == EPI_GENERIC) HVX_BIG(EPI_GENERIC, f16_t);
+        else HVX_BIG(EPI_QKV_DIT, f16_t);
     } else {
-        if (a.epi == EPI_GENERIC) hipLaunchKernelGGL((gemm_big_kernel<EPI_GENERIC, BN, BK, NWAVE, bf16_t>), grid, block, 0, s, a, tiles_m, tiles_n, gw);
-        else hipLaunchKernelGGL((gemm_big_kernel<EPI_QKV_DIT, BN, BK, NWAVE, bf16_t>), grid, block, 0, s, a, tiles_m, tiles_n, gw);
+        if (a.epi == EPI_GENERIC) HVX_BIG(EPI_GENERIC, bf16_t);
+        else HVX_BIG(EPI_QKV_DIT, bf16_t);
     }
+#undef HVX_BIG
     prof_end(slot, s);
     return hipGetLastError() == hipSuccess ? 1 : (set_error("gemm (256-tile form) launch failed"), -1);
 }

@@ -47,8 +47,35 @@ template <bool RT, int ACT, int RES, int OF32, int O2, int ACT2 = 0> struct Lean
 
 // LEAN: compile the streamlined pass for whole, aligned column tiles (costs ~50 VGPRs: only the one-workgroup-per-CU 256-tile form takes it)
 // QT: the storage type of q / k / V^T in EPI_QKV_DIT (the attention's operand type; differs from T only for fp16-operand Linears, whose attention stays bf16)
-template <class T, int MT, int NT, int WN, int EPI, int LEAN = 0, class QT = T>       // LEAN 1: DiT Linears (no per-column activation tables); 2: + Snake tables (vocoder)
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT][NT], float* scr, int lane, int mw0, int nw0, int bz, int g) {
+// AT: the accumulator array — f32x4 [MT][NT] (16 x 16 x 32 MFMA tiles: lane (fr, fg) holds rows 4 fg .. 4 fg + 3 of column fr) or f32x16 [MT / 2][NT / 2]
+// (32 x 32 x 16 tiles: lane (c = lane & 31, hi = lane >> 5), register r holds row (r & 3) + 8 (r >> 2) + 4 hi of column c).  The layout matters in ONE place, the
+// staging of 16-row passes into the wave's LDS tile (acc_stage below); everything behind it reads whole rows from there.
+typedef float f32x16_epi __attribute__((ext_vector_type(16)));
+template <int MT, int NT, int NII>
+__device__ __forceinline__ void acc_stage(const f32x4 (&acc)[MT][NT], int ip, float* scr, int sl, int lane) {
+    const int fr = lane & 15, fg = lane >> 4;
+#pragma unroll
+    for (int ii = 0; ii < NII; ++ii)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) scr[(ii * 16 + fg * 4 + r) * sl + j * 16 + fr] = acc[ip + ii][j][r];
+}
+template <int MT2, int NT2, int NII>
+__device__ __forceinline__ void acc_stage(const f32x16_epi (&acc)[MT2][NT2], int ip, float* scr, int sl, int lane) {
+    const int c = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int ii = 0; ii < NII; ++ii) {
+        const int t = ip + ii;                                   // 16-row unit of the wave tile: the (t & 1)-th half of 32-row tile t / 2
+#pragma unroll
+        for (int j = 0; j < NT2; ++j)
+#pragma unroll
+            for (int r8 = 0; r8 < 8; ++r8) scr[(ii * 16 + (r8 & 3) + 8 * (r8 >> 2) + 4 * hi) * sl + j * 32 + c] = acc[t >> 1][j][8 * (t & 1) + r8];
+    }
+}
+
+template <class T, int MT, int NT, int WN, int EPI, int LEAN = 0, class QT = T, class AT = f32x4[MT][NT]>       // LEAN 1: DiT Linears (no per-column activation tables); 2: + Snake tables (vocoder)
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs a, AT& acc, float* scr, int lane, int mw0, int nw0, int bz, int g) {
     constexpr int SLD = WN + 4;                      // staging row stride (floats)
     constexpr int ROWS_PASS = (64 / WN) * 16;        // rows a wave stages per pass: 64 lanes x 16 columns each
     const int fr = lane & 15, fg = lane >> 4;
@@ -61,12 +88,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT]
     static_assert(MT % MT_PASS == 0, "wave tile must be a whole number of staging passes");
     auto stage = [&](auto IP) __attribute__((always_inline)) {
         constexpr int ip = decltype(IP)::value;                // compile-time: a runtime index would push acc[][] to scratch
-#pragma unroll
-        for (int ii = 0; ii < MT_PASS; ++ii)
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) scr[(ii * 16 + fg * 4 + r) * SLD + j * 16 + fr] = acc[ip + ii][j][r];
+        if constexpr (std::is_same<AT, f32x4[MT][NT]>::value) acc_stage<MT, NT, MT_PASS>(acc, ip, scr, SLD, lane);
+        else acc_stage<MT / 2, NT / 2, MT_PASS>(acc, ip, scr, SLD, lane);
         wave_lds_order();
     };
     auto unstage = [&]() __attribute__((always_inline)) {
@@ -504,12 +527,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, f32x4 (&acc)[MT]
                 QT* const dbase = reinterpret_cast<QT*>(a.vT) + (((long long)bz * a.heads + h) * 64 + ((cb + ch4) & 63)) * a.t_pad + tq * 8;
                 auto v_pass = [&](auto IP) __attribute__((always_inline)) {
                     constexpr int ip = decltype(IP)::value;
-#pragma unroll
-                    for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-                        for (int j = 0; j < NT; ++j)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) scr[(ii * 16 + fg * 4 + r) * SLV + j * 16 + fr] = acc[ip + ii][j][r];
+                    if constexpr (std::is_same<AT, f32x4[MT][NT]>::value) acc_stage<MT, NT, 2>(acc, ip, scr, SLV, lane);
+                    else acc_stage<MT / 2, NT / 2, 2>(acc, ip, scr, SLV, lane);
                     wave_lds_order();
                     float x[4][8];
 #pragma unroll

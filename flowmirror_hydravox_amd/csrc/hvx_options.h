@@ -17,6 +17,7 @@ enum OptId : int {
     OPT_ATT_WAVES,             // 8: the one-tile bf16 decode attention merges 8 waves per split workgroup; 4: four
     OPT_GEMM_BIG_GW,           // column tiles per row group of the 256-tile Linear's workgroup order; 0 = all columns in one group
     OPT_GEMM_BIG_MIN_TILES,    // fewest 256 x 256 tiles for which the 256-tile Linear is chosen over the 128-tile one
+    OPT_GEMM_BIG_MFMA,         // MFMA shape of the 256-tile Linear's K-loop: 16 (16x16x32) or 32 (32x32x16)
     OPT_DEC_GEMM,              // 1: 33..256-row decode grids on gemm_dec.hip (fragment-order activations); 0: the generic skinny kernels (the tests compare the two)
     OPT_DEC_HEADS,             // bit 0: MTP head MLPs, bit 1: the shared output projection on gemm_dec.hip
     OPT_CONV_RESIDENT,         // 1: the DiT position embedding's 64-channel grouped convolution in the resident-row form; 0: tiled

@@ -821,6 +821,9 @@ def decision_agreement(teacher, student, requests, max_steps=None, refill_every=
     arrays, its own KV cache, filled with the teacher's history) and draws from ITS log-probs with the teacher's repetition window and the teacher's
     noise position.  Sampling is discontinuous in the logits, so a free-running bf16 stream leaves the fp32 one at its first flipped draw; what is
     well defined — SURVEY.md §7, "reported as match-rate in bf16 mode" — is the fraction of draws that come out equal given the same past.
+    Per-head caveat: the student's K draws of a step start from the teacher's noise cursor at the START of the step and consume the stream in head order, like the
+    teacher's; if an earlier head of the same step already disagreed (another number of values consumed), a later head reads shifted noise — the figure is exact for
+    head 0 and slightly pessimistic for heads >= 1 (tests/test_gpu_models.py::test_decision_agreement_...: an LM against itself scores 1.0).
     requests: dicts like HvxLLM.generate_stream's (text, seed, min / max ratio).  Returns dict(decisions, equal, steps, steps_all_equal)."""
     S = len(requests)
     K = teacher.head_k()

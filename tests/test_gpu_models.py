@@ -1086,3 +1086,27 @@ def test_zero_shot_mixed_length_batch_vs_oracle(tiny_cfg):
     ref_wav, _ = hift_ref.hift_inference(mel, hift_sd, cfg.hift, tables)
     assert wav.numel() == ref_wav.numel() == 960 * len(toks)
     assert (wav.cpu() - ref_wav[0]).abs().max().item() < 5e-2
+
+
+def test_decision_agreement_of_an_lm_with_itself_is_one_and_bf16_stays_close(tiny_cfg, llm_setup):
+    """llm.decision_agreement (the `bf16_id_agreement` object of the bench line) had no test.  Teacher == student arithmetic (two fp32 handles over the same
+    weights) must agree on EVERY decision of every head — that pins the bookkeeping: same history, same repetition window, same noise cursor at the start of a step,
+    the student's heads drawn in order from it — and the bf16 forms against the fp32 forms on the toy model stay above a loose floor (measured 0.97 at these widths).
+    Caveat kept in the docstring of decision_agreement: head j >= 1 of the student starts from the cursor its own head 0 .. j-1 left, so a disagreement of an earlier head
+    of the same step can shift a later head's noise (the figure is slightly pessimistic for heads >= 1, exact for head 0)."""
+    from functools import partial
+    from flowmirror_hydravox_amd.llm import HvxLLM, decision_agreement
+    from flowmirror_hydravox_amd.sampling import ras_sampling
+    g, sd = llm_setup
+    samp = partial(ras_sampling, top_p=0.9, top_k=10, win_size=24, tau_r=0.2)
+    gen = torch.Generator().manual_seed(5)
+    reqs = [dict(text=torch.randint(0, tiny_cfg.llm.text_vocab, (n,), generator=gen, dtype=torch.int32), seed=600 + i, max_token_text_ratio=4, min_token_text_ratio=4)
+            for i, n in enumerate((9, 14, 11))]
+    mk = lambda dt: HvxLLM(tiny_cfg.llm, sd, dtype=dt, max_batch=3, max_ctx=256, sampling=samp, inference_head_num=3)      # noqa: E731
+    teacher, same, student = mk(torch.float32), mk(torch.float32), mk(torch.bfloat16)
+    a = decision_agreement(teacher, same, [dict(r) for r in reqs])
+    assert a["decisions"] > 0 and a["decisions"] % 3 == 0
+    assert a['equal'] == a['decisions'] and a['steps_all_equal'] == a['steps'] and a['agreement'] == 1.0, a
+    b = decision_agreement(teacher, student, [dict(r) for r in reqs])
+    assert b['decisions'] == a['decisions'] and 0.8 < b['agreement'] <= 1.0, b
+    print('decision_agreement on the toy LM: fp32 vs fp32 %.3f (%d decisions), bf16 vs fp32 %.3f' % (a['agreement'], a['decisions'], b['agreement']))

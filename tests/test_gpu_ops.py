@@ -683,3 +683,30 @@ def test_attention_dit_32x32x16_tile_vs_fp32_reference_and_the_product_tile():
         assert float((o[0, :, :64] - r).abs().max()) < 2e-2
     finally:
         _lib.set_option('attn_dit_form', 0)
+
+
+def test_snake_stays_bounded_for_huge_arguments():
+    """hvx_device.h: sin_sq reduces its argument against a two-part pi, exact for |k| < 2^13; a stray activation beyond that must not turn the degree-11
+    polynomial loose — Snake(x) = x + sin^2(a x) / (a + 1e-9) has to stay within [x, x + 1 / a] like the reference's torch.sin form (activation.py:79-82) for ANY finite x.
+    A 1-tap identity convolution carries the chosen values through the Snake epilogue (exact-fp32 form: x is reproduced bit for bit)."""
+    _lib, ops, packing = _mods()
+    vals = torch.tensor([0.0, 1.0, -3.0, 100.0, 2.4e4, 2.6e4, 1e5, -7.7e5, 3.3e6, 4.2e6, 8.4e6, 1.7e7, 1e9, -1e12, 1e30, -3e37], dtype=torch.float32)
+    C, T = 32, vals.numel()
+    x = torch.zeros(1, C, T)
+    x[0, 0] = vals
+    x[0, 1] = vals * 0.37
+    w = torch.zeros(C, C, 1)
+    w[torch.arange(C), torch.arange(C), 0] = 1.0
+    alpha = torch.full((C,), 1.0)
+    alpha[1] = 2.5
+    out = ops.conv1d(_rows(x, torch.float32).to(DEV), _pack_conv(w, torch.float32).to(DEV), torch.zeros(C).to(DEV), n_out=C, taps=1, cin_pad=C, act=_lib.ACT_SNAKE,
+                     act_alpha=alpha.to(DEV), x3=False).cpu()[0]
+    for ch in (0, 1):
+        xs, a = x[0, ch].double(), float(alpha[ch])
+        got = out[:, ch].double()
+        ref = xs + torch.sin(xs * a) ** 2 / (a + 1e-9)
+        assert torch.isfinite(got).all()
+        lo, hi = xs - 1e-6 * xs.abs(), xs + 1.0 / a + 1e-6 * xs.abs() + 1e-6
+        assert bool(((got >= lo) & (got <= hi)).all()), (ch, got, lo, hi)
+        small = xs.abs() * a < 2.0e4                                     # where fp32 still resolves the phase: the value itself
+        assert float((got - ref)[small].abs().max()) < 2e-5 * max(1.0, float(xs[small].abs().max()))

@@ -14,6 +14,13 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        return str(sk.getsockname()[1])
+
+
 # ---- C ABI ---------------------------------------------------------------------------------------------------------------
 def _header_symbols():
     src = open(os.path.join(ROOT, 'include', 'hvx.h')).read()
@@ -264,7 +271,7 @@ def test_longest_first_deal_and_handoff_rounds_world_size_2_gloo(tmp_path):
     same number of times on every rank; rank 0 ends up with exactly the single-rank waveforms, keyed by global id."""
     script = tmp_path / 'd.py'
     script.write_text(_DEAL_WORKER % ROOT)
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29633', WORLD_SIZE='2')
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=_free_port(), WORLD_SIZE='2')
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
              for r in range(2)]
     outs = [p.communicate(timeout=180)[0] for p in procs]
@@ -275,7 +282,7 @@ def test_longest_first_deal_and_handoff_rounds_world_size_2_gloo(tmp_path):
 def test_waveform_gather_world_size_2_gloo(tmp_path):
     script = tmp_path / 'w.py'
     script.write_text(_GLOO_WORKER % ROOT)
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29631', WORLD_SIZE='2')
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=_free_port(), WORLD_SIZE='2')
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
              for r in range(2)]
     outs = [p.communicate(timeout=180)[0] for p in procs]
@@ -833,13 +840,6 @@ def test_onnx_auto_pad_and_opset_defaults_are_honoured_not_ignored():
     want = torch.softmax(torch.from_numpy(xs).reshape(3, -1), 1).reshape(xs.shape).numpy()
     np.testing.assert_allclose(onnx_ref._node(og.Node('Softmax', ['x'], ['y'], {}), [xs], 11), want, rtol=1e-5, atol=1e-7)
     np.testing.assert_allclose(onnx_ref._node(og.Node('Softmax', ['x'], ['y'], {}), [xs], 13), torch.softmax(torch.from_numpy(xs), -1).numpy(), rtol=1e-5, atol=1e-7)
-
-
-def _free_port():
-    import socket
-    with socket.socket() as sk:
-        sk.bind(('127.0.0.1', 0))
-        return str(sk.getsockname()[1])
 
 
 @pytest.mark.parametrize('config,world,steps,B', [('tts', 2, 3, 4), ('zero_shot', 2, 3, 4), ('zero_shot', 8, 1, 8)])

@@ -14,6 +14,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--utts', type=int, default=4)
 ap.add_argument('--iters', type=int, default=2)
 ap.add_argument('--tokens', type=int, default=2816)
+ap.add_argument('--ab', default='', help='A / B of a library option inside this process, interleaved rounds: name=v1,v2 (e.g. gemm_big_mfma=16,32); also prints the mel distance between the two')
 a = ap.parse_args()
 from flowmirror_hydravox_amd import cv3_config  # noqa: E402
 from flowmirror_hydravox_amd import weights as W  # noqa: E402
@@ -23,6 +24,27 @@ flow = HvxFlow(cfg.flow, W.make_flow_state(cfg.flow, seed=1987, init='normal02')
 g = torch.Generator().manual_seed(5)
 toks = [torch.randint(0, cfg.flow.vocab, (a.tokens,), generator=g, dtype=torch.int32).cuda() for _ in range(a.utts)]
 embs = [torch.randn(cfg.flow.spk_embed_dim, generator=g).cuda() for _ in range(a.utts)]
+if a.ab:
+    from flowmirror_hydravox_amd import _lib
+    name, vals = a.ab.split('=')
+    vals = [int(v) for v in vals.split(',')]
+    mels, times = {}, {v: [] for v in vals}
+    for v in vals:
+        _lib.set_option(name, v)
+        mels[v] = [m.float().cpu() for m in flow.inference_batch(toks, embs)]
+    for _ in range(max(2, a.iters)):
+        for v in vals:
+            _lib.set_option(name, v)
+            torch.cuda.synchronize()
+            t0 = time.time()
+            flow.inference_batch(toks, embs)
+            torch.cuda.synchronize()
+            times[v].append(time.time() - t0)
+    for v in vals:
+        ts = sorted(times[v])
+        d = max(float((x - y).abs().max() / y.abs().max()) for x, y in zip(mels[v], mels[vals[0]]))
+        print('%s = %d: flow %d x %d frames median %.1f ms, min %.1f ms; mel vs %s = %d: %.2e of its scale' % (name, v, a.utts, 2 * a.tokens, 1e3 * ts[len(ts) // 2], 1e3 * ts[0], name, vals[0], d))
+    sys.exit(0)
 flow.inference_batch(toks, embs)
 torch.cuda.synchronize()
 t0 = time.time()
