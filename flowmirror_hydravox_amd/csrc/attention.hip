@@ -1162,6 +1162,362 @@ __global__ __launch_bounds__(256, WPS) void attn_dit32_kernel(AttnArgs a) {
 }
 #undef zero16
 
+#ifdef HVX_LAB      // (lab builds only: measured slower than the product tile, profiles/r06_attn_tile_ab.md; the hazards of its asm MFMAs are met by construction, not by the compiler)
+// ---------------------------------------------------------------------------------------------------------------------
+// DiT attention, ONE wave per SIMD with the whole 512-register file (round 6; the structure of the guide's fastest attention, at head_dim 64): a wave owns
+// FOUR query tiles of 32 rows (128 rows; 512 per workgroup), so every K / V^T fragment read from LDS feeds 4 MFMAs, and keeps O^T (128 registers) and Q (64)
+// in the ACCUMULATOR half of the file, where only MFMAs touch them; the scores start from 0
+// in VGPRs and the row's reference is ONE v_add per score on the way into the exponential (a 16-register start-value splat per query tile does not stay resident:
+// hipcc copies it into place in front of every use).  With a 512-register budget hipcc selects the AGPR-destination MFMA forms for its builtins and
+// copies every score out of the accumulator file (profiles/r06_attn_tile_ab.md), so the MFMAs here are inline asm with the register class of every operand spelled
+// out: O^T / row sums in AGPRs, scores and the K / V^T / P / Q fragments in VGPRs.  asm volatile statements keep their order; the compiler places the vector
+// instructions and the LDS reads between them and allocates the registers.  What the compiler does NOT do for an asm MFMA (cdna guide §5.7) is done by construction:
+//   * an MFMA result is read by a vector instruction only in the NEXT unit's region (sched_barrier between units), behind >= 2 further MFMAs (>= 64 cycles);
+//   * the P operand of a PV / row-sum MFMA was written by the vector ALU in the PREVIOUS region, a QK MFMA ahead of its first reader (no s_nop needed);
+//   * dependent MFMAs are either adjacent (accumulate chain: forwarded) or one independent MFMA (32 cycles) apart.
+// Same tile mathematics as attn_dit32_kernel (units of 32 keys x one query tile, QK(u + 1) | SM(u) | PV(u - 1), fixed-reference softmax, row sums on a selector MFMA).
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void a4_qk_first0(f32x16& d, const bf16x8& k, const bf16x8& q) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(k), "v"(q));
+}
+__device__ __forceinline__ void a4_qk(f32x16& d, const bf16x8& k, const bf16x8& q) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(k), "v"(q));
+}
+__device__ __forceinline__ void a4_pv(f32x16& o, const bf16x8& v, const bf16x8& p) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(o) : "v"(v), "v"(p));
+}
+__device__ __forceinline__ void a4_sum(f32x4& l, const bf16x8& ones, const bf16x8& p) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(l) : "v"(ones), "v"(p));
+}
+
+template <bool PRE>
+__global__ __launch_bounds__(256, 1) void attn_dit_a4_kernel(AttnArgs a) {
+    typedef bf16_t T;
+    constexpr int QT = 4, KT = 64, LD = 72;
+    __shared__ __attribute__((aligned(16))) T Ks[2][KT * LD];
+    __shared__ __attribute__((aligned(16))) T Vs[2][64 * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fq = lane & 31, hi = lane >> 5;
+    int b = blockIdx.z, h = blockIdx.y, bx = blockIdx.x;
+    {   // XCD-aware order (see attn_dit_kernel)
+        const int nx = gridDim.x, nh = gridDim.y * gridDim.z;
+        if ((nh & 7) == 0) {
+            const int L = blockIdx.x + nx * (blockIdx.y + gridDim.y * blockIdx.z);
+            const int j = L >> 3, hb = (j / nx) * 8 + (L & 7);
+            bx = j % nx;
+            h = hb % gridDim.y;
+            b = hb / gridDim.y;
+        }
+    }
+    constexpr int WG_ROWS = 4 * QT * 32;
+    const int row0 = bx * WG_ROWS + wave * (QT * 32);
+    const int kv_len = a.kv_len ? a.kv_len[b] : a.kv_len_const;
+    const T* __restrict__ kb = reinterpret_cast<const T*>(a.k) + (long long)b * a.k_bs + (long long)h * a.k_hs;
+    const T* __restrict__ vb = reinterpret_cast<const T*>(a.vT) + (long long)b * a.v_bs + (long long)h * a.v_hs;
+
+    bf16x8 qf[QT][4];
+#pragma unroll
+    for (int i = 0; i < QT; ++i) {
+        const int r = row0 + i * 32 + fq;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+            qf[i][kk] = r < a.n_rows ? load8(reinterpret_cast<const T*>(a.q) + (long long)b * a.q_bs + (long long)h * a.q_hs + (long long)r * a.q_lo + kk * 16 + hi * 8) : zero8<T>();
+    }
+    const int lrow = tid >> 3, lchunk = (tid & 7) * 8;
+    bf16x8 rk[2], rv[2];
+    auto gload = [&](int key0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int key = key0 + lrow + i * 32;
+            key = key < kv_len ? key : kv_len - 1;
+            rk[i] = load8(kb + (long long)key * 64 + lchunk);
+            rv[i] = load8(vb + (long long)(lrow + i * 32) * a.v_ld + key0 + lchunk);
+        }
+    };
+    const int vc = tid & 7;
+    const int vpos = (vc >> 1) * 16 + (vc & 1) * 4;
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            store8(&Ks[buf][(lrow + i * 32) * LD + lchunk], rk[i]);
+            bf16x4 lo, hv;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                lo[j] = rv[i][j];
+                hv[j] = rv[i][4 + j];
+            }
+            *reinterpret_cast<bf16x4*>(&Vs[buf][(lrow + i * 32) * LD + vpos]) = lo;
+            *reinterpret_cast<bf16x4*>(&Vs[buf][(lrow + i * 32) * LD + vpos + 8]) = hv;
+        }
+    };
+    auto zero16f = [] {
+        f32x16 z;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+        return z;
+    };
+    f32x16 o_acc[QT][2];
+    f32x4 l_mm[QT];
+#pragma unroll
+    for (int i = 0; i < QT; ++i) {
+        o_acc[i][0] = zero16f();
+        o_acc[i][1] = zero16f();
+        l_mm[i] = f32x4{0, 0, 0, 0};
+    }
+    const float c = PRE ? 1.0f : a.scale * 1.4426950408889634f;
+    float nm_ref[QT];                                                    // -m_ref of the lane's query: one register per query tile, subtracted on the way into the exponential
+    bf16x8 ones_sel;
+    {
+        const bool on = ((lane & 15) == 0 && ((lane >> 4) & 1) == 0) || ((lane & 15) == 1 && ((lane >> 4) & 1) == 1);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ones_sel[e] = f32_to_bf16(on ? 1.0f : 0.0f);
+    }
+    auto kfrag = [&](int buf, int kh, bf16x8 (&kf)[4]) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) kf[kk] = load8(&Ks[buf][(kh * 32 + fq) * LD + kk * 16 + hi * 8]);
+    };
+    auto vfrag = [&](int buf, int kh, bf16x8 (&vf)[2][2]) {
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) vf[dt][s] = load8(&Vs[buf][(dt * 32 + fq) * LD + (kh * 2 + s) * 16 + hi * 8]);
+    };
+    auto mask = [&](f32x16& s, int key0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (key0 + (r & 3) + 8 * (r >> 2) + 4 * hi >= kv_len) s[r] = -INFINITY;
+    };
+    // four scores of a unit -> probabilities (slice q = registers 4 q .. 4 q + 3 of the score tile): the vector work is cut into slices so that it can be PINNED between
+    // the MFMAs.  The compiler sees an asm MFMA as an instruction that takes no time and gathers all vector work in front of the MFMA run (nothing overlaps: 1137 us, and
+    // the first slice then reads scores its MFMA has not finished: wrong results); slices pinned behind PAIRS of MFMAs: 1103 us (this form); one 5-instruction slice behind
+    // EVERY MFMA — which puts vector instructions between MFMAs on the same accumulator: 2990 us (the guide's 43-cycle cliff, three times per unit).
+    auto sm_slice = [&](int i, int q, f32x16& s, bf16x8 (&pf)[2], int key0, auto tail_tag) {
+        constexpr bool TAIL = decltype(tail_tag)::value;
+#pragma unroll
+        for (int r = 4 * q; r < 4 * q + 4; ++r) {
+            float x = s[r];
+            if constexpr (TAIL)
+                if (key0 + (r & 3) + 8 * (r >> 2) + 4 * hi >= kv_len) x = -INFINITY;
+            const float e = __builtin_amdgcn_exp2f(PRE ? x + nm_ref[i] : __builtin_fmaf(x, c, nm_ref[i]));
+            pf[r >> 3][r & 7] = f32_to_bf16(e);
+        }
+    };
+    // one 64-key tile: 8 units u = kh * 4 + i.  Region of unit u:  Q0 P0 Q1 P1 | slice 0 | Q2 P2 | slice 1 | Q3 P3 | slice 2 | sum sum | slice 3   (Q = score MFMA of unit
+    // u + 1, P = PV MFMA of unit u - 1, slices = softmax of unit u; every `|` is a sched_barrier).  The first slice sits behind >= 2 MFMAs: the scores it reads were
+    // finished by the previous region's Q3 (>= 12 wait states ago in every case, the tile's first region included).
+    auto tile_fast = [&](int buf, int key0, auto tail_tag) {
+        constexpr int NU = 2 * QT;
+        bf16x8 kf[4], vf[2][2];
+        f32x16 sa, sb;
+        bf16x8 pa[2], pb[2];
+        kfrag(buf, 0, kf);
+        vfrag(buf, 0, vf);
+        a4_qk_first0(sa, kf[0], qf[0][0]);
+#pragma unroll
+        for (int kk = 1; kk < 4; ++kk) a4_qk(sa, kf[kk], qf[0][kk]);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            __builtin_amdgcn_sched_barrier(0);
+            const int kh = u / QT, i = u % QT;
+            f32x16& s_cur = (u & 1) ? sb : sa;
+            f32x16& s_nxt = (u & 1) ? sa : sb;
+            bf16x8 (&p_cur)[2] = (u & 1) ? pb : pa;
+            bf16x8 (&p_prv)[2] = (u & 1) ? pa : pb;
+            const bool has_qk = u + 1 < NU, has_pv = u > 0;
+            const int in = (u + 1) % QT, ip = (u + QT - 1) % QT;
+            if (has_qk && in == 0) kfrag(buf, (u + 1) / QT, kf);
+            auto pair = [&](int st) __attribute__((always_inline)) {
+                if (has_qk) {
+                    if (st == 0) a4_qk_first0(s_nxt, kf[0], qf[in][0]);
+                    else a4_qk(s_nxt, kf[st], qf[in][st]);
+                }
+                if (has_pv) a4_pv(o_acc[ip][st & 1], vf[st & 1][st >> 1], p_prv[st >> 1]);
+            };
+            pair(0);
+            pair(1);
+            __builtin_amdgcn_sched_barrier(0);
+            sm_slice(i, 0, s_cur, p_cur, key0 + kh * 32, tail_tag);
+            __builtin_amdgcn_sched_barrier(0);
+            pair(2);
+            __builtin_amdgcn_sched_barrier(0);
+            sm_slice(i, 1, s_cur, p_cur, key0 + kh * 32, tail_tag);
+            __builtin_amdgcn_sched_barrier(0);
+            pair(3);
+            __builtin_amdgcn_sched_barrier(0);
+            sm_slice(i, 2, s_cur, p_cur, key0 + kh * 32, tail_tag);
+            __builtin_amdgcn_sched_barrier(0);
+            if (has_pv) {
+                a4_sum(l_mm[ip], ones_sel, p_prv[0]);
+                a4_sum(l_mm[ip], ones_sel, p_prv[1]);
+            }
+            if (has_pv && i == 0 && kh == 1) vfrag(buf, 1, vf);
+            __builtin_amdgcn_sched_barrier(0);
+            sm_slice(i, 3, s_cur, p_cur, key0 + kh * 32, tail_tag);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            bf16x8 (&p_lst)[2] = ((NU - 1) & 1) ? pb : pa;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) a4_pv(o_acc[QT - 1][st & 1], vf[st & 1][st >> 1], p_lst[st >> 1]);
+            a4_sum(l_mm[QT - 1], ones_sel, p_lst[0]);
+            a4_sum(l_mm[QT - 1], ones_sel, p_lst[1]);
+        }
+    };
+    // classical online-softmax tile (fall-back), one query tile at a time; the compiler moves O^T between the register halves for the rescale
+    float m_run[QT], l_acc[QT];
+    auto tile_classical = [&](int buf, int key0, auto tail_tag) {
+        constexpr bool TAIL = decltype(tail_tag)::value;
+#pragma unroll
+        for (int i = 0; i < QT; ++i) {
+            bf16x8 kf[4], vf[2][2];
+            f32x16 s[2];
+            bf16x8 pf[2][2];
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) {
+                kfrag(buf, kh, kf);
+                a4_qk_first0(s[kh], kf[0], qf[i][0]);
+#pragma unroll
+                for (int kk = 1; kk < 4; ++kk) a4_qk(s[kh], kf[kk], qf[i][kk]);
+            }
+            asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");             // the last chain's result: 16 states before the vector ALU reads it
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (TAIL) {
+                mask(s[0], key0);
+                mask(s[1], key0 + 32);
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmax2(mx, s[kh][r]);
+            mx = fmax2(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmax2(m_run[i], mx * c);
+            const float alpha = m_new == -INFINITY ? 1.0f : __builtin_amdgcn_exp2f(m_run[i] - m_new);
+            float sum = 0.0f;
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float e = m_new == -INFINITY ? 0.0f : __builtin_amdgcn_exp2f(__builtin_fmaf(s[kh][r], c, -m_new));
+                    sum += e;
+                    pf[kh][r >> 3][r & 7] = f32_to_bf16(e);
+                }
+            l_acc[i] = l_acc[i] * alpha + sum;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o_acc[i][dt][r] *= alpha;
+            m_run[i] = m_new;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) {
+                vfrag(buf, kh, vf);
+#pragma unroll
+                for (int st = 0; st < 4; ++st) a4_pv(o_acc[i][st & 1], vf[st & 1][st >> 1], pf[kh][st >> 1]);
+            }
+            asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    const int n_tiles = (kv_len + KT - 1) / KT, n_full = kv_len / KT;
+    auto run = [&](auto&& tf) {
+        for (int it = 0; it < n_full; ++it) {                             // (two loops, not one with a branch: the register assignment of O^T then never has to be shuffled between two loop bodies)
+            const int buf = it & 1, key0 = it * KT;
+            const bool more = (it + 1) < n_tiles;
+            if (more) gload(key0 + KT);
+            tf(buf, key0, std::false_type{});
+            if (more) stash(buf ^ 1);
+            __syncthreads();
+        }
+        for (int it = n_full; it < n_tiles; ++it) {                       // the ragged last tile
+            const int buf = it & 1, key0 = it * KT;
+            tf(buf, key0, std::true_type{});
+            __syncthreads();
+        }
+    };
+    if (n_tiles > 0) {
+        gload(0);
+        stash(0);
+    }
+    __syncthreads();
+    bool classical = false;
+    if (n_tiles > 0) {
+#pragma unroll
+        for (int i = 0; i < QT; ++i) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) {
+                bf16x8 kf[4];
+                f32x16 s;
+                kfrag(0, kh, kf);
+                a4_qk_first0(s, kf[0], qf[i][0]);
+#pragma unroll
+                for (int kk = 1; kk < 4; ++kk) a4_qk(s, kf[kk], qf[i][kk]);
+                asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                mask(s, kh * 32);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmax2(mx, s[r]);
+            }
+            float m = fmax2(mx, __shfl_xor(mx, 32, 64));
+            m = -fmax2(m * c, -1e30f);
+            nm_ref[i] = m;
+        }
+        run(tile_fast);
+        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");                 // the last MFMAs' results before anything reads O^T / the row sums
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < QT; ++i) {
+            const float v0 = __shfl(l_mm[i][0], lane & 15, 64), v1 = __shfl(l_mm[i][1], lane & 15, 64);
+            l_acc[i] = 0.5f * ((fq & 16) ? v1 : v0);
+        }
+        unsigned bad = 0;
+#pragma unroll
+        for (int i = 0; i < QT; ++i) {
+            bad |= ((__float_as_uint(l_acc[i]) & 0x7f800000u) == 0x7f800000u);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) bad |= ((__float_as_uint(o_acc[i][dt][r]) & 0x7f800000u) == 0x7f800000u);
+        }
+        classical = __syncthreads_or((int)bad) != 0;
+        if (classical) {
+#pragma unroll
+            for (int i = 0; i < QT; ++i) {
+                l_acc[i] = 0.0f;
+                m_run[i] = -INFINITY;
+                o_acc[i][0] = zero16f();
+                o_acc[i][1] = zero16f();
+            }
+            gload(0);
+            stash(0);
+            __syncthreads();
+            run(tile_classical);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < QT; ++i) l_acc[i] = 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < QT; ++i) {
+        const float l = l_acc[i] + __shfl_xor(l_acc[i], 32, 64);
+        const int r = row0 + i * 32 + fq;
+        if (r >= a.n_rows) continue;
+        const float inv = l > 0.0f ? 1.0f / l : 0.0f;
+        T* op = reinterpret_cast<T*>(a.out) + (long long)b * a.o_bs + (long long)h * a.o_hs + (long long)r * a.o_lo;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 o4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o4[e] = f32_to_bf16(o_acc[i][dt][4 * g + e] * inv);
+                *reinterpret_cast<bf16x4*>(op + dt * 32 + 8 * g + 4 * hi) = o4;
+            }
+    }
+}
+#endif  // HVX_LAB
+
 template <class T>
 static int launch_t(const AttnArgs& a_in, hipStream_t s) {
     AttnArgs a = a_in;
@@ -1213,6 +1569,15 @@ static int launch_t(const AttnArgs& a_in, hipStream_t s) {
         // attn_dit_form: 0 = per shape (below), 16 = the 16x16x32 tile whatever the shape says, 32 = the 32x32x16 tile (attn_dit32_kernel: measured SLOWER on MI355X,
         // profiles/r06_attn_tile_ab.md — kept selectable, parity-tested, not the default)
         const int form = (int)opt(OPT_ATTN_DIT_FORM);
+#ifdef HVX_LAB
+        if (form == 48 && a.chunk <= 0) {                               // (lab: the one-wave-per-SIMD, 512-register form with asm MFMAs)
+            const dim3 g4q((a.n_rows + 511) / 512, a.heads, a.batch);
+            if (a.q_log2) hipLaunchKernelGGL((attn_dit_a4_kernel<true>), g4q, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((attn_dit_a4_kernel<false>), g4q, dim3(256), 0, s, a);
+            prof_end(slot, s);
+            return hipGetLastError() == hipSuccess ? 0 : (set_error("attention launch failed"), -1);
+        }
+#endif
         if (form == 32 && a.chunk <= 0) {
             const dim3 g1q((a.n_rows + 127) / 128, a.heads, a.batch);
             if (a.q_log2) hipLaunchKernelGGL((attn_dit32_kernel<1, true>), g1q, dim3(256), 0, s, a);

@@ -115,7 +115,12 @@ int hvx_set_option(const char* key, int64_t value) {
     if (i == OPT_ATT_CHUNK && value != 0 && (value < 128 || value % 128)) return set_error("hvx_set_option: att_chunk must be 0 or a multiple of 128, got %lld", (long long)value), -1;
     if (i == OPT_GEMM_BIG_MFMA && value != 16 && value != 32) return set_error("hvx_set_option: gemm_big_mfma must be 16 or 32, got %lld", (long long)value), -1;
     if (i == OPT_ATT_WAVES && value != 4 && value != 8) return set_error("hvx_set_option: att_waves must be 4 or 8, got %lld", (long long)value), -1;
-    if (i == OPT_ATTN_DIT_FORM && value != 0 && value != 16 && value != 32) return set_error("hvx_set_option: attn_dit_form must be 0, 16 or 32, got %lld", (long long)value), -1;
+    #ifdef HVX_LAB
+    const bool form_ok = value == 0 || value == 16 || value == 32 || value == 48;
+#else
+    const bool form_ok = value == 0 || value == 16 || value == 32;
+#endif
+    if (i == OPT_ATTN_DIT_FORM && !form_ok) return set_error("hvx_set_option: attn_dit_form must be 0, 16 or 32 (48: lab builds only), got %lld", (long long)value), -1;
     opt_init();
     g_opt_val[i].store(value, std::memory_order_relaxed);
     return 0;
