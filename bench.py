@@ -645,9 +645,9 @@ def main():
         # ranks that took part in the collective group of THIS run (torch.distributed over RCCL: backend "nccl"), so that a scaling record can be checked for N ranks
         'rccl_ranks': (torch.distributed.get_world_size() if world > 1 else 1), 'collective_backend': ((torch.distributed.get_backend() + ('' if stub else ' (= RCCL on ROCm)')) if world > 1 else None),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16' if args.llm_dtype == 'bf16' else 'f32 (LM) + bf16 (flow)', 'data': 'synthetic',
-        'config': {'workload': 'HydraVox-CV3%s inference_head_num=%d, batch=%dx%d-char utterances per GPU (' + ('zero-shot: text lengths U{64..512} per utterance, ' if zero_shot else '') + '%d text -> %d speech tokens -> %d mel frames '
+        'config': {'workload': ('HydraVox-CV3%s inference_head_num=%d, batch=%dx%d-char utterances per GPU (' + ('zero-shot: text lengths U{64..512} per utterance, ' if zero_shot else '') + '%d text -> %d speech tokens -> %d mel frames '
                                'each' + (' AT THE MAXIMUM LENGTH' if zero_shot else '') + '), %s / hift split-bf16 (fp32 operands as (hi, lo) bf16 pairs, 3 MFMAs per step: ~16 mantissa bits; `exact_vocoder` = the exact fp32 form), '
-                               'llm->flow->hift end to end, seeded N(0,0.02) weights'
+                               'llm->flow->hift end to end, seeded N(0,0.02) weights')
                                % (' [STUB PIPELINE ON CPU / GLOO - RANK LOGIC ONLY, NOT A BENCHMARK]' if stub else ' [TINY DIMS - NOT A BENCHMARK]' if args.tiny else '', K, B, chars, chars, n_spk, 2 * n_spk,
                                   'llm+flow bf16' if args.llm_dtype == 'bf16' else 'llm fp32 (speech-token ids bit-exact against the reference) + flow bf16'),
                    'baseline_config': {'tts': 'configs[1]', 'stress': 'configs[2]', 'zero_shot': 'configs[3]: text lengths U{64..512} per utterance (the chars figure above is the maximum), '

@@ -23,8 +23,7 @@ enum OptId : int {
     OPT_CONV_RESIDENT,         // 1: the DiT position embedding's 64-channel grouped convolution in the resident-row form; 0: tiled
     OPT_CONV64_RESIDENT,       // 1: the vocoder's 64-channel split-bf16 convolutions in the resident-row form; 0: tiled (the tests compare the two)
     OPT_X3P8,                  // 1: the 8-wave 128 x 128 x 64 tile for the vocoder's 128- / 256-channel split-bf16 convolutions; 0: the 4-wave tile
-    OPT_RB_FUSED,              // 1: conv1 -> Snake -> conv2 -> residual of a 64-channel ResBlock dilation in ONE launch (gemm_x3.hip: rb64_fused_kernel); 0: two launches
-    OPT_ATTN_DIT_FORM,         // DiT attention tile: 0 = chosen per shape, 16 = the 16x16x32 form, 32 = the 32x32x16 form (attention.hip)
+    OPT_ATTN_DIT_FORM,         // DiT attention tile: 0 = chosen per shape (the 16x16x32 tile), 16 = the same, 32 = the 32x32x16 tile (attention.hip: measured slower, kept selectable)
     // ---- lab (settable with -DHVX_LAB only) ----
     OPT_HEAD_DOWN_SPLIT,       // forced K split of the MTP heads' down projection; 0 = chosen per grid
     OPT_DEC_GPW_QKV, OPT_DEC_GPW_RES, OPT_DEC_GPW_MLP, OPT_DEC_GPW_DOWN, OPT_DEC_GPW_OUT, OPT_DEC_GPW_HMLP,   // column groups per workgroup of the decode GEMM launches
