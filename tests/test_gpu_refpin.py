@@ -47,7 +47,9 @@ def flow_sd():
     return c, sd, state_checksum(sd)
 
 
-# handle keyword arguments per mode; bounds on (max|d| / max|ref|, relative L2): fp32 = the north star's 1e-3, the others <= 2x measured on MI355X (round 5)
+# handle keyword arguments per mode; bounds on (max|d| / max|ref|, relative L2).  CONTRACT (north_star): 1e-3 — met by the fp32 forms (asserted at 1e-3, measured 2.5e-6).
+# The production forms do NOT meet 1e-3 (2.4e-3; the reference's own fp16 deployment of this decoder sits at 1.36e-3 from its fp32 run): their bounds below are <= 2x what was
+# measured on MI355X — a regression guard on today's arithmetic, printed next to the contract number so that nobody reads them as the contract.
 _EST_KW = {'fp32': dict(dtype=torch.float32), 'production': dict(dtype=torch.bfloat16),
            'plain-bf16': dict(dtype=torch.bfloat16, f16_linears=False, f32_small=False)}
 #   measured: fp32 2.5e-6 / 2.1e-6; production 2.4e-3 / 2.35e-3; plain bf16 6.6e-3 / 5.9e-3
@@ -69,14 +71,15 @@ def test_dit_22_blocks_5632_frames_vs_reference(flow_sd, mode):
     est = (flow.estimator(x, mask, mu, torch.from_numpy(g['t']), spk, cond).cpu() * mask).numpy()
     assert np.isfinite(est).all()
     e = [(_scale_rel(est[i, :, :n], g['out'][i, :, :n]), _l2_rel(est[i, :, :n], g['out'][i, :, :n])) for i, n in enumerate(lens)]
-    print('DiT 22 blocks, T = %d, lens %s, %s forms vs the REFERENCE: max|d|/max|ref| %s, relative L2 %s'
-          % (T, lens, mode, ['%.2e' % a for a, _ in e], ['%.2e' % b for _, b in e]))
+    print('DiT 22 blocks, T = %d, lens %s, %s forms vs the REFERENCE: max|d|/max|ref| %s, relative L2 %s  [contract 1e-3: %s]'
+          % (T, lens, mode, ['%.2e' % a for a, _ in e], ['%.2e' % b for _, b in e], 'met' if max(a for a, _ in e) < 1e-3 else 'NOT met by this mode (regression bound only)'))
     bm, bl = (1e-3, 1e-3) if mode == 'fp32' else _EST_BOUNDS[mode]
     assert max(a for a, _ in e) < bm and max(b for _, b in e) < bl, (mode, e)
     # padded columns of the second row are zero after the mask, like the reference's
     assert np.abs(est[1, :, lens[1]:]).max() == 0.0
 
 
+#   CONTRACT 1e-3 (fp32 forms: asserted); production: regression bound <= 2x measured, above the contract
 #   measured: fp32 1.1e-6 / 1.1e-6; production 1.52e-3 / 1.54e-3 (alone and as entry 0 of a padded batch of 4)
 _SOLVE_BOUNDS = {'fp32': (1e-3, 1e-3), 'production': (3.0e-3, 3.0e-3)}
 
@@ -95,7 +98,8 @@ def test_cfm_solve_of_a_512_char_utterance_vs_reference(flow_sd, mode):
     mel = mel.cpu().numpy()
     assert mel.shape == g['mel'].shape and np.isfinite(mel).all()
     e = (_scale_rel(mel, g['mel']), _l2_rel(mel, g['mel']))
-    print('10-step CFG solve, 2816 tokens -> 5632 frames, %s forms vs the REFERENCE: max|d|/max|ref| %.2e, relative L2 %.2e' % (mode, e[0], e[1]))
+    print('10-step CFG solve, 2816 tokens -> 5632 frames, %s forms vs the REFERENCE: max|d|/max|ref| %.2e, relative L2 %.2e  [contract 1e-3: %s]'
+          % (mode, e[0], e[1], 'met' if e[0] < 1e-3 else 'NOT met by this mode (regression bound only; the reference\'s own fp16 run: 1.36e-3)'))
     assert e[0] < _SOLVE_BOUNDS[mode][0] and e[1] < _SOLVE_BOUNDS[mode][1], (mode, e)
     if mode == 'production':
         # the padded batch solve of the bench (hvx_cfm_solve_batch, 4 entries x CFG 2 per estimator call): the same utterance beside three others
@@ -245,7 +249,8 @@ def test_hift_5632_frames_vs_reference(tmp_path):
     assert m['envelope'] < 1.5 * worst['envelope'] and m['stft2048_l2'] < 1.5 * worst['stft2048_l2'] and m['band_energy'] < 1.5 * worst['band_energy'], m
 
 
-# measured on MI355X (round 5), bounds <= 2x: see DESIGN.md §3
+# measured on MI355X (round 5), bounds <= 2x: see DESIGN.md §3.  CONTRACT 1e-3 for the vocoder stages: every stage-wise number below meets it (asserted far inside);
+# the end-to-end waveform is held to the reference's own conditioning band instead (hift_full_cond.npz), which is wider than 1e-3 for the reference itself.
 #   f0 5.3e-4 Hz; source (reference f0) 3.0e-8; decode(reference source): split-bf16 2.1e-4 max / 1.5e-4 L2 (fp16 copy 3.9e-4), exact fp32 4.6e-5 / 2.8e-5 (2.7e-4)
 _HIFT_BOUNDS = {'source': 1e-6, 'x3': (4.5e-4, 8e-4), 'x3_l2': 3e-4, 'exact': (1e-4, 6e-4), 'exact_l2': 6e-5}
 
