@@ -255,12 +255,18 @@ int launch_form(const GemmArgs& a, hipStream_t s, long long min_tiles) {
     if (gw_env > 0 && gw_env < tiles_n && tiles_n % gw_env == 0) gw = gw_env;
     const int slot = prof_begin(PK_GEMM, 2.0 * a.M * a.N * (double)a.K * a.batch, s);
     const dim3 grid((unsigned)tiles), block(NWAVE * 64);
-    const bool m32 = opt(OPT_GEMM_BIG_MFMA) == 32;          // (A / B option gemm_big_mfma: 16 | 32)
+    // (lab option gemm_big_mfma: 16 | 32.  The 32x32x16 K-loop is bit-identical and 4 % slower at flow level — profiles/r06_attn_tile_ab.md — and doubles this file's
+    // compile time, so only lab builds carry it)
+#ifdef HVX_LAB
+    const bool m32 = opt(OPT_GEMM_BIG_MFMA) == 32;
 #define HVX_BIG(EPI_, T_)                                                                                                            \
     do {                                                                                                                            \
         if (m32) hipLaunchKernelGGL((gemm_big_kernel<EPI_, BN, BK, NWAVE, T_, 32>), grid, block, 0, s, a, tiles_m, tiles_n, gw);    \
         else hipLaunchKernelGGL((gemm_big_kernel<EPI_, BN, BK, NWAVE, T_, 16>), grid, block, 0, s, a, tiles_m, tiles_n, gw);        \
     } while (0)
+#else
+#define HVX_BIG(EPI_, T_) hipLaunchKernelGGL((gemm_big_kernel<EPI_, BN, BK, NWAVE, T_, 16>), grid, block, 0, s, a, tiles_m, tiles_n, gw)
+#endif
     if (a.dtype == DT_F16) {
         if (a.epi == EPI_GENERIC) HVX_BIG(EPI_GENERIC, f16_t);
         else HVX_BIG(EPI_QKV_DIT, f16_t);

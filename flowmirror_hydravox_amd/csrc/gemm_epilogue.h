@@ -51,18 +51,8 @@ template <bool RT, int ACT, int RES, int OF32, int O2, int ACT2 = 0> struct Lean
 // (32 x 32 x 16 tiles: lane (c = lane & 31, hi = lane >> 5), register r holds row (r & 3) + 8 (r >> 2) + 4 hi of column c).  The layout matters in ONE place, the
 // staging of 16-row passes into the wave's LDS tile (acc_stage below); everything behind it reads whole rows from there.
 typedef float f32x16_epi __attribute__((ext_vector_type(16)));
-template <int MT, int NT, int NII>
-__device__ __forceinline__ void acc_stage(const f32x4 (&acc)[MT][NT], int ip, float* scr, int sl, int lane) {
-    const int fr = lane & 15, fg = lane >> 4;
-#pragma unroll
-    for (int ii = 0; ii < NII; ++ii)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) scr[(ii * 16 + fg * 4 + r) * sl + j * 16 + fr] = acc[ip + ii][j][r];
-}
-template <int MT2, int NT2, int NII>
-__device__ __forceinline__ void acc_stage(const f32x16_epi (&acc)[MT2][NT2], int ip, float* scr, int sl, int lane) {
+template <int MT2, int NT2, int NII, int ip>
+__device__ __forceinline__ void acc_stage(const f32x16_epi (&acc)[MT2][NT2], float* scr, int sl, int lane) {
     const int c = lane & 31, hi = lane >> 5;
 #pragma unroll
     for (int ii = 0; ii < NII; ++ii) {
@@ -88,8 +78,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, AT& acc, float* 
     static_assert(MT % MT_PASS == 0, "wave tile must be a whole number of staging passes");
     auto stage = [&](auto IP) __attribute__((always_inline)) {
         constexpr int ip = decltype(IP)::value;                // compile-time: a runtime index would push acc[][] to scratch
-        if constexpr (std::is_same<AT, f32x4[MT][NT]>::value) acc_stage<MT, NT, MT_PASS>(acc, ip, scr, SLD, lane);
-        else acc_stage<MT / 2, NT / 2, MT_PASS>(acc, ip, scr, SLD, lane);
+        if constexpr (std::is_same<AT, f32x4[MT][NT]>::value) {
+#pragma unroll
+            for (int ii = 0; ii < MT_PASS; ++ii)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) scr[(ii * 16 + fg * 4 + r) * SLD + j * 16 + fr] = acc[ip + ii][j][r];
+        } else acc_stage<MT / 2, NT / 2, MT_PASS, ip>(acc, scr, SLD, lane);
         wave_lds_order();
     };
     auto unstage = [&]() __attribute__((always_inline)) {
@@ -527,8 +523,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs a, AT& acc, float* 
                 QT* const dbase = reinterpret_cast<QT*>(a.vT) + (((long long)bz * a.heads + h) * 64 + ((cb + ch4) & 63)) * a.t_pad + tq * 8;
                 auto v_pass = [&](auto IP) __attribute__((always_inline)) {
                     constexpr int ip = decltype(IP)::value;
-                    if constexpr (std::is_same<AT, f32x4[MT][NT]>::value) acc_stage<MT, NT, 2>(acc, ip, scr, SLV, lane);
-                    else acc_stage<MT / 2, NT / 2, 2>(acc, ip, scr, SLV, lane);
+                    if constexpr (std::is_same<AT, f32x4[MT][NT]>::value) {
+#pragma unroll
+                        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) scr[(ii * 16 + fg * 4 + r) * SLV + j * 16 + fr] = acc[ip + ii][j][r];
+                    } else acc_stage<MT / 2, NT / 2, 2, ip>(acc, scr, SLV, lane);
                     wave_lds_order();
                     float x[4][8];
 #pragma unroll

@@ -58,9 +58,9 @@ void prof_end(int slot, hipStream_t s) {
 
 // ---- run-time options (hvx_options.h) ---------------------------------------------------------------------------------------
 const OptDef g_opt_defs[OPT_COUNT] = {
-    {"att_chunk", 0, 0}, {"att_waves", 8, 0}, {"gemm_big_gw", 4, 0}, {"gemm_big_min_tiles", 128, 0}, {"gemm_big_mfma", 16, 0}, {"dec_gemm", 1, 0}, {"dec_heads", 3, 0},
+    {"att_chunk", 0, 0}, {"att_waves", 8, 0}, {"gemm_big_gw", 4, 0}, {"gemm_big_min_tiles", 128, 0}, {"dec_gemm", 1, 0}, {"dec_heads", 3, 0},
     {"conv_resident", 1, 0}, {"conv64_resident", 1, 0}, {"x3p8", 1, 0}, {"attn_dit_form", 0, 0},
-    {"head_down_split", 0, 1}, {"dec_gpw_qkv", 1, 1}, {"dec_gpw_res", 1, 1}, {"dec_gpw_mlp", 3, 1}, {"dec_gpw_down", 2, 1}, {"dec_gpw_out", 3, 1}, {"dec_gpw_hmlp", 11, 1},
+    {"gemm_big_mfma", 16, 1}, {"head_down_split", 0, 1}, {"dec_gpw_qkv", 1, 1}, {"dec_gpw_res", 1, 1}, {"dec_gpw_mlp", 3, 1}, {"dec_gpw_down", 2, 1}, {"dec_gpw_out", 3, 1}, {"dec_gpw_hmlp", 11, 1},
     {"attn_lab", 0, 1}, {"attn_nw", 4, 1},
 };
 static std::atomic<long long> g_opt_val[OPT_COUNT];

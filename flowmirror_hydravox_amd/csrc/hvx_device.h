@@ -137,17 +137,15 @@ enum Act : int {
 // two-part pi (exact for |k| < 2^13, far beyond any activation argument), then the odd Taylor polynomial of sin through r^11 on |r| <= pi / 2
 // (truncation 6e-8): 1.5e-7 absolute against libm's sinf squared, with 13 full-rate instructions and no branch — libm's sinf (range-reduction ladder,
 // ~45 instructions) was 9 % of the vocoder once its convolutions stopped waiting on memory (round 5: 17.0 ms per 5632-frame utterance, 15.5 without the sines).
-// Beyond |y| = 2.5e4 (k near 2^13: the two-part reduction stops being exact and r would leave [-pi / 2, pi / 2], where the polynomial is unbounded) the value
-// comes from libm's sinf, which stays in [0, 1] for any finite argument: a stray huge activation gives a bounded sample, as with the reference's torch.sin.
-// The branch is all but never taken (activation arguments are O(1..100)) and uniform when it is not.
+// Beyond |y| ~ 2.5e4 (k near 2^13) the two-part reduction stops being exact and r would leave [-pi / 2, pi / 2], where the polynomial is unbounded: r is clamped
+// to that interval (ONE v_med3_f32), so a stray huge activation gives a value in [0, 1] — a bounded sample, like the reference's torch.sin — instead of a huge or
+// infinite one; the value itself is then arbitrary, as any fp32 sine of an argument whose ulp exceeds pi is.  (A libm sinf fall-back on that branch was tried first: inlined
+// into every epilogue instantiation it multiplied the compile time of the GEMM files by six and cost registers in kernels that never take it.)
 __device__ __forceinline__ float sin_sq(float y) {
-    if (__builtin_expect(!(__builtin_fabsf(y) <= 2.5e4f), 0)) {
-        const float s = sinf(y);                                   // (NaN / inf arguments propagate as NaN, like torch.sin)
-        return s * s;
-    }
     const float k = __builtin_rintf(y * 0.3183098861837907f);
     float r = __builtin_fmaf(-k, 3.140625f, y);                    // pi = 3.140625 (exact in 8 bits) + 9.67653589793e-4
     r = __builtin_fmaf(-k, 9.67653589793e-4f, r);
+    r = __builtin_amdgcn_fmed3f(r, -1.5707964f, 1.5707964f);
     const float r2 = r * r;
     float p = -2.5052108385441720e-8f;                             // -1 / 11!
     p = __builtin_fmaf(p, r2, 2.7557319223985893e-6f);            //  1 / 9!

@@ -17,7 +17,6 @@ enum OptId : int {
     OPT_ATT_WAVES,             // 8: the one-tile bf16 decode attention merges 8 waves per split workgroup; 4: four
     OPT_GEMM_BIG_GW,           // column tiles per row group of the 256-tile Linear's workgroup order; 0 = all columns in one group
     OPT_GEMM_BIG_MIN_TILES,    // fewest 256 x 256 tiles for which the 256-tile Linear is chosen over the 128-tile one
-    OPT_GEMM_BIG_MFMA,         // MFMA shape of the 256-tile Linear's K-loop: 16 (16x16x32) or 32 (32x32x16)
     OPT_DEC_GEMM,              // 1: 33..256-row decode grids on gemm_dec.hip (fragment-order activations); 0: the generic skinny kernels (the tests compare the two)
     OPT_DEC_HEADS,             // bit 0: MTP head MLPs, bit 1: the shared output projection on gemm_dec.hip
     OPT_CONV_RESIDENT,         // 1: the DiT position embedding's 64-channel grouped convolution in the resident-row form; 0: tiled
@@ -25,6 +24,7 @@ enum OptId : int {
     OPT_X3P8,                  // 1: the 8-wave 128 x 128 x 64 tile for the vocoder's 128- / 256-channel split-bf16 convolutions; 0: the 4-wave tile
     OPT_ATTN_DIT_FORM,         // DiT attention tile: 0 = chosen per shape (the 16x16x32 tile), 16 = the same, 32 = the 32x32x16 tile (attention.hip: measured slower, kept selectable)
     // ---- lab (settable with -DHVX_LAB only) ----
+    OPT_GEMM_BIG_MFMA,         // MFMA shape of the 256-tile Linear's K-loop: 16 (16x16x32) or 32 (32x32x16: bit-identical, measured 4 % slower)
     OPT_HEAD_DOWN_SPLIT,       // forced K split of the MTP heads' down projection; 0 = chosen per grid
     OPT_DEC_GPW_QKV, OPT_DEC_GPW_RES, OPT_DEC_GPW_MLP, OPT_DEC_GPW_DOWN, OPT_DEC_GPW_OUT, OPT_DEC_GPW_HMLP,   // column groups per workgroup of the decode GEMM launches
     OPT_ATTN_LAB,              // timing-only variants of the DiT attention loop (results are garbage): bit mask, see attention.hip

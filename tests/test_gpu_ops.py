@@ -687,7 +687,8 @@ def test_attention_dit_32x32x16_tile_vs_fp32_reference_and_the_product_tile():
 
 def test_snake_stays_bounded_for_huge_arguments():
     """hvx_device.h: sin_sq reduces its argument against a two-part pi, exact for |k| < 2^13; a stray activation beyond that must not turn the degree-11
-    polynomial loose — Snake(x) = x + sin^2(a x) / (a + 1e-9) has to stay within [x, x + 1 / a] like the reference's torch.sin form (activation.py:79-82) for ANY finite x.
+    polynomial loose (the reduced argument is clamped to +- pi / 2) — Snake(x) = x + sin^2(a x) / (a + 1e-9) has to stay within [x, x + 1 / a] like the reference's torch.sin
+    form (activation.py:79-82) for ANY finite x; where fp32 still resolves the phase (|a x| < 2e4) the value itself is held.
     A 1-tap identity convolution carries the chosen values through the Snake epilogue (exact-fp32 form: x is reproduced bit for bit)."""
     _lib, ops, packing = _mods()
     vals = torch.tensor([0.0, 1.0, -3.0, 100.0, 2.4e4, 2.6e4, 1e5, -7.7e5, 3.3e6, 4.2e6, 8.4e6, 1.7e7, 1e9, -1e12, 1e30, -3e37], dtype=torch.float32)
