@@ -1612,7 +1612,7 @@ static int launch_t(const AttnArgs& a_in, hipStream_t s) {
     else if (merge) hipLaunchKernelGGL((attn_fwd_kernel<T, 1, true, false>), grid, dim3(256), 0, s, a);
     else if (big) hipLaunchKernelGGL((attn_fwd_kernel<T, 2, false, false>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((attn_fwd_kernel<T, 1, false, false>), grid, dim3(256), 0, s, a);
-    if (a.n_splits > 1) {
+    if (a.n_splits > 1 && !a.skip_combine) {
         dim3 g2((a.n_rows + 3) / 4, a.heads, a.batch);
         hipLaunchKernelGGL((attn_combine_kernel<T>), g2, dim3(256), 0, s, a);
     }

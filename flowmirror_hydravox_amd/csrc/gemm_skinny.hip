@@ -591,9 +591,68 @@ static int launch_one(const SkinnyArgs& a, hipStream_t s) {
 // do 4x redundant work (free: the kernel is bound by bytes per CU), the K split stays inside the workgroup (LDS, fixed order), and
 // the residual update x += ... has one writer per element.
 // ---------------------------------------------------------------------------------------------------------------------------------
-template <class T, int KW, int UB>
+// COMB: the two A fragments (d = 8 fg .. + 8 and 32 + 8 fg .. + 8) of query head hq for grid row `row`, combined from the key-split partials
+// of the attention launch in front — operation for operation what attn_combine_kernel computes and rounds (attention.hip), so the fused
+// and the two-launch forms feed the MFMA the same bits.
+template <class T>
+__device__ __forceinline__ void combined_pair(const SkinnyArgs& a, int row, int hq, int fg, typename Vec8<T>::type& f_lo, typename Vec8<T>::type& f_hi) {
+    const int si = row / a.kn, lt = row - si * a.kn;
+    const int G = a.q_heads / a.kv_heads;
+    const int h = hq / G, rh = hq - h * G;
+    const int vis = min(a.att_kvlen[si], a.pos0[si] + lt + 1);
+    const int n_live = lt < a.n_new[si] ? min(a.att_splits, (vis + a.att_chunk - 1) / a.att_chunk) : 0;
+    const long long base0 = (((long long)si * a.kv_heads + h) * a.att_splits) * a.att_rows_pad + rh * a.kn + lt;
+    const long long sstride = a.att_rows_pad;
+    constexpr int SB = 8;
+    float m = -INFINITY, l = 0.0f, acc[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+    for (int s0 = 0; s0 < n_live; s0 += SB) {
+        float ms[SB], ls[SB];
+        f32x4 os[SB][4];
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+            // (the combine kernel re-reads the last live split for the dead slots of a batch and weighs it with 0; here a dead slot is 0 itself and costs
+            // no load: 0 * finite == 0 * 0 in every accumulator)
+            ms[u] = -INFINITY;
+            ls[u] = 0.0f;
+            os[u][0] = os[u][1] = os[u][2] = os[u][3] = f32x4{0, 0, 0, 0};
+            if (s0 + u < n_live) {
+                const long long base = base0 + (long long)(s0 + u) * sstride;
+                const float2 ml = *reinterpret_cast<const float2*>(a.att_ml + base * 2);
+                ms[u] = ml.x;
+                ls[u] = ml.y;
+                const f32x4* po = reinterpret_cast<const f32x4*>(a.att_o + base * 64 + fg * 8);
+                os[u][0] = po[0]; os[u][1] = po[1]; os[u][2] = po[8]; os[u][3] = po[9];
+            }
+        }
+        float mb = m;
+#pragma unroll
+        for (int u = 0; u < SB; ++u) mb = fmaxf(mb, ms[u]);
+        const float resc = (m == -INFINITY) ? 0.0f : expf(m - mb);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] *= resc;
+        l *= resc;
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+            const float wgt = (ms[u] == -INFINITY) ? 0.0f : expf(ms[u] - mb);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] += wgt * os[u][e >> 2][e & 3];
+            l += wgt * ls[u];
+        }
+        m = mb;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        f_lo[e] = from_f32<T>(l > 0.0f ? acc[e] / l : 0.0f);
+        f_hi[e] = from_f32<T>(l > 0.0f ? acc[8 + e] / l : 0.0f);
+    }
+}
+
+template <class T, int KW, int UB, bool COMB = false>
 __global__ __launch_bounds__(64 * KW) void gemm_narrow_resid_kernel(SkinnyArgs a) {
     typedef typename Vec8<T>::type V8;
+    static_assert(!COMB || UB == 1, "the combining form requests one K block per wave");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c16 = lane & 15, fg = lane >> 4;
     const int c4 = c16 & 3, ksub = c16 >> 2;
@@ -626,8 +685,19 @@ __global__ __launch_bounds__(64 * KW) void gemm_narrow_resid_kernel(SkinnyArgs a
         for (int u = 0; u < UB; ++u) {
             const int k = min(kb + u, kb1 - 1);
             wf[u] = load8_nt(wp + (long long)k * 512);
+            if constexpr (COMB) {                       // K block k = query heads 2k, 2k + 1; sub-blocks (0, 1) / (2, 3) are their d halves
 #pragma unroll
-            for (int sblk = 0; sblk < 4; ++sblk) af[u][sblk] = load8(arow + k * 128 + sblk * 32);
+                for (int sblk = 0; sblk < 4; ++sblk)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) af[u][sblk][e] = from_f32<T>(0.0f);
+                if (m0 + c16 < a.M) {                   // rows past the grid are masked at the store: their lanes ask for nothing (a single request has 1..2 live rows of 16)
+                    combined_pair<T>(a, r, 2 * k, fg, af[u][0], af[u][1]);
+                    combined_pair<T>(a, r, 2 * k + 1, fg, af[u][2], af[u][3]);
+                }
+            } else {
+#pragma unroll
+                for (int sblk = 0; sblk < 4; ++sblk) af[u][sblk] = load8(arow + k * 128 + sblk * 32);
+            }
         }
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
@@ -664,12 +734,12 @@ __global__ __launch_bounds__(64 * KW) void gemm_narrow_resid_kernel(SkinnyArgs a
     }
 }
 
-template <class T, int KW, int UB>
+template <class T, int KW, int UB, bool COMB = false>
 static int launch_narrow(const SkinnyArgs& a, hipStream_t s) {
     dim3 grid(a.N / 4, 1, (a.M + 15) / 16);
     const double bytes = (double)a.N * a.K * sizeof(T) + (double)a.M * a.K * sizeof(T) + (double)a.M * a.N * 8.0;
     const int slot = prof_begin(PK_SKINNY, bytes, s);
-    hipLaunchKernelGGL((gemm_narrow_resid_kernel<T, KW, UB>), grid, dim3(64 * KW), 0, s, a);
+    hipLaunchKernelGGL((gemm_narrow_resid_kernel<T, KW, UB, COMB>), grid, dim3(64 * KW), 0, s, a);
     prof_end(slot, s);
     return hipGetLastError() == hipSuccess ? 0 : (set_error("narrow gemm launch failed"), -1);
 }
@@ -677,6 +747,11 @@ static int launch_narrow(const SkinnyArgs& a, hipStream_t s) {
 template <class T>
 static int launch_narrow_t(const SkinnyArgs& a, hipStream_t s) {
     const int KB = a.K >> 7;
+    if (a.att_o) {
+        if (KB > 8 || a.K != a.q_heads * 64 || !a.att_ml || !a.att_kvlen || !a.pos0 || !a.n_new || a.kn < 1 || a.kv_heads < 1 || a.q_heads % a.kv_heads)
+            return set_error("launch_skinny: the combining o_proj needs K = q_heads * 64 <= 1024 and the attention launch's controls"), -1;
+        return launch_narrow<T, 8, 1, true>(a, s);
+    }
     if (KB <= 8) return launch_narrow<T, 8, 1>(a, s);                                  // o_proj: one block per wave
     if (KB <= 40) return launch_narrow<T, 8, (sizeof(T) == 2 ? 5 : 3)>(a, s);          // down_proj (K = 4864: 38 blocks, 5 per wave)
     return launch_narrow<T, 8, 4>(a, s);

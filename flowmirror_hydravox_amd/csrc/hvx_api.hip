@@ -59,7 +59,7 @@ void prof_end(int slot, hipStream_t s) {
 // ---- run-time options (hvx_options.h) ---------------------------------------------------------------------------------------
 const OptDef g_opt_defs[OPT_COUNT] = {
     {"att_chunk", 0, 0}, {"att_waves", 8, 0}, {"gemm_big_gw", 4, 0}, {"gemm_big_min_tiles", 128, 0}, {"dec_gemm", 1, 0}, {"dec_heads", 3, 0},
-    {"conv_resident", 1, 0}, {"conv64_resident", 1, 0}, {"x3p8", 1, 0}, {"attn_dit_form", 0, 0},
+    {"conv_resident", 1, 0}, {"conv64_resident", 1, 0}, {"x3p8", 1, 0}, {"attn_dit_form", 0, 0}, {"dec_fuse_rows", 0, 0},
     {"gemm_big_mfma", 16, 1}, {"head_down_split", 0, 1}, {"dec_gpw_qkv", 1, 1}, {"dec_gpw_res", 1, 1}, {"dec_gpw_mlp", 3, 1}, {"dec_gpw_down", 2, 1}, {"dec_gpw_out", 3, 1}, {"dec_gpw_hmlp", 11, 1},
     {"attn_lab", 0, 1}, {"attn_nw", 4, 1},
 };
@@ -114,6 +114,7 @@ int hvx_set_option(const char* key, int64_t value) {
 #endif
     if (i == OPT_ATT_CHUNK && value != 0 && (value < 128 || value % 128)) return set_error("hvx_set_option: att_chunk must be 0 or a multiple of 128, got %lld", (long long)value), -1;
     if (i == OPT_GEMM_BIG_MFMA && value != 16 && value != 32) return set_error("hvx_set_option: gemm_big_mfma must be 16 or 32, got %lld", (long long)value), -1;
+    if (i == OPT_DEC_FUSE_ROWS && (value < 0 || value > 256)) return set_error("hvx_set_option: dec_fuse_rows must be 0..256, got %lld", (long long)value), -1;
     if (i == OPT_ATT_WAVES && value != 4 && value != 8) return set_error("hvx_set_option: att_waves must be 4 or 8, got %lld", (long long)value), -1;
     #ifdef HVX_LAB
     const bool form_ok = value == 0 || value == 16 || value == 32 || value == 48;

@@ -112,6 +112,11 @@ struct SkinnyArgs {
     // SK_RESID: optional copy of the updated rows in `dtype` (the A operand of the next fused-norm GEMM)
     void* out2; int ldo2;
     int w_narrow;                 // SK_RESID: W is packed [N/4][K/128][64][8] (packing.pack_narrow4) for the 4-column workgroup form
+    // w_narrow, one row tile (o_proj of a narrow decode grid): A is not read — its fragments are built from the key-split partials of the
+    // attention launch in front (AttnArgs.part_o / part_ml with skip_combine), with the arithmetic of attn_combine_kernel, so the combine
+    // launch between the two disappears.  Row m = si * kn + lt, column = q head * 64 + d; kn, q_heads, kv_heads, pos0, n_new as above.
+    const float* att_o; const float* att_ml; const int* att_kvlen;
+    int att_splits, att_chunk, att_rows_pad;
     // ---- wide decode grids (33..128 rows, bf16): activations in fragment order (hvx_device.h: frag_index) -----------------------
     int a_frag;                   // A is [ceil(M/16)][K/32][64][8] instead of row-major (launch_dec_gemm only)
     int out_frag;                 // SK_SWIGLU: out, SK_RESID: out2 are written in fragment order (their consumer is another launch_dec_gemm)
@@ -151,6 +156,7 @@ struct AttnArgs {
                                                       // each and merge their (m, l, o) in LDS, so the combine reads 4x fewer partials
     float* part_o; float* part_ml;                    // [batch][heads][n_splits][n_rows_pad][64], [...][n_rows_pad][2]
     int n_rows_pad;
+    int skip_combine;                                 // n_splits > 1: leave the partials to the consumer (SkinnyArgs.att_o), `out` is not written
     int kv_frag;                                      // k / vT are the LLM's fragment-order caches (hvx_device.h: frag_index(key, d, 2), vfrag_index(key, d)
                                                       // per (batch, head) block of k_hs / v_hs elements); v_ld = the cache's context capacity
     int o_frag_kt;                                    // > 0 (LLM decode, 16-bit): out is the [batch * kn][heads * rows_hi * 64] activation matrix in fragment

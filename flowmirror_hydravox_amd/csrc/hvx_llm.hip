@@ -434,11 +434,20 @@ static int forward_impl(hvx_llm* h, hipStream_t s, int32_t n_seq, int32_t kn, co
         } else {
             at.n_splits = 1;
         }
+        // option dec_fuse_rows (default 0): no combine launch — the o_proj builds its activation fragments from the partials (gemm_skinny.hip:
+        // combined_pair).  Bit-identical; measured slower (826 -> 925 us per step for one request, 975 -> 1186 for 8): the launch it removes costs less
+        // than the dependent control -> partials -> exp chain it puts in front of the o_proj's MFMAs (the plain o_proj loads its rows beside its weights)
+        const bool fuse = use_split && !dec && R <= (int)opt(OPT_DEC_FUSE_ROWS) && Q <= 1024;
+        at.skip_combine = fuse;
         if (launch_attention(at, s)) return -1;
         // 3. x += o_proj(attn)
         memset(&g, 0, sizeof(g));
         g.dtype = dt; g.M = R; g.N = H; g.K = Q; g.A = h->attn; g.lda = Q; g.W = lw[3]; g.nz = 1; g.split_k = 1;
         g.epi = SK_RESID; g.out = h->x; g.out_f32 = 1; g.ldo = H; g.out2 = xcopy; g.ldo2 = H; g.w_narrow = 1;
+        if (fuse) {
+            g.att_o = at.part_o; g.att_ml = at.part_ml; g.att_kvlen = d_kvlen; g.att_splits = at.n_splits; g.att_chunk = at.split_chunk; g.att_rows_pad = at.n_rows_pad;
+            g.kn = kn; g.q_heads = c.q_heads; g.kv_heads = c.kv_heads; g.pos0 = d_pos0; g.n_new = d_nnew;
+        }
         if (dec) {
             g.W = lw[7]; g.w_narrow = 0; g.a_frag = 1; g.out_frag = 1;                          // (fragment-packed copy of the weights)
             if (gemm(g)) return -1;

@@ -200,3 +200,19 @@ def test_wide_grid_decode_gemm_form_agrees_with_the_generic_kernels(S, K):
     r = dec_ab.compare(seqs=S, heads=K, ctx=300, layers=2)
     print(S, K, r)
     assert r['finite'] and r['max_logp'] < 3e-2 and r['mean_logp'] < 5e-3 and r['kv_max'] < 2e-2 and r['argmax'] > 0.95, r
+
+
+@pytest.mark.parametrize('S,K,ctx', [(1, 1, 700), (1, 2, 1536), (3, 4, 700), (8, 2, 1100), (3, 5, 600)])
+def test_narrow_grid_o_proj_from_attention_partials_is_bit_identical_to_the_combine_launch(S, K, ctx):
+    """Decode grids of <= 16 rows (a single request, the literal batch of 8 x 2 heads): the o_proj builds its activation fragments from the attention's
+    key-split partials (gemm_skinny.hip: combined_pair; option dec_fuse_rows) instead of reading what attn_combine_kernel wrote — the same operations in the
+    same order, so one decode step of a 2-layer CV3-width LM over a random KV cache (ragged positions and row counts, 3..6 live splits) must give the same
+    BITS in both forms, bf16 and fp32.  (3 x 5: 35 GQA rows per KV head — no key split, nothing fused: the option must then change nothing.)"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    import fuse_ab
+    for dt in (torch.bfloat16, torch.float32):
+        r = fuse_ab.one(S, K, ctx, 2, dt, steps=0, ragged=True)
+        print(r)
+        assert r['finite'] and r['same_logp'] and r['same_kv'], r

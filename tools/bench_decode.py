@@ -27,11 +27,14 @@ def main():
     ap.add_argument('--max-ctx', type=int, default=0, help='capacity of the KV cache (default: --ctx + 64); the engine of the bench runs with 4096: the attention grid is sized by it')
     ap.add_argument('--head-fp8', action='store_true', help="the MTP heads' gate / up projections as e4m3 codes (HvxLLM(head_mlp_fp8=True))")
     ap.add_argument('--cus', type=int, default=0, help='confine the stream to this many compute units (hvx_stream_create_cu_range)')
+    ap.add_argument('--opt', action='append', default=[], metavar='NAME=VALUE', help='library option(s) set before the model is built (hvx_set_option), e.g. dec_fuse_rows=0')
     args = ap.parse_args()
     from flowmirror_hydravox_amd import _lib, cv3_config
     from flowmirror_hydravox_amd.llm import HvxLLM
     from flowmirror_hydravox_amd.weights import make_llm_state
     _lib.require_gpu()
+    for kv in args.opt:
+        _lib.set_option(kv.split('=')[0], int(kv.split('=')[1]))
     cfg = cv3_config().llm
     S, K = args.seqs, args.heads
     dt = torch.float32 if args.fp32 else torch.bfloat16
