@@ -1,9 +1,11 @@
 """oracle/frontend_ref.py — CPU restatement of the two third-party feature extractors of the zero-shot frontend
 (server/model_utils/cosyvoice/cli/frontend.py:92-110).  TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
 
-PARITY UNPINNED: both algorithms live in third-party packages that are neither under /root/reference nor installed in this image
-(requirements.txt: openai-whisper==20231117, torchaudio==2.3.1), and the reference holds no test vectors for them.  They are restated
-from the published sources of those versions and anchored on the reference's call sites only:
+PINNED TO AN INDEPENDENT IMPLEMENTATION, NOT TO THE REFERENCE'S OWN PACKAGES: both algorithms live in third-party packages that are neither under /root/reference
+nor installed in this image (requirements.txt: openai-whisper==20231117, torchaudio==2.3.1), and the reference holds no test vectors for them.  They are restated from
+the published sources of those versions, anchored on the reference's call sites, and held (tests/test_oracle_golden.py, tests/golden/frontend_pins.npz minted by
+tests/golden/make_golden_frontend_pins.py) to the numpy feature extractors of `transformers` 5.15 — WhisperFeatureExtractor and SeamlessM4TFeatureExtractor ("mimic
+Kaldi"), which re-implement the same two front ends and share no code with this file or the product: whisper log-mel within 2e-5, kaldi fbank within 1e-4.
 
   * `whisper.log_mel_spectrogram(speech, n_mels=128)`  (frontend.py:95)  — whisper/audio.py:110-157: 16 kHz, N_FFT 400, HOP 160,
     periodic Hann window, torch.stft(center=True, reflect), the last frame dropped, |X|^2, the librosa Slaney mel filterbank

@@ -33,6 +33,73 @@ def _mod(name, **attrs):
     return m
 
 
+def stand_ins():
+    """The restated third-party classes / functions (module docstring), importable WITHOUT the reference: tests/test_oracle_golden.py holds them to independent
+    implementations that this image does have (torch's own scaled_dot_product_attention = what diffusers' AttnProcessor2_0 calls; transformers' GPT-J rotary
+    functions = the same interleaved-pair rotation as x_transformers')."""
+    import torch
+    from torch import nn
+
+    class Attention(nn.Module):
+        def __init__(self, query_dim, cross_attention_dim=None, heads=8, dim_head=64, dropout=0.0, bias=False, upcast_attention=False, **kw):
+            super().__init__()
+            assert cross_attention_dim is None
+            inner = heads * dim_head
+            self.heads, self.scale = heads, dim_head ** -0.5
+            self.to_q = nn.Linear(query_dim, inner, bias=bias)
+            self.to_k = nn.Linear(query_dim, inner, bias=bias)
+            self.to_v = nn.Linear(query_dim, inner, bias=bias)
+            self.to_out = nn.ModuleList([nn.Linear(inner, query_dim), nn.Dropout(dropout)])
+
+        def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None, **kw):
+            assert encoder_hidden_states is None
+            B, T, _ = hidden_states.shape
+            q, k, v = self.to_q(hidden_states), self.to_k(hidden_states), self.to_v(hidden_states)
+            d = q.shape[-1] // self.heads
+            q, k, v = (t.view(B, T, self.heads, d).transpose(1, 2) for t in (q, k, v))
+            s = torch.matmul(q, k.transpose(-1, -2)) * self.scale
+            if attention_mask is not None:
+                m = attention_mask
+                m = m[:, None, None, :] if m.dim() == 2 else m[:, None]
+                s = s + m.to(s.dtype)
+            o = torch.matmul(torch.softmax(s, dim=-1), v).transpose(1, 2).reshape(B, T, self.heads * d)
+            return self.to_out[1](self.to_out[0](o))
+
+
+    class RotaryEmbedding(nn.Module):
+        def __init__(self, dim, base=10000):
+            super().__init__()
+            inv_freq = 1.0 / (base ** (torch.arange(0, dim, 2).float() / dim))
+            self.register_buffer('inv_freq', inv_freq)
+
+        def forward_from_seq_len(self, seq_len):
+            t = torch.arange(seq_len, device=self.inv_freq.device)
+            return self.forward(t)
+
+        def forward(self, t):
+            if t.ndim == 1:
+                t = t[None]
+            freqs = torch.einsum('b i , j -> b i j', t.type_as(self.inv_freq), self.inv_freq)
+            freqs = torch.stack((freqs, freqs), dim=-1).flatten(-2)   # interleaved duplicate
+            return freqs, 1.0
+
+    def rotate_half(x):
+        x = x.reshape(*x.shape[:-1], -1, 2)
+        x1, x2 = x.unbind(dim=-1)
+        return torch.stack((-x2, x1), dim=-1).flatten(-2)
+
+    def apply_rotary_pos_emb(t, freqs, scale=1):
+        rot_dim, seq_len, orig_dtype = freqs.shape[-1], t.shape[-2], t.dtype
+        freqs = freqs[:, -seq_len:, :]
+        if t.ndim == 4 and freqs.ndim == 3:
+            freqs = freqs[:, None]
+        t_rot, t_pass = t[..., :rot_dim], t[..., rot_dim:]
+        t_rot = (t_rot * freqs.cos() * scale) + (rotate_half(t_rot) * freqs.sin() * scale)
+        return torch.cat((t_rot, t_pass), dim=-1).type(orig_dtype)
+
+    return dict(Attention=Attention, RotaryEmbedding=RotaryEmbedding, rotate_half=rotate_half, apply_rotary_pos_emb=apply_rotary_pos_emb)
+
+
 def install():
     import torch
     from torch import nn
@@ -85,31 +152,7 @@ def install():
     _mod('diffusers.models')
     _mod('diffusers.models.activations', get_activation=lambda n: {'silu': nn.SiLU(), 'swish': nn.SiLU(), 'mish': nn.Mish(), 'gelu': nn.GELU()}[n])
     _mod('diffusers.models.attention', GEGLU=_Dummy, GELU=_Dummy, AdaLayerNorm=_Dummy, AdaLayerNormZero=_Dummy, ApproximateGELU=_Dummy)
-    class Attention(nn.Module):
-        def __init__(self, query_dim, cross_attention_dim=None, heads=8, dim_head=64, dropout=0.0, bias=False, upcast_attention=False, **kw):
-            super().__init__()
-            assert cross_attention_dim is None
-            inner = heads * dim_head
-            self.heads, self.scale = heads, dim_head ** -0.5
-            self.to_q = nn.Linear(query_dim, inner, bias=bias)
-            self.to_k = nn.Linear(query_dim, inner, bias=bias)
-            self.to_v = nn.Linear(query_dim, inner, bias=bias)
-            self.to_out = nn.ModuleList([nn.Linear(inner, query_dim), nn.Dropout(dropout)])
-
-        def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None, **kw):
-            assert encoder_hidden_states is None
-            B, T, _ = hidden_states.shape
-            q, k, v = self.to_q(hidden_states), self.to_k(hidden_states), self.to_v(hidden_states)
-            d = q.shape[-1] // self.heads
-            q, k, v = (t.view(B, T, self.heads, d).transpose(1, 2) for t in (q, k, v))
-            s = torch.matmul(q, k.transpose(-1, -2)) * self.scale
-            if attention_mask is not None:
-                m = attention_mask
-                m = m[:, None, None, :] if m.dim() == 2 else m[:, None]
-                s = s + m.to(s.dtype)
-            o = torch.matmul(torch.softmax(s, dim=-1), v).transpose(1, 2).reshape(B, T, self.heads * d)
-            return self.to_out[1](self.to_out[0](o))
-
+    Attention = stand_ins()['Attention']
     _mod('diffusers.models.attention_processor', Attention=Attention)
     _mod('diffusers.models.lora', LoRACompatibleLinear=nn.Linear)
     _mod('diffusers.utils')
@@ -138,36 +181,7 @@ def install():
     _mod('matcha.utils.pylogger', get_pylogger=lambda name=None: logging.getLogger(name))
 
     # ---- x_transformers: restated arithmetic (see module docstring) -------------------------------
-    class RotaryEmbedding(nn.Module):
-        def __init__(self, dim, base=10000):
-            super().__init__()
-            inv_freq = 1.0 / (base ** (torch.arange(0, dim, 2).float() / dim))
-            self.register_buffer('inv_freq', inv_freq)
-
-        def forward_from_seq_len(self, seq_len):
-            t = torch.arange(seq_len, device=self.inv_freq.device)
-            return self.forward(t)
-
-        def forward(self, t):
-            if t.ndim == 1:
-                t = t[None]
-            freqs = torch.einsum('b i , j -> b i j', t.type_as(self.inv_freq), self.inv_freq)
-            freqs = torch.stack((freqs, freqs), dim=-1).flatten(-2)   # interleaved duplicate
-            return freqs, 1.0
-
-    def rotate_half(x):
-        x = x.reshape(*x.shape[:-1], -1, 2)
-        x1, x2 = x.unbind(dim=-1)
-        return torch.stack((-x2, x1), dim=-1).flatten(-2)
-
-    def apply_rotary_pos_emb(t, freqs, scale=1):
-        rot_dim, seq_len, orig_dtype = freqs.shape[-1], t.shape[-2], t.dtype
-        freqs = freqs[:, -seq_len:, :]
-        if t.ndim == 4 and freqs.ndim == 3:
-            freqs = freqs[:, None]
-        t_rot, t_pass = t[..., :rot_dim], t[..., rot_dim:]
-        t_rot = (t_rot * freqs.cos() * scale) + (rotate_half(t_rot) * freqs.sin() * scale)
-        return torch.cat((t_rot, t_pass), dim=-1).type(orig_dtype)
+    RotaryEmbedding, apply_rotary_pos_emb = stand_ins()['RotaryEmbedding'], stand_ins()['apply_rotary_pos_emb']
 
     _mod('x_transformers')
     _mod('x_transformers.x_transformers', RotaryEmbedding=RotaryEmbedding, apply_rotary_pos_emb=apply_rotary_pos_emb)

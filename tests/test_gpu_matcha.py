@@ -203,6 +203,24 @@ def test_kaldi_fbank_vs_oracle(n):
     assert HvxKaldiFbank(80)(y[:399]).shape == (0, 80)
 
 
+def test_device_whisper_and_kaldi_features_vs_the_independent_fixture():
+    """The device front ends against tests/golden/frontend_pins.npz directly: arrays computed by the numpy feature extractors of `transformers` (an implementation
+    independent of oracle/ and of the product; tests/golden/make_golden_frontend_pins.py) — whisper's 128-bin log-mel and Kaldi's 80-bin fbank (+ the frontend's mean
+    subtraction, cosyvoice/cli/frontend.py:92-115).  Same tolerances as against the oracle: 2e-3 of the log10 / 4 scale, 5e-3 natural-log."""
+    import os
+    from flowmirror_hydravox_amd.frontend import HvxKaldiFbank, HvxWhisperLogMel
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'frontend_pins.npz'))
+    wl, kf, kfm = HvxWhisperLogMel(128), HvxKaldiFbank(80, subtract_mean=False), HvxKaldiFbank(80)
+    for tag in ('a', 'b'):
+        y = torch.from_numpy(g['y_' + tag])
+        dw = np.abs(wl(y).cpu().numpy() - g['whisper128_' + tag]).max()
+        k = g['kaldi80_' + tag]
+        dk = np.abs(kf(y[None]).cpu().numpy() - k).max()
+        dkm = np.abs(kfm(y[None]).cpu().numpy() - (k - k.mean(0, keepdims=True))).max()
+        print('device vs the independent implementation (%s): whisper %.2e, kaldi %.2e, mean-normalised %.2e' % (tag, dw, dk, dkm))
+        assert dw < 2e-3 and dk < 5e-3 and dkm < 5e-3, (dw, dk, dkm)
+
+
 def test_zero_shot_frontend_graphs_run_on_the_device():
     """SURVEY.md §8(f) N2, the rest of the row: `_extract_speech_token` / `_extract_spk_embedding` (cosyvoice/cli/frontend.py:92-115) with the ONNX graphs
     executed on the device (frontend.HvxSpeechTokenizer / HvxSpeakerEncoder over onnx_graph.OnnxRunner) instead of onnxruntime CPU sessions.  The real

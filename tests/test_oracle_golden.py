@@ -284,6 +284,14 @@ def test_slaney_mel_table_is_pinned_and_the_product_table_equals_it():
         assert mine.dtype == torch.float32 and mine.shape == ref.shape
         d = float((mine.double() - ref).abs().max() / ref.max())
         assert d < 1e-7, (sr, n_fft, n_mels, fmin, fmax, d)
+        # (3) an independent implementation of the same table, where this image has one: transformers.audio_utils.mel_filter_bank(norm / mel_scale "slaney")
+        try:
+            from transformers.audio_utils import mel_filter_bank
+        except Exception:
+            continue
+        ind = mel_filter_bank(num_frequency_bins=n_fft // 2 + 1, num_mel_filters=n_mels, min_frequency=fmin, max_frequency=sr / 2.0 if fmax is None else fmax,
+                              sampling_rate=sr, norm='slaney', mel_scale='slaney').T
+        assert np.abs(ind - ref.numpy()).max() / float(ref.max()) < 1e-9, (sr, n_fft, n_mels)
 
 
 # ------------------------------------------------------------------------------------------------------------------------
@@ -690,3 +698,97 @@ def test_wave_metrics_and_the_reference_conditioning_fixture():
     # the measurement itself: one ulp of f0 moves the reference's own waveform by ~1e-3 within the first second and by > 0.2 of a 0.99 peak over the utterance
     assert float(g['ulp_up_first_second']) < 5e-3 and float(g['ulp_up_max']) > 0.1 and float(g['ulp_down_max']) > 0.1 and 0.9 < float(g['peak']) <= 0.99 + 1e-6
     assert float(g['f0_fp64_minus_fp32']) < 1e-3
+
+
+def test_whisper_and_kaldi_features_are_pinned_to_an_independent_implementation():
+    """SURVEY.md §8(f) N2 (cosyvoice/cli/frontend.py:92-115): openai-whisper and torchaudio are absent, so `whisper.log_mel_spectrogram(n_mels=128)` and
+    `kaldi.fbank(num_mel_bins=80, dither=0)` are restatements in oracle/frontend_ref.py — pinned here to the numpy feature extractors of `transformers` (the Whisper
+    and SeamlessM4T ones: an implementation that shares no code with the oracle or the product; tests/golden/make_golden_frontend_pins.py minted
+    tests/golden/frontend_pins.npz from it), and to the live functions where transformers is importable.  Measured: mel table 7e-16, whisper 6e-5 of a log10 / 4 scale,
+    kaldi 6e-4 on natural-log energies up to 26 (fp32 FFTs on both sides)."""
+    import os
+    import sys
+    from oracle import frontend_ref as R
+    GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    g = np.load(os.path.join(GOLD, 'frontend_pins.npz'))
+    table = R.slaney_mel_table(16000, 400, 128)
+    assert np.abs(table.numpy() - g['whisper_mel_table_128']).max() < 1e-12
+    worst = [0.0, 0.0]
+    for tag in ('a', 'b'):
+        y = torch.from_numpy(g['y_' + tag])
+        w = R.whisper_log_mel(y, table.float()).numpy()
+        assert w.shape == g['whisper128_' + tag].shape == (128, len(y) // 160)
+        worst[0] = max(worst[0], float(np.abs(w - g['whisper128_' + tag]).max()))
+        k = R.kaldi_fbank(y[None], subtract_mean=False).numpy()
+        assert k.shape == g['kaldi80_' + tag].shape == (1 + (len(y) - 400) // 160, 80)
+        worst[1] = max(worst[1], float(np.abs(k - g['kaldi80_' + tag]).max()))
+        # the frontend's cepstral mean normalisation on top (frontend.py:106)
+        km = R.kaldi_fbank(y[None]).numpy()
+        assert np.abs(km - (g['kaldi80_' + tag] - g['kaldi80_' + tag].mean(0, keepdims=True))).max() < 2e-3
+    print('oracle vs the independent implementation: whisper log-mel %.2e, kaldi fbank %.2e' % tuple(worst))
+    assert worst[0] < 3e-4 and worst[1] < 2e-3, worst
+    try:
+        import transformers  # noqa: F401
+    except Exception:
+        return
+    sys.path.insert(0, GOLD)
+    import make_golden_frontend_pins as M
+    y = M.waveform(16000 * 2 + 123, seed=77)
+    w, tab = M.independent_whisper(y)
+    assert np.abs(tab - table.numpy()).max() < 1e-12
+    assert np.abs(R.whisper_log_mel(y, table.float()).numpy() - w).max() < 3e-4
+    assert np.abs(R.kaldi_fbank(y[None], subtract_mean=False).numpy() - M.independent_kaldi(y)).max() < 2e-3
+
+
+def test_import_shim_stand_ins_vs_independent_implementations():
+    """the reference imports x_transformers' rotary embedding (flow/DiT/modules.py, F7) and diffusers' Attention (matcha's BasicTransformerBlock,
+    M3); neither package is in this image, so tests/golden/_ref_shim.py restates them and every reference-run fixture of the DiT / the Matcha decoder went through
+    those restatements.  They are held here to independent implementations of the same arithmetic that the image DOES have:
+      * rotary: transformers' GPT-J functions (create_sinusoidal_positions / apply_rotary_pos_emb: rotate_every_two on interleaved pairs, sin / cos duplicated
+        interleaved) — x_transformers' convention, not the half-split of Llama / Qwen2 —, including the DiT's partial rotation (first 64 of 1024 channels);
+      * Attention: torch.nn.functional.scaled_dot_product_attention (what diffusers' AttnProcessor2_0 calls) on the stand-in's own projections, with the additive
+        2-D key mask of the Matcha decoder."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    import _ref_shim
+    S = _ref_shim.stand_ins()
+    g = torch.Generator().manual_seed(5)
+    # ---- rotary ----
+    B, H, T, D = 2, 3, 37, 64
+    x = torch.randn(B, H, T, D, generator=g)
+    rot = S['RotaryEmbedding'](D)
+    freqs, scale = rot.forward_from_seq_len(T)
+    mine = S['apply_rotary_pos_emb'](x, freqs, scale)
+    try:
+        from transformers.models.gptj import modeling_gptj as G
+        sincos = G.create_sinusoidal_positions(T, D)
+        sin, cos = sincos[:, :D // 2][None], sincos[:, D // 2:][None]
+        ind = G.apply_rotary_pos_emb(x.transpose(1, 2), sin, cos).transpose(1, 2)            # GPT-J's layout is (B, T, H, D)
+        assert (mine - ind).abs().max().item() < 2e-6, (mine - ind).abs().max().item()
+        # the DiT rotates the first 64 channels of its 1024-wide q / k BEFORE the head split (modules.py: apply_rotary_pos_emb on (B, T, 1024)): the rest passes through
+        wide = torch.randn(B, T, 1024, generator=g)
+        w = S['apply_rotary_pos_emb'](wide, freqs, scale)
+        assert torch.equal(w[..., D:], wide[..., D:])
+        ind_w = G.apply_rotary_pos_emb(wide[:, :, None, :D], sin, cos)[:, :, 0]
+        assert (w[..., :D] - ind_w).abs().max().item() < 2e-6
+    except ImportError:
+        pass
+    # a property no implementation is needed for: position 0 is the identity, and the rotation preserves every (2i, 2i+1) pair's norm
+    assert torch.allclose(mine[:, :, 0], x[:, :, 0], atol=1e-7)
+    assert torch.allclose(mine.reshape(B, H, T, D // 2, 2).norm(dim=-1), x.reshape(B, H, T, D // 2, 2).norm(dim=-1), atol=1e-5)
+    # ---- attention ----
+    att = S['Attention'](query_dim=48, heads=4, dim_head=16, bias=False)
+    with torch.no_grad():
+        for p in att.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * 0.2)
+    hs = torch.randn(2, 29, 48, generator=g)
+    keep = torch.ones(2, 29)
+    keep[1, 20:] = 0.0
+    add_mask = (1.0 - keep) * -10000.0                                                       # the decoder's additive key mask (matcha/models/components/transformer.py)
+    with torch.no_grad():
+        mine = att(hs, attention_mask=add_mask)
+        q, k, v = (t.view(2, 29, 4, 16).transpose(1, 2) for t in (att.to_q(hs), att.to_k(hs), att.to_v(hs)))
+        o = torch.nn.functional.scaled_dot_product_attention(q, k, v, attn_mask=add_mask[:, None, None, :])
+        ind = att.to_out[0](o.transpose(1, 2).reshape(2, 29, 64))
+    assert (mine - ind).abs().max().item() < 2e-6, (mine - ind).abs().max().item()
