@@ -389,8 +389,14 @@ __global__ void attn_combine_kernel(AttnArgs a) {
 // 8 no exp2 / bf16 conversion, 16 no MFMA.  0 = the product.
 // NW: waves per workgroup.  4: 64 QR rows per workgroup, two workgroups per CU.  8: 128 QR rows per workgroup, ONE per CU — the same two waves per SIMD,
 // but a K / V^T tile is staged once for twice the rows, so every thread moves half the bytes per tile (one 16-byte piece of K and one of V^T).
-template <int QR, bool FAST, bool PRE, int LAB = 0, int NW = 4>   // 16-row query tiles per wave: every K / V^T fragment read from LDS feeds QR MFMAs
+// ROT 1: the in-wave pipeline ROTATED ACROSS key tiles (QR = 4, FAST, PRE): every step of the loop is QK(i + 1) + SM(i) + PV(i - 1) — 18 MFMAs against 16 exponentials + 8
+// conversions — including the tile boundary (QK(0) of tile t + 1 beside SM(3) and PV(2) of tile t; PV(3) of tile t beside QK(1) / SM(0) of tile t + 1), where the
+// in-tile pipeline above runs 8 bare QK MFMAs at the head and 10 bare PV MFMAs at the tail of every tile and packs the vector work behind the 54 in between.
+// tools/mfma_valu_lab.hip prices the difference: one exponential behind a 16x16x32 MFMA is free (8.3 ns with or without), a second one costs 3.8 ns.  The K / V^T
+// fragment registers are re-filled in place behind their last use (K(t + 1) during QK(3, t), V(t) during PV(3, t - 1)), so the working set is the in-tile form's.
+template <int QR, bool FAST, bool PRE, int LAB = 0, int NW = 4, int ROT = 0>   // 16-row query tiles per wave: every K / V^T fragment read from LDS feeds QR MFMAs
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_dit_kernel(AttnArgs a) {
+    static_assert(ROT == 0 || (QR == 4 && FAST && PRE && LAB == 0 && NW == 4), "the rotated pipeline exists for the 64-row, pre-scaled fast form");
     typedef bf16_t T;
     constexpr int KT = 64;                 // keys per tile
     constexpr int LD = 72;                 // LDS row stride (elements): 144 B keeps the 16 rows of a lane group on distinct 16-B slots
@@ -734,7 +740,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_dit_kernel(Attn
     }
     bool classical = !FAST;
     if constexpr (FAST) {
-        if (n_tiles > 0) {
+        if (ROT == 0 && n_tiles > 0) {
             // reference maximum of every row: its (masked) scores against the first key tile
 #pragma unroll
             for (int i = 0; i < QR; ++i) {
@@ -755,12 +761,142 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_dit_kernel(Attn
                 nm_ref[i] = f32x4{mx, mx, mx, mx};
             }
         }
+        if constexpr (ROT != 0) {
+            // ---- the rotated loop (see the kernel header) ---------------------------------------------------------------------------------------
+            bf16x8 kf[4][2], vf[4][2];
+            f32x4 sa[4], sb[4];
+            bf16x8 pa[2], pb[2];
+            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            // One pipeline step in a HAND-WRITTEN order (sched_barrier(0) freezes every slot; the packed conversions are pinned to their slot through an empty asm): 18 MFMAs —
+            // QK(iq) pairs alternating with PV(ip) pairs, the two row-sum MFMAs last — with ONE exponential of SM(is) behind each of the first 16 and a packed conversion
+            // behind every second one.  RF 1: the V^T fragments are re-filled from LDS buffer nbuf (step A), RF 2: the K fragments (step C) — two pairs behind their last use,
+            // so that no MFMA is still reading the register the LDS data returns into.  ROT 1: M E M E C; ROT 2: M M E E C (no vector instruction between the two MFMAs of
+            // an accumulator).  The scores start from 0 (no per-row reference: softmax is shift-invariant and p = exp2(s) keeps bf16's relative precision at any magnitude;
+            // a row whose p overflows fp32 or whose sum underflows to 0 sends the workgroup to the classical loop, see the vote below).
+            auto step = [&](auto IQ, f32x4 (&sq)[4], auto IS, f32x4 (&ss)[4], bf16x8 (&po)[2], auto IP, const bf16x8 (&pi)[2], auto RF, int nbuf, int key0, auto tail_tag)
+                            __attribute__((always_inline)) {
+                constexpr int iq = decltype(IQ)::value, is = decltype(IS)::value, ip = decltype(IP)::value, rf = decltype(RF)::value;
+                if constexpr (decltype(tail_tag)::value) mask_tail(ss, key0, is);
+                __builtin_amdgcn_sched_barrier(0);
+                float x[16];
+                u32x4 pw[2];
+                auto ex = [&](int k) __attribute__((always_inline)) {           // exponential k of the 16: probabilities (m, e) = (k / 8, k % 8) <- score tile 2 m + e / 4, row e % 4
+                    x[k] = __builtin_amdgcn_exp2f(ss[2 * (k >> 3) + ((k & 7) >> 2)][k & 3]);       // -inf -> 0
+                };
+                auto cv = [&](int k) __attribute__((always_inline)) {           // k odd: the pair (k - 1, k) leaves as one packed conversion, in this slot
+                    const bf16x2 h = {f32_to_bf16(x[k - 1]), f32_to_bf16(x[k])};
+                    unsigned w = __builtin_bit_cast(unsigned, h);
+                    asm volatile("" : "+v"(w));
+                    pw[k >> 3][(k & 7) >> 1] = w;
+                };
+                // pair order: the row-sum pair first (its result is added to l at the END of the step: no MFMA -> VALU wait), then QK / PV pairs alternating — PV first in the
+                // step that re-fills V^T, QK first otherwise, so that every re-fill sits one pair behind the last use of its registers and inside the step
+                f32x4 lt = {0, 0, 0, 0};
+#pragma unroll
+                for (int u = 0; u < 9; ++u) {
+                    const int k0 = 2 * u, k1 = 2 * u + 1;
+                    const int j = (u - 1) >> 1;                                  // fragment index of pair u >= 1
+                    const bool is_pv = u >= 1 && (((u - 1) & 1) == (rf == 1 ? 0 : 1));
+                    auto first = [&]() __attribute__((always_inline)) {
+                        if (u == 0) mma32(lt, ones, pi[0]);
+                        else if (is_pv) mma32(o_acc[ip][j], vf[j][0], pi[0]);
+                        else sq[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[j][0], qf[iq][0], f32x4{0, 0, 0, 0}, 0, 0, 0);
+                    };
+                    auto second = [&]() __attribute__((always_inline)) {
+                        if (u == 0) mma32(lt, ones, pi[1]);
+                        else if (is_pv) mma32(o_acc[ip][j], vf[j][1], pi[1]);
+                        else mma32(sq[j], kf[j][1], qf[iq][1]);
+                    };
+                    auto refill = [&]() __attribute__((always_inline)) {        // behind pair u: the fragments pair u - 1 used last
+                        if (u < 2 || (u & 1)) return;                            // (u = 2, 4, 6, 8: pair u - 1 is the re-filled kind's pair j' = u / 2 - 1)
+                        const int jr = (u >> 1) - 1;
+                        if (rf == 1) {
+                            vf[jr][0] = load8(&Vs[nbuf][(jr * 16 + fr) * LD + fg * 8]);
+                            vf[jr][1] = load8(&Vs[nbuf][(jr * 16 + fr) * LD + 32 + fg * 8]);
+                        }
+                        if (rf == 2) {
+                            kf[jr][0] = load8(&Ks[nbuf][(jr * 16 + fr) * LD + fg * 8]);
+                            kf[jr][1] = load8(&Ks[nbuf][(jr * 16 + fr) * LD + 32 + fg * 8]);
+                        }
+                    };
+                    if constexpr (ROT == 1) {
+                        first();
+                        if (k0 < 16) ex(k0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        second();
+                        if (k1 < 16) { ex(k1); cv(k1); }
+                        refill();
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else {
+                        first();
+                        second();
+                        if (k1 < 16) { ex(k0); ex(k1); cv(k1); }
+                        refill();
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                l_acc[ip] += lt[0];
+                po[0] = __builtin_bit_cast(bf16x8, pw[0]);
+                po[1] = __builtin_bit_cast(bf16x8, pw[1]);
+            };
+            typedef std::integral_constant<int, 0> I0;
+            typedef std::integral_constant<int, 1> I1;
+            typedef std::integral_constant<int, 2> I2;
+            typedef std::integral_constant<int, 3> I3;
+            auto body = [&](int it, auto tail_tag) __attribute__((always_inline)) {
+                const int buf = it & 1, key0 = it * KT;
+                // A: QK(1) | SM(0) | PV(3) of the tile before — its V^T fragments give way to this tile's
+                step(I1{}, sb, I0{}, sa, pa, I3{}, pb, I1{}, buf, key0, tail_tag);
+                // B: QK(2) | SM(1) | PV(0)
+                step(I2{}, sa, I1{}, sb, pb, I0{}, pa, I0{}, buf, key0, tail_tag);
+                // the next tile goes into the other LDS buffer (its last readers finished a tile ago: V^T in step A of tile t - 1, K in step C of tile t - 2)
+                // (unconditional, so that the tile stays ONE basic block: past the last tile the registers hold a copy of an earlier tile)
+                stash(buf ^ 1);
+                __syncthreads();
+                gload(min(key0 + 2 * KT, (n_tiles - 1) * KT));
+                // C: QK(3) — its K fragments give way to the next tile's — | SM(2) | PV(1)
+                step(I3{}, sb, I2{}, sa, pa, I1{}, pb, I2{}, buf ^ 1, key0, tail_tag);
+                // D: QK(0) of the NEXT tile | SM(3) | PV(2) (past the last tile: scores of stale keys, never used)
+                step(I0{}, sa, I3{}, sb, pb, I2{}, pa, I0{}, buf, key0, tail_tag);
+            };
+            if (n_tiles > 0) {
+                if (n_tiles > 1) gload(KT);
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) {
+                    kf[kt][0] = load8(&Ks[0][(kt * 16 + fr) * LD + fg * 8]);
+                    kf[kt][1] = load8(&Ks[0][(kt * 16 + fr) * LD + 32 + fg * 8]);
+                }
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) vf[dt][m] = zero8<T>();
+                pb[0] = zero8<T>();
+                pb[1] = zero8<T>();
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) {                                   // QK(0) of the first tile
+                    sa[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt][0], qf[0][0], f32x4{0, 0, 0, 0}, 0, 0, 0);
+                    mma32(sa[kt], kf[kt][1], qf[0][1]);
+                }
+                for (int it = 0; it < n_full; ++it) body(it, std::false_type{});
+                for (int it = n_full; it < n_tiles; ++it) body(it, std::true_type{});
+                f32x4 lt = {0, 0, 0, 0};                                             // PV(3) of the last tile
+                mma32(lt, ones, pb[0]);
+                mma32(lt, ones, pb[1]);
+                l_acc[3] += lt[0];
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) mma32(o_acc[3][dt], vf[dt][m], pb[m]);
+            }
+        } else
         run(tile_fast);
         // overflow vote: any non-finite row sum / output (exponent bits all ones) sends the whole workgroup to the classical loop
         unsigned bad = 0;
 #pragma unroll
         for (int i = 0; i < QR; ++i) {
             bad |= ((__float_as_uint(l_acc[i]) & 0x7f800000u) == 0x7f800000u);
+            if constexpr (ROT != 0) bad |= ((__float_as_uint(l_acc[i]) & 0x7f800000u) == 0u) && (row0 + i * 16 + fr) < a.n_rows;    // no reference: a sum that underflowed (0 / denormal)
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
@@ -1578,7 +1714,12 @@ static int launch_t(const AttnArgs& a_in, hipStream_t s) {
             return hipGetLastError() == hipSuccess ? 0 : (set_error("attention launch failed"), -1);
         }
 #endif
-        if (form == 32 && a.chunk <= 0) {
+        if (form == 17 && a.chunk <= 0 && a.n_rows >= 2048 && a.q_log2) {
+            hipLaunchKernelGGL((attn_dit_kernel<4, true, true, 0, 4, 1>), g4, dim3(256), 0, s, a);
+        } else if (form == 18 && a.chunk <= 0 && a.n_rows >= 2048 && a.q_log2) {
+            hipLaunchKernelGGL((attn_dit_kernel<4, true, true, 0, 4, 2>), g4, dim3(256), 0, s, a);
+
+        } else if (form == 32 && a.chunk <= 0) {
             const dim3 g1q((a.n_rows + 127) / 128, a.heads, a.batch);
             if (a.q_log2) hipLaunchKernelGGL((attn_dit32_kernel<1, true>), g1q, dim3(256), 0, s, a);
             else hipLaunchKernelGGL((attn_dit32_kernel<1, false>), g1q, dim3(256), 0, s, a);
