@@ -389,11 +389,14 @@ __global__ void attn_combine_kernel(AttnArgs a) {
 // 8 no exp2 / bf16 conversion, 16 no MFMA.  0 = the product.
 // NW: waves per workgroup.  4: 64 QR rows per workgroup, two workgroups per CU.  8: 128 QR rows per workgroup, ONE per CU — the same two waves per SIMD,
 // but a K / V^T tile is staged once for twice the rows, so every thread moves half the bytes per tile (one 16-byte piece of K and one of V^T).
-// ROT 1: the in-wave pipeline ROTATED ACROSS key tiles (QR = 4, FAST, PRE): every step of the loop is QK(i + 1) + SM(i) + PV(i - 1) — 18 MFMAs against 16 exponentials + 8
-// conversions — including the tile boundary (QK(0) of tile t + 1 beside SM(3) and PV(2) of tile t; PV(3) of tile t beside QK(1) / SM(0) of tile t + 1), where the
-// in-tile pipeline above runs 8 bare QK MFMAs at the head and 10 bare PV MFMAs at the tail of every tile and packs the vector work behind the 54 in between.
-// tools/mfma_valu_lab.hip prices the difference: one exponential behind a 16x16x32 MFMA is free (8.3 ns with or without), a second one costs 3.8 ns.  The K / V^T
-// fragment registers are re-filled in place behind their last use (K(t + 1) during QK(3, t), V(t) during PV(3, t - 1)), so the working set is the in-tile form's.
+// ROT 1 (round 6; the default where it exists: 64-row waves, pre-scaled queries, no chunk mask): the in-wave pipeline ROTATED ACROSS key tiles.  Every step of the loop is
+// QK(i + 1) + SM(i) + PV(i - 1) — 18 MFMAs against 16 exponentials + 8 conversions — including the tile boundary (QK(0) of tile t + 1 beside SM(3) and PV(2) of tile t; PV(3)
+// of tile t beside QK(1) / SM(0) of tile t + 1), where the in-tile pipeline above runs 8 bare QK MFMAs at the head and 10 bare PV MFMAs at the tail of every tile and packs the
+// vector work behind the 54 in between.  tools/mfma_valu_lab.hip prices the difference: ONE exponential behind a 16x16x32 MFMA is free (8.3 ns with or without), a second one
+// costs 3.8 ns — so the step is written slot by slot (MFMA, exponential, MFMA, exponential, packed conversion; sched_barrier(0) between slots).  The K / V^T fragment registers
+// are re-filled in place one MFMA pair behind their last use (K(t + 1) during QK(3, t), V(t) during PV(3, t - 1)), so the working set is the in-tile form's — minus the 16
+// registers of the per-row reference, which this form drops (scores start from 0; see the step's comment and the vote after the loop): with them the loop spills.
+// Measured at B = 8, H = 16, T = 5632: 849 against 967 us (profiles/r06_attn_tile_ab.md), flow solve 398.7 against 419.6 ms.
 template <int QR, bool FAST, bool PRE, int LAB = 0, int NW = 4, int ROT = 0>   // 16-row query tiles per wave: every K / V^T fragment read from LDS feeds QR MFMAs
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_dit_kernel(AttnArgs a) {
     static_assert(ROT == 0 || (QR == 4 && FAST && PRE && LAB == 0 && NW == 4), "the rotated pipeline exists for the 64-row, pre-scaled fast form");
@@ -771,8 +774,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_dit_kernel(Attn
             // One pipeline step in a HAND-WRITTEN order (sched_barrier(0) freezes every slot; the packed conversions are pinned to their slot through an empty asm): 18 MFMAs —
             // QK(iq) pairs alternating with PV(ip) pairs, the two row-sum MFMAs last — with ONE exponential of SM(is) behind each of the first 16 and a packed conversion
             // behind every second one.  RF 1: the V^T fragments are re-filled from LDS buffer nbuf (step A), RF 2: the K fragments (step C) — two pairs behind their last use,
-            // so that no MFMA is still reading the register the LDS data returns into.  ROT 1: M E M E C; ROT 2: M M E E C (no vector instruction between the two MFMAs of
-            // an accumulator).  The scores start from 0 (no per-row reference: softmax is shift-invariant and p = exp2(s) keeps bf16's relative precision at any magnitude;
+            // so that no MFMA is still reading the register the LDS data returns into.  Slot order M E M E C (M M E E C, no vector instruction between the two MFMAs of
+            // an accumulator, measured 880 against 849 us).  The scores start from 0 (no per-row reference: softmax is shift-invariant and p = exp2(s) keeps bf16's relative precision at any magnitude;
             // a row whose p overflows fp32 or whose sum underflows to 0 sends the workgroup to the classical loop, see the vote below).
             auto step = [&](auto IQ, f32x4 (&sq)[4], auto IS, f32x4 (&ss)[4], bf16x8 (&po)[2], auto IP, const bf16x8 (&pi)[2], auto RF, int nbuf, int key0, auto tail_tag)
                             __attribute__((always_inline)) {
@@ -820,21 +823,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_dit_kernel(Attn
                             kf[jr][1] = load8(&Ks[nbuf][(jr * 16 + fr) * LD + 32 + fg * 8]);
                         }
                     };
-                    if constexpr (ROT == 1) {
-                        first();
-                        if (k0 < 16) ex(k0);
-                        __builtin_amdgcn_sched_barrier(0);
-                        second();
-                        if (k1 < 16) { ex(k1); cv(k1); }
-                        refill();
-                        __builtin_amdgcn_sched_barrier(0);
-                    } else {
-                        first();
-                        second();
-                        if (k1 < 16) { ex(k0); ex(k1); cv(k1); }
-                        refill();
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
+                    first();
+                    if (k0 < 16) ex(k0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    second();
+                    if (k1 < 16) { ex(k1); cv(k1); }
+                    refill();
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 l_acc[ip] += lt[0];
                 po[0] = __builtin_bit_cast(bf16x8, pw[0]);
@@ -1714,11 +1709,10 @@ static int launch_t(const AttnArgs& a_in, hipStream_t s) {
             return hipGetLastError() == hipSuccess ? 0 : (set_error("attention launch failed"), -1);
         }
 #endif
-        if (form == 17 && a.chunk <= 0 && a.n_rows >= 2048 && a.q_log2) {
+        // 0 / 17: the rotated pipeline (ROT 1) where it exists — pre-scaled queries, no chunk mask, >= 2048 rows: the DiT of the batched path —; 16: the in-tile
+        // pipeline everywhere (the round-5 product tile)
+        if ((form == 0 || form == 17) && a.chunk <= 0 && a.n_rows >= 2048 && a.q_log2) {
             hipLaunchKernelGGL((attn_dit_kernel<4, true, true, 0, 4, 1>), g4, dim3(256), 0, s, a);
-        } else if (form == 18 && a.chunk <= 0 && a.n_rows >= 2048 && a.q_log2) {
-            hipLaunchKernelGGL((attn_dit_kernel<4, true, true, 0, 4, 2>), g4, dim3(256), 0, s, a);
-
         } else if (form == 32 && a.chunk <= 0) {
             const dim3 g1q((a.n_rows + 127) / 128, a.heads, a.batch);
             if (a.q_log2) hipLaunchKernelGGL((attn_dit32_kernel<1, true>), g1q, dim3(256), 0, s, a);

@@ -117,11 +117,11 @@ int hvx_set_option(const char* key, int64_t value) {
     if (i == OPT_DEC_FUSE_ROWS && (value < 0 || value > 256)) return set_error("hvx_set_option: dec_fuse_rows must be 0..256, got %lld", (long long)value), -1;
     if (i == OPT_ATT_WAVES && value != 4 && value != 8) return set_error("hvx_set_option: att_waves must be 4 or 8, got %lld", (long long)value), -1;
     #ifdef HVX_LAB
-    const bool form_ok = value == 0 || value == 16 || value == 17 || value == 18 || value == 19 || value == 32 || value == 48;
+    const bool form_ok = value == 0 || value == 16 || value == 17 || value == 32 || value == 48;
 #else
-    const bool form_ok = value == 0 || value == 16 || value == 17 || value == 18 || value == 19 || value == 32;
+    const bool form_ok = value == 0 || value == 16 || value == 17 || value == 32;
 #endif
-    if (i == OPT_ATTN_DIT_FORM && !form_ok) return set_error("hvx_set_option: attn_dit_form must be 0, 16 or 32 (48: lab builds only), got %lld", (long long)value), -1;
+    if (i == OPT_ATTN_DIT_FORM && !form_ok) return set_error("hvx_set_option: attn_dit_form must be 0, 16, 17 or 32 (48: lab builds only), got %lld", (long long)value), -1;
     opt_init();
     g_opt_val[i].store(value, std::memory_order_relaxed);
     return 0;

@@ -22,7 +22,8 @@ enum OptId : int {
     OPT_CONV_RESIDENT,         // 1: the DiT position embedding's 64-channel grouped convolution in the resident-row form; 0: tiled
     OPT_CONV64_RESIDENT,       // 1: the vocoder's 64-channel split-bf16 convolutions in the resident-row form; 0: tiled (the tests compare the two)
     OPT_X3P8,                  // 1: the 8-wave 128 x 128 x 64 tile for the vocoder's 128- / 256-channel split-bf16 convolutions; 0: the 4-wave tile
-    OPT_ATTN_DIT_FORM,         // DiT attention tile: 0 = chosen per shape (the 16x16x32 tile), 16 = the same, 32 = the 32x32x16 tile (attention.hip: measured slower, kept selectable)
+    OPT_ATTN_DIT_FORM,         // DiT attention tile: 0 = chosen per shape (16x16x32 MFMAs; the pipeline rotated across key tiles where that form exists), 17 = the same,
+                               // 16 = the in-tile pipeline everywhere (the round-5 tile), 32 = the 32x32x16 tile (measured slower, kept selectable)
     OPT_DEC_FUSE_ROWS,         // decode grids of up to this many rows build the o_proj's activation fragments from the attention's key-split partials (no combine launch);
                                // 0 = never (the default: bit-identical and measured 12 % SLOWER per step, profiles/r06_decode_fuse_ab.log — kept selectable for that A / B)
     // ---- lab (settable with -DHVX_LAB only) ----

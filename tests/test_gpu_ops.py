@@ -424,6 +424,51 @@ def test_attention_dit_fallback_on_score_spike(T, spike):
     torch.testing.assert_close(out, ref, rtol=3e-2, atol=3e-2)
 
 
+@pytest.mark.parametrize('case', ['plain', 'spike12', 'spike60', 'spike3000', 'sunk', 'sunk_row', 'ragged'])
+def test_attention_dit_rotated_pipeline_without_a_reference(case):
+    """The DiT tile of the batched path (pre-scaled queries, >= 2048 rows, no chunk mask: attn_dit_kernel<.., ROT = 1>) rotates its in-wave pipeline across key tiles and
+    starts its scores from 0 — no per-row reference, p = exp2(s).  Softmax is shift-invariant, so that is exact as long as no p overflows fp32 and no row sum underflows;
+    either sends the workgroup to the classical online-softmax loop.  Held against a float64 reference AND against the in-tile product form (option attn_dit_form = 16):
+      spike*: a few (row, key) pairs score that many nats above everything else (60: p ~ 2^87 stays on the fast path; 3000: overflow -> classical);
+      sunk:   EVERY score of (batch 0, head 1) lies ~ 300 nats below zero (every p underflows -> classical);  sunk_row: the same for three rows only;
+      ragged: key lengths 2300 / 2211 (masked last tile), rows past T in the padded operand."""
+    _lib, ops, packing = _mods()
+    B, H, T = 2, 2, 2300
+    q, k, v, qd, kd, vd = _attn_inputs(B, H, T, torch.bfloat16, seed=91)
+    q, k = q.float(), k.float()
+    if case.startswith('spike'):
+        spike = float(case[5:])
+        for row, key in ((5, 100), (130, T - 70), (T - 1, 77), (2100, 2200)):
+            d = q[0, 1, row] / q[0, 1, row].norm()
+            k[0, 1, key] = d * (spike * 8.0 / q[0, 1, row].norm())
+    if case.startswith('sunk'):
+        c = torch.zeros(64)
+        c[3] = 40.0
+        k[0, 1] = k[0, 1] + c                                                     # every key of the head carries a common component ...
+        rows = range(T) if case == 'sunk' else (7, 1000, T - 2)
+        for r in rows:
+            q[0, 1, r] = q[0, 1, r] * 0.1 - c * 1.5                               # ... and these queries point against it: q . k / 8 ~ -300 for every key
+    q, k = q.bfloat16(), k.bfloat16()
+    ql = (q.float() * (0.125 * math.log2(math.e))).bfloat16()
+    Tp = qd.shape[2]
+    qp = torch.zeros(B, H, Tp, 64, dtype=torch.bfloat16)
+    kp = torch.zeros_like(qp)
+    qp[:, :, :T] = ql
+    kp[:, :, :T] = k
+    kv_len = torch.tensor([T, T - 89 if case == 'ragged' else T - 9], dtype=torch.int32)
+    ref = _attn_ref(ql.double() * (8.0 * math.log(2.0)), k.double(), v.double(), kv_len=kv_len).float()
+    outs = {}
+    try:
+        for form in (0, 16):
+            _lib.set_option('attn_dit_form', form)
+            outs[form] = ops.attention(qp.to(DEV), kp.to(DEV), vd, T, kv_len=kv_len.to(DEV), q_log2=True).float().cpu()
+    finally:
+        _lib.set_option('attn_dit_form', 0)
+    assert torch.isfinite(outs[0]).all()
+    torch.testing.assert_close(outs[0], ref, rtol=3e-2, atol=3e-2)
+    torch.testing.assert_close(outs[0], outs[16], rtol=3e-2, atol=3e-2)
+
+
 @pytest.mark.parametrize('T,n_splits,chunk', [(50, 1, 0), (300, 1, 0), (200, 4, 64), (97, 5, 32)])
 def test_attention_causal_and_splits(T, n_splits, chunk):
     _lib, ops, packing = _mods()

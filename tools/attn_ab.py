@@ -3,7 +3,7 @@
 
     python tools/attn_ab.py [--forms 16,32,33] [--batch 8] [--t 5632] [--rounds 5]
 
-Every form (option attn_dit_form: 16 = the 16x16x32 tile, 32.. = the 32x32x16 tile and its variants, csrc/attention.hip) is first checked against an fp32 torch
+Every form (option attn_dit_form: 16 = the 16x16x32 tile with the in-tile pipeline, 17 = with the pipeline rotated across key tiles (the default), 32 = the 32x32x16 tile, csrc/attention.hip) is first checked against an fp32 torch
 reference on one (batch, head) and against the 16x16x32 form on everything, then timed: median and minimum of `rounds` interleaved rounds of `iters` launches."""
 import argparse
 import os

@@ -17,7 +17,7 @@ timeout 500 $B --config acoustic > $O/acoustic.log 2>&1
 timeout 500 python tools/bench_worker.py > $O/worker.log 2>&1
 timeout 500 python tools/bench_matcha.py --decoder cv2 > $O/matcha_cv2.log 2>&1
 timeout 500 python tools/bench_matcha.py --decoder matcha > $O/matcha.log 2>&1
-timeout 300 python tools/attn_ab.py --forms 16,32 --rounds 5 --iters 5 > $O/attn_ab.log 2>&1
+timeout 300 python tools/attn_ab.py --forms 16,17,32 --rounds 5 --iters 5 > $O/attn_ab.log 2>&1
 timeout 300 python tools/flow_probe.py --utts 4 --iters 4 > $O/flow_probe.log 2>&1
 for f in stress zero_shot acoustic worker matcha_cv2 matcha; do echo $f; tail -1 $O/$f.log | cut -c1-220; done
 P="rocprofv3 --output-format csv"
