@@ -72,6 +72,7 @@ def parse():
     ap.add_argument('--sweep-steps', type=int, default=8, help='steps of 8 utterances per point of the head_num sweep')
     ap.add_argument('--hift-exact', action='store_true', help='the vocoder on the exact fp32 MFMA forms (hvx_hift_config.exact_fp32) instead of split-bf16 pairs')
     ap.add_argument('--config-steps', type=int, default=4, help='steps of each of the other BASELINE configs (stress, zero_shot, acoustic) run behind the headline as the `configs` object; 0: skip')
+    ap.add_argument('--lib-opt', action='append', default=[], metavar='NAME=VALUE', help='library option(s) set before anything runs (hvx_set_option; A / B runs, e.g. attn_dit_form=16 = the round-5 attention tile); recorded in config.lib_options')
     ap.add_argument('--cpu-baseline-worker', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--stub-pipeline', action='store_true', help=argparse.SUPPRESS)      # plumbing check of the rank logic on CPU / gloo (tools/bench_stub.py); INVALID as a benchmark
     return ap.parse_args()
@@ -438,6 +439,10 @@ def main():
     if world != args.gpus:
         raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node %d, or without torch.distributed.run)' % (args.gpus, world, args.gpus))
     stub = args.stub_pipeline
+    if args.lib_opt and not stub:
+        from flowmirror_hydravox_amd import _lib as _hvx_lib
+        for kv in args.lib_opt:
+            _hvx_lib.set_option(kv.split('=')[0], int(kv.split('=')[1]))
     dev = 'cpu' if stub else 'cuda'
     sync = (lambda: None) if stub else torch.cuda.synchronize
     if world > 1:
@@ -652,7 +657,7 @@ def main():
                                   'llm+flow bf16' if args.llm_dtype == 'bf16' else 'llm fp32 (speech-token ids bit-exact against the reference) + flow bf16'),
                    'baseline_config': {'tts': 'configs[1]', 'stress': 'configs[2]', 'zero_shot': 'configs[3]: text lengths U{64..512} per utterance (the chars figure above is the maximum), '
                                        'prompt = 75 speech tokens + 150 mel frames + 20 prompt-text tokens'}[args.config],
-                   'global_batch': B * world, 'parallelism': 'utterance-dp%d' % world,
+                   'global_batch': B * world, 'parallelism': 'utterance-dp%d' % world, 'lib_options': args.lib_opt or None,
                    'schedule': {'continuous': 'continuous batching: one decode grid of %d slots, utterances of later steps join as earlier ones finish; '
                                               'flow + vocoder of finished utterances run beside it' % args.lm_slots,
                                 'chains': '%d independent decode chains of one step each + %d acoustic chain(s)' % (args.lm_chains, args.acoustic_chains),
