@@ -424,14 +424,15 @@ def test_attention_dit_fallback_on_score_spike(T, spike):
     torch.testing.assert_close(out, ref, rtol=3e-2, atol=3e-2)
 
 
-@pytest.mark.parametrize('case', ['plain', 'spike12', 'spike60', 'spike3000', 'sunk', 'sunk_row', 'ragged'])
+@pytest.mark.parametrize('case', ['plain', 'spike12', 'spike60', 'spike3000', 'sunk', 'sunk_row', 'ragged', 'short_keys', 'one_key'])
 def test_attention_dit_rotated_pipeline_without_a_reference(case):
     """The DiT tile of the batched path (pre-scaled queries, >= 2048 rows, no chunk mask: attn_dit_kernel<.., ROT = 1>) rotates its in-wave pipeline across key tiles and
     starts its scores from 0 — no per-row reference, p = exp2(s).  Softmax is shift-invariant, so that is exact as long as no p overflows fp32 and no row sum underflows;
     either sends the workgroup to the classical online-softmax loop.  Held against a float64 reference AND against the in-tile product form (option attn_dit_form = 16):
       spike*: a few (row, key) pairs score that many nats above everything else (60: p ~ 2^87 stays on the fast path; 3000: overflow -> classical);
       sunk:   EVERY score of (batch 0, head 1) lies ~ 300 nats below zero (every p underflows -> classical);  sunk_row: the same for three rows only;
-      ragged: key lengths 2300 / 2211 (masked last tile), rows past T in the padded operand."""
+      ragged: key lengths 2300 / 2211 (masked last tile), rows past T in the padded operand;  short_keys / one_key: 2300 query rows against 70 / 5 and 2300 / 1 keys
+      (one or two key tiles: the rotated loop's prologue, its look-ahead past the last tile and its epilogue with nothing in between)."""
     _lib, ops, packing = _mods()
     B, H, T = 2, 2, 2300
     q, k, v, qd, kd, vd = _attn_inputs(B, H, T, torch.bfloat16, seed=91)
@@ -456,6 +457,10 @@ def test_attention_dit_rotated_pipeline_without_a_reference(case):
     qp[:, :, :T] = ql
     kp[:, :, :T] = k
     kv_len = torch.tensor([T, T - 89 if case == 'ragged' else T - 9], dtype=torch.int32)
+    if case == 'short_keys':
+        kv_len = torch.tensor([70, 5], dtype=torch.int32)
+    if case == 'one_key':
+        kv_len = torch.tensor([T, 1], dtype=torch.int32)
     ref = _attn_ref(ql.double() * (8.0 * math.log(2.0)), k.double(), v.double(), kv_len=kv_len).float()
     outs = {}
     try:
