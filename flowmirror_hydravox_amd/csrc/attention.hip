@@ -891,7 +891,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_dit_kernel(Attn
 #pragma unroll
         for (int i = 0; i < QR; ++i) {
             bad |= ((__float_as_uint(l_acc[i]) & 0x7f800000u) == 0x7f800000u);
-            if constexpr (ROT != 0) bad |= ((__float_as_uint(l_acc[i]) & 0x7f800000u) == 0u) && (row0 + i * 16 + fr) < a.n_rows;    // no reference: a sum that underflowed (0 / denormal)
+            // no reference: a row sum below 2^-80 means the row's largest p is that small, and probabilities below 2^-126 — within 2^-46 of it — were flushed to 0; such a
+            // row (and one whose every p underflowed: l == 0) takes the classical loop too
+            if constexpr (ROT != 0) bad |= ((__float_as_uint(l_acc[i]) & 0x7f800000u) < (47u << 23)) && (row0 + i * 16 + fr) < a.n_rows;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
 #pragma unroll

@@ -424,13 +424,14 @@ def test_attention_dit_fallback_on_score_spike(T, spike):
     torch.testing.assert_close(out, ref, rtol=3e-2, atol=3e-2)
 
 
-@pytest.mark.parametrize('case', ['plain', 'spike12', 'spike60', 'spike3000', 'sunk', 'sunk_row', 'ragged', 'short_keys', 'one_key'])
+@pytest.mark.parametrize('case', ['plain', 'spike12', 'spike60', 'spike3000', 'sunk', 'sunk_row', 'dim', 'ragged', 'short_keys', 'one_key'])
 def test_attention_dit_rotated_pipeline_without_a_reference(case):
     """The DiT tile of the batched path (pre-scaled queries, >= 2048 rows, no chunk mask: attn_dit_kernel<.., ROT = 1>) rotates its in-wave pipeline across key tiles and
     starts its scores from 0 — no per-row reference, p = exp2(s).  Softmax is shift-invariant, so that is exact as long as no p overflows fp32 and no row sum underflows;
     either sends the workgroup to the classical online-softmax loop.  Held against a float64 reference AND against the in-tile product form (option attn_dit_form = 16):
       spike*: a few (row, key) pairs score that many nats above everything else (60: p ~ 2^87 stays on the fast path; 3000: overflow -> classical);
       sunk:   EVERY score of (batch 0, head 1) lies ~ 300 nats below zero (every p underflows -> classical);  sunk_row: the same for three rows only;
+      dim:    the scores of a head lie around -85 nats (2^-123): the largest p are representable, the tail of the distribution is not -> row sums below 2^-80 -> classical;
       ragged: key lengths 2300 / 2211 (masked last tile), rows past T in the padded operand;  short_keys / one_key: 2300 query rows against 70 / 5 and 2300 / 1 keys
       (one or two key tiles: the rotated loop's prologue, its look-ahead past the last tile and its epilogue with nothing in between)."""
     _lib, ops, packing = _mods()
@@ -449,6 +450,11 @@ def test_attention_dit_rotated_pipeline_without_a_reference(case):
         rows = range(T) if case == 'sunk' else (7, 1000, T - 2)
         for r in rows:
             q[0, 1, r] = q[0, 1, r] * 0.1 - c * 1.5                               # ... and these queries point against it: q . k / 8 ~ -300 for every key
+    if case == 'dim':
+        c = torch.zeros(64)
+        c[3] = 40.0
+        k[0, 1] = k[0, 1] + c
+        q[0, 1] = q[0, 1] - c * (85.0 * 8.0 / 1600.0)                             # q . k / 8 ~ -85 nats + the usual spread of a few nats
     q, k = q.bfloat16(), k.bfloat16()
     ql = (q.float() * (0.125 * math.log2(math.e))).bfloat16()
     Tp = qd.shape[2]
