@@ -924,7 +924,11 @@ def test_library_options_are_one_switchboard_and_lab_ones_are_refused():
     with _lib.option_scope(dec_gemm=0, att_chunk=512):
         assert _lib.get_option('dec_gemm') == 0 and _lib.get_option('att_chunk') == 512
     assert _lib.get_option('dec_gemm') == 1 and _lib.get_option('att_chunk') == 0
-    for key, val, msg in (('no_such_option', 1, 'unknown option'), ('att_chunk', 100, 'multiple of 128'), ('att_waves', 5, '4 or 8'), ('attn_lab', 3, 'lab option')):
+    with _lib.option_scope(attn_dit_form=16, dec_fuse_rows=16):           # the round-5 attention tile / the fused narrow-grid o_proj stay selectable for A / B runs
+        assert _lib.get_option('attn_dit_form') == 16 and _lib.get_option('dec_fuse_rows') == 16
+    assert _lib.get_option('attn_dit_form') == 0 and _lib.get_option('dec_fuse_rows') == 0
+    for key, val, msg in (('no_such_option', 1, 'unknown option'), ('att_chunk', 100, 'multiple of 128'), ('att_waves', 5, '4 or 8'), ('attn_lab', 3, 'lab option'),
+                          ('attn_dit_form', 18, '0, 16, 17 or 32'), ('attn_dit_form', 48, 'lab builds only'), ('dec_fuse_rows', 300, '0..256')):
         with pytest.raises(_lib.HvxError, match=msg):
             _lib.set_option(key, val)
     csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'flowmirror_hydravox_amd', 'csrc')
